@@ -1,0 +1,183 @@
+"""ctypes front-end for oracle/oracle.c -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(see oracle.c header).  The product package satmvs_amd/ never does.
+
+All functions take/return numpy arrays; layouts follow the reference tensors
+(features (B,C,H,W) f32, rpc (B,170)/(B,V,170) f64, depth (B,D) or (B,D,H,W) f32).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile oracle.c with gcc (seconds).  Returns the .so path."""
+    src = os.path.join(_HERE, "oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_homo_compose.restype = C.c_int
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
+
+
+def rpc_project(rpc170, a, b, h, direction):
+    """direction 0: photo->object (samp,line,h)->(lat,lon); 1: object->photo."""
+    rpc170, a, b, h = _f64(rpc170), _f64(a).ravel(), _f64(b).ravel(), _f64(h).ravel()
+    o0, o1 = np.empty_like(a), np.empty_like(a)
+    lib().orc_rpc_project(_p(rpc170), _p(a), _p(b), _p(h), _p(o0), _p(o1), C.c_size_t(a.size), C.c_int(direction))
+    return o0, o1
+
+
+def grid_sample(inp, grid):
+    inp, grid = _f32(inp), _f32(grid)
+    B, Cc, H, W = inp.shape
+    _, Ho, Wo, _ = grid.shape
+    out = np.empty((B, Cc, Ho, Wo), np.float32)
+    lib().orc_grid_sample(_p(inp), _p(grid), _p(out), B, Cc, H, W, Ho, Wo)
+    return out
+
+
+def _depth_args(depth, B, D, H, W):
+    depth = _f32(depth)
+    if depth.ndim == 2:
+        assert depth.shape == (B, D)
+        return depth, 0
+    assert depth.shape == (B, D, H, W), (depth.shape, (B, D, H, W))
+    return depth, 1
+
+
+def rpc_warping(src_fea, src_rpc, ref_rpc, depth):
+    src_fea, src_rpc, ref_rpc = _f32(src_fea), _f64(src_rpc), _f64(ref_rpc)
+    B, Cc, H, W = src_fea.shape
+    D = depth.shape[1]
+    depth, is4 = _depth_args(depth, B, D, H, W)
+    out = np.empty((B, Cc, D, H, W), np.float32)
+    lib().orc_rpc_warping(_p(src_fea), _p(src_rpc), _p(ref_rpc), _p(depth), is4, _p(out), B, Cc, D, H, W)
+    return out
+
+
+def rpc_warp_coords(src_rpc, ref_rpc, depth, H, W):
+    src_rpc, ref_rpc = _f64(src_rpc), _f64(ref_rpc)
+    B = src_rpc.shape[0]
+    D = depth.shape[1]
+    depth, is4 = _depth_args(depth, B, D, H, W)
+    outs = [np.empty((B, D, H, W), np.float64) for _ in range(4)]
+    lib().orc_rpc_warp_coords(_p(src_rpc), _p(ref_rpc), _p(depth), is4, *[_p(o) for o in outs], B, D, H, W)
+    return outs  # lat, lon, samp, line
+
+
+def homo_compose(src_proj, ref_proj):
+    src_proj, ref_proj = _f64(src_proj), _f64(ref_proj)
+    B = src_proj.shape[0]
+    out = np.empty((B, 4, 4), np.float64)
+    rc = lib().orc_homo_compose(_p(src_proj), _p(ref_proj), _p(out), B)
+    if rc:
+        raise np.linalg.LinAlgError("singular ref_proj")
+    return out
+
+
+def homo_warping(src_fea, src_proj, ref_proj, depth):
+    src_fea = _f32(src_fea)
+    B, Cc, H, W = src_fea.shape
+    D = depth.shape[1]
+    depth, is4 = _depth_args(depth, B, D, H, W)
+    proj = homo_compose(src_proj, ref_proj)
+    out = np.empty((B, Cc, D, H, W), np.float32)
+    lib().orc_homo_warping(_p(src_fea), _p(proj), _p(depth), is4, _p(out), B, Cc, D, H, W)
+    return out
+
+
+def costvol_variance(features, geo_params, depth, geo_model="rpc", d_begin=0, d_end=None, out=None):
+    """features: list of V arrays (B,C,H,W), view 0 = reference.
+    geo_params: rpc -> (B,V,170) f64;  pinhole -> (B,V,4,4) f64 projection matrices."""
+    feats = [_f32(f) for f in features]
+    V = len(feats)
+    B, Cc, H, W = feats[0].shape
+    D = depth.shape[1]
+    depth, is4 = _depth_args(depth, B, D, H, W)
+    d_end = D if d_end is None else d_end
+    if geo_model == "rpc":
+        gp = _f64(geo_params)
+        assert gp.shape == (B, V, 170)
+        geo = 0
+    else:
+        P = _f64(geo_params)
+        assert P.shape == (B, V, 4, 4)
+        gp = np.stack([homo_compose(P[:, v], P[:, 0]) for v in range(1, V)], axis=1)  # (B,V-1,4,4)
+        gp = _f64(gp)
+        geo = 1
+    if out is None:
+        out = np.zeros((B, Cc, D, H, W), np.float32)
+    ptrs = (C.c_void_p * V)(*[f.ctypes.data for f in feats])
+    lib().orc_costvol_variance(ptrs, _p(gp), geo, _p(depth), is4, _p(out), B, V, Cc, D, H, W, d_begin, d_end)
+    return out
+
+
+def softmax_regress(reg, depth):
+    reg = _f32(reg)
+    B, D, H, W = reg.shape
+    depth, is4 = _depth_args(depth, B, D, H, W)
+    od = np.empty((B, H, W), np.float32)
+    oc = np.empty((B, H, W), np.float32)
+    lib().orc_softmax_regress(_p(reg), _p(depth), is4, _p(od), _p(oc), B, D, H, W)
+    return od, oc
+
+
+class StreamRegress:
+    """The three float64 accumulators of networks/casred.py:182-184 and their updates."""
+
+    def __init__(self, B, H, W):
+        self.B, self.H, self.W = B, H, W
+        self.exp_sum = np.zeros((B, 1, H, W), np.float64)
+        self.depth_img = np.zeros((B, 1, H, W), np.float64)
+        self.max_prob = np.zeros((B, 1, H, W), np.float64)
+
+    def step(self, reg_plane, depth, d):
+        reg_plane = _f32(reg_plane)
+        depth = _f32(depth)
+        D = depth.shape[1]
+        is_plane = 1 if depth.ndim == 4 else 0
+        lib().orc_stream_regress_step(_p(reg_plane), _p(depth), is_plane, _p(self.exp_sum), _p(self.depth_img),
+                                      _p(self.max_prob), self.B, self.H, self.W, D, d)
+
+    def final(self):
+        n = self.B * self.H * self.W
+        od = np.empty((self.B, self.H, self.W), np.float32)
+        oc = np.empty((self.B, self.H, self.W), np.float32)
+        lib().orc_stream_regress_final(_p(self.exp_sum), _p(self.depth_img), _p(self.max_prob), _p(od), _p(oc),
+                                       C.c_size_t(n))
+        return od, oc

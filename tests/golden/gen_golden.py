@@ -1,0 +1,392 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in tests/golden/*.npz by IMPORTING the Python reference.
+
+Runs only in the build container (needs /root/reference, read-only).  The fixtures are data:
+seeded inputs and the reference's outputs.  No reference source travels to the GPU box.
+
+    python tests/golden/gen_golden.py            # writes tests/golden/*.npz
+
+Inputs are synthesised by satmvs_amd/rpc_synth.py (our own host code); every expected output
+comes from the reference's functions, file:line noted per fixture.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = os.environ.get("SATMVS_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+# The reference hard-codes .cuda(); on this CPU-only container make it a no-op.
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.set_num_threads(4)
+
+import warnings  # noqa: E402
+
+warnings.filterwarnings("ignore")
+
+from modules import warping as ref_warping  # noqa: E402
+from modules import module as ref_module  # noqa: E402
+from modules import depth_range as ref_depth_range  # noqa: E402
+from networks import casred as ref_casred  # noqa: E402
+from networks import casmvs as ref_casmvs  # noqa: E402
+from networks import ucs as ref_ucs  # noqa: E402
+from tools.RPCCore import RPCModelParameter  # noqa: E402
+from tools.iccv_solver import solve_iccv  # noqa: E402
+
+from satmvs_amd import rpc_synth  # noqa: E402
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s %8.1f KB  %s" % (name, os.path.getsize(path) / 1024.0, sorted(arrays)))
+
+
+def np_state(module):
+    return {k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+
+
+def ref_rpcs(num_views, H, W, seed, batch=1):
+    """(B,V,170) via OUR synthesiser for the direct part and the REFERENCE's ICCV inverse fit."""
+    out = np.zeros((batch, num_views, 170))
+    for b in range(batch):
+        for v in range(num_views):
+            d = rpc_synth.make_direct_rpc(H, W, seed=seed * 101 + 17 * b + v,
+                                          tilt=rpc_synth._DEFAULT_TILTS[(v + b) % 7])
+            m = RPCModelParameter(d.copy())
+            m.Calculate_Inverse_RPC()                      # tools/RPCCore.py:188
+            out[b, v] = np.array(m.get_data())
+    return out
+
+
+def height_volume(B, D, H, W, seed, lo=0.0, hi=400.0, jitter=6.0):
+    """Stage-2/3-like per-pixel hypotheses: plane-wise linspace + smooth per-pixel offset."""
+    rng = np.random.default_rng(seed)
+    base = np.linspace(lo, hi, D, dtype=np.float64).reshape(1, D, 1, 1)
+    yy, xx = np.meshgrid(np.linspace(0, 3, H), np.linspace(0, 5, W), indexing="ij")
+    bump = jitter * (np.sin(yy + rng.uniform(0, 3)) * np.cos(xx + rng.uniform(0, 3)))
+    return (base + bump[None, None] + rng.normal(0, 0.3, (B, D, H, W))).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------
+def gen_iccv():
+    """tools/iccv_solver.py:42-64 known answers + the inverse fit of tools/RPCCore.py:188-240."""
+    A1 = np.array([[94.61, -22.11, -11.45, -6.96], [-22.11, 70.51, -6.95, -8.42],
+                   [-11.45, -6.95, 96.09, -20.21], [-6.96, -8.42, -20.21, 66.63]])
+    L1 = np.array([-43.52, 178.81, -120.11, -30.07])
+    A2 = np.array([[5, -2, -1, -2], [-2, 5, -1, -2], [-1, -1, 3, -1], [-2, -2, -1, 5]], float)
+    L2 = np.array([-11, 10, -2, 3], float)
+    x1, t1 = solve_iccv(A1, L1)
+    x2, t2 = solve_iccv(A2, L2)
+    direct = np.stack([rpc_synth.make_direct_rpc(128, 256, seed=s, tilt=t)
+                       for s, t in ((3, 0.0), (4, 0.05), (5, -0.08))])
+    full = []
+    for d in direct:
+        m = RPCModelParameter(d.copy())
+        m.Calculate_Inverse_RPC()
+        full.append(np.array(m.get_data()))
+    save("iccv", A1=A1, L1=L1, x1=x1, it1=np.int64(t1), A2=A2, L2=L2, x2=x2, it2=np.int64(t2),
+         direct=direct, full=np.stack(full))
+
+
+def gen_project():
+    """RPC_Photo2Obj / RPC_Obj2Photo (modules/warping.py:255,218) and the numpy twins
+    (tools/RPCCore.py:424-489) on random points."""
+    rng = np.random.default_rng(7)
+    H, W, n = 128, 256, 600
+    rpc = ref_rpcs(3, H, W, seed=2)[0]                     # (3,170)
+    samp = rng.uniform(-10, W + 10, n)
+    line = rng.uniform(-10, H + 10, n)
+    hei = rng.uniform(-20, 420, n)
+    out = {"rpc": rpc, "samp": samp, "line": line, "hei": hei}
+    for v in range(3):
+        r = torch.from_numpy(rpc[v:v + 1])
+        coef = torch.ones((1, n, 20), dtype=torch.double)
+        lat, lon = ref_warping.RPC_Photo2Obj(torch.from_numpy(samp)[None], torch.from_numpy(line)[None],
+                                             torch.from_numpy(hei)[None], r, coef)
+        s2, l2 = ref_warping.RPC_Obj2Photo(lat, lon, torch.from_numpy(hei)[None], r, coef)
+        m = RPCModelParameter(rpc[v].copy())
+        nlat, nlon = m.RPC_PHOTO2OBJ(samp, line, hei)
+        ns, nl = m.RPC_OBJ2PHOTO(nlat, nlon, hei)
+        out.update({"lat%d" % v: lat[0].numpy(), "lon%d" % v: lon[0].numpy(),
+                    "samp_back%d" % v: s2[0].numpy(), "line_back%d" % v: l2[0].numpy(),
+                    "np_lat%d" % v: nlat, "np_lon%d" % v: nlon, "np_samp%d" % v: ns, "np_line%d" % v: nl})
+    save("rpc_project", **out)
+
+
+def gen_grid_sample():
+    """F.grid_sample(bilinear, zeros) with the default align_corners (modules/warping.py:358)."""
+    torch.manual_seed(11)
+    inp = torch.randn(2, 3, 19, 23)
+    grid = torch.rand(2, 16, 40, 2) * 2.6 - 1.3
+    grid[0, 0, :4, 0] = torch.tensor([-1.0, 1.0, float("nan"), 1e30])
+    out = torch.nn.functional.grid_sample(inp, grid, mode="bilinear", padding_mode="zeros")
+    save("grid_sample", inp=inp.numpy(), grid=grid.numpy(), out=out.numpy())
+
+
+def gen_rpc_warp():
+    """rpc_warping (modules/warping.py:310-365): 4-D and 2-D depth_values, B=2, plus the f64
+    intermediates of RPC_Photo2Obj/RPC_Obj2Photo on the same lattice."""
+    B, C, D, H, W = 2, 8, 6, 32, 64
+    torch.manual_seed(5)
+    rpc = ref_rpcs(2, H, W, seed=9, batch=B)               # (B,2,170): view0=ref, view1=src
+    src_fea = torch.randn(B, C, H, W)
+    dv4 = height_volume(B, D, H, W, seed=1)
+    dv2 = np.linspace(0, 400, D, dtype=np.float32)[None].repeat(B, 0) + np.array([[0.0], [7.5]], np.float32)
+    ref_r, src_r = torch.from_numpy(rpc[:, 0]), torch.from_numpy(rpc[:, 1])
+    coef = torch.ones((B, H * W * D, 20), dtype=torch.double)
+    w4 = ref_warping.rpc_warping(src_fea, src_r, ref_r, torch.from_numpy(dv4), coef)
+    w2 = ref_warping.rpc_warping(src_fea, src_r, ref_r, torch.from_numpy(dv2), coef)
+    # intermediates exactly as warping.py:323-341 builds them
+    y, x = torch.meshgrid([torch.arange(0, H, dtype=torch.double), torch.arange(0, W, dtype=torch.double)])
+    y = y.contiguous().view(1, 1, H, W).repeat(B, D, 1, 1).view(B, -1)
+    x = x.contiguous().view(1, 1, H, W).repeat(B, D, 1, 1).view(B, -1)
+    h = torch.from_numpy(dv4).view(B, -1).double()
+    lat, lon = ref_warping.RPC_Photo2Obj(x, y, h, ref_r, coef)
+    samp, line = ref_warping.RPC_Obj2Photo(lat, lon, h, src_r, coef)
+    save("rpc_warp", rpc=rpc, src_fea=src_fea.numpy(), depth4=dv4, depth2=dv2,
+         warped4=w4.numpy(), warped2=w2.numpy(),
+         lat=lat.view(B, D, H, W).numpy(), lon=lon.view(B, D, H, W).numpy(),
+         samp=samp.view(B, D, H, W).numpy(), line=line.view(B, D, H, W).numpy())
+
+
+def _qc_dict(rpc_b):
+    """(B,170) -> the dict of dataset/data_io.py:123-150, built with the reference-layout tensor."""
+    keys = ["line_off", "samp_off", "lat_off", "lon_off", "height_off",
+            "line_scale", "samp_scale", "lat_scale", "lon_scale", "height_scale"]
+    d = {k: torch.from_numpy(np.ascontiguousarray(rpc_b[:, i])) for i, k in enumerate(keys)}
+    names = ["line_num", "line_den", "samp_num", "samp_den", "lat_num", "lat_den", "lon_num", "lon_den"]
+    for j, nm in enumerate(names):
+        t = np.stack([rpc_synth.coeffs_to_qc_tensor(r[10 + 20 * j: 30 + 20 * j]) for r in rpc_b])
+        d[nm + "_tensor"] = torch.from_numpy(t)
+    return d
+
+
+def gen_qc():
+    """rpc_warping_enisum (modules/warping.py:139-178) with the QC tensors of
+    dataset/data_io.py:95-120; also pins coeffs_to_qc_tensor against the reference to_tensor."""
+    B, C, D, H, W = 1, 4, 3, 16, 24
+    torch.manual_seed(6)
+    rpc = ref_rpcs(2, H, W, seed=21, batch=B)
+    src_fea = torch.randn(B, C, H, W)
+    dv4 = height_volume(B, D, H, W, seed=2)
+    # reference to_tensor, executed from its source with the GDAL import stripped
+    src = open(os.path.join(REF, "dataset", "data_io.py")).read()
+    start = src.index("def to_tensor")
+    end = src.index("def load_rpc_as_qc_tensor")
+    ns = {"np": np}
+    exec(src[start:end], ns)
+    c20 = np.random.default_rng(3).normal(size=20)
+    t_ref = ns["to_tensor"](c20)
+    assert np.array_equal(t_ref, rpc_synth.coeffs_to_qc_tensor(c20)), "QC tensor layout differs from reference"
+    out = ref_warping.rpc_warping_enisum(src_fea, _qc_dict(rpc[:, 1]), _qc_dict(rpc[:, 0]), torch.from_numpy(dv4))
+    save("rpc_warp_qc", rpc=rpc, src_fea=src_fea.numpy(), depth4=dv4, warped=out.numpy(),
+         qc_c20=c20, qc_tensor=t_ref)
+
+
+def _pinhole_mats(V, H, W, seed, batch=1):
+    """K.E 4x4 'projection matrices' as dataset/virdataset.py:96-105 hands them over."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((batch, V, 4, 4))
+    for b in range(batch):
+        for v in range(V):
+            f = 1.1 * W
+            K = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1.0]])
+            ang = rng.normal(0, 0.02, 3) * (v > 0)
+            Rx = np.array([[1, 0, 0], [0, np.cos(ang[0]), -np.sin(ang[0])], [0, np.sin(ang[0]), np.cos(ang[0])]])
+            Ry = np.array([[np.cos(ang[1]), 0, np.sin(ang[1])], [0, 1, 0], [-np.sin(ang[1]), 0, np.cos(ang[1])]])
+            Rz = np.array([[np.cos(ang[2]), -np.sin(ang[2]), 0], [np.sin(ang[2]), np.cos(ang[2]), 0], [0, 0, 1]])
+            R = Rz @ Ry @ Rx
+            t = np.array([30.0 * v * (-1) ** v, 4.0 * v, 1.0 * v]) + rng.normal(0, 1.0, 3) * (v > 0)
+            E = np.eye(4)
+            E[:3, :3], E[:3, 3] = R, t
+            P = np.eye(4)
+            P[:3, :4] = K @ E[:3, :4]
+            out[b, v] = P
+    return out
+
+
+def gen_homo():
+    """homo_warping (modules/warping.py:6-44), 2-D and 4-D depth."""
+    B, C, D, H, W = 2, 6, 5, 24, 40
+    torch.manual_seed(8)
+    proj = _pinhole_mats(2, H, W, seed=4, batch=B)
+    src_fea = torch.randn(B, C, H, W)
+    d2 = np.linspace(400, 700, D, dtype=np.float32)[None].repeat(B, 0)
+    d4 = (d2[:, :, None, None] + height_volume(B, D, H, W, seed=3, lo=0, hi=0, jitter=15.0)).astype(np.float32)
+    sp, rp = torch.from_numpy(proj[:, 1]), torch.from_numpy(proj[:, 0])
+    w2 = ref_warping.homo_warping(src_fea, sp, rp, torch.from_numpy(d2))
+    w4 = ref_warping.homo_warping(src_fea, sp, rp, torch.from_numpy(d4))
+    composed = torch.matmul(sp, torch.inverse(rp)).numpy()
+    save("homo_warp", proj=proj, src_fea=src_fea.numpy(), depth2=d2, depth4=d4,
+         warped2=w2.numpy(), warped4=w4.numpy(), composed=composed)
+
+
+class _Capture(torch.nn.Module):
+    """Stand-in regulariser that records its input (the variance volume) and returns a peaky cost."""
+
+    def __init__(self, lam=8.0):
+        super().__init__()
+        self.lam = lam
+        self.seen = None
+
+    def forward(self, vol):
+        self.seen = vol.detach().clone()
+        return -self.lam * vol.mean(1)                     # (B,D,H,W)
+
+
+def gen_costvol():
+    """Body of compute_depth_when_train (networks/casred.py:22-62): variance volume, softmax,
+    depth_regression, max-prob -- RPC and pinhole, 3 views."""
+    B, C, D, H, W, V = 1, 8, 8, 32, 64, 3
+    torch.manual_seed(12)
+    feats = [torch.randn(B, C, H, W) for _ in range(V)]
+    rpc = ref_rpcs(V, H, W, seed=31, batch=B)
+    dv = height_volume(B, D, H, W, seed=5)
+    cap = _Capture()
+    out = ref_casred.compute_depth_when_train(feats, torch.from_numpy(rpc), torch.from_numpy(dv), D, cap, "rpc", False)
+    var_rpc = cap.seen.numpy()
+    reg_rpc = (-cap.lam * cap.seen.mean(1)).numpy()
+    proj = _pinhole_mats(V, H, W, seed=6, batch=B)
+    dvp = np.linspace(400, 700, D, dtype=np.float32).reshape(1, D, 1, 1).repeat(H, 2).repeat(W, 3)
+    out_p = ref_casred.compute_depth_when_train(feats, torch.from_numpy(proj), torch.from_numpy(dvp), D, cap, "pinhole", False)
+    save("costvol", feats=np.stack([f.numpy() for f in feats]), rpc=rpc, depth=dv, variance_rpc=var_rpc,
+         reg_rpc=reg_rpc, depth_rpc=out["depth"].numpy(), conf_rpc=out["photometric_confidence"].numpy(),
+         proj=proj, depth_pin=dvp, variance_pin=cap.seen.numpy(),
+         depth_pin_out=out_p["depth"].numpy(), conf_pin_out=out_p["photometric_confidence"].numpy())
+
+
+def gen_pred():
+    """compute_depth_when_pred (networks/casred.py:161-238) with seeded slice_RED_Regularization
+    weights, and compute_depth_when_train with RED_Regularization on the same weights."""
+    B, C, D, H, W, V = 1, 8, 6, 32, 64, 3
+    torch.manual_seed(13)
+    feats = [torch.randn(B, C, H, W) * 0.5 for _ in range(V)]
+    rpc = ref_rpcs(V, H, W, seed=41, batch=B)
+    dv = height_volume(B, D, H, W, seed=7)
+    reg = ref_module.slice_RED_Regularization(C, 8).eval()
+    reg_train = ref_module.RED_Regularization(C, 8).eval()
+    reg_train.load_state_dict(reg.state_dict())
+    with torch.no_grad():
+        o_pred = ref_casred.compute_depth_when_pred(feats, torch.from_numpy(rpc), torch.from_numpy(dv), D, reg, "rpc", False)
+        o_train = ref_casred.compute_depth_when_train(feats, torch.from_numpy(rpc), torch.from_numpy(dv), D, reg_train, "rpc", False)
+        # one slice step for the regulariser alone
+        x = torch.randn(B, C, H, W)
+        st = [torch.zeros(B, 8, H, W), torch.zeros(B, 16, H // 2, W // 2),
+              torch.zeros(B, 32, H // 4, W // 4), torch.zeros(B, 64, H // 8, W // 8)]
+        r1 = reg(x, *st)
+        r2 = reg(x * 0.5, *r1[1:])
+    arrays = {"w." + k: v for k, v in np_state(reg).items()}
+    save("red_pred", feats=np.stack([f.numpy() for f in feats]), rpc=rpc, depth=dv,
+         pred_depth=o_pred["depth"].numpy(), pred_conf=o_pred["photometric_confidence"].numpy(),
+         train_depth=o_train["depth"].numpy(), train_conf=o_train["photometric_confidence"].numpy(),
+         slice_x=x.numpy(), slice_out1=r1[0].numpy(), slice_out2=r2[0].numpy(),
+         slice_s1=r2[1].numpy(), slice_s2=r2[2].numpy(), slice_s3=r2[3].numpy(), slice_s4=r2[4].numpy(),
+         **arrays)
+
+
+def gen_regress():
+    """softmax + depth_regression + max (casred.py:58-62) and the streaming accumulators
+    (casred.py:218-236) on random regulariser outputs."""
+    B, D, H, W = 2, 7, 12, 20
+    torch.manual_seed(14)
+    reg = torch.randn(B, D, H, W) * 3
+    dv = torch.from_numpy(height_volume(B, D, H, W, seed=8))
+    p = torch.softmax(reg, dim=1)
+    depth = ref_module.depth_regression(p, depth_values=dv)
+    conf = p.max(1)[0]
+    exp_sum = torch.zeros(B, 1, H, W, dtype=torch.double)
+    dimg = torch.zeros_like(exp_sum)
+    mx = torch.zeros_like(exp_sum)
+    for d in range(D):                                     # casred.py:218-231, transcribed as a driver loop
+        prob = reg[:, d:d + 1].double().exp()
+        flag = (mx < prob).double()
+        mx = flag * prob + (1 - flag) * mx
+        dimg = dv[:, d:d + 1].double() * prob + dimg
+        exp_sum = exp_sum + prob
+    fes = exp_sum + 1e-10
+    save("regress", reg=reg.numpy(), depth_values=dv.numpy(), sm_depth=depth.numpy(), sm_conf=conf.numpy(),
+         st_exp_sum=exp_sum.numpy(), st_depth_img=dimg.numpy(), st_max=mx.numpy(),
+         st_depth=(dimg / fes).squeeze(1).float().numpy(), st_conf=(mx / fes).squeeze(1).float().numpy())
+
+
+def gen_depth_range():
+    """modules/depth_range.py:4-42 + the trilinear resize of networks/casred.py:138-145."""
+    B, H, W = 1, 32, 64
+    torch.manual_seed(15)
+    dv = torch.tensor([[10.0, 410.0]])
+    s1 = ref_depth_range.get_depth_range_samples(dv, 8, 10.0, "cpu", torch.float32, [B, H, W])
+    cur = torch.rand(B, H, W) * 300 + 50
+    s2 = ref_depth_range.get_depth_range_samples(cur, 6, 5.0, "cpu", torch.float32, [B, H, W])
+    r1 = torch.nn.functional.interpolate(s1.unsqueeze(1), [8, H // 4, W // 4], mode="trilinear", align_corners=False).squeeze(1)
+    r2 = torch.nn.functional.interpolate(s2.unsqueeze(1), [6, H // 2, W // 2], mode="trilinear", align_corners=False).squeeze(1)
+    save("depth_range", dv=dv.numpy(), s1=s1.numpy(), cur=cur.numpy(), s2=s2.numpy(), r1=r1.numpy(), r2=r2.numpy())
+
+
+def gen_cascade():
+    """Full forwards at 3-view 64x128 (ndepths 16/8/8): CascadeREDNet, Infer_CascadeREDNet
+    (networks/casred.py:114,285), CascadeMVSNet (networks/casmvs.py:79), UCSNet (networks/ucs.py:79).
+
+    Weights are NOT stored (13 MB of random floats): each net is built right after
+    torch.manual_seed(seed) with torch's default initialisers, and the fixture carries the seed
+    plus a per-parameter (sum, sum-of-squares) checksum so the test can prove that its own module
+    tree, built under the same seed, holds the identical parameters before comparing outputs.
+    """
+    B, V, H, W = 1, 3, 64, 128
+    nd = [16, 8, 8]
+    torch.manual_seed(16)
+    imgs = torch.randn(B, V, 3, H, W)
+    rpc_full = ref_rpcs(V, H, W, seed=51, batch=B)
+    proj = {"stage1": torch.from_numpy(rpc_synth.rescale_rpc(rpc_full, 4)),
+            "stage2": torch.from_numpy(rpc_synth.rescale_rpc(rpc_full, 2)),
+            "stage3": torch.from_numpy(rpc_full)}
+    dv = torch.tensor([[20.0, 380.0]])
+    arrays = {"imgs": imgs.numpy(), "rpc": rpc_full, "dv": dv.numpy(), "ndepths": np.array(nd)}
+
+    def record(tag, net, out):
+        for s in ("stage1", "stage2", "stage3"):
+            for k, v in out[s].items():
+                arrays["%s.%s.%s" % (tag, s, k)] = v.numpy()
+        names, sums = [], []
+        for k, v in net.state_dict().items():
+            if "num_batches_tracked" in k:
+                continue
+            names.append(k)
+            sums.append([float(v.double().sum()), float((v.double() ** 2).sum())])
+        arrays[tag + ".param_names"] = np.array(names)
+        arrays[tag + ".param_sums"] = np.array(sums)
+
+    def run(tag, seed, ctor):
+        torch.manual_seed(seed)
+        net = ctor().eval()
+        arrays[tag + ".seed"] = np.int64(seed)
+        with torch.no_grad():
+            out = net(imgs, proj, dv)
+        record(tag, net, out)
+        return net
+
+    red = run("red", 17, lambda: ref_casred.CascadeREDNet("rpc", min_interval=2.5, ndepths=nd))
+    inf = ref_casred.Infer_CascadeREDNet("rpc", min_interval=2.5, ndepths=nd).eval()
+    inf.load_state_dict(red.state_dict())
+    with torch.no_grad():
+        o = inf(imgs, proj, dv)
+    for s in ("stage1", "stage2", "stage3"):
+        for k, v in o[s].items():
+            arrays["redinf.%s.%s" % (s, k)] = v.numpy()
+    run("casmvs", 18, lambda: ref_casmvs.CascadeMVSNet("rpc", min_interval=2.5, ndepths=nd))
+    run("ucs", 19, lambda: ref_ucs.UCSNet("rpc", stage_configs=nd))
+    save("cascade", **arrays)
+
+
+if __name__ == "__main__":
+    only = set(sys.argv[1:])
+    for fn in (gen_iccv, gen_project, gen_grid_sample, gen_rpc_warp, gen_qc, gen_homo, gen_costvol, gen_pred,
+               gen_regress, gen_depth_range, gen_cascade):
+        if only and fn.__name__[4:] not in only:
+            continue
+        fn()
