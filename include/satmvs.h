@@ -1,0 +1,125 @@
+/*
+ * satmvs.h -- C ABI of the MI355X-native RPC plane-sweep cost-volume engine (libsatmvs_hip.so).
+ *
+ * The reference (WHU-GPCV/SatMVS) has no FFI layer: its boundary is the Python operator surface
+ * of modules/warping.py and networks/casred.py.  Each entry point below names the reference
+ * function(s) it replaces (file:line under /root/reference); satmvs_amd/modules/warping.py and
+ * satmvs_amd/networks/casred.py bind them with ctypes under the reference's own names, and
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - The caller owns every buffer.  All pointers are DEVICE pointers (HBM) unless stated;
+ *     tensors are contiguous, float32 features/volumes in NCHW / NCDHW order, float64 camera
+ *     parameters.  Nothing is allocated or freed inside the library.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Work is enqueued
+ *     on it and the call returns without synchronising.
+ *   - Return value: SMVS_OK (0) or an SMVS_ERR_* code; smvs_last_error() then returns a
+ *     thread-local message.  Nothing is written on an argument error.
+ *   - Re-entrant; no per-process device/stream cache.  The caller selects the device
+ *     (hipSetDevice / torch.cuda.device) before calling.
+ *   - depth_is_4d: 1 = per-voxel heights (B,D,H,W); 0 = per-plane heights (B,D) -- both forms
+ *     of `depth_values` accepted by modules/warping.py:329-332.
+ */
+#ifndef SATMVS_H
+#define SATMVS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { SMVS_OK = 0, SMVS_ERR_ARG = 1, SMVS_ERR_LAUNCH = 2, SMVS_ERR_UNSUPPORTED = 3 };
+
+/* Library identification: "satmvs-hip <version> gfx950". */
+const char* smvs_version(void);
+/* Message of the last failing call on this thread ("" if none). */
+const char* smvs_last_error(void);
+
+/* ---- fused warp + variance cost volume ----------------------------------------------------
+ * Replaces the per-source loop  rpc_warping() + volume_sum/volume_sq_sum + variance
+ *   modules/warping.py:310-365 (rpc_warping), networks/casred.py:22-53 (train, whole volume),
+ *   networks/casred.py:191-212 (pred, one plane), networks/casmvs.py:26-59, networks/ucs.py:27-58.
+ * ref_fea (B,C,H,W); src_fea: HOST array of n_src device pointers, each (B,C,H,W), in view order;
+ * rpc (B,V,170) float64 with V = n_src+1 and view 0 = reference -- the layout of
+ * `proj_matrices` before torch.unbind(.,1) (casred.py:13); depth per depth_is_4d.
+ * Builds planes [d_begin,d_end) of the D hypotheses; plane d is written to plane index
+ * d - d_begin + d_out_off of out_var (B,C,D_out,H,W).  (Whole volume: 0,D,D,0.  One plane of the
+ * pred loop: d,d+1,1,0.  Depth shard g of G: g*D/G,(g+1)*D/G,D/G,0.)
+ * variance = sq/V - (sum/V)^2 in float32, accumulated ref, src0, src1, ... like the reference. */
+int smvs_rpc_costvol_fwd(const float* ref_fea, const float* const* src_fea, int n_src,
+                         const double* rpc, const float* depth, int depth_is_4d, float* out_var,
+                         int B, int C, int D, int H, int W,
+                         int d_begin, int d_end, int D_out, int d_out_off, void* stream);
+
+/* Same with the pinhole homography of modules/warping.py:6-44 (geo_model="pinhole").
+ * proj (B,n_src,4,4) float64 = src_proj @ inverse(ref_proj) per source view, as produced by
+ * smvs_homo_compose. */
+int smvs_homo_costvol_fwd(const float* ref_fea, const float* const* src_fea, int n_src,
+                          const double* proj, const float* depth, int depth_is_4d, float* out_var,
+                          int B, int C, int D, int H, int W,
+                          int d_begin, int d_end, int D_out, int d_out_off, void* stream);
+
+/* ---- stand-alone warps (the operator surface itself) ------------------------------------------
+ * smvs_rpc_warp_fwd  = rpc_warping(src_fea, src_rpc, ref_rpc, depth_values, coef)
+ *                      modules/warping.py:310-365 (coef is not needed); also serves
+ *                      rpc_warping_enisum (:139-178) after the QC tensors are mapped back to the
+ *                      20 coefficients on the host.  src_rpc, ref_rpc (B,170); out (B,C,D,H,W).
+ * smvs_rpc_warp_bwd  = its autograd w.r.t. src_fea (the grid is built under no_grad,
+ *                      warping.py:322): grad_src (B,C,H,W) must be zero-filled by the caller,
+ *                      contributions are accumulated with float32 atomics. */
+int smvs_rpc_warp_fwd(const float* src_fea, const double* src_rpc, const double* ref_rpc,
+                      const float* depth, int depth_is_4d, float* out,
+                      int B, int C, int D, int H, int W, void* stream);
+int smvs_rpc_warp_bwd(const float* grad_out, const double* src_rpc, const double* ref_rpc,
+                      const float* depth, int depth_is_4d, float* grad_src,
+                      int B, int C, int D, int H, int W, void* stream);
+
+/* homo_warping(src_fea, src_proj, ref_proj, depth_values), modules/warping.py:6-44.
+ * proj (B,4,4) = src_proj @ inverse(ref_proj) from smvs_homo_compose. */
+int smvs_homo_warp_fwd(const float* src_fea, const double* proj, const float* depth, int depth_is_4d,
+                       float* out, int B, int C, int D, int H, int W, void* stream);
+int smvs_homo_warp_bwd(const float* grad_out, const double* proj, const float* depth, int depth_is_4d,
+                       float* grad_src, int B, int C, int D, int H, int W, void* stream);
+/* out[b] = src_proj[b] @ inverse(ref_proj[b]) (warping.py:19), 4x4 float64, n matrices. */
+int smvs_homo_compose(const double* src_proj, const double* ref_proj, double* out, int n, void* stream);
+
+/* ---- backward of the fused volume (train.py:284 loss.backward through casred.py:22-53) -------
+ * grad_var (B,C,D,H,W) -> grad_ref (B,C,H,W) and grad_src[s] (B,C,H,W), all ACCUMULATED with
+ * float32 atomics (zero-filled by the caller; grad_src is a HOST array of n_src device pointers).  geo_kind 0 = rpc (B,V,170), 1 = homography
+ * (B,n_src,4,4).  Recomputes the taps instead of saving a warped volume. */
+int smvs_costvol_bwd(int geo_kind, const float* grad_var, const float* ref_fea, const float* const* src_fea,
+                     int n_src, const double* geo, const float* depth, int depth_is_4d,
+                     float* grad_ref, float* const* grad_src,
+                     int B, int C, int D, int H, int W, void* stream);
+
+/* ---- batch projectors --------------------------------------------------------------------------
+ * RPC_Photo2Obj / RPC_Obj2Photo (modules/warping.py:255-307, :218-252) and the offline-tool twins
+ * tools/RPCCore.py:424-489, tools/rpc_tensor.py:109-165 on flat float64 arrays.
+ * dir 0: (samp, line, h) -> (lat, lon);  dir 1: (lat, lon, h) -> (samp, line).
+ * rpc170: one 170-vector (device).  a, b, h, o0, o1: n doubles each (device). */
+int smvs_rpc_project(const double* rpc170, const double* a, const double* b, const double* h,
+                     double* o0, double* o1, size_t n, int dir, void* stream);
+
+/* ---- regression ----------------------------------------------------------------------------------
+ * Train path: softmax over D + expected height + max probability,
+ *   networks/casred.py:58-62 and modules/module.py:433-439 (depth_regression).
+ * reg (B,D,H,W) float32 regulariser output; out_depth, out_conf (B,H,W). */
+int smvs_softmax_regress_fwd(const float* reg, const float* depth, int depth_is_4d,
+                             float* out_depth, float* out_conf, int B, int D, int H, int W, void* stream);
+/* Pred path, one plane d: prob = exp(double(reg)); max_prob = max(.,prob); depth_img += h*prob;
+ * exp_sum += prob (networks/casred.py:218-231).  Accumulators (B,H,W) float64, zeroed by the
+ * caller before plane 0.  reg_plane (B,H,W). */
+int smvs_stream_regress_step(const float* reg_plane, const float* depth, int depth_is_4d,
+                             double* exp_sum, double* depth_img, double* max_prob,
+                             int B, int D, int H, int W, int d, void* stream);
+/* depth = depth_img/(exp_sum+1e-10), conf = max_prob/(exp_sum+1e-10) -> float32
+ * (networks/casred.py:234-236).  n = B*H*W. */
+int smvs_stream_regress_final(const double* exp_sum, const double* depth_img, const double* max_prob,
+                              float* out_depth, float* out_conf, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SATMVS_H */

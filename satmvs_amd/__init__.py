@@ -1,0 +1,8 @@
+"""satmvs_amd -- MI355X-native RPC plane-sweep cost-volume engine.
+
+Drop-in for the hot path of WHU-GPCV/SatMVS (modules/warping.py, networks/casred.py and twins):
+RPC / homography plane-sweep warping -> per-channel variance cost volume -> regularise ->
+soft-argmin height, as hand-written HIP kernels for gfx950 behind a C ABI (include/satmvs.h).
+See DESIGN.md for the path, data layout and roofline, INTEGRATION.md for the reference-side binding.
+"""
+__version__ = "0.1.0"

@@ -1,0 +1,101 @@
+"""ctypes binding of libsatmvs_hip.so (the C ABI declared in include/satmvs.h).
+
+There is no CPU fallback: if the library is missing, or a tensor is not on a HIP device, the
+call raises.  PyTorch is used only for device memory and streams; every pointer handed to the
+library is `tensor.data_ptr()` and the stream is torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsatmvs_hip.so")
+
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+
+# name -> argtypes; mirrors include/satmvs.h one to one
+_SIGNATURES = {
+    "smvs_rpc_costvol_fwd": [_vp, _vp, _i, _vp, _vp, _i, _vp] + [_i] * 9 + [_vp],
+    "smvs_homo_costvol_fwd": [_vp, _vp, _i, _vp, _vp, _i, _vp] + [_i] * 9 + [_vp],
+    "smvs_rpc_warp_fwd": [_vp, _vp, _vp, _vp, _i, _vp] + [_i] * 5 + [_vp],
+    "smvs_rpc_warp_bwd": [_vp, _vp, _vp, _vp, _i, _vp] + [_i] * 5 + [_vp],
+    "smvs_homo_warp_fwd": [_vp, _vp, _vp, _i, _vp] + [_i] * 5 + [_vp],
+    "smvs_homo_warp_bwd": [_vp, _vp, _vp, _i, _vp] + [_i] * 5 + [_vp],
+    "smvs_homo_compose": [_vp, _vp, _vp, _i, _vp],
+    "smvs_costvol_bwd": [_i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp] + [_i] * 5 + [_vp],
+    "smvs_rpc_project": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
+    "smvs_softmax_regress_fwd": [_vp, _vp, _i, _vp, _vp] + [_i] * 4 + [_vp],
+    "smvs_stream_regress_step": [_vp, _vp, _i, _vp, _vp, _vp] + [_i] * 5 + [_vp],
+    "smvs_stream_regress_final": [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
+}
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["smvs_version", "smvs_last_error"])
+
+_lib = None
+
+
+class SatMVSNativeError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library (once).  Raises ImportError with build instructions if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "satmvs_amd: %s not found. Build it with `python -m satmvs_amd.build` (hipcc, gfx950); "
+            "there is no CPU fallback for the product path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.smvs_version.restype = C.c_char_p
+    lib.smvs_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def version():
+    return load().smvs_version().decode()
+
+
+def call(name, *args):
+    """Invoke an entry point; non-zero return -> SatMVSNativeError(smvs_last_error())."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise SatMVSNativeError("%s failed (code %d): %s" % (name, rc, lib.smvs_last_error().decode()))
+
+
+def current_stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_device(*tensors):
+    """All tensors on one HIP device; returns it.  CPU tensors are an error, not a fallback."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise SatMVSNativeError(
+                "satmvs_amd operators run on an MI355X only: got a %s tensor (no CPU fallback)" % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise SatMVSNativeError("tensors on different devices: %s vs %s" % (dev, t.device))
+    return dev
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (for the `const float* const*` arguments)."""
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])

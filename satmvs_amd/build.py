@@ -1,0 +1,45 @@
+"""Build recipe for libsatmvs_hip.so (hipcc, gfx950 only, in-tree so the .so ships with the repo snapshot).
+
+    python -m satmvs_amd.build [--force] [--verbose]
+
+hipcc cross-compiles without a GPU, so this runs in the build container as well as on the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIB_DIR, "libsatmvs_hip.so")
+SOURCES = ["costvol.hip", "costvol_bwd.hip", "warp.hip", "regress.hip"]
+HEADERS = ["smvs_device.h", "smvs_host.h", os.path.join("..", "..", "include", "satmvs.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fvisibility=hidden", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    """Compile every HIP source into one shared library.  Returns its path."""
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

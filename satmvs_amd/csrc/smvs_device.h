@@ -1,0 +1,210 @@
+// smvs_device.h -- device-side building blocks of the RPC plane-sweep engine (gfx950 only).
+//
+//   rpc_*      float64 rational-cubic camera model, forward (ground -> image) and pre-fitted
+//              inverse (image + height -> ground); reference semantics:
+//              /root/reference/modules/warping.py:183-307.
+//   Tap        the reference's bug-compatible bilinear sampler: grid normalised with the
+//              align_corners=True formula, sampled by grid_sample(align_corners=False)
+//              (/root/reference/modules/warping.py:350-359).  Rounding order follows
+//              ATen's CPU kernel so the float32 result is bit-identical to oracle/oracle.c.
+//   BufRsrc    raw buffer descriptor of one (B,C,H,W) feature tensor; the hardware range check
+//              (num_records = one H*W plane, channel offset in the scalar offset) turns
+//              out-of-image taps into zeros for free -- grid_sample's padding_mode='zeros'.
+//
+// Compile with -ffp-contract=off: every FMA in here is explicit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace smvs {
+
+// ---- 170-vector layout (tools/RPCCore.py:8-28) -----------------------------------------------
+enum : int {
+    I_LINE_OFF = 0, I_SAMP_OFF = 1, I_LAT_OFF = 2, I_LON_OFF = 3, I_H_OFF = 4,
+    I_LINE_SCALE = 5, I_SAMP_SCALE = 6, I_LAT_SCALE = 7, I_LON_SCALE = 8, I_H_SCALE = 9,
+    I_LNUM = 10, I_LDEN = 30, I_SNUM = 50, I_SDEN = 70,
+    I_LATNUM = 90, I_LATDEN = 110, I_LONNUM = 130, I_LONDEN = 150, RPC_LEN = 170
+};
+
+// Wave-uniform camera parameters are read through the constant address space so that every
+// access is a scalar load (s_load_*) into SGPRs; a generic pointer would turn them into
+// per-lane flat loads.
+typedef const double __attribute__((address_space(4))) * cgeo_t;
+
+__device__ __forceinline__ cgeo_t as_cgeo(const double* p) { return (cgeo_t)(uintptr_t)p; }
+
+// Re-materialise a uniform pointer in SGPRs so loads through it cannot be hoisted out of the
+// enclosing loop (see costvol.hip: hoisting 80*V coefficients spills ~570 SGPRs).
+__device__ __forceinline__ cgeo_t launder(cgeo_t p)
+{
+    uintptr_t v = (uintptr_t)p;
+    asm volatile("" : "+s"(v));
+    return (cgeo_t)v;
+}
+
+// Four cubics sharing one monomial set: n0/d0 and n1/d1 are the two rational outputs.
+// k0..k3 point at 20 wave-uniform coefficients each (scalar loads; they never touch a VGPR
+// except as FMA operands).  Monomial order is RPC00B, built by the reference's product chain.
+__device__ __forceinline__ void cubic4(cgeo_t k0, cgeo_t k1, cgeo_t k2, cgeo_t k3,
+                                       double P, double L, double H,
+                                       double& n0, double& d0, double& n1, double& d1)
+{
+    double a0 = k0[0], a1 = k1[0], a2 = k2[0], a3 = k3[0];
+#define SMVS_ACC(i, t)                                                         \
+    a0 = fma((t), k0[i], a0); a1 = fma((t), k1[i], a1);                        \
+    a2 = fma((t), k2[i], a2); a3 = fma((t), k3[i], a3);
+    const double LP = L * P, LH = L * H, PH = P * H, LL = L * L, PP = P * P, HH = H * H;
+    SMVS_ACC(1, L)  SMVS_ACC(2, P)  SMVS_ACC(3, H)
+    SMVS_ACC(4, LP) SMVS_ACC(5, LH) SMVS_ACC(6, PH)
+    SMVS_ACC(7, LL) SMVS_ACC(8, PP) SMVS_ACC(9, HH)
+    SMVS_ACC(10, P * LH) SMVS_ACC(11, L * LL) SMVS_ACC(12, L * PP) SMVS_ACC(13, L * HH)
+    SMVS_ACC(14, L * LP) SMVS_ACC(15, P * PP) SMVS_ACC(16, P * HH) SMVS_ACC(17, L * LH)
+    SMVS_ACC(18, P * PH) SMVS_ACC(19, H * HH)
+#undef SMVS_ACC
+    n0 = a0; d0 = a1; n1 = a2; d1 = a3;
+}
+
+// Loop-invariant normalisation constants of one view (reciprocals taken once, in float64).
+struct RpcNorm {
+    double samp_off, line_off, h_off, lat_off, lon_off;
+    double inv_samp_scale, inv_line_scale, inv_h_scale, inv_lat_scale, inv_lon_scale;
+};
+
+__device__ __forceinline__ RpcNorm rpc_norm(cgeo_t r)
+{
+    RpcNorm n;
+    n.samp_off = r[I_SAMP_OFF]; n.line_off = r[I_LINE_OFF]; n.h_off = r[I_H_OFF];
+    n.lat_off = r[I_LAT_OFF];   n.lon_off = r[I_LON_OFF];
+    n.inv_samp_scale = 1.0 / r[I_SAMP_SCALE]; n.inv_line_scale = 1.0 / r[I_LINE_SCALE];
+    n.inv_h_scale = 1.0 / r[I_H_SCALE];
+    n.inv_lat_scale = 1.0 / r[I_LAT_SCALE];   n.inv_lon_scale = 1.0 / r[I_LON_SCALE];
+    return n;
+}
+
+// image (samp, line) + height -> ground (lat, lon); RPC_Photo2Obj, warping.py:255-307.
+__device__ __forceinline__ void rpc_photo2obj(cgeo_t r, const RpcNorm& n,
+                                              double samp, double line, double hei,
+                                              double& lat, double& lon)
+{
+    const double s = (samp - n.samp_off) * n.inv_samp_scale;
+    const double l = (line - n.line_off) * n.inv_line_scale;
+    const double h = (hei - n.h_off) * n.inv_h_scale;
+    double an, ad, on, od;
+    cubic4(r + I_LATNUM, r + I_LATDEN, r + I_LONNUM, r + I_LONDEN, s, l, h, an, ad, on, od);
+    lat = fma(an / ad, r[I_LAT_SCALE], n.lat_off);
+    lon = fma(on / od, r[I_LON_SCALE], n.lon_off);
+}
+
+// ground (lat, lon, h) -> image (samp, line); RPC_Obj2Photo, warping.py:218-252.
+__device__ __forceinline__ void rpc_obj2photo(cgeo_t r, const RpcNorm& n,
+                                              double lat, double lon, double hei,
+                                              double& samp, double& line)
+{
+    const double p = (lat - n.lat_off) * n.inv_lat_scale;
+    const double l = (lon - n.lon_off) * n.inv_lon_scale;
+    const double h = (hei - n.h_off) * n.inv_h_scale;
+    double sn, sd, ln, ld;
+    cubic4(r + I_SNUM, r + I_SDEN, r + I_LNUM, r + I_LDEN, p, l, h, sn, sd, ln, ld);
+    samp = fma(sn / sd, r[I_SAMP_SCALE], n.samp_off);
+    line = fma(ln / ld, r[I_LINE_SCALE], n.line_off);
+}
+
+// ---- raw buffer access -------------------------------------------------------------------------
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ float llvm_raw_buffer_load_f32(i32x4 rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.load.f32");
+
+struct BufRsrc { i32x4 v; };
+
+// Descriptor over `bytes` bytes at `base` (wave-uniform).  Raw buffer, stride 0: a load is in
+// range iff voffset + 4 <= bytes; the scalar offset is NOT part of the range check, so the
+// channel plane offset rides in it and `bytes` = one H*W plane.
+__device__ __forceinline__ BufRsrc make_rsrc(const void* base, uint32_t bytes)
+{
+    const uint64_t a = (uint64_t)base;
+    BufRsrc r;
+    r.v.x = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
+    r.v.y = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));  // stride 0, no swizzle
+    r.v.z = (int32_t)__builtin_amdgcn_readfirstlane(bytes);
+    r.v.w = 0x00020000;                                                    // gfx9-family raw dword access
+    return r;
+}
+
+#define SMVS_OOB 0x80000000u   // any voffset >= num_records reads back 0
+
+// ---- sampler -------------------------------------------------------------------------------------
+struct Tap {
+    uint32_t o_nw, o_ne, o_sw, o_se;   // byte offsets inside one H*W plane, or SMVS_OOB
+    float nw, ne, sw, se;
+};
+
+// Normalised grid coordinate -> tap.  fx = W/2, fy = H/2 (exact in float32).
+__device__ __forceinline__ Tap tap_from_grid(float gx, float gy, int H, int W)
+{
+    Tap t;
+    const float x = fmaf(gx + 1.0f, (float)W * 0.5f, -0.5f);   // ATen unnormalise, align_corners=False
+    const float y = fmaf(gy + 1.0f, (float)H * 0.5f, -0.5f);
+    const float xw = floorf(x), yn = floorf(y);
+    const float w = x - xw, e = 1.0f - w, n = y - yn, s = 1.0f - n;
+    t.nw = s * e; t.ne = s * w; t.sw = n * e; t.se = n * w;
+    // bounds in float: NaN / huge coordinates compare false everywhere -> all four taps dropped
+    const bool xin0 = (xw >= 0.0f) && (xw <= (float)(W - 1));
+    const bool xin1 = (xw >= -1.0f) && (xw <= (float)(W - 2));
+    const bool yin0 = (yn >= 0.0f) && (yn <= (float)(H - 1));
+    const bool yin1 = (yn >= -1.0f) && (yn <= (float)(H - 2));
+    const int x0 = (xin0 || xin1) ? (int)xw : 0;
+    const int y0 = (yin0 || yin1) ? (int)yn : 0;
+    const int base = (y0 * W + x0) * 4;
+    t.o_nw = (xin0 && yin0) ? (uint32_t)base : SMVS_OOB;
+    t.o_ne = (xin1 && yin0) ? (uint32_t)(base + 4) : SMVS_OOB;
+    t.o_sw = (xin0 && yin1) ? (uint32_t)(base + 4 * W) : SMVS_OOB;
+    t.o_se = (xin1 && yin1) ? (uint32_t)(base + 4 * W + 4) : SMVS_OOB;
+    return t;
+}
+
+// float32 pixel coordinates (samp.float(), line.float()) -> tap.  half_wm1 = (W-1)/2 as float32
+// (the python scalar the reference divides by), warping.py:350-351.
+__device__ __forceinline__ Tap tap_from_pixel(float px, float py, int H, int W, float half_wm1, float half_hm1)
+{
+    const float gx = px / half_wm1 - 1.0f;
+    const float gy = py / half_hm1 - 1.0f;
+    return tap_from_grid(gx, gy, H, W);
+}
+
+// One channel of one source view.  `choff` = c*H*W*4, wave-uniform (scalar offset).
+__device__ __forceinline__ float tap_fetch(const BufRsrc& rs, const Tap& t, int choff)
+{
+    const float a = llvm_raw_buffer_load_f32(rs.v, (int)t.o_nw, choff, 0);
+    const float b = llvm_raw_buffer_load_f32(rs.v, (int)t.o_ne, choff, 0);
+    const float c = llvm_raw_buffer_load_f32(rs.v, (int)t.o_sw, choff, 0);
+    const float d = llvm_raw_buffer_load_f32(rs.v, (int)t.o_se, choff, 0);
+    float r = a * t.nw;
+    r = fmaf(b, t.ne, r);
+    r = fmaf(c, t.sw, r);
+    r = fmaf(d, t.se, r);
+    return r;
+}
+
+// x / v for a small integer-valued float v (the view count), correctly rounded in 3 ops:
+// q0 = x*rv, r = fma(-q0, v, x) (exact), q = fma(r, rv, q0); rv = RN(1/v).  For v <= 8 the quotient
+// x/v is never within 2^-27 relative of a rounding boundary while q0 + r*rv differs from it by
+// < 2^-46 relative, so the final rounding is the IEEE one (checked bit-for-bit against the oracle's
+// true division in tests/test_hip_parity.py).
+__device__ __forceinline__ float div_by_views(float x, float v, float rv)
+{
+    const float q0 = x * rv;
+    const float r = fmaf(-q0, v, x);
+    return fmaf(r, rv, q0);
+}
+
+// XCD-aware remap of a linear workgroup id (hardware places workgroup i on XCD i % 8): give each
+// XCD one contiguous run of the logical id space so neighbouring tiles share that XCD's L2.
+// Bijective for any n.  Performance only -- nothing depends on the placement.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t i, uint32_t n)
+{
+    const uint32_t nx = 8, q = n / nx, r = n % nx, x = i % nx, j = i / nx;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+}  // namespace smvs

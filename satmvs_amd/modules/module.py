@@ -1,0 +1,375 @@
+"""Regularisers, regression and feature extractor with the reference's names and parameter trees.
+
+Mirror of the parts of /root/reference/modules/module.py that the cascade networks use, so that
+`state_dict()` keys and shapes are identical and reference checkpoints (train.py:215-220) load:
+
+    ConvGRUCell2 (:6)            RED_Regularization (:595)     slice_RED_Regularization (:653)
+    ConvReLU (:178) ConvTransReLU (:208)                       CostRegNet (:546)
+    Conv2d (:78) Deconv2d (:120) DeConv2dFuse (:303) Conv3d (:324) Deconv3d (:369)
+    FeatureNet (:442)            depth_regression (:433)
+
+What is native here: the height regression (softmax_depth_regression -> smvs_softmax_regress_fwd,
+StreamingRegression -> smvs_stream_regress_*).  The convolutions inside the regularisers and the
+feature extractor are stock PyTorch modules (MIOpen on ROCm) in this round; their MFMA kernels are
+the next rows of SURVEY.md section 8 (a11/a12).  Sub-modules are created in the same order as the
+reference so that a given torch.manual_seed yields the same initial parameters.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+
+
+# ---- small conv wrappers (parameter names: .conv / .bn) ----------------------------------------------
+class Conv2d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, relu=True, bn=True, bn_momentum=0.1,
+                 init_method="xavier", **kwargs):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
+        self.kernel_size, self.stride = kernel_size, stride
+        self.bn = nn.BatchNorm2d(out_channels, momentum=bn_momentum) if bn else None
+        self.relu = relu
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.bn is not None:
+            x = self.bn(x)
+        return F.relu(x, inplace=True) if self.relu else x
+
+
+class Deconv2d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, relu=True, bn=True, bn_momentum=0.1,
+                 init_method="xavier", **kwargs):
+        super().__init__()
+        assert stride in (1, 2)
+        self.out_channels, self.stride = out_channels, stride
+        self.conv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
+        self.bn = nn.BatchNorm2d(out_channels, momentum=bn_momentum) if bn else None
+        self.relu = relu
+
+    def forward(self, x):
+        y = self.conv(x)
+        if self.stride == 2:
+            h, w = x.shape[2], x.shape[3]
+            y = y[:, :, :2 * h, :2 * w].contiguous()
+        if self.bn is not None:
+            y = self.bn(y)
+        return F.relu(y, inplace=True) if self.relu else y
+
+
+class DeConv2dFuse(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, relu=True, bn=True, bn_momentum=0.1):
+        super().__init__()
+        self.deconv = Deconv2d(in_channels, out_channels, kernel_size, stride=2, padding=1, output_padding=1,
+                               bn=True, relu=relu, bn_momentum=bn_momentum)
+        self.conv = Conv2d(2 * out_channels, out_channels, kernel_size, stride=1, padding=1, bn=bn, relu=relu,
+                           bn_momentum=bn_momentum)
+
+    def forward(self, x_pre, x):
+        return self.conv(torch.cat((self.deconv(x), x_pre), dim=1))
+
+
+class Conv3d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, relu=True, bn=True, bn_momentum=0.1,
+                 init_method="xavier", **kwargs):
+        super().__init__()
+        assert stride in (1, 2)
+        self.out_channels, self.kernel_size, self.stride = out_channels, kernel_size, stride
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
+        self.bn = nn.BatchNorm3d(out_channels, momentum=bn_momentum) if bn else None
+        self.relu = relu
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.bn is not None:
+            x = self.bn(x)
+        return F.relu(x, inplace=True) if self.relu else x
+
+
+class Deconv3d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, relu=True, bn=True, bn_momentum=0.1,
+                 init_method="xavier", **kwargs):
+        super().__init__()
+        assert stride in (1, 2)
+        self.out_channels, self.stride = out_channels, stride
+        self.conv = nn.ConvTranspose3d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
+        self.bn = nn.BatchNorm3d(out_channels, momentum=bn_momentum) if bn else None
+        self.relu = relu
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.bn is not None:
+            x = self.bn(x)
+        return F.relu(x, inplace=True) if self.relu else x
+
+
+class ConvReLU(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
+
+    def forward(self, x):
+        return F.relu(self.conv(x), inplace=True)
+
+
+class ConvTransReLU(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1, output_pad=1):
+        super().__init__()
+        self.conv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=pad,
+                                       output_padding=output_pad, bias=False)
+
+    def forward(self, x):
+        return F.relu(self.conv(x), inplace=True)
+
+
+# ---- recurrent regulariser (RED) ------------------------------------------------------------------------
+class ConvGRUCell2(nn.Module):
+    """3x3 convolutional GRU with GroupNorm(1, C) on every gate.  reference: module.py:6-58."""
+
+    def __init__(self, input_channel, output_channel, kernel_size):
+        super().__init__()
+        cat_ch = input_channel + output_channel
+        self.output_channel = output_channel
+        self.gate_conv = nn.Conv2d(cat_ch, output_channel * 2, kernel_size, padding=1)
+        self.reset_gate_norm = nn.GroupNorm(1, output_channel, 1e-5, True)
+        self.update_gate_norm = nn.GroupNorm(1, output_channel, 1e-5, True)
+        self.output_conv = nn.Conv2d(cat_ch, output_channel, kernel_size, padding=1)
+        self.output_norm = nn.GroupNorm(1, output_channel, 1e-5, True)
+        self.activation = nn.Tanh()
+
+    def forward(self, x, h=None):
+        if h is None:
+            h = torch.zeros((x.shape[0], self.output_channel, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device)
+        gates = self.gate_conv(torch.cat((x, h), dim=1))
+        r, u = torch.split(gates, gates.shape[1] // 2, 1)
+        r = torch.sigmoid(self.reset_gate_norm(r))
+        u = torch.sigmoid(self.update_gate_norm(u))
+        cand = self.activation(self.output_norm(self.output_conv(torch.cat((x, r * h), dim=1))))
+        new_h = u * h + (1 - u) * cand
+        return new_h, new_h
+
+
+class _REDCore(nn.Module):
+    """Layers shared by the train and pred variants (same attribute names, same creation order)."""
+
+    def __init__(self, in_channels, base_channels=8):
+        super().__init__()
+        self.base_channels = base_channels
+        self.conv_gru1 = ConvGRUCell2(in_channels, base_channels, 3)
+        self.conv_gru2 = ConvGRUCell2(base_channels * 2, base_channels * 2, 3)
+        self.conv_gru3 = ConvGRUCell2(base_channels * 4, base_channels * 4, 3)
+        self.conv_gru4 = ConvGRUCell2(base_channels * 8, base_channels * 8, 3)
+        self.conv1 = ConvReLU(in_channels, base_channels * 2, 3, 2, 1)
+        self.conv2 = ConvReLU(base_channels * 2, base_channels * 4, 3, 2, 1)
+        self.conv3 = ConvReLU(base_channels * 4, base_channels * 8, 3, 2, 1)
+        self.upconv3 = ConvTransReLU(base_channels * 8, base_channels * 4, 3, 2, 1, 1)
+        self.upconv2 = ConvTransReLU(base_channels * 4, base_channels * 2, 3, 2, 1, 1)
+        self.upconv1 = ConvTransReLU(base_channels * 2, base_channels, 3, 2, 1, 1)
+        self.upconv2d = nn.ConvTranspose2d(base_channels, 1, kernel_size=3, stride=1, padding=1, output_padding=0)
+
+    @staticmethod
+    def initial_states(b, h, w, device, dtype=torch.float32):
+        # hidden sizes are hard-coded 8/16/32/64 in the reference (module.py:617-620)
+        return [torch.zeros((b, 8, h, w), device=device, dtype=dtype),
+                torch.zeros((b, 16, h // 2, w // 2), device=device, dtype=dtype),
+                torch.zeros((b, 32, h // 4, w // 4), device=device, dtype=dtype),
+                torch.zeros((b, 64, h // 8, w // 8), device=device, dtype=dtype)]
+
+    def step(self, cost, s1, s2, s3, s4):
+        """One plane: 2-D encoder/decoder with a ConvGRU at each of the 4 scales (module.py:625-644)."""
+        neg = -cost
+        e1 = self.conv1(neg)
+        e2 = self.conv2(e1)
+        e3 = self.conv3(e2)
+        r4, s4 = self.conv_gru4(e3, s4)
+        u3 = self.upconv3(r4)
+        r3, s3 = self.conv_gru3(e2, s3)
+        u2 = self.upconv2(u3 + r3)
+        r2, s2 = self.conv_gru2(e1, s2)
+        u1 = self.upconv1(u2 + r2)
+        r1, s1 = self.conv_gru1(neg, s1)
+        return self.upconv2d(u1 + r1), s1, s2, s3, s4
+
+
+class RED_Regularization(_REDCore):
+    """Whole-volume (train) variant: (B,C,D,H,W) -> (B,D,H,W).  reference: module.py:595-649."""
+
+    def forward(self, volume_variance):
+        b, _, d_num, h, w = volume_variance.shape
+        s = self.initial_states(b, h, w, volume_variance.device)
+        outs = []
+        for d in range(d_num):
+            reg, *s = self.step(volume_variance[:, :, d], *s)
+            outs.append(reg)
+        return torch.stack(outs, dim=1).squeeze(2)
+
+
+class slice_RED_Regularization(_REDCore):
+    """Plane-at-a-time (pred) variant with explicit state.  reference: module.py:653-693."""
+
+    def forward(self, cost, state1, state2, state3, state4):
+        return self.step(cost, state1, state2, state3, state4)
+
+
+# ---- 3-D conv regulariser (casmvs / ucs) ----------------------------------------------------------------
+class CostRegNet(nn.Module):
+    """reference: module.py:546-577."""
+
+    def __init__(self, in_channels, base_channels):
+        super().__init__()
+        self.conv0 = Conv3d(in_channels, base_channels, padding=1)
+        self.conv1 = Conv3d(base_channels, base_channels * 2, stride=2, padding=1)
+        self.conv2 = Conv3d(base_channels * 2, base_channels * 2, padding=1)
+        self.conv3 = Conv3d(base_channels * 2, base_channels * 4, stride=2, padding=1)
+        self.conv4 = Conv3d(base_channels * 4, base_channels * 4, padding=1)
+        self.conv5 = Conv3d(base_channels * 4, base_channels * 8, stride=2, padding=1)
+        self.conv6 = Conv3d(base_channels * 8, base_channels * 8, padding=1)
+        self.conv7 = Deconv3d(base_channels * 8, base_channels * 4, stride=2, padding=1, output_padding=1)
+        self.conv9 = Deconv3d(base_channels * 4, base_channels * 2, stride=2, padding=1, output_padding=1)
+        self.conv11 = Deconv3d(base_channels * 2, base_channels * 1, stride=2, padding=1, output_padding=1)
+        self.prob = nn.Conv3d(base_channels, 1, 3, stride=1, padding=1, bias=False)
+
+    def forward(self, x):
+        c0 = self.conv0(x)
+        c2 = self.conv2(self.conv1(c0))
+        c4 = self.conv4(self.conv3(c2))
+        x = self.conv6(self.conv5(c4))
+        x = c4 + self.conv7(x)
+        x = c2 + self.conv9(x)
+        x = c0 + self.conv11(x)
+        return self.prob(x)
+
+
+# ---- feature extractor ------------------------------------------------------------------------------------
+class FeatureNet(nn.Module):
+    """2-D U-Net / FPN producing stage1..3 features with 32/16/8 channels.  reference: module.py:442-543."""
+
+    def __init__(self, base_channels, num_stage=3, stride=4, arch_mode="unet"):
+        super().__init__()
+        assert arch_mode in ("unet", "fpn"), "mode must be in 'unet' or 'fpn', but get:{}".format(arch_mode)
+        self.arch_mode, self.stride, self.base_channels, self.num_stage = arch_mode, stride, base_channels, num_stage
+        c = base_channels
+        self.conv0 = nn.Sequential(Conv2d(3, c, 3, 1, padding=1), Conv2d(c, c, 3, 1, padding=1))
+        self.conv1 = nn.Sequential(Conv2d(c, c * 2, 5, stride=2, padding=2), Conv2d(c * 2, c * 2, 3, 1, padding=1),
+                                   Conv2d(c * 2, c * 2, 3, 1, padding=1))
+        self.conv2 = nn.Sequential(Conv2d(c * 2, c * 4, 5, stride=2, padding=2), Conv2d(c * 4, c * 4, 3, 1, padding=1),
+                                   Conv2d(c * 4, c * 4, 3, 1, padding=1))
+        self.out1 = nn.Conv2d(c * 4, c * 4, 1, bias=False)
+        self.out_channels = [4 * c]
+        if arch_mode == "unet":
+            if num_stage == 3:
+                self.deconv1 = DeConv2dFuse(c * 4, c * 2, 3)
+                self.deconv2 = DeConv2dFuse(c * 2, c, 3)
+                self.out2 = nn.Conv2d(c * 2, c * 2, 1, bias=False)
+                self.out3 = nn.Conv2d(c, c, 1, bias=False)
+                self.out_channels += [2 * c, c]
+            elif num_stage == 2:
+                self.deconv1 = DeConv2dFuse(c * 4, c * 2, 3)
+                self.out2 = nn.Conv2d(c * 2, c * 2, 1, bias=False)
+                self.out_channels.append(2 * c)
+        else:
+            final = c * 4
+            if num_stage == 3:
+                self.inner1 = nn.Conv2d(c * 2, final, 1, bias=True)
+                self.inner2 = nn.Conv2d(c, final, 1, bias=True)
+                self.out2 = nn.Conv2d(final, c * 2, 3, padding=1, bias=False)
+                self.out3 = nn.Conv2d(final, c, 3, padding=1, bias=False)
+                self.out_channels += [2 * c, c]
+            elif num_stage == 2:
+                self.inner1 = nn.Conv2d(c * 2, final, 1, bias=True)
+                self.out2 = nn.Conv2d(final, c, 3, padding=1, bias=False)
+                self.out_channels.append(c)
+
+    def forward(self, x):
+        c0 = self.conv0(x)
+        c1 = self.conv1(c0)
+        c2 = self.conv2(c1)
+        feat = c2
+        outs = {"stage1": self.out1(feat)}
+        if self.arch_mode == "unet":
+            if self.num_stage >= 2:
+                feat = self.deconv1(c1, feat)
+                outs["stage2"] = self.out2(feat)
+            if self.num_stage == 3:
+                feat = self.deconv2(c0, feat)
+                outs["stage3"] = self.out3(feat)
+        else:
+            if self.num_stage >= 2:
+                feat = F.interpolate(feat, scale_factor=2, mode="nearest") + self.inner1(c1)
+                outs["stage2"] = self.out2(feat)
+            if self.num_stage == 3:
+                feat = F.interpolate(feat, scale_factor=2, mode="nearest") + self.inner2(c0)
+                outs["stage3"] = self.out3(feat)
+        return outs
+
+
+# ---- regression ---------------------------------------------------------------------------------------------
+def depth_regression(p, depth_values):
+    """sum_D p * depth_values; differentiable torch composite.  reference: module.py:433-439."""
+    if depth_values.dim() <= 2:
+        depth_values = depth_values.view(*depth_values.shape, 1, 1)
+    else:
+        depth_values = F.interpolate(depth_values, [p.shape[2], p.shape[3]], mode="bilinear", align_corners=False)
+    return torch.sum(p * depth_values, 1)
+
+
+def softmax_depth_regression(reg, depth_values):
+    """softmax over D + expected height + max probability in one HIP kernel (no_grad paths).
+
+    reg (B,D,H,W) float32; depth_values (B,D) or (B,D,H,W).  Returns (depth, confidence), each
+    (B,H,W).  Equals F.softmax(reg,1) -> depth_regression -> max(1) of networks/casred.py:58-62.
+    With autograd enabled on `reg` the torch composite is used instead (it is differentiable).
+    """
+    if torch.is_grad_enabled() and reg.requires_grad:
+        p = F.softmax(reg, dim=1)
+        return depth_regression(p, depth_values), p.max(1)[0]
+    dev = _lib.require_device(reg, depth_values)
+    r = reg.detach().to(torch.float32).contiguous()
+    B, D, H, W = r.shape
+    dv = depth_values.detach().to(torch.float32).contiguous()
+    is4d = 1 if dv.dim() == 4 else 0
+    if is4d and tuple(dv.shape) != (B, D, H, W):
+        dv = F.interpolate(dv, [H, W], mode="bilinear", align_corners=False).contiguous()
+    depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    conf = torch.empty_like(depth)
+    with torch.cuda.device(dev):
+        _lib.call("smvs_softmax_regress_fwd", _lib.ptr(r), _lib.ptr(dv), is4d, _lib.ptr(depth), _lib.ptr(conf),
+                  B, D, H, W, _lib.current_stream(dev))
+    return depth, conf
+
+
+class StreamingRegression:
+    """The float64 accumulators of the pred loop (networks/casred.py:182-184, 218-236) on the device.
+
+    step(reg_plane (B,1,H,W)|(B,H,W), depth_values, d) folds plane d in; result() -> (depth, conf).
+    `state` (3,B,H,W) float64 = [exp_sum, depth_img, max_prob]: additive (sum, sum, max) over
+    planes, which is what a depth-sharded run all-reduces (satmvs_amd/shard.py).
+    """
+
+    def __init__(self, B, H, W, device):
+        self.B, self.H, self.W = B, H, W
+        self.state = torch.zeros((3, B, H, W), dtype=torch.float64, device=device)
+
+    def step(self, reg_plane, depth_values, d):
+        dev = _lib.require_device(reg_plane, depth_values, self.state)
+        r = reg_plane.detach().to(torch.float32).contiguous()
+        dv = depth_values.detach().to(torch.float32).contiguous()
+        is4d = 1 if dv.dim() == 4 else 0
+        D = dv.shape[1]
+        with torch.cuda.device(dev):
+            _lib.call("smvs_stream_regress_step", _lib.ptr(r), _lib.ptr(dv), is4d, _lib.ptr(self.state[0]),
+                      _lib.ptr(self.state[1]), _lib.ptr(self.state[2]), self.B, D, self.H, self.W, d,
+                      _lib.current_stream(dev))
+
+    def result(self):
+        dev = self.state.device
+        depth = torch.empty((self.B, self.H, self.W), dtype=torch.float32, device=dev)
+        conf = torch.empty_like(depth)
+        with torch.cuda.device(dev):
+            _lib.call("smvs_stream_regress_final", _lib.ptr(self.state[0]), _lib.ptr(self.state[1]),
+                      _lib.ptr(self.state[2]), _lib.ptr(depth), _lib.ptr(conf), self.B * self.H * self.W,
+                      _lib.current_stream(dev))
+        return depth, conf

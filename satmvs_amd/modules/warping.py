@@ -1,0 +1,265 @@
+"""Drop-in operator surface of the reference's modules/warping.py, backed by the HIP library.
+
+Same names, argument order and tensor layouts as /root/reference/modules/warping.py:
+    homo_warping(src_fea, src_proj, ref_proj, depth_values)                    (:6)
+    rpc_warping(src_fea, src_rpc, ref_rpc, depth_values, coef)                 (:310)
+    rpc_warping_enisum(src_fea, src_rpc, ref_rpc, depth_values)                (:139)
+    RPC_Photo2Obj(insamp, inline, inhei, rpc, coef)                            (:255)
+    RPC_Obj2Photo(inlat, inlon, inhei, rpc, coef)                              (:218)
+    RPC_Photo2Obj_enisum / RPC_Obj2Photo_enisum                                (:96, :60)
+plus the fused operator the networks use instead of the per-source loop:
+    variance_cost_volume(features, proj_matrices, depth_values, geo_model, use_qc)
+        == the body of networks/casred.py:22-53 up to `volume_variance`.
+
+Everything runs on the MI355X through include/satmvs.h; CPU tensors raise (no fallback).
+`coef` (the reference's (B, N, 20) float64 scratch) is accepted and ignored.
+Gradients flow to the feature maps only -- the sampling grid is built under no_grad in the
+reference too (warping.py:322).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+from ..rpc_synth import qc_tensor_to_coeffs  # noqa: F401  (host-side layout helper)
+
+__all__ = ["homo_warping", "rpc_warping", "rpc_warping_enisum", "RPC_Photo2Obj", "RPC_Obj2Photo",
+           "RPC_Photo2Obj_enisum", "RPC_Obj2Photo_enisum", "variance_cost_volume", "qc_dict_to_rpc"]
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _f64c(t):
+    return t.detach().to(torch.float64).contiguous()
+
+
+def _depth_arg(depth_values, B, H, W):
+    """(B,D) or (B,D,H,W) float32 contiguous + the depth_is_4d flag (warping.py:329-332)."""
+    d = _f32c(depth_values)
+    if d.dim() == 2:
+        if d.shape[0] != B:
+            raise ValueError("depth_values batch %d != %d" % (d.shape[0], B))
+        return d, 0, d.shape[1]
+    if d.dim() == 4:
+        if d.shape[0] != B or d.shape[2] != H or d.shape[3] != W:
+            raise ValueError("depth_values %s does not match features (B=%d,H=%d,W=%d)" % (tuple(d.shape), B, H, W))
+        return d, 1, d.shape[1]
+    raise ValueError("depth_values must be (B,D) or (B,D,H,W), got %s" % (tuple(depth_values.shape),))
+
+
+# ---- QC dict <-> 170-vector -----------------------------------------------------------------------
+_QC_SCALARS = ["line_off", "samp_off", "lat_off", "lon_off", "height_off",
+               "line_scale", "samp_scale", "lat_scale", "lon_scale", "height_scale"]
+_QC_TENSORS = ["line_num", "line_den", "samp_num", "samp_den", "lat_num", "lat_den", "lon_num", "lon_den"]
+# (i,j,k) of the 20 monomials in the symmetric (4,4,4) tensor and their multiplicities
+_QC_IDX = [(0, 0, 0), (0, 0, 1), (0, 0, 2), (0, 0, 3), (0, 1, 2), (0, 1, 3), (0, 2, 3), (0, 1, 1), (0, 2, 2),
+           (0, 3, 3), (1, 2, 3), (1, 1, 1), (1, 2, 2), (1, 3, 3), (1, 1, 2), (2, 2, 2), (2, 3, 3), (1, 1, 3),
+           (2, 2, 3), (3, 3, 3)]
+_QC_MULT = [1, 3, 3, 3, 6, 6, 6, 3, 3, 3, 6, 1, 3, 3, 3, 1, 3, 3, 3, 1]
+
+
+def qc_dict_to_rpc(rpc):
+    """The `use_qc` dict of dataset/data_io.py:123-150 -> (B,170) float64 on the same device.
+
+    T[i,j,k] holds coefficient/multiplicity (data_io.py:95-120), so c_m = T[idx_m] * mult_m.
+    """
+    cols = [rpc[k].reshape(-1).to(torch.float64) for k in _QC_SCALARS]
+    B = cols[0].shape[0]
+    out = torch.empty((B, 170), dtype=torch.float64, device=cols[0].device)
+    for i, c in enumerate(cols):
+        out[:, i] = c
+    mult = torch.tensor(_QC_MULT, dtype=torch.float64, device=out.device)
+    ii = torch.tensor([t[0] for t in _QC_IDX], device=out.device)
+    jj = torch.tensor([t[1] for t in _QC_IDX], device=out.device)
+    kk = torch.tensor([t[2] for t in _QC_IDX], device=out.device)
+    for n, name in enumerate(_QC_TENSORS):
+        T = rpc[name + "_tensor"].to(torch.float64).reshape(B, 4, 4, 4)
+        out[:, 10 + 20 * n: 30 + 20 * n] = T[:, ii, jj, kk] * mult
+    return out
+
+
+# ---- single-source warps ---------------------------------------------------------------------------
+class _WarpFn(torch.autograd.Function):
+    """geo 0: rpc (src_geo, ref_geo = (B,170));  geo 1: homography (src_geo = composed (B,4,4))."""
+
+    @staticmethod
+    def forward(ctx, src_fea, src_geo, ref_geo, depth, is4d, geo):
+        dev = _lib.require_device(src_fea, src_geo, depth)
+        fea = _f32c(src_fea)
+        B, C, H, W = fea.shape
+        D = depth.shape[1]
+        out = torch.empty((B, C, D, H, W), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _lib.current_stream(dev)
+            if geo == 0:
+                _lib.call("smvs_rpc_warp_fwd", _lib.ptr(fea), _lib.ptr(src_geo), _lib.ptr(ref_geo), _lib.ptr(depth),
+                          is4d, _lib.ptr(out), B, C, D, H, W, st)
+            else:
+                _lib.call("smvs_homo_warp_fwd", _lib.ptr(fea), _lib.ptr(src_geo), _lib.ptr(depth), is4d,
+                          _lib.ptr(out), B, C, D, H, W, st)
+        ctx.save_for_backward(src_geo, ref_geo if ref_geo is not None else src_geo, depth)
+        ctx.meta = (is4d, geo, (B, C, D, H, W))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        src_geo, ref_geo, depth = ctx.saved_tensors
+        is4d, geo, (B, C, D, H, W) = ctx.meta
+        g = _f32c(grad_out)
+        dev = g.device
+        grad_src = torch.zeros((B, C, H, W), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _lib.current_stream(dev)
+            if geo == 0:
+                _lib.call("smvs_rpc_warp_bwd", _lib.ptr(g), _lib.ptr(src_geo), _lib.ptr(ref_geo), _lib.ptr(depth),
+                          is4d, _lib.ptr(grad_src), B, C, D, H, W, st)
+            else:
+                _lib.call("smvs_homo_warp_bwd", _lib.ptr(g), _lib.ptr(src_geo), _lib.ptr(depth), is4d,
+                          _lib.ptr(grad_src), B, C, D, H, W, st)
+        return grad_src, None, None, None, None, None
+
+
+def _compose_homography(src_proj, ref_proj):
+    """src_proj @ inverse(ref_proj) on the device (warping.py:19), any leading shape (...,4,4)."""
+    dev = _lib.require_device(src_proj, ref_proj)
+    s, r = _f64c(src_proj), _f64c(ref_proj)
+    n = s.numel() // 16
+    out = torch.empty_like(s)
+    with torch.cuda.device(dev):
+        _lib.call("smvs_homo_compose", _lib.ptr(s), _lib.ptr(r), _lib.ptr(out), n, _lib.current_stream(dev))
+    return out
+
+
+def rpc_warping(src_fea, src_rpc, ref_rpc, depth_values, coef=None):
+    """(B,C,H,W), (B,170), (B,170), (B,D)|(B,D,H,W) -> (B,C,D,H,W).  reference: warping.py:310-365."""
+    B, _, H, W = src_fea.shape
+    depth, is4d, _ = _depth_arg(depth_values, B, H, W)
+    return _WarpFn.apply(src_fea, _f64c(src_rpc), _f64c(ref_rpc), depth, is4d, 0)
+
+
+def rpc_warping_enisum(src_fea, src_rpc, ref_rpc, depth_values):
+    """QC-tensor variant (warping.py:139-178): same kernel after T -> 20 coefficients."""
+    return rpc_warping(src_fea, qc_dict_to_rpc(src_rpc), qc_dict_to_rpc(ref_rpc), depth_values, None)
+
+
+def homo_warping(src_fea, src_proj, ref_proj, depth_values):
+    """(B,C,H,W), (B,4,4), (B,4,4), (B,D)|(B,D,H,W) -> (B,C,D,H,W).  reference: warping.py:6-44."""
+    B, _, H, W = src_fea.shape
+    depth, is4d, _ = _depth_arg(depth_values, B, H, W)
+    proj = _compose_homography(src_proj, ref_proj)
+    return _WarpFn.apply(src_fea, proj, None, depth, is4d, 1)
+
+
+# ---- flat projectors ----------------------------------------------------------------------------------
+def _project(a, b, h, rpc, direction):
+    dev = _lib.require_device(a, b, h, rpc)
+    shape = a.shape
+    rpc = _f64c(rpc).reshape(-1, 170)
+    B = rpc.shape[0]
+    a2, b2, h2 = (_f64c(t).reshape(B, -1) for t in (a, b, h))
+    o0, o1 = torch.empty_like(a2), torch.empty_like(a2)
+    n = a2.shape[1]
+    with torch.cuda.device(dev):
+        st = _lib.current_stream(dev)
+        for i in range(B):
+            _lib.call("smvs_rpc_project", _lib.ptr(rpc[i]), _lib.ptr(a2[i]), _lib.ptr(b2[i]), _lib.ptr(h2[i]),
+                      _lib.ptr(o0[i]), _lib.ptr(o1[i]), n, direction, st)
+    return o0.reshape(shape), o1.reshape(shape)
+
+
+def RPC_Photo2Obj(insamp, inline, inhei, rpc, coef=None):
+    """(B,N) samp, line, height float64 + rpc (B,170) -> lat, lon (B,N).  reference: warping.py:255-307."""
+    return _project(insamp, inline, inhei, rpc, 0)
+
+
+def RPC_Obj2Photo(inlat, inlon, inhei, rpc, coef=None):
+    """(B,N) lat, lon, height float64 + rpc (B,170) -> samp, line (B,N).  reference: warping.py:218-252."""
+    return _project(inlat, inlon, inhei, rpc, 1)
+
+
+def RPC_Photo2Obj_enisum(insamp, inline, inhei, rpc):
+    return _project(insamp, inline, inhei, qc_dict_to_rpc(rpc), 0)
+
+
+def RPC_Obj2Photo_enisum(inlat, inlon, inhei, rpc):
+    return _project(inlat, inlon, inhei, qc_dict_to_rpc(rpc), 1)
+
+
+# ---- fused cost volume ---------------------------------------------------------------------------------
+class _CostVolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, geo_kind, geo, depth, is4d, d_begin, d_end, ref_fea, *src_feas):
+        dev = _lib.require_device(ref_fea, geo, depth, *src_feas)
+        ref = _f32c(ref_fea)
+        srcs = [_f32c(s) for s in src_feas]
+        B, C, H, W = ref.shape
+        D = depth.shape[1]
+        for s in srcs:
+            if s.shape != ref.shape:
+                raise ValueError("source feature %s != reference feature %s" % (tuple(s.shape), tuple(ref.shape)))
+        nd = d_end - d_begin
+        out = torch.empty((B, C, nd, H, W), dtype=torch.float32, device=dev)
+        name = "smvs_rpc_costvol_fwd" if geo_kind == 0 else "smvs_homo_costvol_fwd"
+        with torch.cuda.device(dev):
+            _lib.call(name, _lib.ptr(ref), _lib.ptr_array(srcs), len(srcs), _lib.ptr(geo), _lib.ptr(depth), is4d,
+                      _lib.ptr(out), B, C, D, H, W, d_begin, d_end, nd, 0, _lib.current_stream(dev))
+        ctx.save_for_backward(geo, depth, ref, *srcs)
+        ctx.meta = (geo_kind, is4d, d_begin, d_end, (B, C, D, H, W))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_var):
+        geo, depth, ref, *srcs = ctx.saved_tensors
+        geo_kind, is4d, d_begin, d_end, (B, C, D, H, W) = ctx.meta
+        if d_begin != 0 or d_end != D:
+            raise _lib.SatMVSNativeError("backward of a depth-sharded cost volume is not supported")
+        g = _f32c(grad_var)
+        dev = g.device
+        g_ref = torch.zeros_like(ref)
+        g_srcs = [torch.zeros_like(s) for s in srcs]
+        with torch.cuda.device(dev):
+            _lib.call("smvs_costvol_bwd", geo_kind, _lib.ptr(g), _lib.ptr(ref), _lib.ptr_array(srcs), len(srcs),
+                      _lib.ptr(geo), _lib.ptr(depth), is4d, _lib.ptr(g_ref), _lib.ptr_array(g_srcs),
+                      B, C, D, H, W, _lib.current_stream(dev))
+        return (None, None, None, None, None, None, g_ref, *g_srcs)
+
+
+def variance_cost_volume(features, proj_matrices, depth_values, geo_model="rpc", use_qc=False,
+                         d_begin=0, d_end=None):
+    """Fused per-channel variance cost volume: (B,C,d_end-d_begin,H,W) float32.
+
+    features: list of V tensors (B,C,H,W), view 0 = reference (networks/casred.py:22).
+    proj_matrices: rpc -> (B,V,170) float64 (or, with use_qc, the list of V QC dicts);
+                   pinhole -> (B,V,4,4) float64 -- exactly what the reference networks receive.
+    depth_values: (B,D) or (B,D,H,W) float32.  [d_begin,d_end) selects the planes to build
+    (the pred loop passes d,d+1; a depth shard passes its own range).
+    """
+    ref_fea = features[0]
+    B, _, H, W = ref_fea.shape
+    depth, is4d, D = _depth_arg(depth_values, B, H, W)
+    d_end = D if d_end is None else d_end
+    if not (0 <= d_begin <= d_end <= D):
+        raise ValueError("bad plane range [%d,%d) of %d" % (d_begin, d_end, D))
+    V = len(features)
+    if geo_model == "rpc":
+        if use_qc:
+            geo = torch.stack([qc_dict_to_rpc(p) for p in proj_matrices], dim=1)
+        else:
+            geo = proj_matrices
+        geo = _f64c(geo)
+        if tuple(geo.shape) != (B, V, 170):
+            raise ValueError("rpc proj_matrices must be (B,V,170) = %s, got %s" % ((B, V, 170), tuple(geo.shape)))
+        kind = 0
+    elif geo_model == "pinhole":
+        P = _f64c(proj_matrices)
+        if tuple(P.shape) != (B, V, 4, 4):
+            raise ValueError("pinhole proj_matrices must be (B,V,4,4), got %s" % (tuple(P.shape),))
+        src = P[:, 1:].contiguous()
+        ref = P[:, :1].expand(B, V - 1, 4, 4).contiguous()
+        geo = _compose_homography(src, ref)               # (B,V-1,4,4)
+        kind = 1
+    else:
+        raise ValueError("geo_model must be 'rpc' or 'pinhole', got %r" % (geo_model,))
+    return _CostVolFn.apply(kind, geo, depth, is4d, d_begin, d_end, ref_fea, *features[1:])

@@ -1,0 +1,88 @@
+"""Height-plane sharding across the GPUs of one node (one process per GPU, torch.distributed;
+backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests of the host logic).
+
+The warp + variance build has no cross-plane dependence (networks/casred.py:191-212 of the
+reference: the loop body only meets other planes in the regulariser), so rank g of G builds planes
+[plane_range(D, g, G)) with replicated feature maps and camera parameters and NO communication.
+The only exchange on the path is the regression: the pred loop's accumulators
+(exp_sum, depth_img, max_prob -- casred.py:182-184) are additive over planes, so one all-reduce
+(sum, sum, max) of a (3,B,H,W) float64 slab yields the height map on every rank.  The C-channel
+variance volume is never gathered (2.4 GB at the metric shape vs 7 MB for the slab).
+
+Caveat kept explicit: the RED regulariser is recurrent over planes (modules/module.py:625-644), so
+for exact parity its four hidden states are handed from shard g to shard g+1
+(`recurrent_handoff=True`, point-to-point, sequential within one tile); plane-local regularisers
+shard with no hand-off.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def plane_range(num_planes, rank, world):
+    """Contiguous, balanced split of `num_planes`: the first (num_planes % world) ranks get one more."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world %d/%d" % (rank, world))
+    q, r = divmod(num_planes, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def allreduce_regression_state(state, group=None):
+    """In-place all-reduce of the (3,B,H,W) float64 accumulators: rows 0,1 summed, row 2 maxed."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return state
+    if state.shape[0] != 3:
+        raise ValueError("state must be (3,B,H,W): [exp_sum, depth_img, max_prob]")
+    dist.all_reduce(state[:2], op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(state[2], op=dist.ReduceOp.MAX, group=group)
+    return state
+
+
+def finish_regression(state):
+    """(3,B,H,W) float64 -> depth, confidence (float32), networks/casred.py:234-236 (torch ops; any device)."""
+    den = state[0] + 1e-10
+    return (state[1] / den).float(), (state[2] / den).float()
+
+
+def sharded_compute_depth_when_pred(features, proj_matrices, depth_values, num_depth, cost_regularization,
+                                    geo_model="rpc", use_qc=False, group=None, recurrent_handoff=True):
+    """compute_depth_when_pred (networks/casred.py:161-238) with the height planes sharded over `group`.
+
+    Every rank passes the same replicated inputs and gets the same full-resolution result.
+    """
+    from .modules.module import StreamingRegression
+    from .modules.warping import variance_cost_volume
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = plane_range(num_depth, rank, world)
+    ref = features[0]
+    b, _, h, w = ref.shape
+    recurrent = hasattr(cost_regularization, "initial_states")
+    states = cost_regularization.initial_states(b, h, w, ref.device) if recurrent else []
+    if recurrent and recurrent_handoff and world > 1 and rank > 0:
+        for s in states:
+            dist.recv(s, src=_global_rank(group, rank - 1), group=group)
+    acc = StreamingRegression(b, h, w, ref.device)
+    dv = depth_values.detach().to(torch.float32).contiguous()
+    for d in range(lo, hi):
+        plane = variance_cost_volume(features, proj_matrices, dv, geo_model, use_qc, d_begin=d, d_end=d + 1)
+        if recurrent:
+            reg, *states = cost_regularization(plane.squeeze(2), *states)
+        else:
+            reg = cost_regularization(plane.squeeze(2))
+        acc.step(reg, dv, d)
+    if recurrent and recurrent_handoff and world > 1 and rank < world - 1:
+        for s in states:
+            dist.send(s.contiguous(), dst=_global_rank(group, rank + 1), group=group)
+    allreduce_regression_state(acc.state, group)
+    depth, confidence = acc.result()
+    return {"depth": depth, "photometric_confidence": confidence}
+
+
+def _global_rank(group, group_rank):
+    if group is None:
+        return group_rank
+    return dist.get_global_rank(group, group_rank)

@@ -1,0 +1,138 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports exactly
+what include/satmvs.h declares (no compute calls without a GPU), argument errors are reported the
+documented way, and the host-side helpers behave like the reference's."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from satmvs_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "satmvs.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(smvs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    from satmvs_amd import _lib
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(lib, name), "include/satmvs.h declares %s but the library does not export it" % name
+    assert declared == _lib.EXPORTED_SYMBOLS, "ctypes table and header disagree"
+
+
+def test_version_and_error_strings(lib):
+    assert lib.smvs_version().decode().startswith("satmvs-hip")
+    assert lib.smvs_last_error().decode() == "" or isinstance(lib.smvs_last_error().decode(), str)
+
+
+def test_argument_errors_do_not_touch_the_gpu(lib):
+    """Null pointers / bad ranges are rejected before any HIP call, with a message."""
+    from satmvs_amd import _lib
+    with pytest.raises(_lib.SatMVSNativeError, match="null pointer"):
+        _lib.call("smvs_rpc_costvol_fwd", None, None, 2, None, None, 1, None, 1, 8, 4, 8, 8, 0, 4, 4, 0, None)
+    dummy = C.c_void_p(16)
+    arr = (C.c_void_p * 2)(16, 16)
+    with pytest.raises(_lib.SatMVSNativeError, match="n_src"):
+        _lib.call("smvs_rpc_costvol_fwd", dummy, arr, 9, dummy, dummy, 1, dummy, 1, 8, 4, 8, 8, 0, 4, 4, 0, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="plane range"):
+        _lib.call("smvs_rpc_costvol_fwd", dummy, arr, 2, dummy, dummy, 1, dummy, 1, 8, 4, 8, 8, 3, 9, 4, 0, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="does not fit"):
+        _lib.call("smvs_rpc_costvol_fwd", dummy, arr, 2, dummy, dummy, 1, dummy, 1, 8, 4, 8, 8, 0, 4, 2, 0, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="dir must be"):
+        _lib.call("smvs_rpc_project", dummy, dummy, dummy, dummy, dummy, dummy, 4, 7, None)
+
+
+def test_product_path_has_no_cpu_fallback():
+    from satmvs_amd import _lib
+    from satmvs_amd.modules import warping
+    with pytest.raises(_lib.SatMVSNativeError, match="no CPU fallback"):
+        warping.variance_cost_volume([torch.zeros(1, 2, 4, 4)] * 2, torch.zeros(1, 2, 170, dtype=torch.float64),
+                                     torch.zeros(1, 2), "rpc")
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under satmvs_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "satmvs_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+# ---- host helpers -------------------------------------------------------------------------------------
+def test_iccv_known_answers(golden):
+    """tools/iccv_solver.py:42-64 Test1/Test2 (the reference's only known-answer tests)."""
+    from satmvs_amd import rpc_synth
+    g = golden("iccv")
+    x1, it1 = rpc_synth.iccv_solve(g["A1"], g["L1"])
+    np.testing.assert_allclose(x1, [-0.1030, 2.3208, -1.2069, -0.5348], atol=5e-5)
+    np.testing.assert_allclose(x1, g["x1"], rtol=1e-12)
+    assert it1 == int(g["it1"])
+    x2, it2 = rpc_synth.iccv_solve(g["A2"], g["L2"])
+    np.testing.assert_allclose(x2, [-1.5, 1.5, -0.5, 0.5], atol=1e-8)
+    assert it2 == int(g["it2"])
+
+
+def test_inverse_fit_matches_reference(golden):
+    from satmvs_amd import rpc_synth
+    g = golden("iccv")
+    rng = np.random.default_rng(0)
+    x, y, h = rng.uniform(0, 256, 200), rng.uniform(0, 128, 200), rng.uniform(0, 400, 200)
+    for d, full in zip(g["direct"], g["full"]):
+        mine, its = rpc_synth.fit_inverse_rpc(d)
+        assert its == 1000                                   # the fit always hits the cap
+        np.testing.assert_array_equal(mine[:90], full[:90])
+        la, lo = rpc_synth.photo2obj(mine, x, y, h)
+        la2, lo2 = rpc_synth.photo2obj(full, x, y, h)
+        np.testing.assert_allclose(la, la2, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(lo, lo2, rtol=0, atol=1e-11)
+        assert rpc_synth.roundtrip_error(mine, 256, 128).max() < 5e-4
+
+
+def test_qc_tensor_roundtrip(golden):
+    from satmvs_amd import rpc_synth
+    from satmvs_amd.modules.warping import qc_dict_to_rpc
+    g = golden("rpc_warp_qc")
+    np.testing.assert_array_equal(rpc_synth.coeffs_to_qc_tensor(g["qc_c20"]), g["qc_tensor"])
+    rpc = g["rpc"][:, 0]
+    keys = ["line_off", "samp_off", "lat_off", "lon_off", "height_off", "line_scale", "samp_scale", "lat_scale",
+            "lon_scale", "height_scale"]
+    d = {k: torch.from_numpy(np.ascontiguousarray(rpc[:, i])) for i, k in enumerate(keys)}
+    for j, nm in enumerate(["line_num", "line_den", "samp_num", "samp_den", "lat_num", "lat_den", "lon_num", "lon_den"]):
+        d[nm + "_tensor"] = torch.from_numpy(np.stack([rpc_synth.coeffs_to_qc_tensor(r[10 + 20 * j:30 + 20 * j]) for r in rpc]))
+    np.testing.assert_allclose(qc_dict_to_rpc(d).numpy(), rpc, rtol=3e-16, atol=0)
+
+
+def test_depth_range_golden(golden):
+    from satmvs_amd.modules import depth_range
+    g = golden("depth_range")
+    B, H, W = g["cur"].shape
+    s1 = depth_range.get_depth_range_samples(torch.from_numpy(g["dv"]), 8, 10.0, "cpu", torch.float32, [B, H, W])
+    s2 = depth_range.get_depth_range_samples(torch.from_numpy(g["cur"]), 6, 5.0, "cpu", torch.float32, [B, H, W])
+    np.testing.assert_array_equal(s1.numpy(), g["s1"])
+    np.testing.assert_array_equal(s2.numpy(), g["s2"])
+
+
+def test_plane_range_partition():
+    from satmvs_amd.shard import plane_range
+    for D in (1, 7, 8, 48, 64):
+        for G in (1, 2, 3, 8):
+            spans = [plane_range(D, g, G) for g in range(G)]
+            assert spans[0][0] == 0 and spans[-1][1] == D
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,304 @@
+"""GPU parity: the HIP path (through the C ABI, via the reference-named Python surface) against the
+CPU oracle on identical seeded inputs, against the committed golden vectors of the Python
+reference, and -- at the BASELINE.json sizes -- through size-independent properties.
+
+Tolerances (see also tests/test_oracle_golden.py):
+  * float64 geodesy: lat/lon 1e-12 deg, pixels 1e-8 px (GPU uses FMA + reciprocal scales).
+  * float32 volumes: the sampler/variance arithmetic is bit-identical to the oracle by
+    construction; a voxel can differ only when the float64 source coordinate (|diff| ~1e-13 px)
+    straddles a float32 rounding boundary.  We require <= 1e-4 of the voxels to differ and
+    max |diff| <= 2e-4 for unit-variance features.
+  * regressed height: <= 1e-3 m (north_star).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def _t(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev)
+
+
+def _close_f32(got, want, frac=1e-4, atol=2e-4):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    nbad = int((got != want).sum())
+    diff = np.abs(got.astype(np.float64) - want.astype(np.float64)).max()
+    assert nbad <= max(1, frac * got.size), "%d of %d voxels differ (max %g)" % (nbad, got.size, diff)
+    assert diff <= atol, diff
+    return nbad, diff
+
+
+def _inputs(B, V, C, D, H, W, seed, jitter=True, geo="rpc"):
+    from satmvs_amd import rpc_synth
+    rng = np.random.default_rng(seed)
+    feats = [rng.standard_normal((B, C, H, W)).astype(np.float32) for _ in range(V)]
+    if geo == "rpc":
+        gp = np.stack([rpc_synth.make_view_rpcs(V, H, W, seed=seed + 7 * b) for b in range(B)])
+        lo, hi = 0.0, 400.0
+    else:
+        gp = np.zeros((B, V, 4, 4))
+        for b in range(B):
+            for v in range(V):
+                f = 1.1 * W
+                K = np.array([[f, 0, W / 2.0, 0], [0, f, H / 2.0, 0], [0, 0, 1.0, 0], [0, 0, 0, 1]])
+                E = np.eye(4)
+                a = rng.normal(0, 0.02) * (v > 0)
+                E[:3, :3] = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+                E[:3, 3] = [25.0 * v * (-1) ** v, 3.0 * v, 0.5 * v]
+                gp[b, v] = K @ E
+        lo, hi = 400.0, 700.0
+    if jitter:
+        depth = (np.linspace(lo, hi, D).reshape(1, D, 1, 1) + rng.normal(0, 2.0, (B, D, H, W))).astype(np.float32)
+    else:
+        depth = np.linspace(lo, hi, D, dtype=np.float32)[None].repeat(B, 0)
+    return feats, gp, depth
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_library_loads_on_gpu(dev):
+    from satmvs_amd import _lib
+    assert "gfx950" in _lib.version()
+
+
+def test_cpu_tensors_are_rejected(dev):
+    from satmvs_amd import _lib
+    from satmvs_amd.modules import warping
+    with pytest.raises(_lib.SatMVSNativeError):
+        warping.rpc_warping(torch.zeros(1, 2, 4, 4), torch.zeros(1, 170, dtype=torch.float64),
+                            torch.zeros(1, 170, dtype=torch.float64), torch.zeros(1, 2), None)
+
+
+def test_rpc_project_golden(dev, golden, oracle):
+    from satmvs_amd.modules import warping
+    g = golden("rpc_project")
+    hei = _t(g["hei"], dev)[None]
+    for v in range(3):
+        rpc = _t(g["rpc"][v:v + 1], dev)
+        lat, lon = warping.RPC_Photo2Obj(_t(g["samp"], dev)[None], _t(g["line"], dev)[None], hei, rpc, None)
+        np.testing.assert_allclose(lat[0].cpu().numpy(), g["lat%d" % v], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(lon[0].cpu().numpy(), g["lon%d" % v], rtol=0, atol=1e-12)
+        s, l = warping.RPC_Obj2Photo(_t(g["lat%d" % v], dev)[None], _t(g["lon%d" % v], dev)[None], hei, rpc, None)
+        np.testing.assert_allclose(s[0].cpu().numpy(), g["samp_back%d" % v], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(l[0].cpu().numpy(), g["line_back%d" % v], rtol=0, atol=1e-8)
+        olat, olon = oracle.rpc_project(g["rpc"][v], g["samp"], g["line"], g["hei"], 0)
+        np.testing.assert_allclose(lat[0].cpu().numpy(), olat, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("kind", ["4", "2"])
+def test_rpc_warping_golden(dev, golden, oracle, kind):
+    from satmvs_amd.modules import warping
+    g = golden("rpc_warp")
+    out = warping.rpc_warping(_t(g["src_fea"], dev), _t(g["rpc"][:, 1], dev), _t(g["rpc"][:, 0], dev),
+                              _t(g["depth" + kind], dev), None)
+    _close_f32(out, g["warped" + kind], frac=1e-3)
+    _close_f32(out, oracle.rpc_warping(g["src_fea"], g["rpc"][:, 1], g["rpc"][:, 0], g["depth" + kind]), frac=1e-3)
+
+
+def test_rpc_warping_enisum_golden(dev, golden):
+    from satmvs_amd.modules import warping
+    from satmvs_amd import rpc_synth
+    g = golden("rpc_warp_qc")
+
+    def qc(r):
+        keys = ["line_off", "samp_off", "lat_off", "lon_off", "height_off", "line_scale", "samp_scale", "lat_scale",
+                "lon_scale", "height_scale"]
+        d = {k: _t(r[:, i], dev) for i, k in enumerate(keys)}
+        for j, nm in enumerate(["line_num", "line_den", "samp_num", "samp_den", "lat_num", "lat_den", "lon_num", "lon_den"]):
+            d[nm + "_tensor"] = _t(np.stack([rpc_synth.coeffs_to_qc_tensor(x[10 + 20 * j:30 + 20 * j]) for x in r]), dev)
+        return d
+
+    out = warping.rpc_warping_enisum(_t(g["src_fea"], dev), qc(g["rpc"][:, 1]), qc(g["rpc"][:, 0]), _t(g["depth4"], dev))
+    _close_f32(out, g["warped"], frac=1e-3)
+
+
+@pytest.mark.parametrize("kind", ["4", "2"])
+def test_homo_warping_golden(dev, golden, kind):
+    from satmvs_amd.modules import warping
+    g = golden("homo_warp")
+    out = warping.homo_warping(_t(g["src_fea"], dev), _t(g["proj"][:, 1], dev), _t(g["proj"][:, 0], dev),
+                               _t(g["depth" + kind], dev))
+    _close_f32(out, g["warped" + kind], frac=1e-3)
+    comp = warping._compose_homography(_t(g["proj"][:, 1], dev), _t(g["proj"][:, 0], dev))
+    np.testing.assert_allclose(comp.cpu().numpy(), g["composed"], rtol=1e-11, atol=1e-9)
+
+
+def test_costvol_golden(dev, golden):
+    from satmvs_amd.modules import warping
+    g = golden("costvol")
+    feats = [_t(f, dev) for f in g["feats"]]
+    var = warping.variance_cost_volume(feats, _t(g["rpc"], dev), _t(g["depth"], dev), "rpc")
+    _close_f32(var, g["variance_rpc"], frac=1e-3)
+    varp = warping.variance_cost_volume(feats, _t(g["proj"], dev), _t(g["depth_pin"], dev), "pinhole")
+    _close_f32(varp, g["variance_pin"], frac=1e-3)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=1, V=3, C=32, D=32, H=128, W=256, jitter=True),     # BASELINE config 1 shape
+    dict(B=2, V=5, C=16, D=5, H=33, W=70, jitter=True),        # ragged tile, 5 views, batch 2
+    dict(B=1, V=2, C=10, D=9, H=17, W=130, jitter=False),      # generic channel count, (B,D) heights
+    dict(B=1, V=8, C=8, D=3, H=8, W=64, jitter=True),          # maximum view count
+    dict(B=1, V=3, C=8, D=1, H=4, W=3, jitter=True),           # smaller than one tile
+])
+def test_costvol_vs_oracle(dev, oracle, cfg):
+    from satmvs_amd.modules import warping
+    feats, rpc, depth = _inputs(cfg["B"], cfg["V"], cfg["C"], cfg["D"], cfg["H"], cfg["W"], seed=3, jitter=cfg["jitter"])
+    want = oracle.costvol_variance(feats, rpc, depth, "rpc")
+    got = warping.variance_cost_volume([_t(f, dev) for f in feats], _t(rpc, dev), _t(depth, dev), "rpc")
+    _close_f32(got, want)
+
+
+def test_costvol_pinhole_vs_oracle(dev, oracle):
+    from satmvs_amd.modules import warping
+    feats, proj, depth = _inputs(1, 3, 16, 12, 48, 96, seed=4, geo="pinhole")
+    want = oracle.costvol_variance(feats, proj, depth, "pinhole")
+    got = warping.variance_cost_volume([_t(f, dev) for f in feats], _t(proj, dev), _t(depth, dev), "pinhole")
+    _close_f32(got, want)
+
+
+def test_costvol_out_of_image_and_nan(dev, oracle):
+    """Large parallax pushes taps off the source image (zero padding); NaN heights must not fault."""
+    from satmvs_amd.modules import warping
+    feats, rpc, depth = _inputs(1, 3, 8, 6, 32, 64, seed=5)
+    depth[:, 0] = -4000.0
+    depth[:, 1] = 6000.0
+    depth[0, 2, 3, 5] = np.nan
+    want = oracle.costvol_variance(feats, rpc, depth, "rpc")
+    got = warping.variance_cost_volume([_t(f, dev) for f in feats], _t(rpc, dev), _t(depth, dev), "rpc").cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    m = ~np.isnan(want)
+    _close_f32(got[m], want[m])
+
+
+def test_costvol_plane_ranges(dev):
+    """[d_begin,d_end) builds exactly those planes, bit-identical to the whole-volume launch."""
+    from satmvs_amd.modules import warping
+    feats, rpc, depth = _inputs(1, 3, 16, 20, 40, 72, seed=6)
+    f = [_t(x, dev) for x in feats]
+    r, d = _t(rpc, dev), _t(depth, dev)
+    full = warping.variance_cost_volume(f, r, d, "rpc")
+    for lo, hi in ((0, 1), (3, 11), (19, 20), (8, 20)):
+        part = warping.variance_cost_volume(f, r, d, "rpc", d_begin=lo, d_end=hi)
+        assert part.shape[2] == hi - lo
+        assert torch.equal(part, full[:, :, lo:hi])
+
+
+def test_regression_golden(dev, golden, oracle):
+    from satmvs_amd.modules import module as M
+    g = golden("regress")
+    with torch.no_grad():
+        depth, conf = M.softmax_depth_regression(_t(g["reg"], dev), _t(g["depth_values"], dev))
+    np.testing.assert_allclose(depth.cpu().numpy(), g["sm_depth"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(conf.cpu().numpy(), g["sm_conf"], rtol=1e-5, atol=1e-6)
+    B, D, H, W = g["reg"].shape
+    acc = M.StreamingRegression(B, H, W, dev)
+    for d in range(D):
+        acc.step(_t(g["reg"][:, d], dev), _t(g["depth_values"], dev), d)
+    st = acc.state.cpu().numpy()
+    np.testing.assert_allclose(st[0], g["st_exp_sum"][:, 0], rtol=1e-13)
+    np.testing.assert_allclose(st[1], g["st_depth_img"][:, 0], rtol=1e-12)
+    np.testing.assert_allclose(st[2], g["st_max"][:, 0], rtol=1e-13)
+    depth, conf = acc.result()
+    np.testing.assert_allclose(depth.cpu().numpy(), g["st_depth"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(conf.cpu().numpy(), g["st_conf"], rtol=1e-6)
+    c = golden("costvol")
+    with torch.no_grad():
+        depth, conf = M.softmax_depth_regression(_t(c["reg_rpc"], dev), _t(c["depth"], dev))
+    np.testing.assert_allclose(depth.cpu().numpy(), c["depth_rpc"], rtol=0, atol=1e-3)
+
+
+def test_warp_backward_matches_torch(dev, oracle):
+    """grad w.r.t. src_fea == autograd of F.grid_sample on the same (oracle-built) grid."""
+    from satmvs_amd.modules import warping
+    B, C, D, H, W = 1, 4, 3, 16, 24
+    feats, rpc, depth = _inputs(B, 2, C, D, H, W, seed=8)
+    src = _t(feats[1], dev).requires_grad_(True)
+    out = warping.rpc_warping(src, _t(rpc[:, 1], dev), _t(rpc[:, 0], dev), _t(depth, dev), None)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    _, _, samp, line = oracle.rpc_warp_coords(rpc[:, 1], rpc[:, 0], depth, H, W)
+    gx = samp.astype(np.float32) / np.float32((W - 1) / 2.0) - np.float32(1)
+    gy = line.astype(np.float32) / np.float32((H - 1) / 2.0) - np.float32(1)
+    grid = _t(np.stack([gx, gy], -1).reshape(B, D * H, W, 2), dev)
+    src2 = _t(feats[1], dev).requires_grad_(True)
+    ref = torch.nn.functional.grid_sample(src2, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    ref.view(B, C, D, H, W).backward(gout)
+    torch.testing.assert_close(src.grad, src2.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_costvol_backward_matches_torch(dev, oracle):
+    """Backward of the fused volume == autograd through the reference's composite
+    (grid_sample per source, sum / sq accumulation, variance) evaluated with torch on the GPU."""
+    from satmvs_amd.modules import warping
+    B, V, C, D, H, W = 1, 3, 4, 3, 16, 24
+    feats, rpc, depth = _inputs(B, V, C, D, H, W, seed=9)
+    fs = [_t(f, dev).requires_grad_(True) for f in feats]
+    var = warping.variance_cost_volume(fs, _t(rpc, dev), _t(depth, dev), "rpc")
+    gout = torch.randn_like(var)
+    var.backward(gout)
+    fs2 = [_t(f, dev).requires_grad_(True) for f in feats]
+    vol = fs2[0].unsqueeze(2).repeat(1, 1, D, 1, 1)
+    s, q = vol, vol ** 2
+    for v in range(1, V):
+        _, _, samp, line = oracle.rpc_warp_coords(rpc[:, v], rpc[:, 0], depth, H, W)
+        gx = samp.astype(np.float32) / np.float32((W - 1) / 2.0) - np.float32(1)
+        gy = line.astype(np.float32) / np.float32((H - 1) / 2.0) - np.float32(1)
+        grid = _t(np.stack([gx, gy], -1).reshape(B, D * H, W, 2), dev)
+        w = torch.nn.functional.grid_sample(fs2[v], grid, mode="bilinear", padding_mode="zeros",
+                                            align_corners=False).view(B, C, D, H, W)
+        s = s + w
+        q = q + w ** 2
+    var2 = q / V - (s / V) ** 2
+    torch.testing.assert_close(var, var2, rtol=1e-5, atol=1e-5)
+    var2.backward(gout)
+    for a, b in zip(fs, fs2):
+        torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=1e-4)
+
+
+# ---- BASELINE.json full sizes: properties + oracle spot checks ------------------------------------
+@pytest.mark.parametrize("cfg", [
+    dict(V=3, C=32, D=64, H=384, W=768, planes=(0, 31, 63)),      # config 2 (headline metric shape)
+    dict(V=5, C=32, D=8, H=768, W=1536, planes=(5,)),             # config 4: one GPU's 8-plane shard
+])
+def test_full_size_properties(dev, oracle, cfg):
+    from satmvs_amd.modules import warping
+    V, C, D, H, W = cfg["V"], cfg["C"], cfg["D"], cfg["H"], cfg["W"]
+    feats, rpc, depth = _inputs(1, V, C, D, H, W, seed=11)
+    f = [_t(x, dev) for x in feats]
+    r, d = _t(rpc, dev), _t(depth, dev)
+    full = warping.variance_cost_volume(f, r, d, "rpc")
+    assert full.shape == (1, C, D, H, W)
+    assert torch.isfinite(full).all()
+    # (1) variance is non-negative up to rounding: |min| << typical value
+    assert full.min().item() > -1e-4
+    # (2) shard consistency: two half-range launches reproduce the whole volume bit for bit, and
+    #     the checksum of checksums matches
+    a = warping.variance_cost_volume(f, r, d, "rpc", d_begin=0, d_end=D // 2)
+    b = warping.variance_cost_volume(f, r, d, "rpc", d_begin=D // 2, d_end=D)
+    assert torch.equal(torch.cat([a, b], 2), full)
+    assert a.double().sum().item() + b.double().sum().item() == pytest.approx(full.double().sum().item(), rel=1e-12)
+    # (3) idempotence: same launch twice, identical bits (no atomics / races in the forward)
+    assert torch.equal(warping.variance_cost_volume(f, r, d, "rpc"), full)
+    # (4) identical views => zero parallax geometry: with every source = ref feature map and
+    #     src_rpc = ref_rpc the chain is the inverse-fit round trip (<= 3e-4 px), so variance ~ 0
+    #     wherever the bilinear footprint is inside the image
+    same = r[:, :1].expand(1, V, 170).contiguous()
+    z = warping.variance_cost_volume([f[0]] * V, same, d, "rpc", d_begin=0, d_end=1)
+    assert z[..., 2:-2, 2:-2].abs().max().item() < 5e-3
+    # (5) oracle spot check on whole planes of the full-size volume
+    for pl in cfg["planes"]:
+        want = oracle.costvol_variance(feats, rpc, depth, "rpc", d_begin=pl, d_end=pl + 1)[:, :, pl]
+        _close_f32(full[:, :, pl], want)
