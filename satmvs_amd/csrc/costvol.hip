@@ -66,7 +66,7 @@ void costvol_fwd_kernel(const CostVolParams p)
     BufRsrc rs[NSRC];
 #pragma unroll
     for (int s = 0; s < NSRC; ++s)
-        rs[s] = make_rsrc(p.src[s] + (size_t)b * C * HW, (uint32_t)HW * 4u);
+        rs[s] = make_rsrc(p.src[s] + (size_t)b * C * HW, (uint32_t)C * (uint32_t)HW * 4u);
 
     // ref feature of this pixel: plane-invariant, kept in registers when C is a compile-time size
     const float* refp = p.ref + (size_t)b * C * HW + pix;

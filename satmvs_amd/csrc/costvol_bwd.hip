@@ -48,7 +48,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
 
     BufRsrc rs[NSRC];
 #pragma unroll
-    for (int s = 0; s < NSRC; ++s) rs[s] = make_rsrc(p.src[s] + (size_t)b * C * HW, (uint32_t)HW * 4u);
+    for (int s = 0; s < NSRC; ++s) rs[s] = make_rsrc(p.src[s] + (size_t)b * C * HW, (uint32_t)C * (uint32_t)HW * 4u);
 
     const cgeo_t geo_b = as_cgeo((GEO == 0) ? p.geo + (size_t)b * p.V * RPC_LEN : p.geo + (size_t)b * (p.V - 1) * 16);
     RpcNorm ref_n, src_n[NSRC];

@@ -7,9 +7,9 @@
 //              align_corners=True formula, sampled by grid_sample(align_corners=False)
 //              (/root/reference/modules/warping.py:350-359).  Rounding order follows
 //              ATen's CPU kernel so the float32 result is bit-identical to oracle/oracle.c.
-//   BufRsrc    raw buffer descriptor of one (B,C,H,W) feature tensor; the hardware range check
-//              (num_records = one H*W plane, channel offset in the scalar offset) turns
-//              out-of-image taps into zeros for free -- grid_sample's padding_mode='zeros'.
+//   BufRsrc    raw buffer descriptor of one batch item's (C,H,W) feature block; out-of-image taps
+//              are given an out-of-range offset and the hardware range check returns 0 for them
+//              for free -- grid_sample's padding_mode='zeros' without a select per channel.
 //
 // Compile with -ffp-contract=off: every FMA in here is explicit.
 #pragma once
@@ -118,8 +118,10 @@ __device__ float llvm_raw_buffer_load_f32(i32x4 rsrc, int voffset, int soffset, 
 struct BufRsrc { i32x4 v; };
 
 // Descriptor over `bytes` bytes at `base` (wave-uniform).  Raw buffer, stride 0: a load is in
-// range iff voffset + 4 <= bytes; the scalar offset is NOT part of the range check, so the
-// channel plane offset rides in it and `bytes` = one H*W plane.
+// range iff voffset + soffset + 4 <= bytes (on gfx950 the scalar offset IS part of the range check
+// -- measured: with num_records = one plane every channel >= 1 read back 0).  `bytes` therefore
+// spans the whole (C,H,W) block of one batch item, the channel plane offset rides in the scalar
+// offset, and a dropped tap carries voffset = 0x80000000, out of range for any channel.
 __device__ __forceinline__ BufRsrc make_rsrc(const void* base, uint32_t bytes)
 {
     const uint64_t a = (uint64_t)base;
@@ -131,11 +133,11 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* base, uint32_t bytes)
     return r;
 }
 
-#define SMVS_OOB 0x80000000u   // any voffset >= num_records reads back 0
+#define SMVS_OOB 0x80000000u   // voffset (+ any channel offset < 2^31) >= num_records: reads back 0
 
 // ---- sampler -------------------------------------------------------------------------------------
 struct Tap {
-    uint32_t o_nw, o_ne, o_sw, o_se;   // byte offsets inside one H*W plane, or SMVS_OOB
+    uint32_t o_nw, o_ne, o_sw, o_se;   // byte offsets inside one H*W plane, or SMVS_OOB (tap dropped)
     float nw, ne, sw, se;
 };
 

@@ -69,7 +69,7 @@ void warp_kernel(const WarpParams p)
     if (GEO == 0) { rn = rpc_norm(rg0); sn = rpc_norm(sg0); }
 
     BufRsrc rs;
-    if (!BWD) rs = make_rsrc(p.fea + (size_t)b * C * HW, (uint32_t)HW * 4u);
+    if (!BWD) rs = make_rsrc(p.fea + (size_t)b * C * HW, (uint32_t)C * (uint32_t)HW * 4u);
 
     for (int d = d0; d < d1; ++d) {
         const float hf = p.depth_is_4d ? p.depth[((size_t)b * D + d) * HW + pix] : p.depth[(size_t)b * D + d];
