@@ -51,11 +51,11 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
     for (int s = 0; s < NSRC; ++s) rs[s] = make_rsrc(p.src[s] + (size_t)b * C * HW, (uint32_t)C * (uint32_t)HW * 4u);
 
     const cgeo_t geo_b = as_cgeo((GEO == 0) ? p.geo + (size_t)b * p.V * RPC_LEN : p.geo + (size_t)b * (p.V - 1) * 16);
-    RpcNorm ref_n, src_n[NSRC];
+    RpcInv ref_n, src_n[NSRC];
     if (GEO == 0) {
-        ref_n = rpc_norm(geo_b);
+        ref_n = rpc_inv_image(geo_b);
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) src_n[s] = rpc_norm(geo_b + (size_t)(s + 1) * RPC_LEN);
+        for (int s = 0; s < NSRC; ++s) src_n[s] = rpc_inv_ground(geo_b + (size_t)(s + 1) * RPC_LEN);
     }
     const double fx = (double)x, fy = (double)y;
     const float* refp = p.ref + (size_t)b * C * HW + pix;

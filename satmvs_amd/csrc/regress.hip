@@ -80,10 +80,9 @@ void rpc_project_kernel(const double* __restrict__ rpc, const double* __restrict
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const cgeo_t r = as_cgeo(rpc);
-    const RpcNorm nm = rpc_norm(r);
     double u, v;
-    if (dir == 0) rpc_photo2obj(r, nm, a[i], b[i], h[i], u, v);
-    else          rpc_obj2photo(r, nm, a[i], b[i], h[i], u, v);
+    if (dir == 0) rpc_photo2obj(r, rpc_inv_image(r), a[i], b[i], h[i], u, v);
+    else          rpc_obj2photo(r, rpc_inv_ground(r), a[i], b[i], h[i], u, v);
     o0[i] = u;
     o1[i] = v;
 }

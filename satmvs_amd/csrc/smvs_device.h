@@ -64,49 +64,64 @@ __device__ __forceinline__ void cubic4(cgeo_t k0, cgeo_t k1, cgeo_t k2, cgeo_t k
     n0 = a0; d0 = a1; n1 = a2; d1 = a3;
 }
 
-// Loop-invariant normalisation constants of one view (reciprocals taken once, in float64).
-struct RpcNorm {
-    double samp_off, line_off, h_off, lat_off, lon_off;
-    double inv_samp_scale, inv_line_scale, inv_h_scale, inv_lat_scale, inv_lon_scale;
-};
-
-__device__ __forceinline__ RpcNorm rpc_norm(cgeo_t r)
+// n / d in float64 without the IEEE special-case scaffolding (v_div_scale / v_div_fmas /
+// v_div_fixup): hardware reciprocal seed, two Newton steps, one residual correction.  |d| is a
+// cubic with leading coefficient 1 on normalised arguments, i.e. ~1: no overflow/denormal cases to
+// patch.  Error <= 1 ulp (typically correctly rounded); the stated geodesy tolerance is 1e-12 deg.
+__device__ __forceinline__ double fast_div(double n, double d)
 {
-    RpcNorm n;
-    n.samp_off = r[I_SAMP_OFF]; n.line_off = r[I_LINE_OFF]; n.h_off = r[I_H_OFF];
-    n.lat_off = r[I_LAT_OFF];   n.lon_off = r[I_LON_OFF];
-    n.inv_samp_scale = 1.0 / r[I_SAMP_SCALE]; n.inv_line_scale = 1.0 / r[I_LINE_SCALE];
-    n.inv_h_scale = 1.0 / r[I_H_SCALE];
-    n.inv_lat_scale = 1.0 / r[I_LAT_SCALE];   n.inv_lon_scale = 1.0 / r[I_LON_SCALE];
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    const double q = n * r;
+    return fma(fma(-d, q, n), r, q);
+}
+
+// Loop-invariant part of one view's normalisation: only the three reciprocal scales a direction
+// needs are kept live (6 SGPRs per view); offsets and forward scales are re-read with the
+// coefficient block (scalar cache).  Reciprocals are taken once, in float64.
+struct RpcInv { double a, b, h; };
+
+__device__ __forceinline__ RpcInv rpc_inv_image(cgeo_t r)    // for photo -> object (ref view)
+{
+    RpcInv n;
+    n.a = 1.0 / r[I_SAMP_SCALE]; n.b = 1.0 / r[I_LINE_SCALE]; n.h = 1.0 / r[I_H_SCALE];
+    return n;
+}
+
+__device__ __forceinline__ RpcInv rpc_inv_ground(cgeo_t r)   // for object -> photo (source views)
+{
+    RpcInv n;
+    n.a = 1.0 / r[I_LAT_SCALE]; n.b = 1.0 / r[I_LON_SCALE]; n.h = 1.0 / r[I_H_SCALE];
     return n;
 }
 
 // image (samp, line) + height -> ground (lat, lon); RPC_Photo2Obj, warping.py:255-307.
-__device__ __forceinline__ void rpc_photo2obj(cgeo_t r, const RpcNorm& n,
+__device__ __forceinline__ void rpc_photo2obj(cgeo_t r, const RpcInv& n,
                                               double samp, double line, double hei,
                                               double& lat, double& lon)
 {
-    const double s = (samp - n.samp_off) * n.inv_samp_scale;
-    const double l = (line - n.line_off) * n.inv_line_scale;
-    const double h = (hei - n.h_off) * n.inv_h_scale;
+    const double s = (samp - r[I_SAMP_OFF]) * n.a;
+    const double l = (line - r[I_LINE_OFF]) * n.b;
+    const double h = (hei - r[I_H_OFF]) * n.h;
     double an, ad, on, od;
     cubic4(r + I_LATNUM, r + I_LATDEN, r + I_LONNUM, r + I_LONDEN, s, l, h, an, ad, on, od);
-    lat = fma(an / ad, r[I_LAT_SCALE], n.lat_off);
-    lon = fma(on / od, r[I_LON_SCALE], n.lon_off);
+    lat = fma(fast_div(an, ad), r[I_LAT_SCALE], r[I_LAT_OFF]);
+    lon = fma(fast_div(on, od), r[I_LON_SCALE], r[I_LON_OFF]);
 }
 
 // ground (lat, lon, h) -> image (samp, line); RPC_Obj2Photo, warping.py:218-252.
-__device__ __forceinline__ void rpc_obj2photo(cgeo_t r, const RpcNorm& n,
+__device__ __forceinline__ void rpc_obj2photo(cgeo_t r, const RpcInv& n,
                                               double lat, double lon, double hei,
                                               double& samp, double& line)
 {
-    const double p = (lat - n.lat_off) * n.inv_lat_scale;
-    const double l = (lon - n.lon_off) * n.inv_lon_scale;
-    const double h = (hei - n.h_off) * n.inv_h_scale;
+    const double p = (lat - r[I_LAT_OFF]) * n.a;
+    const double l = (lon - r[I_LON_OFF]) * n.b;
+    const double h = (hei - r[I_H_OFF]) * n.h;
     double sn, sd, ln, ld;
     cubic4(r + I_SNUM, r + I_SDEN, r + I_LNUM, r + I_LDEN, p, l, h, sn, sd, ln, ld);
-    samp = fma(sn / sd, r[I_SAMP_SCALE], n.samp_off);
-    line = fma(ln / ld, r[I_LINE_SCALE], n.line_off);
+    samp = fma(fast_div(sn, sd), r[I_SAMP_SCALE], r[I_SAMP_OFF]);
+    line = fma(fast_div(ln, ld), r[I_LINE_SCALE], r[I_LINE_OFF]);
 }
 
 // ---- raw buffer access -------------------------------------------------------------------------
@@ -186,6 +201,35 @@ __device__ __forceinline__ float tap_fetch(const BufRsrc& rs, const Tap& t, int 
     r = fmaf(c, t.sw, r);
     r = fmaf(d, t.se, r);
     return r;
+}
+
+// Two channels (c, c+1) of one source view at once: the arithmetic is the same per lane element,
+// written on float2 so it maps onto v_pk_mul_f32 / v_pk_fma_f32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 tap_fetch2(const BufRsrc& rs, const Tap& t, int choff, int chstride)
+{
+    f32x2 a, b, c, d;
+    a.x = llvm_raw_buffer_load_f32(rs.v, (int)t.o_nw, choff, 0);
+    b.x = llvm_raw_buffer_load_f32(rs.v, (int)t.o_ne, choff, 0);
+    c.x = llvm_raw_buffer_load_f32(rs.v, (int)t.o_sw, choff, 0);
+    d.x = llvm_raw_buffer_load_f32(rs.v, (int)t.o_se, choff, 0);
+    a.y = llvm_raw_buffer_load_f32(rs.v, (int)t.o_nw, choff + chstride, 0);
+    b.y = llvm_raw_buffer_load_f32(rs.v, (int)t.o_ne, choff + chstride, 0);
+    c.y = llvm_raw_buffer_load_f32(rs.v, (int)t.o_sw, choff + chstride, 0);
+    d.y = llvm_raw_buffer_load_f32(rs.v, (int)t.o_se, choff + chstride, 0);
+    f32x2 r = a * t.nw;
+    r = __builtin_elementwise_fma(b, (f32x2)(t.ne), r);
+    r = __builtin_elementwise_fma(c, (f32x2)(t.sw), r);
+    r = __builtin_elementwise_fma(d, (f32x2)(t.se), r);
+    return r;
+}
+
+__device__ __forceinline__ f32x2 div_by_views2(f32x2 x, float v, float rv)
+{
+    const f32x2 q0 = x * rv;
+    const f32x2 r = __builtin_elementwise_fma(-q0, (f32x2)(v), x);
+    return __builtin_elementwise_fma(r, (f32x2)(rv), q0);
 }
 
 // x / v for a small integer-valued float v (the view count), correctly rounded in 3 ops:

@@ -22,7 +22,7 @@ struct WarpParams {
 
 template <int GEO>
 __device__ __forceinline__ Tap voxel_tap(const WarpParams& p, cgeo_t sg, cgeo_t rg,
-                                         const RpcNorm& rn, const RpcNorm& sn, int x, int y, double h,
+                                         const RpcInv& rn, const RpcInv& sn, int x, int y, double h,
                                          float half_wm1, float half_hm1)
 {
     if (GEO == 0) {
@@ -65,8 +65,8 @@ void warp_kernel(const WarpParams p)
 
     const cgeo_t sg0 = as_cgeo(p.src_geo + (size_t)b * (GEO == 0 ? RPC_LEN : 16));
     const cgeo_t rg0 = as_cgeo((GEO == 0) ? p.ref_geo + (size_t)b * RPC_LEN : p.src_geo);
-    RpcNorm rn, sn;
-    if (GEO == 0) { rn = rpc_norm(rg0); sn = rpc_norm(sg0); }
+    RpcInv rn, sn;
+    if (GEO == 0) { rn = rpc_inv_image(rg0); sn = rpc_inv_ground(sg0); }
 
     BufRsrc rs;
     if (!BWD) rs = make_rsrc(p.fea + (size_t)b * C * HW, (uint32_t)C * (uint32_t)HW * 4u);
