@@ -24,6 +24,8 @@
 #include <limits.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "smvs_device.h"
 #include "smvs_host.h"
 
@@ -156,8 +158,8 @@ void costvol_fwd_kernel(const CostVolParams p)
                 const f32x2 m = div_by_views2(sum, fV, rV);
                 const f32x2 q = div_by_views2(sq, fV, rV);
                 const f32x2 var = q - m * m;
-                od[(size_t)c * ostride] = var.x;
-                od[(size_t)(c + 1) * ostride] = var.y;
+                __builtin_nontemporal_store(var.x, od + (size_t)c * ostride);
+                __builtin_nontemporal_store(var.y, od + (size_t)(c + 1) * ostride);
             }
         } else {
 #pragma unroll 2
@@ -490,15 +492,395 @@ void costvol_wave_kernel(const CostVolParams p)
     }
 }
 
+// =====================================================================================================
+// DMA kernel: the staged design with the staging moved off the ALUs and out of the wave's critical
+// path.  Per wave (32 x 2 ref pixels, DM_DP planes per group):
+//   * one channel PAIR per step; the pair's source rows are written into LDS by LDS-DMA
+//     (buffer_load ... lds: lane -> (column, channel-of-pair), so the DMA itself produces the
+//     pair-interleaved float2 layout; out-of-image lanes/rows deposit zeros = zero padding);
+//   * two LDS buffers: the DMA for step st+1 is issued before step st is computed and only waited for
+//     (counted s_waitcnt vmcnt(N), N = the stores issued after it) when step st+1 begins, so neither
+//     load latency nor store acknowledgements stall the arithmetic;
+//   * all four bilinear weights stay in registers; results leave through buffer stores whose channel
+//     base lives in the descriptor (no 64-bit address arithmetic per store).
+// No workgroup barrier anywhere.  A box that does not fit takes the direct gathers for that group.
+// =====================================================================================================
+constexpr int DM_DP = 4;       // planes per group
+constexpr int DM_BW = 64;      // staged box width (columns)
+constexpr int DM_R = 5;        // staged box rows
+constexpr int DM_NBUF = 2;
+#ifndef SMVS_STORE_AUX
+#define SMVS_STORE_AUX 2              // nt: the variance volume streams out once, keep it from evicting feature rows in L2
+#endif
+constexpr int STORE_AUX = SMVS_STORE_AUX;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// wait until at most n (0..8, wave-uniform) vector-memory operations are outstanding
+__device__ __forceinline__ void wait_vmcnt_upto8(int n)
+{
+    switch (n) {
+    case 0: wait_vmcnt<0>(); break;  case 1: wait_vmcnt<1>(); break;  case 2: wait_vmcnt<2>(); break;
+    case 3: wait_vmcnt<3>(); break;  case 4: wait_vmcnt<4>(); break;  case 5: wait_vmcnt<5>(); break;
+    case 6: wait_vmcnt<6>(); break;  case 7: wait_vmcnt<7>(); break;  default: wait_vmcnt<8>(); break;
+    }
+}
+
+// base: LDS byte address of the north-west corner in staging buffer 0.  The weights are kept as two
+// register pairs so that v_pk_* can broadcast either half through op_sel (no v_mov to build {w,w}).
+struct TapD { uint32_t base; f32x2 wn, ws; };       // wn = {nw, ne}, ws = {sw, se}
+
+template <int GEO, int NSRC, int CT>
+__global__ __launch_bounds__(64 * WV_WAVES, 3)
+void costvol_dma_kernel(const CostVolParams p)
+{
+    constexpr int DP = DM_DP, BW = DM_BW, R = DM_R;
+    constexpr int SRC_STRIDE = R * BW;                       // float2 elements per source box
+    constexpr int ZPAD = BW + 2;                             // always-zero cells a dropped tap reads (NW..SE span)
+    constexpr int BUF_STRIDE = NSRC * SRC_STRIDE + ZPAD;
+    constexpr int NSTEP = CT / 2;
+    static_assert(CT % 2 == 0 && 2 * DP <= 63 && DP % 2 == 0, "steps / vmcnt bookkeeping");
+    __shared__ f32x2 tile_all[WV_WAVES][DM_NBUF * BUF_STRIDE];
+
+    uint32_t L = xcd_remap(blockIdx.x, gridDim.x);
+    const int xtile = L % p.xt; L /= p.xt;
+    const int dchunk = L % p.dct; L /= p.dct;
+    const int ytile = L % p.yt;
+    const int b = L / p.yt;
+
+    const int H = p.H, W = p.W;
+    const int HW = H * W;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    f32x2* tile = tile_all[wave];
+    const uint32_t tile_lds = __builtin_amdgcn_readfirstlane(lds_addr(tile));
+    const int x = xtile * WV_TX + (lane & (WV_TX - 1));
+    const int y = (ytile * WV_WAVES + wave) * WV_TY + (lane >> 5);
+    const bool active = (x < W) && (y < H);
+    const int pix = min(y, H - 1) * W + min(x, W - 1);
+    const int d0 = p.d_begin + dchunk * p.dch;
+    const int d1 = min(d0 + p.dch, p.d_end);
+    if ((ytile * WV_WAVES + wave) * WV_TY >= H) return;      // whole wave below the image (no barriers used)
+
+    // zero cells behind each buffer: a tap whose footprint misses the image reads these, so it
+    // contributes 0 * weight exactly like four masked gathers (never stale LDS bits)
+    for (int i = lane; i < ZPAD; i += 64) {
+        tile[NSRC * SRC_STRIDE + i] = (f32x2)(0.0f);
+        tile[BUF_STRIDE + NSRC * SRC_STRIDE + i] = (f32x2)(0.0f);
+    }
+
+    BufRsrc rs[NSRC];
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s)
+        rs[s] = make_rsrc(p.src[s] + (size_t)b * CT * HW, (uint32_t)CT * (uint32_t)HW * 4u);
+    const BufRsrc rref = make_rsrc(p.ref + (size_t)b * CT * HW, (uint32_t)CT * (uint32_t)HW * 4u);
+
+    const float fV = (float)p.V;
+    const float rV = __fdiv_rn(1.0f, fV);
+    const float half_wm1 = (float)((W - 1) * 0.5);
+    const float half_hm1 = (float)((H - 1) * 0.5);
+
+    const cgeo_t geo_b = as_cgeo((GEO == 0) ? p.geo + (size_t)b * p.V * RPC_LEN
+                                            : p.geo + (size_t)b * (p.V - 1) * 16);
+    const double fx = (double)min(x, W - 1), fy = (double)min(y, H - 1);
+    const size_t ostride = (size_t)p.D_out * HW;             // floats between channels of the output
+    const uint32_t pix4 = (uint32_t)pix * 4u;
+
+    for (int dg = d0; dg < d1; dg += DP) {
+        const int np = min(DP, d1 - dg);
+        // reciprocal scales are recomputed per plane group (9 divisions) instead of being held in
+        // 18 SGPRs across the step loop below
+        RpcInv ref_n;
+        RpcInv src_n[NSRC];
+        if (GEO == 0) {
+            const cgeo_t gl = launder(geo_b);
+            ref_n = rpc_inv_image(gl);
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s) src_n[s] = rpc_inv_ground(gl + (size_t)(s + 1) * RPC_LEN);
+        }
+
+        // ---- A: taps of the group's planes -----------------------------------------------------
+        TapD tap[DP][NSRC];
+        uint32_t txy[DP][NSRC];
+        uint32_t okmask = 0;
+        int lo_x[NSRC], hi_x[NSRC], lo_y[NSRC], hi_y[NSRC];
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) { lo_x[s] = lo_y[s] = INT_MAX; hi_x[s] = hi_y[s] = INT_MIN; }
+#pragma unroll
+        for (int pl = 0; pl < DP; ++pl) {
+            const int d = min(dg + pl, d1 - 1);
+            const float hf = p.depth_is_4d ? p.depth[((size_t)b * p.D + d) * HW + pix]
+                                           : p.depth[(size_t)b * p.D + d];
+            const double h = (double)hf;
+            const cgeo_t geo_d = launder(geo_b);
+            double lat = 0.0, lon = 0.0;
+            if (GEO == 0 && !(p.ablate & 4)) rpc_photo2obj(geo_d, ref_n, fx, fy, h, lat, lon);
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s) {
+                float gx, gy;
+                if (p.ablate & 4) {
+                    gx = ((float)fx + 0.37f + 0.011f * hf * (float)(s + 1)) / half_wm1 - 1.0f;
+                    gy = ((float)fy + 0.21f) / half_hm1 - 1.0f;
+                } else if (GEO == 0) {
+                    double samp, line;
+                    rpc_obj2photo(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat, lon, h, samp, line);
+                    gx = (float)samp / half_wm1 - 1.0f;
+                    gy = (float)line / half_hm1 - 1.0f;
+                } else {
+                    const cgeo_t P = geo_d + s * 16;
+                    const double rx = fma(P[1], fy, P[0] * fx) + P[2];
+                    const double ry = fma(P[5], fy, P[4] * fx) + P[6];
+                    const double rz = fma(P[9], fy, P[8] * fx) + P[10];
+                    const double X = fma(rx, h, P[3]), Y = fma(ry, h, P[7]), Z = fma(rz, h, P[11]);
+                    gx = (float)((X / Z) / ((W - 1) * 0.5) - 1.0);
+                    gy = (float)((Y / Z) / ((H - 1) * 0.5) - 1.0);
+                }
+                // same arithmetic as tap_from_grid (ATen unnormalise, floor, weights)
+                const float px = fmaf(gx + 1.0f, (float)W * 0.5f, -0.5f);
+                const float py = fmaf(gy + 1.0f, (float)H * 0.5f, -0.5f);
+                const float xw = floorf(px), yn = floorf(py);
+                const float w = px - xw, e = 1.0f - w, n = py - yn, so = 1.0f - n;
+                const bool ok = (xw >= -1.0f) && (xw <= (float)(W - 1)) && (yn >= -1.0f) && (yn <= (float)(H - 1));
+                // a footprint that misses the image keeps (NaN-propagating) zero weights: it then
+                // contributes what four masked gathers contribute -- 0, or NaN for a NaN coordinate
+                const float okf = ok ? 1.0f : 0.0f;
+                tap[pl][s].wn.x = (so * e) * okf; tap[pl][s].wn.y = (so * w) * okf;
+                tap[pl][s].ws.x = (n * e) * okf;  tap[pl][s].ws.y = (n * w) * okf;
+                const int ix0 = ok ? (int)xw : 0, iy0 = ok ? (int)yn : 0;
+                txy[pl][s] = ((uint32_t)(iy0 + 1) << 16) | (uint32_t)(ix0 + 1);
+                if (ok) okmask |= 1u << (pl * NSRC + s);
+                if (ok && active && pl < np) {
+                    lo_x[s] = min(lo_x[s], ix0); hi_x[s] = max(hi_x[s], ix0);
+                    lo_y[s] = min(lo_y[s], iy0); hi_y[s] = max(hi_y[s], iy0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- B: the wave's bounding box per source ----------------------------------------------
+        int bx0[NSRC], by0[NSRC], bw[NSRC], bh[NSRC];
+        bool fits = true;
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) {
+            const int a0 = __builtin_amdgcn_readfirstlane(wave_min(lo_x[s]));
+            const int a1 = __builtin_amdgcn_readfirstlane(wave_max(hi_x[s]));
+            const int b0 = __builtin_amdgcn_readfirstlane(wave_min(lo_y[s]));
+            const int b1 = __builtin_amdgcn_readfirstlane(wave_max(hi_y[s]));
+            const bool empty = a1 < a0;
+            bx0[s] = empty ? 0 : a0; by0[s] = empty ? 0 : b0;
+            bw[s] = empty ? 0 : a1 - a0 + 2;
+            bh[s] = empty ? 0 : b1 - b0 + 2;
+            fits = fits && (bw[s] <= BW) && (bh[s] <= R);
+        }
+
+        if (fits) {
+            // DMA lane map: lane -> (column lane>>1 of a 32-column half row, channel lane&1 of the pair)
+            uint32_t vo[NSRC][2];
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int col = hh * 32 + (lane >> 1), c0 = bx0[s] + col;
+                    vo[s][hh] = (col < bw[s] && c0 >= 0 && c0 < W) ? (uint32_t)(c0 * 4 + (lane & 1) * HW * 4) : SMVS_OOB;
+                }
+#pragma unroll
+            for (int pl = 0; pl < DP; ++pl)
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s) {
+                    const bool ok = (okmask >> (pl * NSRC + s)) & 1u;
+                    const int iy0 = (int)(txy[pl][s] >> 16) - 1, ix0 = (int)(txy[pl][s] & 0xffffu) - 1;
+                    tap[pl][s].base = tile_lds + 8u * (uint32_t)(ok ? s * SRC_STRIDE + (iy0 - by0[s]) * BW + (ix0 - bx0[s])
+                                                                      : NSRC * SRC_STRIDE);
+                }
+            uint32_t ovo[DP];                                 // per-plane byte offset of this pixel inside one channel volume
+#pragma unroll
+            for (int pl = 0; pl < DP; ++pl)
+                ovo[pl] = (active && pl < np && !(p.ablate & 1)) ? (uint32_t)(dg + pl - p.d_begin + p.d_out_off) * (uint32_t)HW * 4u + pix4
+                                              : SMVS_OOB;       // inactive lanes / tail planes: store dropped by the range check
+
+            int rowoff[NSRC][R];                               // byte offset of each box row inside one channel plane
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s)
+#pragma unroll
+                for (int er = 0; er < R; ++er) {
+                    const int gyp = by0[s] + er;
+                    rowoff[s][er] = (gyp >= 0 && gyp < H) ? gyp * W * 4 : (int)SMVS_OOB;
+                }
+            auto issue_dma = [&](int st) {
+                if (p.ablate & 2) return;
+                const uint32_t buf = tile_lds + (uint32_t)((st & 1) * BUF_STRIDE * 8);
+                const int choff = 2 * st * HW * 4;
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s) {
+#pragma unroll
+                    for (int er = 0; er < R; ++er) {
+                        if (er < bh[s]) {                                         // wave-uniform
+                            const int so = (rowoff[s][er] != (int)SMVS_OOB) ? rowoff[s][er] + choff : (int)SMVS_OOB;
+                            const uint32_t dst = buf + (uint32_t)((s * SRC_STRIDE + er * BW) * 8);
+                            dma_dword_to_lds(rs[s], dst, vo[s][0], so);
+                            dma_dword_to_lds(rs[s], dst + 256u, vo[s][1], so);
+                        }
+                    }
+                }
+            };
+
+            // prologue: pair 0
+            // ref feature pairs run two steps ahead of their use, in registers
+            f32x2 ref0, ref1;
+            ref0.x = llvm_raw_buffer_load_f32(rref.v, (int)pix4, 0, 0);
+            ref0.y = llvm_raw_buffer_load_f32(rref.v, (int)pix4, HW * 4, 0);
+            ref1.x = llvm_raw_buffer_load_f32(rref.v, (int)pix4, (NSTEP > 1 ? 2 : 0) * HW * 4, 0);
+            ref1.y = llvm_raw_buffer_load_f32(rref.v, (int)pix4, (NSTEP > 1 ? 3 : 1) * HW * 4, 0);
+            wait_vmcnt<0>();                                  // also: nothing of the previous group is still in flight
+            issue_dma(0);
+
+            // One step = one channel pair.  PAR (buffer parity) is a compile-time constant so that the
+            // staging buffer enters every LDS read as an immediate offset.
+            auto step = [&](int st, auto par_tag) {
+                constexpr int PAR = decltype(par_tag)::value;
+                // Issue order behind DMA(st): the two ref loads of step st+1 and the 2*DP stores of step
+                // st-1 (every step issues all of them; lanes/planes without output carry an out-of-range
+                // offset).  vmcnt retires in order, so DMA(st) has landed once at most that many
+                // operations are outstanding.
+                const f32x2 refc = ref0;
+                if (st == 0) wait_vmcnt<0>();
+                else if (st + 1 < NSTEP) wait_vmcnt<2 * DP + 2>();
+                else wait_vmcnt<2 * DP>();
+                ref0 = ref1;
+                if (st + 1 < NSTEP) {
+                    issue_dma(st + 1);
+                    const int nx = (st + 2 < NSTEP) ? 2 * st + 4 : 0;   // dummy reload keeps the count constant
+                    ref1.x = llvm_raw_buffer_load_f32(rref.v, (int)pix4, nx * HW * 4, 0);
+                    ref1.y = llvm_raw_buffer_load_f32(rref.v, (int)pix4, (nx + 1) * HW * 4, 0);
+                }
+                const f32x2 refsq = refc * refc;
+                // one descriptor per channel pair: base = channel 2*st of the output, second channel
+                // through the scalar offset
+                const BufRsrc ro = make_rsrc(p.out + ((size_t)b * CT + 2 * st) * ostride, (uint32_t)(2 * ostride * 4));
+                const int och1 = (int)(ostride * 4);
+                // Software pipeline over the planes: the taps of plane pl+1 are in flight (ds_read_b64 from
+                // inline asm, in-order return, counted lgkmcnt) while plane pl is being computed.
+                f32x2 cv[DP][NSRC][4];
+                auto read_plane = [&](int pl) {
+#pragma unroll
+                    for (int s = 0; s < NSRC; ++s)
+                        lds_read_tap<PAR * BUF_STRIDE * 8, BW * 8>(tap[pl][s].base, cv[pl][s][0], cv[pl][s][1],
+                                                                   cv[pl][s][2], cv[pl][s][3]);
+                };
+                auto compute_plane = [&](int pl) {
+                    f32x2 sum = refc, sq = refsq;
+#pragma unroll
+                    for (int s = 0; s < NSRC; ++s) {
+                        const TapD& t = tap[pl][s];
+                        f32x2 wv = cv[pl][s][0] * __builtin_shufflevector(t.wn, t.wn, 0, 0);
+                        wv = __builtin_elementwise_fma(cv[pl][s][1], __builtin_shufflevector(t.wn, t.wn, 1, 1), wv);
+                        wv = __builtin_elementwise_fma(cv[pl][s][2], __builtin_shufflevector(t.ws, t.ws, 0, 0), wv);
+                        wv = __builtin_elementwise_fma(cv[pl][s][3], __builtin_shufflevector(t.ws, t.ws, 1, 1), wv);
+                        sum = sum + wv;
+                        sq = sq + wv * wv;
+                    }
+                    const f32x2 m = div_by_views2(sum, fV, rV);
+                    const f32x2 q = div_by_views2(sq, fV, rV);
+                    const f32x2 var = q - m * m;
+                    llvm_raw_buffer_store_f32(var.x, ro.v, (int)ovo[pl], 0, STORE_AUX);
+                    llvm_raw_buffer_store_f32(var.y, ro.v, (int)ovo[pl], och1, STORE_AUX);
+                };
+                read_plane(0);
+#pragma unroll
+                for (int pl = 0; pl < DP; ++pl) {
+                    if (pl + 1 < DP) read_plane(pl + 1);
+                    // reads per plane = 4*NSRC; everything older than the next plane's reads has returned
+                    if constexpr (NSRC == 1) {
+                        f32x2 d0, d1, d2, d3;
+                        d0 = d1 = d2 = d3 = (f32x2)(0.0f);
+                        if (pl + 1 < DP) lds_wait<4>(cv[pl][0][0], cv[pl][0][1], cv[pl][0][2], cv[pl][0][3], d0, d1, d2, d3);
+                        else             lds_wait<0>(cv[pl][0][0], cv[pl][0][1], cv[pl][0][2], cv[pl][0][3], d0, d1, d2, d3);
+                    } else {
+#pragma unroll
+                        for (int s = 0; s + 1 < NSRC; s += 2) {
+                            if (pl + 1 < DP) lds_wait<(4 * NSRC <= 15 ? 4 * NSRC : 15)>(cv[pl][s][0], cv[pl][s][1], cv[pl][s][2], cv[pl][s][3],
+                                                           cv[pl][s + 1][0], cv[pl][s + 1][1], cv[pl][s + 1][2], cv[pl][s + 1][3]);
+                            else             lds_wait<0>(cv[pl][s][0], cv[pl][s][1], cv[pl][s][2], cv[pl][s][3],
+                                                         cv[pl][s + 1][0], cv[pl][s + 1][1], cv[pl][s + 1][2], cv[pl][s + 1][3]);
+                        }
+                        if constexpr (NSRC == 3) {
+                            f32x2 d0, d1, d2, d3;
+                            d0 = d1 = d2 = d3 = (f32x2)(0.0f);
+                            if (pl + 1 < DP) lds_wait<12>(cv[pl][2][0], cv[pl][2][1], cv[pl][2][2], cv[pl][2][3], d0, d1, d2, d3);
+                            else             lds_wait<0>(cv[pl][2][0], cv[pl][2][1], cv[pl][2][2], cv[pl][2][3], d0, d1, d2, d3);
+                        }
+                    }
+                    compute_plane(pl);
+                }
+            };
+            static_assert(NSTEP % 2 == 0, "two steps per loop iteration");
+            for (int st = 0; st < NSTEP; st += 2) {
+                step(st, std::integral_constant<int, 0>());
+                step(st + 1, std::integral_constant<int, 1>());
+            }
+        } else {
+            // ---- fallback: direct gathers for this plane group (see costvol_wave_kernel) ----------
+            const float* refp = p.ref + (size_t)b * CT * HW + pix;
+            float* outp = p.out + (size_t)b * CT * p.D_out * HW + pix;
+#pragma unroll 1
+            for (int pl = 0; pl < np; ++pl) {
+                const int d = dg + pl;
+                const float hf = p.depth_is_4d ? p.depth[((size_t)b * p.D + d) * HW + pix]
+                                               : p.depth[(size_t)b * p.D + d];
+                const double h = (double)hf;
+                const cgeo_t geo_d = launder(geo_b);
+                Tap tp[NSRC];
+                double lat = 0.0, lon = 0.0;
+                if (GEO == 0) rpc_photo2obj(geo_d, ref_n, fx, fy, h, lat, lon);
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s) {
+                    if (GEO == 0) {
+                        double samp, line;
+                        rpc_obj2photo(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat, lon, h, samp, line);
+                        tp[s] = tap_from_pixel((float)samp, (float)line, H, W, half_wm1, half_hm1);
+                    } else {
+                        const cgeo_t P = geo_d + s * 16;
+                        const double rx = fma(P[1], fy, P[0] * fx) + P[2];
+                        const double ry = fma(P[5], fy, P[4] * fx) + P[6];
+                        const double rz = fma(P[9], fy, P[8] * fx) + P[10];
+                        const double X = fma(rx, h, P[3]), Y = fma(ry, h, P[7]), Z = fma(rz, h, P[11]);
+                        tp[s] = tap_from_grid((float)((X / Z) / ((W - 1) * 0.5) - 1.0),
+                                              (float)((Y / Z) / ((H - 1) * 0.5) - 1.0), H, W);
+                    }
+                }
+                float* od = outp + (size_t)(d - p.d_begin + p.d_out_off) * HW;
+#pragma unroll 1
+                for (int c = 0; c < CT; ++c) {
+                    const float r = refp[(size_t)c * HW];
+                    float sum = r;
+                    float sq = r * r;
+#pragma unroll
+                    for (int s = 0; s < NSRC; ++s) {
+                        const float wv = tap_fetch(rs[s], tp[s], c * HW * 4);
+                        sum = sum + wv;
+                        sq = sq + wv * wv;
+                    }
+                    const float m = div_by_views(sum, fV, rV);
+                    const float q = div_by_views(sq, fV, rV);
+                    if (active) od[(size_t)c * ostride] = q - m * m;
+                }
+            }
+        }
+    }
+}
+
 // Kernel choice.  The LDS-staged kernel serves the shapes the cascade produces (C = 8/16/32,
 // up to 5 views); everything else, and SMVS_COSTVOL_DIRECT=1 (A/B switch for profiling), takes
 // the direct-gather kernel.  Both produce identical bits.
-static bool use_direct_kernel()
+enum { K_DIRECT = 0, K_STAGED = 1, K_DMA = 2 };
+
+static int kernel_choice()
 {
-    const char* e = getenv("SMVS_COSTVOL_KERNEL");         // "direct" | "staged"; default = the faster one
-    if (e && e[0] == 's') return false;
-    if (e && e[0] == 'd') return true;
-    return true;
+    const char* e = getenv("SMVS_COSTVOL_KERNEL");         // "direct" | "staged" | "dma" (A/B switch)
+    if (e && e[0] == 's') return K_STAGED;
+    if (e && e[0] == 'd' && e[1] == 'm') return K_DMA;
+    if (e && e[0] == 'd') return K_DIRECT;
+    return K_DMA;
 }
 
 template <int GEO, int NSRC>
@@ -506,18 +888,30 @@ static hipError_t launch_ct(CostVolParams p, hipStream_t st)
 {
     const int nd = p.d_end - p.d_begin;
     if constexpr (NSRC <= 4) {
-        if (!use_direct_kernel() && (p.C == 8 || p.C == 16 || p.C == 32) && p.W < 65535 && p.H < 65535) {
+        const int kc = kernel_choice();
+        const bool staged_ok = (p.C == 8 || p.C == 16 || p.C == 32) && p.W < 65535 && p.H < 65535 &&
+                               (long long)p.D_out * p.H * p.W * 4 < (1ll << 32);
+        if (kc != K_DIRECT && staged_ok) {
             p.xt = (p.W + WV_TX - 1) / WV_TX;
             p.yt = (p.H + WV_TY * WV_WAVES - 1) / (WV_TY * WV_WAVES);
-            p.dch = nd < WV_DP ? nd : WV_DP;
+            const int dpg = (kc == K_DMA) ? 2 * DM_DP : WV_DP;
+            p.dch = nd < dpg ? nd : dpg;
             p.dct = (nd + p.dch - 1) / p.dch;
             const long long nb = (long long)p.xt * p.yt * p.dct * p.B;
             if (nb >= (1ll << 31)) return hipErrorInvalidValue;
             dim3 blk(64 * WV_WAVES), grd((unsigned)nb);
-            switch (p.C) {
-            case 8:  hipLaunchKernelGGL((costvol_wave_kernel<GEO, NSRC, 8>), grd, blk, 0, st, p); break;
-            case 16: hipLaunchKernelGGL((costvol_wave_kernel<GEO, NSRC, 16>), grd, blk, 0, st, p); break;
-            default: hipLaunchKernelGGL((costvol_wave_kernel<GEO, NSRC, 32>), grd, blk, 0, st, p); break;
+            if (kc == K_DMA) {
+                switch (p.C) {
+                case 8:  hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 8>), grd, blk, 0, st, p); break;
+                case 16: hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 16>), grd, blk, 0, st, p); break;
+                default: hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 32>), grd, blk, 0, st, p); break;
+                }
+            } else {
+                switch (p.C) {
+                case 8:  hipLaunchKernelGGL((costvol_wave_kernel<GEO, NSRC, 8>), grd, blk, 0, st, p); break;
+                case 16: hipLaunchKernelGGL((costvol_wave_kernel<GEO, NSRC, 16>), grd, blk, 0, st, p); break;
+                default: hipLaunchKernelGGL((costvol_wave_kernel<GEO, NSRC, 32>), grd, blk, 0, st, p); break;
+                }
             }
             return hipGetLastError();
         }

@@ -43,8 +43,13 @@ __device__ __forceinline__ cgeo_t launder(cgeo_t p)
 }
 
 // Four cubics sharing one monomial set: n0/d0 and n1/d1 are the two rational outputs.
-// k0..k3 point at 20 wave-uniform coefficients each (scalar loads; they never touch a VGPR
-// except as FMA operands).  Monomial order is RPC00B, built by the reference's product chain.
+// k0..k3 point at 20 wave-uniform coefficients each (scalar loads).  Monomial order is RPC00B
+//   1,L,P,H,LP,LH,PH,LL,PP,HH,PLH,LLL,LPP,LHH,LLP,PPP,PHH,LLH,PPH,HHH   (warping.py:183-207)
+// built by the reference's product chain; every term is acc = fma(monomial, coeff, acc), i.e. the
+// SGPR coefficient is a MULTIPLICAND of v_fmac_f64 and the accumulator stays in VGPRs.  (A nested
+// Horner form needs 16 fewer multiplies but puts the coefficients in the ADDEND slot, which on
+// gfx950 costs two v_mov_b32 per FMA to copy them out of SGPRs -- measured 1318 vs 57 moves per
+// kernel -- so the flat form is the cheaper one here.)
 __device__ __forceinline__ void cubic4(cgeo_t k0, cgeo_t k1, cgeo_t k2, cgeo_t k3,
                                        double P, double L, double H,
                                        double& n0, double& d0, double& n1, double& d1)
@@ -126,6 +131,7 @@ __device__ __forceinline__ void rpc_obj2photo(cgeo_t r, const RpcInv& n,
 
 // ---- raw buffer access -------------------------------------------------------------------------
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ float llvm_raw_buffer_load_f32(i32x4 rsrc, int voffset, int soffset, int aux)
     __asm("llvm.amdgcn.raw.buffer.load.f32");
@@ -146,6 +152,52 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* base, uint32_t bytes)
     r.v.z = (int32_t)__builtin_amdgcn_readfirstlane(bytes);
     r.v.w = 0x00020000;                                                    // gfx9-family raw dword access
     return r;
+}
+
+__device__ void llvm_raw_buffer_store_f32(float v, i32x4 rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.store.f32");
+
+// LDS-DMA: one dword per lane from a buffer straight into LDS at lds_byte_addr + 4*lane, no VGPR
+// round trip; out-of-range lanes deposit 0.  Issued from inline asm so that hipcc does not drain
+// vmcnt(0) before every LDS read (it cannot tell the two staging buffers apart): completion is
+// tracked by hand with counted s_waitcnt vmcnt(N) (vmcnt retires in issue order).
+__device__ __forceinline__ void dma_dword_to_lds(const BufRsrc& rs, uint32_t lds_byte_addr, uint32_t voffset,
+                                                 int soffset)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(lds_byte_addr), "v"(voffset), "s"(rs.v), "s"(soffset) : "memory", "m0");
+}
+
+// The four corners of one tap for a channel pair, as four ds_read_b64 (256 B/clk) rather than the
+// two ds_read2_b64 (128 B/clk) hipcc merges them into.  Issued from inline asm, so completion is
+// tracked by hand: LDS reads of a wave return in order, lds_wait<N>() = s_waitcnt lgkmcnt(N) and
+// carries the registers it protects as in/out operands so that no use can be scheduled above it.
+// OFF = byte offset of the staging buffer, ROW = byte distance to the south row.
+template <int OFF, int ROW>
+__device__ __forceinline__ void lds_read_tap(uint32_t addr, f32x2& nw, f32x2& ne, f32x2& sw, f32x2& se)
+{
+    static_assert(OFF + ROW + 8 < 65536, "ds_read immediate offset");
+    asm volatile("ds_read_b64 %0, %4 offset:%5\n\t"
+                 "ds_read_b64 %1, %4 offset:%6\n\t"
+                 "ds_read_b64 %2, %4 offset:%7\n\t"
+                 "ds_read_b64 %3, %4 offset:%8"
+                 : "=&v"(nw), "=&v"(ne), "=&v"(sw), "=&v"(se)
+                 : "v"(addr), "n"(OFF), "n"(OFF + 8), "n"(OFF + ROW), "n"(OFF + ROW + 8)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void lds_wait(f32x2& a0, f32x2& a1, f32x2& a2, f32x2& a3,
+                                         f32x2& b0, f32x2& b1, f32x2& b2, f32x2& b3)
+{
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3)
+                 : "n"(N) : "memory");
+}
+
+__device__ __forceinline__ uint32_t lds_addr(const void* p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
 
 #define SMVS_OOB 0x80000000u   // voffset (+ any channel offset < 2^31) >= num_records: reads back 0
@@ -205,7 +257,6 @@ __device__ __forceinline__ float tap_fetch(const BufRsrc& rs, const Tap& t, int 
 
 // Two channels (c, c+1) of one source view at once: the arithmetic is the same per lane element,
 // written on float2 so it maps onto v_pk_mul_f32 / v_pk_fma_f32.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x2 tap_fetch2(const BufRsrc& rs, const Tap& t, int choff, int chstride)
 {
