@@ -182,36 +182,9 @@ void costvol_fwd_kernel(const CostVolParams p)
     }
 }
 
-// =====================================================================================================
-// Staged kernel: wave-private source tiles in LDS.
-//
-// The direct kernel above is bound by the texture-address path: 4 unaligned gathers per channel and
-// source = 261 vector-memory instructions per 64 voxels, TA 75 % busy at 8 cycles each
-// (profiles/r01_v1_direct_gather_summary.txt).  Here every WAVE owns a 32 x 2 patch of ref pixels
-// and works alone (no workgroup barrier anywhere, so waves slide past each other and hide each
-// other's latencies):
-//   A. taps of WV_DP = 8 consecutive planes for its 64 pixels (float64 chain), kept as
-//      {LDS offset, x fraction, y fraction};
-//   B. bounding box of those taps in each source image (wave min/max);
-//   C. per group of CG channels: stage the box -- WV_R rows x 64 columns, zero outside the image --
-//      with one coalesced buffer load per (channel, row) (global row base in the scalar offset, so
-//      no vector ALU work), channel pairs interleaved so that
-//   D. every tap corner of a channel PAIR is one ds_read_b64 with an immediate offset, feeding
-//      packed f32 math (v_pk_fma_f32) without repacking moves.
-// Global loads per voxel-channel-source drop from 4 gathers to ~0.6 coalesced loads; rows shared by
-// the patch's two image rows and by the 8 planes are fetched once.  A box that does not fit
-// (exotic geometry) makes that wave take the direct gathers for the plane group, so results never
-// depend on which path ran.  Bits are identical to the direct kernel and to the oracle.
-// =====================================================================================================
-constexpr int WV_DP = 4;       // planes per staged group
-constexpr int WV_BW = 64;      // staged box width = one lane per column
-constexpr int WV_R = 5;        // staged box rows: 2 pixel rows + south tap + parallax/rotation slack
+// ---- geometry shared by the staged (LDS) kernel ----------------------------------------------------
 constexpr int WV_TX = 32, WV_TY = 2;          // ref pixels per wave
 constexpr int WV_WAVES = 4;                   // waves per workgroup, stacked in y: 32 x 8 pixels
-
-template <int NSRC> struct WaveCfg { static constexpr int CG = NSRC <= 2 ? 4 : 2; };   // 10 KiB LDS per wave
-
-struct TapW { int base; float wx, wy; };      // base: float2 index of the north-west corner in the wave's box
 
 __device__ __forceinline__ int wave_min(int v)
 {
@@ -227,287 +200,36 @@ __device__ __forceinline__ int wave_max(int v)
     return v;
 }
 
-template <int GEO, int NSRC, int CT>
-__global__ __launch_bounds__(64 * WV_WAVES, 3)
-void costvol_wave_kernel(const CostVolParams p)
-{
-    constexpr int CG = WaveCfg<NSRC>::CG, CP = CG / 2;
-    constexpr int DP = WV_DP, BW = WV_BW, R = WV_R;
-    constexpr int SRC_STRIDE = CP * R * BW;               // float2 elements per source in a wave's box
-    static_assert(CT % CG == 0, "channel groups");
-    __shared__ f32x2 tile_all[WV_WAVES][NSRC * SRC_STRIDE];
-
-    uint32_t L = xcd_remap(blockIdx.x, gridDim.x);
-    const int xtile = L % p.xt; L /= p.xt;
-    const int dchunk = L % p.dct; L /= p.dct;
-    const int ytile = L % p.yt;
-    const int b = L / p.yt;
-
-    const int H = p.H, W = p.W;
-    const int HW = H * W;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    f32x2* tile = tile_all[wave];
-    const int x = xtile * WV_TX + (lane & (WV_TX - 1));
-    const int y = (ytile * WV_WAVES + wave) * WV_TY + (lane >> 5);
-    const bool active = (x < W) && (y < H);
-    const int pix = min(y, H - 1) * W + min(x, W - 1);     // inactive lanes shadow an edge pixel, never store
-    const int d0 = p.d_begin + dchunk * p.dch;
-    const int d1 = min(d0 + p.dch, p.d_end);
-    if ((ytile * WV_WAVES + wave) * WV_TY >= H) return;     // whole wave below the image (no barriers used)
-
-    BufRsrc rs[NSRC];
-#pragma unroll
-    for (int s = 0; s < NSRC; ++s)
-        rs[s] = make_rsrc(p.src[s] + (size_t)b * CT * HW, (uint32_t)CT * (uint32_t)HW * 4u);
-
-    const float* refp = p.ref + (size_t)b * CT * HW + pix;
-    const float fV = (float)p.V;
-    const float rV = __fdiv_rn(1.0f, fV);
-    const float half_wm1 = (float)((W - 1) * 0.5);
-    const float half_hm1 = (float)((H - 1) * 0.5);
-
-    const cgeo_t geo_b = as_cgeo((GEO == 0) ? p.geo + (size_t)b * p.V * RPC_LEN
-                                            : p.geo + (size_t)b * (p.V - 1) * 16);
-    RpcInv ref_n;
-    RpcInv src_n[NSRC];
-    if (GEO == 0) {
-        ref_n = rpc_inv_image(geo_b);
-#pragma unroll
-        for (int s = 0; s < NSRC; ++s) src_n[s] = rpc_inv_ground(geo_b + (size_t)(s + 1) * RPC_LEN);
-    }
-    const double fx = (double)min(x, W - 1), fy = (double)min(y, H - 1);
-    float* outp = p.out + (size_t)b * CT * p.D_out * HW + pix;
-    const size_t ostride = (size_t)p.D_out * HW;
-
-    for (int dg = d0; dg < d1; dg += DP) {
-        const int np = min(DP, d1 - dg);
-
-        // ---- A: taps of the group's planes -----------------------------------------------------
-        TapW tap[DP][NSRC];
-        uint32_t txy[DP][NSRC];                              // integer corner (y0+1)<<16 | (x0+1), until the box is known
-        uint32_t okmask = 0;                                 // bit pl*NSRC+s: footprint touches the image
-        int lo_x[NSRC], hi_x[NSRC], lo_y[NSRC], hi_y[NSRC];
-#pragma unroll
-        for (int s = 0; s < NSRC; ++s) { lo_x[s] = lo_y[s] = INT_MAX; hi_x[s] = hi_y[s] = INT_MIN; }
-#pragma unroll
-        for (int pl = 0; pl < DP; ++pl) {
-            const int d = min(dg + pl, d1 - 1);              // tail planes shadow the last one (unused)
-            const float hf = p.depth_is_4d ? p.depth[((size_t)b * p.D + d) * HW + pix]
-                                           : p.depth[(size_t)b * p.D + d];
-            const double h = (double)hf;
-            const cgeo_t geo_d = launder(geo_b);
-            double lat = 0.0, lon = 0.0;
-            if (GEO == 0 && !(p.ablate & 4)) rpc_photo2obj(geo_d, ref_n, fx, fy, h, lat, lon);
-#pragma unroll
-            for (int s = 0; s < NSRC; ++s) {
-                float gx, gy;
-                if (p.ablate & 4) {
-                    gx = ((float)fx + 0.37f + 0.011f * hf * (float)(s + 1)) / half_wm1 - 1.0f;
-                    gy = ((float)fy + 0.21f) / half_hm1 - 1.0f;
-                } else if (GEO == 0) {
-                    double samp, line;
-                    rpc_obj2photo(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat, lon, h, samp, line);
-                    gx = (float)samp / half_wm1 - 1.0f;
-                    gy = (float)line / half_hm1 - 1.0f;
-                } else {
-                    const cgeo_t P = geo_d + s * 16;
-                    const double rx = fma(P[1], fy, P[0] * fx) + P[2];
-                    const double ry = fma(P[5], fy, P[4] * fx) + P[6];
-                    const double rz = fma(P[9], fy, P[8] * fx) + P[10];
-                    const double X = fma(rx, h, P[3]), Y = fma(ry, h, P[7]), Z = fma(rz, h, P[11]);
-                    gx = (float)((X / Z) / ((W - 1) * 0.5) - 1.0);
-                    gy = (float)((Y / Z) / ((H - 1) * 0.5) - 1.0);
-                }
-                // same arithmetic as tap_from_grid (ATen unnormalise, floor, fractions)
-                const float px = fmaf(gx + 1.0f, (float)W * 0.5f, -0.5f);
-                const float py = fmaf(gy + 1.0f, (float)H * 0.5f, -0.5f);
-                const float xw = floorf(px), yn = floorf(py);
-                tap[pl][s].wx = px - xw;
-                tap[pl][s].wy = py - yn;
-                const bool ok = (xw >= -1.0f) && (xw <= (float)(W - 1)) && (yn >= -1.0f) && (yn <= (float)(H - 1));
-                const int ix0 = ok ? (int)xw : 0, iy0 = ok ? (int)yn : 0;
-                txy[pl][s] = ((uint32_t)(iy0 + 1) << 16) | (uint32_t)(ix0 + 1);
-                if (ok) okmask |= 1u << (pl * NSRC + s);
-                if (ok && active && pl < np) {
-                    lo_x[s] = min(lo_x[s], ix0); hi_x[s] = max(hi_x[s], ix0);
-                    lo_y[s] = min(lo_y[s], iy0); hi_y[s] = max(hi_y[s], iy0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);               // one plane's float64 chain at a time (VGPR pressure)
-        }
-
-        // ---- B: the wave's bounding box per source ----------------------------------------------
-        int bx0[NSRC], by0[NSRC], bw[NSRC], bh[NSRC];
-        bool fits = true;
-#pragma unroll
-        for (int s = 0; s < NSRC; ++s) {
-            const int a0 = __builtin_amdgcn_readfirstlane(wave_min(lo_x[s]));
-            const int a1 = __builtin_amdgcn_readfirstlane(wave_max(hi_x[s]));
-            const int b0 = __builtin_amdgcn_readfirstlane(wave_min(lo_y[s]));
-            const int b1 = __builtin_amdgcn_readfirstlane(wave_max(hi_y[s]));
-            const bool empty = a1 < a0;
-            bx0[s] = empty ? 0 : a0; by0[s] = empty ? 0 : b0;
-            bw[s] = empty ? 0 : a1 - a0 + 2;                 // +1 for the east/south corner, +1 for count
-            bh[s] = empty ? 0 : b1 - b0 + 2;
-            fits = fits && (bw[s] <= BW) && (bh[s] <= R);
-        }
-
-        if (fits) {
-            uint32_t vo[NSRC];                               // this lane's column in the staged rows
-#pragma unroll
-            for (int s = 0; s < NSRC; ++s) {
-                const int c0 = bx0[s] + lane;
-                vo[s] = (lane < bw[s] && c0 >= 0 && c0 < W) ? (uint32_t)c0 * 4u : SMVS_OOB;
-            }
-#pragma unroll
-            for (int pl = 0; pl < DP; ++pl)
-#pragma unroll
-                for (int s = 0; s < NSRC; ++s) {
-                    const bool ok = (okmask >> (pl * NSRC + s)) & 1u;
-                    const int iy0 = (int)(txy[pl][s] >> 16) - 1, ix0 = (int)(txy[pl][s] & 0xffffu) - 1;
-                    tap[pl][s].base = ok ? s * SRC_STRIDE + (iy0 - by0[s]) * BW + (ix0 - bx0[s]) : s * SRC_STRIDE;
-                }
-
-            for (int g = 0; g < CT / CG; ++g) {
-                // ---- C: stage CG channels of every source box (channel pairs interleaved) -------
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();             // previous group's reads precede these writes
-#pragma unroll
-                for (int s = 0; s < NSRC; ++s) {
-#pragma unroll
-                    for (int seg = 0; seg < CP * R; ++seg) {
-                        const int cp = seg / R, er = seg % R;
-                        const int gyp = by0[s] + er;
-                        const bool row_in = (er < bh[s]) && (gyp >= 0) && (gyp < H);
-                        const int so0 = row_in ? ((g * CG + 2 * cp) * H + gyp) * W * 4 : (int)SMVS_OOB;
-                        const int so1 = row_in ? so0 + HW * 4 : (int)SMVS_OOB;
-                        f32x2 v = {1.0f, 2.0f};
-                        if (!(p.ablate & 2)) {
-                            v.x = llvm_raw_buffer_load_f32(rs[s].v, (int)vo[s], so0, 0);
-                            v.y = llvm_raw_buffer_load_f32(rs[s].v, (int)vo[s], so1, 0);
-                        }
-                        tile[s * SRC_STRIDE + seg * BW + lane] = v;
-                    }
-                }
-                float refc[CG];
-#pragma unroll
-                for (int c = 0; c < CG; ++c) refc[c] = refp[(size_t)(g * CG + c) * HW];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();             // LDS is in-order per wave: writes land before the reads below
-
-                // ---- D: taps from LDS ------------------------------------------------------------------
-#pragma unroll
-                for (int pl = 0; pl < DP; ++pl) {
-                    if (pl < np) {
-                        float* od = outp + (size_t)(dg + pl - p.d_begin + p.d_out_off) * HW + (size_t)(g * CG) * ostride;
-                        f32x2 sum[CP], sq[CP];
-#pragma unroll
-                        for (int cp = 0; cp < CP; ++cp) {
-                            const f32x2 r = {refc[2 * cp], refc[2 * cp + 1]};
-                            sum[cp] = r;
-                            sq[cp] = r * r;
-                        }
-#pragma unroll
-                        for (int s = 0; s < NSRC; ++s) {
-                            const TapW& t = tap[pl][s];
-                            const float okf = ((okmask >> (pl * NSRC + s)) & 1u) ? 1.0f : 0.0f;
-                            const float w = t.wx, e = 1.0f - w, n = t.wy, so = 1.0f - n;
-                            const float nw = (so * e) * okf, ne = (so * w) * okf, sw = (n * e) * okf, se = (n * w) * okf;
-                            const f32x2* t0 = tile + t.base;
-#pragma unroll
-                            for (int cp = 0; cp < CP; ++cp) {
-                                const f32x2* tc = t0 + cp * (R * BW);
-                                f32x2 wv = tc[0] * nw;
-                                wv = __builtin_elementwise_fma(tc[1], (f32x2)(ne), wv);
-                                wv = __builtin_elementwise_fma(tc[BW], (f32x2)(sw), wv);
-                                wv = __builtin_elementwise_fma(tc[BW + 1], (f32x2)(se), wv);
-                                sum[cp] = sum[cp] + wv;
-                                sq[cp] = sq[cp] + wv * wv;
-                            }
-                        }
-#pragma unroll
-                        for (int cp = 0; cp < CP; ++cp) {
-                            const f32x2 m = div_by_views2(sum[cp], fV, rV);
-                            const f32x2 q = div_by_views2(sq[cp], fV, rV);
-                            const f32x2 var = q - m * m;
-                            if (active && !(p.ablate & 1)) {
-                                od[(size_t)(2 * cp) * ostride] = var.x;
-                                od[(size_t)(2 * cp + 1) * ostride] = var.y;
-                            } else if (p.ablate & 1) {
-                                asm volatile("" :: "v"(var.x), "v"(var.y));
-                            }
-                        }
-                    }
-                }
-            }
-        } else {
-            // ---- fallback: direct gathers for this plane group (box larger than the staged tile).
-            //      Rare and wave-uniform; the taps are recomputed plane by plane in a rolled loop so
-            //      that this path adds no register pressure to the staged one.
-#pragma unroll 1
-            for (int pl = 0; pl < np; ++pl) {
-                const int d = dg + pl;
-                const float hf = p.depth_is_4d ? p.depth[((size_t)b * p.D + d) * HW + pix]
-                                               : p.depth[(size_t)b * p.D + d];
-                const double h = (double)hf;
-                const cgeo_t geo_d = launder(geo_b);
-                Tap tp[NSRC];
-                double lat = 0.0, lon = 0.0;
-                if (GEO == 0) rpc_photo2obj(geo_d, ref_n, fx, fy, h, lat, lon);
-#pragma unroll
-                for (int s = 0; s < NSRC; ++s) {
-                    if (GEO == 0) {
-                        double samp, line;
-                        rpc_obj2photo(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat, lon, h, samp, line);
-                        tp[s] = tap_from_pixel((float)samp, (float)line, H, W, half_wm1, half_hm1);
-                    } else {
-                        const cgeo_t P = geo_d + s * 16;
-                        const double rx = fma(P[1], fy, P[0] * fx) + P[2];
-                        const double ry = fma(P[5], fy, P[4] * fx) + P[6];
-                        const double rz = fma(P[9], fy, P[8] * fx) + P[10];
-                        const double X = fma(rx, h, P[3]), Y = fma(ry, h, P[7]), Z = fma(rz, h, P[11]);
-                        tp[s] = tap_from_grid((float)((X / Z) / ((W - 1) * 0.5) - 1.0),
-                                              (float)((Y / Z) / ((H - 1) * 0.5) - 1.0), H, W);
-                    }
-                }
-                float* od = outp + (size_t)(d - p.d_begin + p.d_out_off) * HW;
-#pragma unroll 1
-                for (int c = 0; c < CT; ++c) {
-                    const float r = refp[(size_t)c * HW];
-                    float sum = r;
-                    float sq = r * r;
-#pragma unroll
-                    for (int s = 0; s < NSRC; ++s) {
-                        const float wv = tap_fetch(rs[s], tp[s], c * HW * 4);
-                        sum = sum + wv;
-                        sq = sq + wv * wv;
-                    }
-                    const float m = div_by_views(sum, fV, rV);
-                    const float q = div_by_views(sq, fV, rV);
-                    if (active) od[(size_t)c * ostride] = q - m * m;
-                }
-            }
-        }
-    }
-}
-
 // =====================================================================================================
-// DMA kernel: the staged design with the staging moved off the ALUs and out of the wave's critical
-// path.  Per wave (32 x 2 ref pixels, DM_DP planes per group):
-//   * one channel PAIR per step; the pair's source rows are written into LDS by LDS-DMA
-//     (buffer_load ... lds: lane -> (column, channel-of-pair), so the DMA itself produces the
-//     pair-interleaved float2 layout; out-of-image lanes/rows deposit zeros = zero padding);
+// Staged kernel (default): source tiles in wave-private LDS, filled by LDS-DMA.
+//
+// The direct kernel above is bound by the texture-address path: 4 unaligned gathers per channel and
+// source = 261 vector-memory instructions per 64 voxels, TA 75 % busy at 8 cycles each
+// (profiles/r01_v1_direct_gather_summary.txt).  Here every WAVE owns a 32 x 2 patch of ref pixels and
+// works alone -- no workgroup barrier anywhere, waves slide past each other:
+//   A. taps of DM_DP consecutive planes for its 64 pixels (float64 chain): LDS address + 4 weights;
+//   B. bounding box of those taps in each source image (wave min/max);
+//   C. per channel PAIR ("step"): the box rows -- DM_R rows x 64 columns -- go into LDS by LDS-DMA
+//      (buffer_load ... lds: lane -> (column, channel-of-pair), so the DMA itself produces the
+//      pair-interleaved float2 layout; out-of-image lanes/rows deposit zeros = zero padding);
+//   D. every tap corner of the pair is one ds_read_b64 with an immediate offset, feeding packed f32
+//      math (v_pk_fma_f32); the variance pair leaves through two non-temporal buffer stores.
+// Global loads per voxel-channel-source drop from 4 gathers to ~0.6 coalesced DMA lanes; rows shared by
+// the patch's two image rows and by the DM_DP planes are fetched once.  Latency is taken off the
+// wave's critical path three ways:
 //   * two LDS buffers: the DMA for step st+1 is issued before step st is computed and only waited for
-//     (counted s_waitcnt vmcnt(N), N = the stores issued after it) when step st+1 begins, so neither
-//     load latency nor store acknowledgements stall the arithmetic;
-//   * all four bilinear weights stay in registers; results leave through buffer stores whose channel
-//     base lives in the descriptor (no 64-bit address arithmetic per store).
-// No workgroup barrier anywhere.  A box that does not fit takes the direct gathers for that group.
+//     (counted s_waitcnt vmcnt(N), N = the operations issued after it) when step st+1 begins, so
+//     neither load latency nor store acknowledgements stall the arithmetic;
+//   * the LDS reads of plane pl+1 are in flight while plane pl is computed (counted lgkmcnt);
+//   * ref features run two steps ahead in registers; results leave through buffer stores whose
+//     channel base lives in the descriptor (no 64-bit address arithmetic per store).
+// A box that does not fit (exotic geometry) makes that wave take the direct gathers for the plane
+// group, so results never depend on which path ran.  Bits are identical to the direct kernel and to
+// the oracle.
 // =====================================================================================================
 constexpr int DM_DP = 4;       // planes per group
 constexpr int DM_BW = 64;      // staged box width (columns)
-constexpr int DM_R = 5;        // staged box rows
+constexpr int DM_R = 5;        // staged box rows: 2 pixel rows + south tap + parallax/rotation slack
 constexpr int DM_NBUF = 2;
 #ifndef SMVS_STORE_AUX
 #define SMVS_STORE_AUX 2              // nt: the variance volume streams out once, keep it from evicting feature rows in L2
@@ -819,7 +541,9 @@ void costvol_dma_kernel(const CostVolParams p)
                 step(st + 1, std::integral_constant<int, 1>());
             }
         } else {
-            // ---- fallback: direct gathers for this plane group (see costvol_wave_kernel) ----------
+            // ---- fallback: direct gathers for this plane group (box larger than the staged tile).
+            //      Rare and wave-uniform; the taps are recomputed plane by plane in a rolled loop so
+            //      that this path adds no register pressure to the staged one.
             const float* refp = p.ref + (size_t)b * CT * HW + pix;
             float* outp = p.out + (size_t)b * CT * p.D_out * HW + pix;
 #pragma unroll 1
@@ -869,17 +593,15 @@ void costvol_dma_kernel(const CostVolParams p)
     }
 }
 
-// Kernel choice.  The LDS-staged kernel serves the shapes the cascade produces (C = 8/16/32,
-// up to 5 views); everything else, and SMVS_COSTVOL_DIRECT=1 (A/B switch for profiling), takes
-// the direct-gather kernel.  Both produce identical bits.
-enum { K_DIRECT = 0, K_STAGED = 1, K_DMA = 2 };
+// Kernel choice.  The staged kernel serves the shapes the cascade produces (C = 8/16/32, up to 5
+// views, one channel volume < 4 GiB); everything else, and SMVS_COSTVOL_KERNEL=direct (A/B switch
+// for profiling), takes the direct-gather kernel.  Both produce identical bits.
+enum { K_DIRECT = 0, K_DMA = 2 };
 
 static int kernel_choice()
 {
-    const char* e = getenv("SMVS_COSTVOL_KERNEL");         // "direct" | "staged" | "dma" (A/B switch)
-    if (e && e[0] == 's') return K_STAGED;
-    if (e && e[0] == 'd' && e[1] == 'm') return K_DMA;
-    if (e && e[0] == 'd') return K_DIRECT;
+    const char* e = getenv("SMVS_COSTVOL_KERNEL");         // "direct" | "staged" (A/B switch for profiling)
+    if (e && e[0] == 'd' && e[1] == 'i') return K_DIRECT;
     return K_DMA;
 }
 
@@ -894,24 +616,17 @@ static hipError_t launch_ct(CostVolParams p, hipStream_t st)
         if (kc != K_DIRECT && staged_ok) {
             p.xt = (p.W + WV_TX - 1) / WV_TX;
             p.yt = (p.H + WV_TY * WV_WAVES - 1) / (WV_TY * WV_WAVES);
-            const int dpg = (kc == K_DMA) ? 2 * DM_DP : WV_DP;
+            int dpg = 2 * DM_DP;                              // planes per wave: two staged groups
+            if (const char* e = getenv("SMVS_PLANES_PER_WAVE")) dpg = atoi(e) > 0 ? atoi(e) : dpg;   // tuning knob
             p.dch = nd < dpg ? nd : dpg;
             p.dct = (nd + p.dch - 1) / p.dch;
             const long long nb = (long long)p.xt * p.yt * p.dct * p.B;
             if (nb >= (1ll << 31)) return hipErrorInvalidValue;
             dim3 blk(64 * WV_WAVES), grd((unsigned)nb);
-            if (kc == K_DMA) {
-                switch (p.C) {
-                case 8:  hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 8>), grd, blk, 0, st, p); break;
-                case 16: hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 16>), grd, blk, 0, st, p); break;
-                default: hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 32>), grd, blk, 0, st, p); break;
-                }
-            } else {
-                switch (p.C) {
-                case 8:  hipLaunchKernelGGL((costvol_wave_kernel<GEO, NSRC, 8>), grd, blk, 0, st, p); break;
-                case 16: hipLaunchKernelGGL((costvol_wave_kernel<GEO, NSRC, 16>), grd, blk, 0, st, p); break;
-                default: hipLaunchKernelGGL((costvol_wave_kernel<GEO, NSRC, 32>), grd, blk, 0, st, p); break;
-                }
+            switch (p.C) {
+            case 8:  hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 8>), grd, blk, 0, st, p); break;
+            case 16: hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 16>), grd, blk, 0, st, p); break;
+            default: hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 32>), grd, blk, 0, st, p); break;
             }
             return hipGetLastError();
         }

@@ -1,0 +1,90 @@
+"""Cascade MVSNet (3-D conv regulariser) on the native cost-volume engine.
+
+Same public surface as /root/reference/networks/casmvs.py: DepthNet (:11), CascadeMVSNet (:79).
+The per-source warp + variance accumulation is the fused HIP launch; CostRegNet's 3-D convolutions
+are stock PyTorch (MIOpen) in this round.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..modules.depth_range import get_depth_range_samples
+from ..modules.module import CostRegNet, FeatureNet, depth_regression
+from ..modules.warping import variance_cost_volume
+
+Align_Corners_Range = False
+
+
+def window4_confidence(prob_volume, num_depth):
+    """Probability mass of the 4 hypotheses around the expected index (casmvs.py:69-74)."""
+    with torch.no_grad():
+        sum4 = 4 * F.avg_pool3d(F.pad(prob_volume.unsqueeze(1), pad=(0, 0, 0, 0, 1, 2)), (4, 1, 1), stride=1,
+                                padding=0).squeeze(1)
+        idx = depth_regression(prob_volume, depth_values=torch.arange(num_depth, device=prob_volume.device,
+                                                                      dtype=torch.float)).long()
+        idx = idx.clamp(min=0, max=num_depth - 1)
+        return torch.gather(sum4, 1, idx.unsqueeze(1)).squeeze(1)
+
+
+class DepthNet(nn.Module):
+    def forward(self, features, proj_matrices, depth_values, num_depth, cost_regularization, geo_model, use_qc=False):
+        n_proj = len(proj_matrices) if use_qc else proj_matrices.shape[1]
+        assert len(features) == n_proj, "Different number of images and projection matrices"
+        assert depth_values.shape[1] == num_depth, "depth_values.shape[1]:{}  num_depth:{}".format(
+            depth_values.shape[1], num_depth)
+        volume_variance = variance_cost_volume(features, proj_matrices, depth_values, geo_model, use_qc)
+        prob_volume = F.softmax(cost_regularization(volume_variance).squeeze(1), dim=1)
+        depth = depth_regression(prob_volume, depth_values=depth_values)
+        return {"depth": depth, "photometric_confidence": window4_confidence(prob_volume, num_depth)}
+
+
+class CascadeMVSNet(nn.Module):
+    def __init__(self, geo_model, refine=False, min_interval=2.5, ndepths=[48, 32, 8], depth_interals_ratio=[4, 2, 1],
+                 share_cr=False, grad_method="detach", arch_mode="fpn", cr_base_chs=[8, 8, 8], use_qc=False):
+        super().__init__()
+        assert geo_model in ["rpc", "pinhole"]
+        assert len(ndepths) == len(depth_interals_ratio)
+        if refine:
+            raise NotImplementedError("RefineNet is dead code in the reference (module.py:580-592, F.cat does not exist)")
+        self.geo_model, self.refine, self.share_cr = geo_model, refine, share_cr
+        self.ndepths, self.depth_interals_ratio = ndepths, depth_interals_ratio
+        self.grad_method, self.arch_mode, self.cr_base_chs = grad_method, arch_mode, cr_base_chs
+        self.num_stage, self.min_interval, self.use_qc = len(ndepths), min_interval, use_qc
+        self.stage_infos = {"stage1": {"scale": 4.0}, "stage2": {"scale": 2.0}, "stage3": {"scale": 1.0}}
+        self.feature = FeatureNet(base_channels=8, stride=4, num_stage=self.num_stage, arch_mode=self.arch_mode)
+        if self.share_cr:
+            self.cost_regularization = CostRegNet(in_channels=self.feature.out_channels, base_channels=8)
+        else:
+            self.cost_regularization = nn.ModuleList([
+                CostRegNet(in_channels=self.feature.out_channels[i], base_channels=self.cr_base_chs[i])
+                for i in range(self.num_stage)])
+        self.DepthNet = DepthNet()
+
+    def forward(self, imgs, proj_matrices, depth_values):
+        features = [self.feature(imgs[:, v]) for v in range(imgs.size(1))]
+        h, w = int(imgs.shape[3]), int(imgs.shape[4])
+        outputs = {}
+        depth = None
+        for stage_idx in range(self.num_stage):
+            key = "stage{}".format(stage_idx + 1)
+            feats = [f[key] for f in features]
+            scale = int(self.stage_infos[key]["scale"])
+            if depth is not None:
+                cur = depth.detach() if self.grad_method == "detach" else depth
+                cur = F.interpolate(cur.unsqueeze(1), [h, w], mode="bilinear", align_corners=Align_Corners_Range).squeeze(1)
+            else:
+                cur = depth_values
+            samples = get_depth_range_samples(cur_depth=cur, ndepth=self.ndepths[stage_idx],
+                                              depth_inteval_pixel=self.depth_interals_ratio[stage_idx] * self.min_interval,
+                                              dtype=imgs.dtype, device=imgs.device, shape=[imgs.shape[0], h, w])
+            dv = F.interpolate(samples.unsqueeze(1), [self.ndepths[stage_idx], h // scale, w // scale], mode="trilinear",
+                               align_corners=Align_Corners_Range).squeeze(1)
+            reg = self.cost_regularization if self.share_cr else self.cost_regularization[stage_idx]
+            out = self.DepthNet(feats, proj_matrices[key], depth_values=dv, num_depth=self.ndepths[stage_idx],
+                                cost_regularization=reg, geo_model=self.geo_model, use_qc=self.use_qc)
+            depth = out["depth"]
+            outputs[key] = out
+            outputs.update(out)
+        return outputs

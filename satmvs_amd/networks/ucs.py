@@ -1,0 +1,70 @@
+"""UCS-Net (uncertainty-aware cascade) on the native cost-volume engine.
+
+Same public surface as /root/reference/networks/ucs.py: compute_depth (:9), UCSNet (:79).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..modules.depth_range import uncertainty_aware_samples
+from ..modules.module import CostRegNet, FeatureNet, depth_regression
+from ..modules.warping import variance_cost_volume
+from .casmvs import window4_confidence
+
+
+def compute_depth(feats, proj_mats, depth_samps, cost_reg, lamb, geo_model, is_training=False, use_qc=False):
+    num_depth = depth_samps.shape[1]
+    n_proj = len(proj_mats) if use_qc else proj_mats.shape[1]
+    assert n_proj == len(feats), "Different number of images and projection matrices"
+    volume_variance = variance_cost_volume(feats, proj_mats, depth_samps, geo_model, use_qc)
+    prob_volume = F.softmax(cost_reg(volume_variance).squeeze(1), dim=1)
+    depth = depth_regression(prob_volume, depth_values=depth_samps)
+    prob_conf = window4_confidence(prob_volume, num_depth)
+    samp_variance = (depth_samps - depth.unsqueeze(1)) ** 2
+    exp_variance = lamb * torch.sum(samp_variance * prob_volume, dim=1, keepdim=False) ** 0.5
+    return {"depth": depth, "photometric_confidence": prob_conf, "variance": exp_variance}
+
+
+class UCSNet(nn.Module):
+    def __init__(self, geo_model, lamb=1.5, stage_configs=[64, 32, 8], grad_method="detach", base_chs=[8, 8, 8],
+                 feat_ext_ch=8, use_qc=False):
+        super().__init__()
+        assert geo_model in ["rpc", "pinhole"]
+        self.geo_model, self.stage_configs, self.grad_method = geo_model, stage_configs, grad_method
+        self.base_chs, self.lamb, self.num_stage, self.use_qc = base_chs, lamb, len(stage_configs), use_qc
+        self.ds_ratio = {"stage1": 4.0, "stage2": 2.0, "stage3": 1.0}
+        self.feature_extraction = FeatureNet(base_channels=feat_ext_ch, num_stage=self.num_stage)
+        self.cost_regularization = nn.ModuleList([
+            CostRegNet(in_channels=self.feature_extraction.out_channels[i], base_channels=self.base_chs[i])
+            for i in range(self.num_stage)])
+
+    def forward(self, imgs, proj_matrices, depth_values):
+        features = [self.feature_extraction(imgs[:, v]) for v in range(imgs.shape[1])]
+        outputs = {}
+        depth, exp_var = None, None
+        depth_min, depth_max = depth_values[:, 0], depth_values[:, -1]
+        for stage_idx in range(self.num_stage):
+            key = "stage{}".format(stage_idx + 1)
+            feats = [f[key] for f in features]
+            scale = int(self.ds_ratio[key])
+            cur_h, cur_w = imgs.shape[3] // scale, imgs.shape[4] // scale
+            if depth is not None:
+                if self.grad_method == "detach":
+                    cur_depth, exp_var = depth.detach(), exp_var.detach()
+                else:
+                    cur_depth = depth
+                cur_depth = F.interpolate(cur_depth.unsqueeze(1), [cur_h, cur_w], mode="bilinear", align_corners=False)
+                exp_var = F.interpolate(exp_var.unsqueeze(1), [cur_h, cur_w], mode="bilinear", align_corners=False)
+            else:
+                cur_depth = depth_values
+            samples = uncertainty_aware_samples(cur_depth=cur_depth, depth_min=depth_min, depth_max=depth_max,
+                                                exp_var=exp_var, ndepth=self.stage_configs[stage_idx],
+                                                dtype=imgs.dtype, device=imgs.device, shape=[imgs.shape[0], cur_h, cur_w])
+            out = compute_depth(feats, proj_matrices[key], depth_samps=samples,
+                                cost_reg=self.cost_regularization[stage_idx], lamb=self.lamb, geo_model=self.geo_model,
+                                is_training=self.training, use_qc=self.use_qc)
+            depth, exp_var = out["depth"], out["variance"]
+            outputs[key] = out
+        return outputs
