@@ -87,8 +87,8 @@ def cpu_baseline(V, C, D, H, W, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg2_rpc_3view_768x384x64_c32", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -180,7 +180,9 @@ def main():
             "config": {"workload": args.workload, "views": V, "channels": C, "planes_per_gpu": D,
                        "planes_total": D_total, "H": H, "W": W, "depth_values": "per-voxel (B,D,H,W)",
                        "sharding": "height planes, %d per GPU" % D},
-            "roofline": {"bound": "hbm", "kernel": "costvol_fwd_kernel<rpc,%d,%d>" % (V - 1, C),
+            "roofline": {"bound": "hbm", "kernel": "%s<rpc,%d,%d>" % (
+                             "costvol_fwd_kernel" if os.environ.get("SMVS_COSTVOL_KERNEL", "").startswith("di")
+                             else "costvol_dma_kernel", V - 1, C),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_voxel": bpv, "kernel_ms": round(kern_ms, 4)},
