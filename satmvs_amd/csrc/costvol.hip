@@ -593,9 +593,9 @@ void costvol_dma_kernel(const CostVolParams p)
     }
 }
 
-// Kernel choice.  The staged kernel serves the shapes the cascade produces (C = 8/16/32, up to 5
-// views, one channel volume < 4 GiB); everything else, and SMVS_COSTVOL_KERNEL=direct (A/B switch
-// for profiling), takes the direct-gather kernel.  Both produce identical bits.
+// Kernel choice.  The staged kernel serves 2-3 views at C = 16/32 (one channel volume < 4 GiB);
+// everything else, and SMVS_COSTVOL_KERNEL=direct (A/B switch for profiling), takes the direct-gather
+// kernel.  Both produce identical bits.
 enum { K_DIRECT = 0, K_DMA = 2 };
 
 static int kernel_choice()
@@ -609,9 +609,12 @@ template <int GEO, int NSRC>
 static hipError_t launch_ct(CostVolParams p, hipStream_t st)
 {
     const int nd = p.d_end - p.d_begin;
-    if constexpr (NSRC <= 4) {
+    if constexpr (NSRC <= 2) {
+        // Measured on MI355X: the staged kernel wins for 2-3 views at C >= 16; at C = 8
+        // the float64 chain dominates and the direct kernel is 8 % faster; with 4+ sources two staging
+        // buffers no longer fit 3 workgroups per CU and the direct kernel is 2x faster.
         const int kc = kernel_choice();
-        const bool staged_ok = (p.C == 8 || p.C == 16 || p.C == 32) && p.W < 65535 && p.H < 65535 &&
+        const bool staged_ok = (p.C == 16 || p.C == 32) && p.W < 65535 && p.H < 65535 &&
                                (long long)p.D_out * p.H * p.W * 4 < (1ll << 32);
         if (kc != K_DIRECT && staged_ok) {
             p.xt = (p.W + WV_TX - 1) / WV_TX;
@@ -624,7 +627,6 @@ static hipError_t launch_ct(CostVolParams p, hipStream_t st)
             if (nb >= (1ll << 31)) return hipErrorInvalidValue;
             dim3 blk(64 * WV_WAVES), grd((unsigned)nb);
             switch (p.C) {
-            case 8:  hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 8>), grd, blk, 0, st, p); break;
             case 16: hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 16>), grd, blk, 0, st, p); break;
             default: hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 32>), grd, blk, 0, st, p); break;
             }

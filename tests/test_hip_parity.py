@@ -152,6 +152,9 @@ def test_costvol_golden(dev, golden):
     dict(B=1, V=2, C=10, D=9, H=17, W=130, jitter=False),      # generic channel count, (B,D) heights
     dict(B=1, V=8, C=8, D=3, H=8, W=64, jitter=True),          # maximum view count
     dict(B=1, V=3, C=8, D=1, H=4, W=3, jitter=True),           # smaller than one tile
+    dict(B=2, V=3, C=16, D=11, H=37, W=70, jitter=True),       # staged kernel: ragged tile, batch 2, odd plane count
+    dict(B=1, V=2, C=32, D=6, H=20, W=40, jitter=False),       # staged kernel: one source, (B,D) heights
+    dict(B=1, V=3, C=16, D=3, H=5, W=9, jitter=True),          # staged kernel: smaller than one wave patch
 ])
 def test_costvol_vs_oracle(dev, oracle, cfg):
     from satmvs_amd.modules import warping
@@ -169,10 +172,11 @@ def test_costvol_pinhole_vs_oracle(dev, oracle):
     _close_f32(got, want)
 
 
-def test_costvol_out_of_image_and_nan(dev, oracle):
+@pytest.mark.parametrize("C", [8, 16])                          # direct kernel / staged kernel
+def test_costvol_out_of_image_and_nan(dev, oracle, C):
     """Large parallax pushes taps off the source image (zero padding); NaN heights must not fault."""
     from satmvs_amd.modules import warping
-    feats, rpc, depth = _inputs(1, 3, 8, 6, 32, 64, seed=5)
+    feats, rpc, depth = _inputs(1, 3, C, 6, 32, 64, seed=5)
     depth[:, 0] = -4000.0
     depth[:, 1] = 6000.0
     depth[0, 2, 3, 5] = np.nan
