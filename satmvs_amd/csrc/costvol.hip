@@ -328,52 +328,72 @@ void costvol_dma_kernel(const CostVolParams p)
         int lo_x[NSRC], hi_x[NSRC], lo_y[NSRC], hi_y[NSRC];
 #pragma unroll
         for (int s = 0; s < NSRC; ++s) { lo_x[s] = lo_y[s] = INT_MAX; hi_x[s] = hi_y[s] = INT_MIN; }
+        // two planes per pass: each RPC coefficient is fetched into SGPRs once for both (cubic4x2)
 #pragma unroll
-        for (int pl = 0; pl < DP; ++pl) {
-            const int d = min(dg + pl, d1 - 1);
-            const float hf = p.depth_is_4d ? p.depth[((size_t)b * p.D + d) * HW + pix]
-                                           : p.depth[(size_t)b * p.D + d];
-            const double h = (double)hf;
+        for (int pq = 0; pq < DP; pq += 2) {
+            float hf[2];
+            double hh[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int d = min(dg + pq + u, d1 - 1);       // tail planes shadow the last one (never stored)
+                hf[u] = p.depth_is_4d ? p.depth[((size_t)b * p.D + d) * HW + pix] : p.depth[(size_t)b * p.D + d];
+                hh[u] = (double)hf[u];
+            }
             const cgeo_t geo_d = launder(geo_b);
-            double lat = 0.0, lon = 0.0;
-            if (GEO == 0 && !(p.ablate & 4)) rpc_photo2obj(geo_d, ref_n, fx, fy, h, lat, lon);
+            double lat[2] = {0.0, 0.0}, lon[2] = {0.0, 0.0};
+            if (GEO == 0 && !(p.ablate & 4))
+                rpc_photo2obj_x2(geo_d, ref_n, fx, fy, hh[0], hh[1], lat[0], lon[0], lat[1], lon[1]);
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) {
-                float gx, gy;
+                float gxs[2], gys[2];
                 if (p.ablate & 4) {
-                    gx = ((float)fx + 0.37f + 0.011f * hf * (float)(s + 1)) / half_wm1 - 1.0f;
-                    gy = ((float)fy + 0.21f) / half_hm1 - 1.0f;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        gxs[u] = ((float)fx + 0.37f + 0.011f * hf[u] * (float)(s + 1)) / half_wm1 - 1.0f;
+                        gys[u] = ((float)fy + 0.21f) / half_hm1 - 1.0f;
+                    }
                 } else if (GEO == 0) {
-                    double samp, line;
-                    rpc_obj2photo(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat, lon, h, samp, line);
-                    gx = (float)samp / half_wm1 - 1.0f;
-                    gy = (float)line / half_hm1 - 1.0f;
+                    double samp[2], line[2];
+                    rpc_obj2photo_x2(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat[0], lon[0], hh[0],
+                                     lat[1], lon[1], hh[1], samp[0], line[0], samp[1], line[1]);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        gxs[u] = (float)samp[u] / half_wm1 - 1.0f;
+                        gys[u] = (float)line[u] / half_hm1 - 1.0f;
+                    }
                 } else {
                     const cgeo_t P = geo_d + s * 16;
-                    const double rx = fma(P[1], fy, P[0] * fx) + P[2];
-                    const double ry = fma(P[5], fy, P[4] * fx) + P[6];
-                    const double rz = fma(P[9], fy, P[8] * fx) + P[10];
-                    const double X = fma(rx, h, P[3]), Y = fma(ry, h, P[7]), Z = fma(rz, h, P[11]);
-                    gx = (float)((X / Z) / ((W - 1) * 0.5) - 1.0);
-                    gy = (float)((Y / Z) / ((H - 1) * 0.5) - 1.0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const double rx = fma(P[1], fy, P[0] * fx) + P[2];
+                        const double ry = fma(P[5], fy, P[4] * fx) + P[6];
+                        const double rz = fma(P[9], fy, P[8] * fx) + P[10];
+                        const double X = fma(rx, hh[u], P[3]), Y = fma(ry, hh[u], P[7]), Z = fma(rz, hh[u], P[11]);
+                        gxs[u] = (float)((X / Z) / ((W - 1) * 0.5) - 1.0);
+                        gys[u] = (float)((Y / Z) / ((H - 1) * 0.5) - 1.0);
+                    }
                 }
-                // same arithmetic as tap_from_grid (ATen unnormalise, floor, weights)
-                const float px = fmaf(gx + 1.0f, (float)W * 0.5f, -0.5f);
-                const float py = fmaf(gy + 1.0f, (float)H * 0.5f, -0.5f);
-                const float xw = floorf(px), yn = floorf(py);
-                const float w = px - xw, e = 1.0f - w, n = py - yn, so = 1.0f - n;
-                const bool ok = (xw >= -1.0f) && (xw <= (float)(W - 1)) && (yn >= -1.0f) && (yn <= (float)(H - 1));
-                // a footprint that misses the image keeps (NaN-propagating) zero weights: it then
-                // contributes what four masked gathers contribute -- 0, or NaN for a NaN coordinate
-                const float okf = ok ? 1.0f : 0.0f;
-                tap[pl][s].wn.x = (so * e) * okf; tap[pl][s].wn.y = (so * w) * okf;
-                tap[pl][s].ws.x = (n * e) * okf;  tap[pl][s].ws.y = (n * w) * okf;
-                const int ix0 = ok ? (int)xw : 0, iy0 = ok ? (int)yn : 0;
-                txy[pl][s] = ((uint32_t)(iy0 + 1) << 16) | (uint32_t)(ix0 + 1);
-                if (ok) okmask |= 1u << (pl * NSRC + s);
-                if (ok && active && pl < np) {
-                    lo_x[s] = min(lo_x[s], ix0); hi_x[s] = max(hi_x[s], ix0);
-                    lo_y[s] = min(lo_y[s], iy0); hi_y[s] = max(hi_y[s], iy0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int pl = pq + u;
+                    // same arithmetic as tap_from_grid (ATen unnormalise, floor, weights)
+                    const float px = fmaf(gxs[u] + 1.0f, (float)W * 0.5f, -0.5f);
+                    const float py = fmaf(gys[u] + 1.0f, (float)H * 0.5f, -0.5f);
+                    const float xw = floorf(px), yn = floorf(py);
+                    const float w = px - xw, e = 1.0f - w, n = py - yn, so = 1.0f - n;
+                    const bool ok = (xw >= -1.0f) && (xw <= (float)(W - 1)) && (yn >= -1.0f) && (yn <= (float)(H - 1));
+                    // a footprint that misses the image keeps (NaN-propagating) zero weights: it then
+                    // contributes what four masked gathers contribute -- 0, or NaN for a NaN coordinate
+                    const float okf = ok ? 1.0f : 0.0f;
+                    tap[pl][s].wn.x = (so * e) * okf; tap[pl][s].wn.y = (so * w) * okf;
+                    tap[pl][s].ws.x = (n * e) * okf;  tap[pl][s].ws.y = (n * w) * okf;
+                    const int ix0 = ok ? (int)xw : 0, iy0 = ok ? (int)yn : 0;
+                    txy[pl][s] = ((uint32_t)(iy0 + 1) << 16) | (uint32_t)(ix0 + 1);
+                    if (ok) okmask |= 1u << (pl * NSRC + s);
+                    if (ok && active && pl < np) {
+                        lo_x[s] = min(lo_x[s], ix0); hi_x[s] = max(hi_x[s], ix0);
+                        lo_y[s] = min(lo_y[s], iy0); hi_y[s] = max(hi_y[s], iy0);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

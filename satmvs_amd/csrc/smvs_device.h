@@ -69,6 +69,36 @@ __device__ __forceinline__ void cubic4(cgeo_t k0, cgeo_t k1, cgeo_t k2, cgeo_t k
     n0 = a0; d0 = a1; n1 = a2; d1 = a3;
 }
 
+// The same four cubics at TWO points at once (two height planes of one pixel): every coefficient is
+// loaded into SGPRs once and feeds eight FMAs instead of four, which halves the scalar-load batches
+// (and their s_waitcnt stalls) per voxel and doubles the independent FMA chains.
+struct Quad { double n0, d0, n1, d1; };
+
+__device__ __forceinline__ void cubic4x2(cgeo_t k0, cgeo_t k1, cgeo_t k2, cgeo_t k3,
+                                         double Pa, double La, double Ha, double Pb, double Lb, double Hb,
+                                         Quad& qa, Quad& qb)
+{
+    double a0 = k0[0], a1 = k1[0], a2 = k2[0], a3 = k3[0];
+    double b0 = a0, b1 = a1, b2 = a2, b3 = a3;
+#define SMVS_ACC2(i, ta, tb)                                                   \
+    { const double c0 = k0[i], c1 = k1[i], c2 = k2[i], c3 = k3[i];             \
+      const double ua = (ta), ub = (tb);                                       \
+      a0 = fma(ua, c0, a0); a1 = fma(ua, c1, a1); a2 = fma(ua, c2, a2); a3 = fma(ua, c3, a3); \
+      b0 = fma(ub, c0, b0); b1 = fma(ub, c1, b1); b2 = fma(ub, c2, b2); b3 = fma(ub, c3, b3); }
+    const double LPa = La * Pa, LHa = La * Ha, PHa = Pa * Ha, LLa = La * La, PPa = Pa * Pa, HHa = Ha * Ha;
+    const double LPb = Lb * Pb, LHb = Lb * Hb, PHb = Pb * Hb, LLb = Lb * Lb, PPb = Pb * Pb, HHb = Hb * Hb;
+    SMVS_ACC2(1, La, Lb)   SMVS_ACC2(2, Pa, Pb)   SMVS_ACC2(3, Ha, Hb)
+    SMVS_ACC2(4, LPa, LPb) SMVS_ACC2(5, LHa, LHb) SMVS_ACC2(6, PHa, PHb)
+    SMVS_ACC2(7, LLa, LLb) SMVS_ACC2(8, PPa, PPb) SMVS_ACC2(9, HHa, HHb)
+    SMVS_ACC2(10, Pa * LHa, Pb * LHb) SMVS_ACC2(11, La * LLa, Lb * LLb) SMVS_ACC2(12, La * PPa, Lb * PPb)
+    SMVS_ACC2(13, La * HHa, Lb * HHb) SMVS_ACC2(14, La * LPa, Lb * LPb) SMVS_ACC2(15, Pa * PPa, Pb * PPb)
+    SMVS_ACC2(16, Pa * HHa, Pb * HHb) SMVS_ACC2(17, La * LHa, Lb * LHb) SMVS_ACC2(18, Pa * PHa, Pb * PHb)
+    SMVS_ACC2(19, Ha * HHa, Hb * HHb)
+#undef SMVS_ACC2
+    qa.n0 = a0; qa.d0 = a1; qa.n1 = a2; qa.d1 = a3;
+    qb.n0 = b0; qb.d0 = b1; qb.n1 = b2; qb.d1 = b3;
+}
+
 // n / d in float64 without the IEEE special-case scaffolding (v_div_scale / v_div_fmas /
 // v_div_fixup): hardware reciprocal seed, two Newton steps, one residual correction.  |d| is a
 // cubic with leading coefficient 1 on normalised arguments, i.e. ~1: no overflow/denormal cases to
@@ -127,6 +157,37 @@ __device__ __forceinline__ void rpc_obj2photo(cgeo_t r, const RpcInv& n,
     cubic4(r + I_SNUM, r + I_SDEN, r + I_LNUM, r + I_LDEN, p, l, h, sn, sd, ln, ld);
     samp = fma(fast_div(sn, sd), r[I_SAMP_SCALE], r[I_SAMP_OFF]);
     line = fma(fast_div(ln, ld), r[I_LINE_SCALE], r[I_LINE_OFF]);
+}
+
+// Two-plane forms (same pixel, heights ha / hb): identical arithmetic per plane.
+__device__ __forceinline__ void rpc_photo2obj_x2(cgeo_t r, const RpcInv& n, double samp, double line,
+                                                 double ha, double hb, double& lat_a, double& lon_a,
+                                                 double& lat_b, double& lon_b)
+{
+    const double s = (samp - r[I_SAMP_OFF]) * n.a;
+    const double l = (line - r[I_LINE_OFF]) * n.b;
+    const double za = (ha - r[I_H_OFF]) * n.h, zb = (hb - r[I_H_OFF]) * n.h;
+    Quad qa, qb;
+    cubic4x2(r + I_LATNUM, r + I_LATDEN, r + I_LONNUM, r + I_LONDEN, s, l, za, s, l, zb, qa, qb);
+    lat_a = fma(fast_div(qa.n0, qa.d0), r[I_LAT_SCALE], r[I_LAT_OFF]);
+    lon_a = fma(fast_div(qa.n1, qa.d1), r[I_LON_SCALE], r[I_LON_OFF]);
+    lat_b = fma(fast_div(qb.n0, qb.d0), r[I_LAT_SCALE], r[I_LAT_OFF]);
+    lon_b = fma(fast_div(qb.n1, qb.d1), r[I_LON_SCALE], r[I_LON_OFF]);
+}
+
+__device__ __forceinline__ void rpc_obj2photo_x2(cgeo_t r, const RpcInv& n,
+                                                 double lat_a, double lon_a, double ha,
+                                                 double lat_b, double lon_b, double hb,
+                                                 double& samp_a, double& line_a, double& samp_b, double& line_b)
+{
+    const double pa = (lat_a - r[I_LAT_OFF]) * n.a, la = (lon_a - r[I_LON_OFF]) * n.b, za = (ha - r[I_H_OFF]) * n.h;
+    const double pb = (lat_b - r[I_LAT_OFF]) * n.a, lb = (lon_b - r[I_LON_OFF]) * n.b, zb = (hb - r[I_H_OFF]) * n.h;
+    Quad qa, qb;
+    cubic4x2(r + I_SNUM, r + I_SDEN, r + I_LNUM, r + I_LDEN, pa, la, za, pb, lb, zb, qa, qb);
+    samp_a = fma(fast_div(qa.n0, qa.d0), r[I_SAMP_SCALE], r[I_SAMP_OFF]);
+    line_a = fma(fast_div(qa.n1, qa.d1), r[I_LINE_SCALE], r[I_LINE_OFF]);
+    samp_b = fma(fast_div(qb.n0, qb.d0), r[I_SAMP_SCALE], r[I_SAMP_OFF]);
+    line_b = fma(fast_div(qb.n1, qb.d1), r[I_LINE_SCALE], r[I_LINE_OFF]);
 }
 
 // ---- raw buffer access -------------------------------------------------------------------------
