@@ -100,13 +100,18 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SMVS_BENCH_BACKEND=gloo + SMVS_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank code path on a box
+    # with a single GPU (all ranks share cuda:0, collectives staged through the host).  Not a measurement.
+    one_device = os.environ.get("SMVS_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)      # "nccl" is RCCL on ROCm
+        dist.init_process_group(os.environ.get("SMVS_BENCH_BACKEND", "nccl"),    # "nccl" is RCCL on ROCm
+                                rank=rank, world_size=world)
 
     from satmvs_amd import _lib
     _lib.load()
