@@ -119,6 +119,27 @@ int smvs_stream_regress_step(const float* reg_plane, const float* depth, int dep
 int smvs_stream_regress_final(const double* exp_sum, const double* depth_img, const double* max_prob,
                               float* out_depth, float* out_conf, size_t n, void* stream);
 
+/* ---- recurrent encoder-decoder regulariser (RED), one height plane per call ----------------------
+ * Replaces slice_RED_Regularization.forward (modules/module.py:672-693) and the loop body of
+ * RED_Regularization.forward (:625-644) incl. ConvGRUCell2 (:6-58).  Hidden sizes 8/16/32/64 as in
+ * the reference (:617-620); C = input (feature) channels.
+ *
+ * smvs_red_pack_weights: params = HOST array of 48 device pointers, the module's parameters in this
+ * order -- for conv_gru1..4: gate_conv.weight, gate_conv.bias, reset_gate_norm.weight, .bias,
+ * update_gate_norm.weight, .bias, output_conv.weight, .bias, output_norm.weight, .bias; then
+ * conv1.conv.weight, conv2.conv.weight, conv3.conv.weight, upconv1.conv.weight, upconv2.conv.weight,
+ * upconv3.conv.weight, upconv2d.weight, upconv2d.bias.  packed: smvs_red_packed_floats(C) floats,
+ * owned by the caller; repack whenever the parameters change.
+ * smvs_red_step_fwd: cost (B,C,H,W) = the variance plane (the network consumes -cost); state1..4
+ * (B,8,H,W) (B,16,H/2,W/2) (B,32,H/4,W/4) (B,64,H/8,W/8) updated in place; reg_out (B,1,H,W);
+ * workspace of smvs_red_workspace_bytes(B,C,H,W) bytes; H, W multiples of 8. */
+size_t smvs_red_packed_floats(int C);
+size_t smvs_red_workspace_bytes(int B, int C, int H, int W);
+int smvs_red_pack_weights(const float* const* params, int C, float* packed, void* stream);
+int smvs_red_step_fwd(const float* packed, const float* cost, float* state1, float* state2, float* state3,
+                      float* state4, float* reg_out, void* workspace, size_t workspace_bytes,
+                      int B, int C, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -456,3 +456,85 @@ ORC_API int orc_num_threads(void)
     return 1;
 #endif
 }
+
+/* ===========================================================================================
+ * RED regulariser primitives (modules/module.py:6-58 ConvGRUCell2, :595-693 RED / slice_RED):
+ * 3x3 convolutions (stride 1/2, pad 1), 3x3 transposed convolutions (stride 1 or 2, pad 1,
+ * output_padding 0/1), GroupNorm(1, C).  torch's float32 accumulation order inside its conv
+ * kernels is unspecified; the oracle accumulates in double and rounds once, so it sits within
+ * float32 round-off of every correct implementation (tolerance stated in the tests: 1e-5).
+ * =========================================================================================== */
+ORC_API void orc_conv2d3x3(const float *in, const float *w, const float *bias, float *out,
+                           int B, int Cin, int Cout, int H, int W, int stride)
+{
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int co = 0; co < Cout; ++co)
+            for (int oy = 0; oy < Ho; ++oy)
+                for (int ox = 0; ox < Wo; ++ox) {
+                    double acc = bias ? (double)bias[co] : 0.0;
+                    for (int ci = 0; ci < Cin; ++ci)
+                        for (int ky = 0; ky < 3; ++ky) {
+                            const int iy = oy * stride - 1 + ky;
+                            if (iy < 0 || iy >= H) continue;
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const int ix = ox * stride - 1 + kx;
+                                if (ix < 0 || ix >= W) continue;
+                                acc += (double)in[(((size_t)b * Cin + ci) * H + iy) * W + ix] *
+                                       (double)w[(((size_t)co * Cin + ci) * 3 + ky) * 3 + kx];
+                            }
+                        }
+                    out[(((size_t)b * Cout + co) * Ho + oy) * Wo + ox] = (float)acc;
+                }
+}
+
+/* nn.ConvTranspose2d(k=3, pad=1): weight (Cin, Cout, 3, 3); out size (H-1)*stride - 2 + 3 + out_pad */
+ORC_API void orc_convT2d3x3(const float *in, const float *w, const float *bias, float *out,
+                            int B, int Cin, int Cout, int H, int W, int stride, int out_pad)
+{
+    const int Ho = (H - 1) * stride - 2 + 3 + out_pad, Wo = (W - 1) * stride - 2 + 3 + out_pad;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int co = 0; co < Cout; ++co)
+            for (int oy = 0; oy < Ho; ++oy)
+                for (int ox = 0; ox < Wo; ++ox) {
+                    double acc = bias ? (double)bias[co] : 0.0;
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int ty = oy + 1 - ky;                 /* = iy * stride */
+                        if (ty < 0 || ty % stride) continue;
+                        const int iy = ty / stride;
+                        if (iy >= H) continue;
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int tx = ox + 1 - kx;
+                            if (tx < 0 || tx % stride) continue;
+                            const int ix = tx / stride;
+                            if (ix >= W) continue;
+                            for (int ci = 0; ci < Cin; ++ci)
+                                acc += (double)in[(((size_t)b * Cin + ci) * H + iy) * W + ix] *
+                                       (double)w[(((size_t)ci * Cout + co) * 3 + ky) * 3 + kx];
+                        }
+                    }
+                    out[(((size_t)b * Cout + co) * Ho + oy) * Wo + ox] = (float)acc;
+                }
+}
+
+/* nn.GroupNorm(1, C, eps, affine): statistics over (C, H*W) per sample, biased variance. */
+ORC_API void orc_groupnorm1(float *x, const float *gamma, const float *beta, float eps, int B, int C, int HW)
+{
+    for (int b = 0; b < B; ++b) {
+        float *p = x + (size_t)b * C * HW;
+        double s = 0.0, q = 0.0;
+        const size_t n = (size_t)C * HW;
+        for (size_t i = 0; i < n; ++i) { s += p[i]; q += (double)p[i] * p[i]; }
+        const double mean = s / (double)n;
+        double var = q / (double)n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        for (int c = 0; c < C; ++c)
+            for (int i = 0; i < HW; ++i) {
+                const size_t k = (size_t)c * HW + i;
+                p[k] = (float)(((double)p[k] - mean) * rstd * (double)gamma[c] + (double)beta[c]);
+            }
+    }
+}

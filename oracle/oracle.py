@@ -181,3 +181,67 @@ class StreamRegress:
         lib().orc_stream_regress_final(_p(self.exp_sum), _p(self.depth_img), _p(self.max_prob), _p(od), _p(oc),
                                        C.c_size_t(n))
         return od, oc
+
+
+# ---- RED regulariser (modules/module.py:6-58, :595-693) -----------------------------------------------------
+def conv2d3x3(x, w, bias=None, stride=1):
+    x, w = _f32(x), _f32(w)
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = np.empty((B, Cout, Ho, Wo), np.float32)
+    bp = _p(_f32(bias)) if bias is not None else None
+    lib().orc_conv2d3x3(_p(x), _p(w), bp, _p(out), B, Cin, Cout, H, W, stride)
+    return out
+
+
+def convT2d3x3(x, w, bias=None, stride=2, out_pad=1):
+    x, w = _f32(x), _f32(w)
+    B, Cin, H, W = x.shape
+    Cout = w.shape[1]
+    Ho, Wo = (H - 1) * stride + 1 + out_pad, (W - 1) * stride + 1 + out_pad
+    out = np.empty((B, Cout, Ho, Wo), np.float32)
+    bp = _p(_f32(bias)) if bias is not None else None
+    lib().orc_convT2d3x3(_p(x), _p(w), bp, _p(out), B, Cin, Cout, H, W, stride, out_pad)
+    return out
+
+
+def groupnorm1(x, gamma, beta, eps=1e-5):
+    x = np.array(x, dtype=np.float32, order="C", copy=True)
+    B, Cc = x.shape[:2]
+    lib().orc_groupnorm1(_p(x), _p(_f32(gamma)), _p(_f32(beta)), C.c_float(eps), B, Cc, int(np.prod(x.shape[2:])))
+    return x
+
+
+def _sigmoid(x):
+    return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(np.float32)
+
+
+def conv_gru(wt, prefix, x, h):
+    """ConvGRUCell2.forward (module.py:49-58) with weights wt[prefix + ...]."""
+    g = conv2d3x3(np.concatenate([x, h], 1), wt[prefix + "gate_conv.weight"], wt[prefix + "gate_conv.bias"])
+    hc = h.shape[1]
+    r = _sigmoid(groupnorm1(g[:, :hc], wt[prefix + "reset_gate_norm.weight"], wt[prefix + "reset_gate_norm.bias"]))
+    u = _sigmoid(groupnorm1(g[:, hc:], wt[prefix + "update_gate_norm.weight"], wt[prefix + "update_gate_norm.bias"]))
+    o = conv2d3x3(np.concatenate([x, r * h], 1), wt[prefix + "output_conv.weight"], wt[prefix + "output_conv.bias"])
+    y = np.tanh(groupnorm1(o, wt[prefix + "output_norm.weight"], wt[prefix + "output_norm.bias"]).astype(np.float64)).astype(np.float32)
+    return u * h + (1 - u) * y
+
+
+def red_step(wt, cost, states):
+    """slice_RED_Regularization.forward (module.py:672-693): one plane.  wt: name -> array (state_dict)."""
+    relu = lambda a: np.maximum(a, 0)  # noqa: E731
+    neg = -_f32(cost)
+    s1, s2, s3, s4 = (_f32(s) for s in states)
+    e1 = relu(conv2d3x3(neg, wt["conv1.conv.weight"], None, 2))
+    e2 = relu(conv2d3x3(e1, wt["conv2.conv.weight"], None, 2))
+    e3 = relu(conv2d3x3(e2, wt["conv3.conv.weight"], None, 2))
+    s4 = conv_gru(wt, "conv_gru4.", e3, s4)
+    u3 = relu(convT2d3x3(s4, wt["upconv3.conv.weight"], None, 2, 1))
+    s3 = conv_gru(wt, "conv_gru3.", e2, s3)
+    u2 = relu(convT2d3x3(u3 + s3, wt["upconv2.conv.weight"], None, 2, 1))
+    s2 = conv_gru(wt, "conv_gru2.", e1, s2)
+    u1 = relu(convT2d3x3(u2 + s2, wt["upconv1.conv.weight"], None, 2, 1))
+    s1 = conv_gru(wt, "conv_gru1.", neg, s1)
+    out = convT2d3x3(u1 + s1, wt["upconv2d.weight"], wt["upconv2d.bias"], 1, 0)
+    return out, [s1, s2, s3, s4]

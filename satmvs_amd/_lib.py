@@ -30,8 +30,11 @@ _SIGNATURES = {
     "smvs_softmax_regress_fwd": [_vp, _vp, _i, _vp, _vp] + [_i] * 4 + [_vp],
     "smvs_stream_regress_step": [_vp, _vp, _i, _vp, _vp, _vp] + [_i] * 5 + [_vp],
     "smvs_stream_regress_final": [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "smvs_red_pack_weights": [_vp, _i, _vp, _vp],
+    "smvs_red_step_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 4 + [_vp],
 }
-EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["smvs_version", "smvs_last_error"])
+_SIZE_FUNCS = {"smvs_red_packed_floats": [_i], "smvs_red_workspace_bytes": [_i] * 4}
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SIZE_FUNCS) + ["smvs_version", "smvs_last_error"])
 
 _lib = None
 
@@ -54,6 +57,10 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    for name, argtypes in _SIZE_FUNCS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_size_t
     lib.smvs_version.restype = C.c_char_p
     lib.smvs_last_error.restype = C.c_char_p
     _lib = lib

@@ -178,8 +178,64 @@ class _REDCore(nn.Module):
                 torch.zeros((b, 32, h // 4, w // 4), device=device, dtype=dtype),
                 torch.zeros((b, 64, h // 8, w // 8), device=device, dtype=dtype)]
 
+    # -- native plane step ---------------------------------------------------------------------------------
+    _PARAM_ORDER = [g + n for g in ("conv_gru1.", "conv_gru2.", "conv_gru3.", "conv_gru4.")
+                    for n in ("gate_conv.weight", "gate_conv.bias", "reset_gate_norm.weight", "reset_gate_norm.bias",
+                              "update_gate_norm.weight", "update_gate_norm.bias", "output_conv.weight",
+                              "output_conv.bias", "output_norm.weight", "output_norm.bias")] + [
+        "conv1.conv.weight", "conv2.conv.weight", "conv3.conv.weight", "upconv1.conv.weight", "upconv2.conv.weight",
+        "upconv3.conv.weight", "upconv2d.weight", "upconv2d.bias"]
+
+    def _packed_weights(self, device):
+        """Device buffer in the kernel's layout; rebuilt when any parameter changed (optimizer step, load)."""
+        params = dict(self.named_parameters())
+        tensors = [params[n] for n in self._PARAM_ORDER]
+        key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
+        cache = getattr(self, "_packed_cache", None)
+        if cache is None or cache[0] != key:
+            in_ch = params["conv1.conv.weight"].shape[1]
+            lib = _lib.load()
+            packed = torch.empty(lib.smvs_red_packed_floats(in_ch), dtype=torch.float32, device=device)
+            src = [t.detach().to(device=device, dtype=torch.float32).contiguous() for t in tensors]
+            with torch.cuda.device(device):
+                _lib.call("smvs_red_pack_weights", _lib.ptr_array(src), in_ch, _lib.ptr(packed), _lib.current_stream(device))
+            self._packed_cache = (key, packed, in_ch)
+        return self._packed_cache[1], self._packed_cache[2]
+
+    def native_step(self, cost, s1, s2, s3, s4):
+        """One plane through smvs_red_step_fwd (HIP).  States are updated in place and returned."""
+        dev = _lib.require_device(cost, s1, s2, s3, s4)
+        packed, in_ch = self._packed_weights(dev)
+        cost = cost.detach().to(torch.float32).contiguous()
+        b, c, h, w = cost.shape
+        if c != in_ch:
+            raise ValueError("cost has %d channels, regulariser expects %d" % (c, in_ch))
+        states = [s.detach().to(torch.float32).contiguous() for s in (s1, s2, s3, s4)]
+        lib = _lib.load()
+        nbytes = lib.smvs_red_workspace_bytes(b, c, h, w)
+        if nbytes == 0:
+            raise ValueError("plane %dx%d is not a positive multiple of 8" % (h, w))
+        ws = getattr(self, "_workspace", None)
+        if ws is None or ws.numel() < nbytes or ws.device != dev:
+            ws = self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = torch.empty((b, 1, h, w), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("smvs_red_step_fwd", _lib.ptr(packed), _lib.ptr(cost), *[_lib.ptr(s) for s in states],
+                      _lib.ptr(out), _lib.ptr(ws), nbytes, b, c, h, w, _lib.current_stream(dev))
+        return (out, *states)
+
+    def _use_native(self, cost):
+        return (cost.is_cuda and not (torch.is_grad_enabled() and (cost.requires_grad or any(
+            p.requires_grad for p in self.parameters()) and self.training)) and cost.shape[2] % 8 == 0
+            and cost.shape[3] % 8 == 0 and self.base_channels == 8)
+
     def step(self, cost, s1, s2, s3, s4):
-        """One plane: 2-D encoder/decoder with a ConvGRU at each of the 4 scales (module.py:625-644)."""
+        """One plane: 2-D encoder/decoder with a ConvGRU at each of the 4 scales (module.py:625-644).
+
+        Inference (no autograd) on the GPU runs the native kernels; training keeps the differentiable
+        PyTorch composite below (same parameters)."""
+        if self._use_native(cost):
+            return self.native_step(cost, s1, s2, s3, s4)
         neg = -cost
         e1 = self.conv1(neg)
         e2 = self.conv2(e1)

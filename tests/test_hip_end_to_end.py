@@ -75,6 +75,39 @@ def _red_pred_setup(g, dev, cls):
     return reg.to(dev), feats, torch.from_numpy(g["rpc"]).to(dev), torch.from_numpy(g["depth"]).to(dev)
 
 
+def test_red_native_step_matches_reference(dev, golden, oracle):
+    """smvs_red_step_fwd (HIP convolutions, GroupNorm, GRU gating) vs the reference's slice_RED outputs
+    and vs the oracle's RED step, two consecutive planes (state carried).  float32 convolution sums in a
+    different order: tolerance 2e-5 absolute on values of magnitude ~3."""
+    from satmvs_amd.modules.module import slice_RED_Regularization
+    g = golden("red_pred")
+    reg = slice_RED_Regularization(8, 8).eval()
+    reg.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")})
+    reg = reg.to(dev)
+    x = torch.from_numpy(g["slice_x"]).to(dev)
+    B, _, H, W = x.shape
+    st = reg.initial_states(B, H, W, dev)
+    with torch.no_grad():
+        assert reg._use_native(x)
+        r1 = reg(x, *st)
+        out1 = r1[0].clone()
+        r2 = reg(x * 0.5, *r1[1:])
+    np.testing.assert_allclose(out1.cpu().numpy(), g["slice_out1"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(r2[0].cpu().numpy(), g["slice_out2"], rtol=0, atol=2e-5)
+    for i, k in enumerate(["slice_s1", "slice_s2", "slice_s3", "slice_s4"]):
+        np.testing.assert_allclose(r2[1 + i].cpu().numpy(), g[k], rtol=0, atol=2e-5)
+    wt = {k[2:]: g[k] for k in g.files if k.startswith("w.")}
+    zeros = [np.zeros((B, 8, H, W), np.float32), np.zeros((B, 16, H // 2, W // 2), np.float32),
+             np.zeros((B, 32, H // 4, W // 4), np.float32), np.zeros((B, 64, H // 8, W // 8), np.float32)]
+    o1, s1 = oracle.red_step(wt, g["slice_x"], zeros)
+    np.testing.assert_allclose(out1.cpu().numpy(), o1, rtol=0, atol=2e-5)
+    # the differentiable PyTorch composite of the same module agrees too (training path)
+    st2 = reg.initial_states(B, H, W, dev)
+    xg = x.clone().requires_grad_(True)
+    t1 = reg(xg, *st2)
+    np.testing.assert_allclose(t1[0].detach().cpu().numpy(), out1.cpu().numpy(), rtol=0, atol=2e-5)
+
+
 def test_pred_path_matches_reference(dev, golden):
     """compute_depth_when_pred (plane loop, recurrent state, streaming float64 regression)."""
     from satmvs_amd.modules.module import slice_RED_Regularization
