@@ -140,6 +140,19 @@ int smvs_red_step_fwd(const float* packed, const float* cost, float* state1, flo
                       float* state4, float* reg_out, void* workspace, size_t workspace_bytes,
                       int B, int C, int H, int W, void* stream);
 
+/* The plane loop of compute_depth_when_pred (networks/casred.py:191-231) for planes [d_begin,d_end) in
+ * one call: per plane  fused warp+variance of that plane -> RED step -> float64 streaming regression,
+ * enqueued back to back.  acc (3,B,H,W) float64 = [exp_sum, depth_img, max_prob] (zeroed by the caller
+ * before plane 0; finish with smvs_stream_regress_final, or all-reduce it first when planes are sharded
+ * over GPUs).  geo: rpc (B,V,170) for geo_kind 0, composed homographies (B,n_src,4,4) for geo_kind 1.
+ * workspace: smvs_red_pred_workspace_bytes(B,C,H,W) bytes. */
+size_t smvs_red_pred_workspace_bytes(int B, int C, int H, int W);
+int smvs_red_pred_planes(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
+                         const double* geo, const float* depth, int depth_is_4d, const float* packed,
+                         float* state1, float* state2, float* state3, float* state4, double* acc,
+                         void* workspace, size_t workspace_bytes,
+                         int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

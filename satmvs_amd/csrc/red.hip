@@ -493,4 +493,47 @@ SMVS_EXPORT int smvs_red_step_fwd(const float* packed, const float* cost, float*
     return SMVS_OK;
 }
 
+// The whole plane loop of compute_depth_when_pred (networks/casred.py:191-231) for planes [d_begin,d_end)
+// in ONE call: per plane the fused warp+variance build of that plane, the RED step and the float64
+// streaming-regression update are enqueued back to back from C (about 27 launches per plane, no Python
+// or allocator work in between).  acc = (3,B,H,W) float64 [exp_sum, depth_img, max_prob], zeroed by the
+// caller before plane 0; states as in smvs_red_step_fwd.  geo_kind 0: rpc (B,V,170); 1: composed
+// homographies (B,n_src,4,4).
+SMVS_EXPORT size_t smvs_red_pred_workspace_bytes(int B, int C, int H, int W)
+{
+    const size_t r = smvs_red_workspace_bytes(B, C, H, W);
+    if (r == 0) return 0;
+    return r + ((size_t)B * C * H * W + (size_t)B * H * W) * sizeof(float) + 64;
+}
+
+SMVS_EXPORT int smvs_red_pred_planes(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
+                                     const double* geo, const float* depth, int depth_is_4d, const float* packed,
+                                     float* state1, float* state2, float* state3, float* state4, double* acc,
+                                     void* workspace, size_t workspace_bytes,
+                                     int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream)
+{
+    using namespace smvs;
+    if (!acc || !workspace) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (geo_kind != 0 && geo_kind != 1) return fail(SMVS_ERR_ARG, "geo_kind must be 0 (rpc) or 1 (homography)");
+    const size_t need = smvs_red_pred_workspace_bytes(B, C, H, W);
+    if (need == 0) return fail(SMVS_ERR_ARG, "plane %dx%d must be a positive multiple of 8 in both dimensions", H, W);
+    if (workspace_bytes < need) return fail(SMVS_ERR_ARG, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    if (d_begin < 0 || d_end > D || d_begin > d_end) return fail(SMVS_ERR_ARG, "bad plane range [%d,%d) of %d", d_begin, d_end, D);
+    const size_t red_bytes = smvs_red_workspace_bytes(B, C, H, W);
+    float* plane = (float*)((char*)workspace + ((red_bytes + 15) & ~(size_t)15));
+    float* reg = plane + (size_t)B * C * H * W;
+    const size_t n = (size_t)B * H * W;
+    for (int d = d_begin; d < d_end; ++d) {
+        int rc = geo_kind == 0
+            ? smvs_rpc_costvol_fwd(ref_fea, src_fea, n_src, geo, depth, depth_is_4d, plane, B, C, D, H, W, d, d + 1, 1, 0, stream)
+            : smvs_homo_costvol_fwd(ref_fea, src_fea, n_src, geo, depth, depth_is_4d, plane, B, C, D, H, W, d, d + 1, 1, 0, stream);
+        if (rc) return rc;
+        rc = smvs_red_step_fwd(packed, plane, state1, state2, state3, state4, reg, workspace, red_bytes, B, C, H, W, stream);
+        if (rc) return rc;
+        rc = smvs_stream_regress_step(reg, depth, depth_is_4d, acc, acc + n, acc + 2 * n, B, D, H, W, d, stream);
+        if (rc) return rc;
+    }
+    return SMVS_OK;
+}
+
 }  // extern "C"

@@ -16,6 +16,8 @@ reference so that a given torch.manual_seed yields the same initial parameters.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -224,7 +226,40 @@ class _REDCore(nn.Module):
                       _lib.ptr(out), _lib.ptr(ws), nbytes, b, c, h, w, _lib.current_stream(dev))
         return (out, *states)
 
+    def native_pred_planes(self, features, proj_matrices, depth_values, geo_model, use_qc, states, acc_state,
+                           d_begin, d_end):
+        """Planes [d_begin,d_end) of the pred loop in one native call (smvs_red_pred_planes): per plane
+        variance build -> RED step -> float64 regression update.  `states` (list of 4) and `acc_state`
+        ((3,B,H,W) float64) are updated in place."""
+        from .warping import _depth_arg, prepare_geometry
+        ref = features[0]
+        dev = _lib.require_device(ref, acc_state, *states)
+        packed, in_ch = self._packed_weights(dev)
+        feats = [f.detach().to(torch.float32).contiguous() for f in features]
+        b, c, h, w = feats[0].shape
+        if c != in_ch:
+            raise ValueError("features have %d channels, regulariser expects %d" % (c, in_ch))
+        kind, geo = prepare_geometry(features, proj_matrices, geo_model, use_qc)
+        depth, is4d, D = _depth_arg(depth_values, b, h, w)
+        lib = _lib.load()
+        nbytes = lib.smvs_red_pred_workspace_bytes(b, c, h, w)
+        if nbytes == 0:
+            raise ValueError("plane %dx%d is not a positive multiple of 8" % (h, w))
+        ws = getattr(self, "_pred_workspace", None)
+        if ws is None or ws.numel() < nbytes or ws.device != dev:
+            ws = self._pred_workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        for s in states:
+            if s.dtype != torch.float32 or not s.is_contiguous():
+                raise ValueError("states must be contiguous float32")
+        with torch.cuda.device(dev):
+            _lib.call("smvs_red_pred_planes", kind, _lib.ptr(feats[0]), _lib.ptr_array(feats[1:]), len(feats) - 1,
+                      _lib.ptr(geo), _lib.ptr(depth), is4d, _lib.ptr(packed), *[_lib.ptr(s) for s in states],
+                      _lib.ptr(acc_state), _lib.ptr(ws), nbytes, b, c, D, h, w, d_begin, d_end,
+                      _lib.current_stream(dev))
+
     def _use_native(self, cost):
+        if os.environ.get("SMVS_RED_TORCH") == "1":        # A/B switch: force the stock PyTorch composite
+            return False
         return (cost.is_cuda and not (torch.is_grad_enabled() and (cost.requires_grad or any(
             p.requires_grad for p in self.parameters()) and self.training)) and cost.shape[2] % 8 == 0
             and cost.shape[3] % 8 == 0 and self.base_channels == 8)

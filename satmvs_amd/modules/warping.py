@@ -24,7 +24,8 @@ from .. import _lib
 from ..rpc_synth import qc_tensor_to_coeffs  # noqa: F401  (host-side layout helper)
 
 __all__ = ["homo_warping", "rpc_warping", "rpc_warping_enisum", "RPC_Photo2Obj", "RPC_Obj2Photo",
-           "RPC_Photo2Obj_enisum", "RPC_Obj2Photo_enisum", "variance_cost_volume", "qc_dict_to_rpc"]
+           "RPC_Photo2Obj_enisum", "RPC_Obj2Photo_enisum", "variance_cost_volume", "qc_dict_to_rpc",
+           "prepare_geometry"]
 
 
 def _f32c(t):
@@ -226,6 +227,25 @@ class _CostVolFn(torch.autograd.Function):
         return (None, None, None, None, None, None, g_ref, *g_srcs)
 
 
+def prepare_geometry(features, proj_matrices, geo_model="rpc", use_qc=False):
+    """(geo_kind, geo tensor) in the layout the C ABI takes: rpc (B,V,170) f64, or composed homographies
+    (B,V-1,4,4) f64 -- from exactly what the reference networks receive as `proj_matrices`."""
+    B = features[0].shape[0]
+    V = len(features)
+    if geo_model == "rpc":
+        geo = torch.stack([qc_dict_to_rpc(p) for p in proj_matrices], dim=1) if use_qc else proj_matrices
+        geo = _f64c(geo)
+        if tuple(geo.shape) != (B, V, 170):
+            raise ValueError("rpc proj_matrices must be (B,V,170) = %s, got %s" % ((B, V, 170), tuple(geo.shape)))
+        return 0, geo
+    if geo_model == "pinhole":
+        P = _f64c(proj_matrices)
+        if tuple(P.shape) != (B, V, 4, 4):
+            raise ValueError("pinhole proj_matrices must be (B,V,4,4), got %s" % (tuple(P.shape),))
+        return 1, _compose_homography(P[:, 1:].contiguous(), P[:, :1].expand(B, V - 1, 4, 4).contiguous())
+    raise ValueError("geo_model must be 'rpc' or 'pinhole', got %r" % (geo_model,))
+
+
 def variance_cost_volume(features, proj_matrices, depth_values, geo_model="rpc", use_qc=False,
                          d_begin=0, d_end=None):
     """Fused per-channel variance cost volume: (B,C,d_end-d_begin,H,W) float32.
@@ -242,24 +262,5 @@ def variance_cost_volume(features, proj_matrices, depth_values, geo_model="rpc",
     d_end = D if d_end is None else d_end
     if not (0 <= d_begin <= d_end <= D):
         raise ValueError("bad plane range [%d,%d) of %d" % (d_begin, d_end, D))
-    V = len(features)
-    if geo_model == "rpc":
-        if use_qc:
-            geo = torch.stack([qc_dict_to_rpc(p) for p in proj_matrices], dim=1)
-        else:
-            geo = proj_matrices
-        geo = _f64c(geo)
-        if tuple(geo.shape) != (B, V, 170):
-            raise ValueError("rpc proj_matrices must be (B,V,170) = %s, got %s" % ((B, V, 170), tuple(geo.shape)))
-        kind = 0
-    elif geo_model == "pinhole":
-        P = _f64c(proj_matrices)
-        if tuple(P.shape) != (B, V, 4, 4):
-            raise ValueError("pinhole proj_matrices must be (B,V,4,4), got %s" % (tuple(P.shape),))
-        src = P[:, 1:].contiguous()
-        ref = P[:, :1].expand(B, V - 1, 4, 4).contiguous()
-        geo = _compose_homography(src, ref)               # (B,V-1,4,4)
-        kind = 1
-    else:
-        raise ValueError("geo_model must be 'rpc' or 'pinhole', got %r" % (geo_model,))
+    kind, geo = prepare_geometry(features, proj_matrices, geo_model, use_qc)
     return _CostVolFn.apply(kind, geo, depth, is4d, d_begin, d_end, ref_fea, *features[1:])

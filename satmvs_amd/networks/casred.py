@@ -53,10 +53,15 @@ def compute_depth_when_pred(features, proj_matrices, depth_values, num_depth, co
     states = cost_regularization.initial_states(b, h, w, ref.device)
     acc = StreamingRegression(b, h, w, ref.device)
     dv = depth_values.detach().to(torch.float32).contiguous()
-    for d in range(num_depth):
-        plane = variance_cost_volume(features, proj_matrices, dv, geo_model, use_qc, d_begin=d, d_end=d + 1)
-        reg, *states = cost_regularization(plane.squeeze(2), *states)
-        acc.step(reg, dv, d)
+    if hasattr(cost_regularization, "native_pred_planes") and cost_regularization._use_native(ref):
+        # the whole plane loop in one native call: variance plane -> RED step -> regression update
+        cost_regularization.native_pred_planes(features, proj_matrices, dv, geo_model, use_qc, states, acc.state,
+                                               0, num_depth)
+    else:
+        for d in range(num_depth):
+            plane = variance_cost_volume(features, proj_matrices, dv, geo_model, use_qc, d_begin=d, d_end=d + 1)
+            reg, *states = cost_regularization(plane.squeeze(2), *states)
+            acc.step(reg, dv, d)
     depth, confidence = acc.result()
     return {"depth": depth, "photometric_confidence": confidence}
 

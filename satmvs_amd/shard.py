@@ -67,13 +67,16 @@ def sharded_compute_depth_when_pred(features, proj_matrices, depth_values, num_d
             dist.recv(s, src=_global_rank(group, rank - 1), group=group)
     acc = StreamingRegression(b, h, w, ref.device)
     dv = depth_values.detach().to(torch.float32).contiguous()
-    for d in range(lo, hi):
-        plane = variance_cost_volume(features, proj_matrices, dv, geo_model, use_qc, d_begin=d, d_end=d + 1)
-        if recurrent:
-            reg, *states = cost_regularization(plane.squeeze(2), *states)
-        else:
-            reg = cost_regularization(plane.squeeze(2))
-        acc.step(reg, dv, d)
+    if recurrent and hasattr(cost_regularization, "native_pred_planes") and cost_regularization._use_native(ref):
+        cost_regularization.native_pred_planes(features, proj_matrices, dv, geo_model, use_qc, states, acc.state, lo, hi)
+    else:
+        for d in range(lo, hi):
+            plane = variance_cost_volume(features, proj_matrices, dv, geo_model, use_qc, d_begin=d, d_end=d + 1)
+            if recurrent:
+                reg, *states = cost_regularization(plane.squeeze(2), *states)
+            else:
+                reg = cost_regularization(plane.squeeze(2))
+            acc.step(reg, dv, d)
     if recurrent and recurrent_handoff and world > 1 and rank < world - 1:
         for s in states:
             dist.send(s.contiguous(), dst=_global_rank(group, rank + 1), group=group)
