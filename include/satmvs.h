@@ -153,6 +153,21 @@ int smvs_red_pred_planes(int geo_kind, const float* ref_fea, const float* const*
                          void* workspace, size_t workspace_bytes,
                          int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream);
 
+/* ---- 3-D convolutional cost regulariser (CostRegNet), inference form ---------------------------------
+ * Replaces CostRegNet.forward (modules/module.py:546-577; Conv3d :324, Deconv3d :369) for
+ * CascadeMVSNet (networks/casmvs.py) and UCSNet (networks/ucs.py); base_channels = 8.  BatchNorm3d uses
+ * its running statistics (eval mode), folded into a per-channel scale/shift.
+ * smvs_costreg_pack_weights: params = HOST array of 51 device pointers -- for conv0, conv1, conv2, conv3,
+ * conv4, conv5, conv6, conv7, conv9, conv11: conv.weight, bn.weight, bn.bias, bn.running_mean,
+ * bn.running_var; then prob.weight.  packed: smvs_costreg_packed_floats(C) floats owned by the caller.
+ * smvs_costreg_fwd: vol (B,C,D,H,W) variance volume -> out (B,1,D,H,W); D, H, W multiples of 8;
+ * workspace of smvs_costreg_workspace_bytes bytes. */
+size_t smvs_costreg_packed_floats(int C);
+size_t smvs_costreg_workspace_bytes(int B, int C, int D, int H, int W);
+int smvs_costreg_pack_weights(const float* const* params, int C, float* packed, void* stream);
+int smvs_costreg_fwd(const float* packed, const float* vol, float* out, void* workspace, size_t workspace_bytes,
+                     int B, int C, int D, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

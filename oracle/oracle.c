@@ -538,3 +538,69 @@ ORC_API void orc_groupnorm1(float *x, const float *gamma, const float *beta, flo
             }
     }
 }
+
+/* ===========================================================================================
+ * CostRegNet primitives (modules/module.py:324-410 Conv3d/Deconv3d, :546-577 CostRegNet):
+ * 3x3x3 convolutions (stride 1/2, pad 1) and transposed convolutions (stride 2, pad 1,
+ * output_padding 1), accumulated in double (see the RED note above).
+ * =========================================================================================== */
+ORC_API void orc_conv3d3(const float *in, const float *w, float *out,
+                         int B, int Cin, int Cout, int D, int H, int W, int stride)
+{
+    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+#pragma omp parallel for collapse(3) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int co = 0; co < Cout; ++co)
+            for (int od = 0; od < Do; ++od)
+                for (int oy = 0; oy < Ho; ++oy)
+                    for (int ox = 0; ox < Wo; ++ox) {
+                        double acc = 0.0;
+                        for (int ci = 0; ci < Cin; ++ci)
+                            for (int kd = 0; kd < 3; ++kd) {
+                                const int id = od * stride - 1 + kd;
+                                if (id < 0 || id >= D) continue;
+                                for (int ky = 0; ky < 3; ++ky) {
+                                    const int iy = oy * stride - 1 + ky;
+                                    if (iy < 0 || iy >= H) continue;
+                                    for (int kx = 0; kx < 3; ++kx) {
+                                        const int ix = ox * stride - 1 + kx;
+                                        if (ix < 0 || ix >= W) continue;
+                                        acc += (double)in[((((size_t)b * Cin + ci) * D + id) * H + iy) * W + ix] *
+                                               (double)w[((((size_t)co * Cin + ci) * 3 + kd) * 3 + ky) * 3 + kx];
+                                    }
+                                }
+                            }
+                        out[((((size_t)b * Cout + co) * Do + od) * Ho + oy) * Wo + ox] = (float)acc;
+                    }
+}
+
+/* nn.ConvTranspose3d(k=3, stride=2, pad=1, output_padding=1): weight (Cin,Cout,3,3,3), out = 2x */
+ORC_API void orc_convT3d3s2(const float *in, const float *w, float *out,
+                            int B, int Cin, int Cout, int D, int H, int W)
+{
+    const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+#pragma omp parallel for collapse(3) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int co = 0; co < Cout; ++co)
+            for (int od = 0; od < Do; ++od)
+                for (int oy = 0; oy < Ho; ++oy)
+                    for (int ox = 0; ox < Wo; ++ox) {
+                        double acc = 0.0;
+                        for (int kd = 0; kd < 3; ++kd) {
+                            const int td = od + 1 - kd;
+                            if (td < 0 || (td & 1) || td / 2 >= D) continue;
+                            for (int ky = 0; ky < 3; ++ky) {
+                                const int ty = oy + 1 - ky;
+                                if (ty < 0 || (ty & 1) || ty / 2 >= H) continue;
+                                for (int kx = 0; kx < 3; ++kx) {
+                                    const int tx = ox + 1 - kx;
+                                    if (tx < 0 || (tx & 1) || tx / 2 >= W) continue;
+                                    for (int ci = 0; ci < Cin; ++ci)
+                                        acc += (double)in[((((size_t)b * Cin + ci) * D + td / 2) * H + ty / 2) * W + tx / 2] *
+                                               (double)w[((((size_t)ci * Cout + co) * 3 + kd) * 3 + ky) * 3 + kx];
+                                }
+                            }
+                        }
+                        out[((((size_t)b * Cout + co) * Do + od) * Ho + oy) * Wo + ox] = (float)acc;
+                    }
+}

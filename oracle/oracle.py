@@ -245,3 +245,48 @@ def red_step(wt, cost, states):
     s1 = conv_gru(wt, "conv_gru1.", neg, s1)
     out = convT2d3x3(u1 + s1, wt["upconv2d.weight"], wt["upconv2d.bias"], 1, 0)
     return out, [s1, s2, s3, s4]
+
+
+# ---- CostRegNet (modules/module.py:546-577), eval mode ---------------------------------------------------------
+def conv3d3(x, w, stride=1):
+    x, w = _f32(x), _f32(w)
+    B, Cin, D, H, W = x.shape
+    Cout = w.shape[0]
+    out = np.empty((B, Cout, (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1), np.float32)
+    lib().orc_conv3d3(_p(x), _p(w), _p(out), B, Cin, Cout, D, H, W, stride)
+    return out
+
+
+def convT3d3s2(x, w):
+    x, w = _f32(x), _f32(w)
+    B, Cin, D, H, W = x.shape
+    Cout = w.shape[1]
+    out = np.empty((B, Cout, 2 * D, 2 * H, 2 * W), np.float32)
+    lib().orc_convT3d3s2(_p(x), _p(w), _p(out), B, Cin, Cout, D, H, W)
+    return out
+
+
+def _bn_eval(x, wt, prefix, eps=1e-5):
+    shp = (1, -1, 1, 1, 1)
+    g, b = wt[prefix + "weight"].astype(np.float64), wt[prefix + "bias"].astype(np.float64)
+    m, v = wt[prefix + "running_mean"].astype(np.float64), wt[prefix + "running_var"].astype(np.float64)
+    y = (x.astype(np.float64) - m.reshape(shp)) / np.sqrt(v.reshape(shp) + eps) * g.reshape(shp) + b.reshape(shp)
+    return y.astype(np.float32)
+
+
+def costregnet(wt, x):
+    """CostRegNet.forward in eval mode.  wt: name -> array (state_dict incl. BN running stats)."""
+    relu = lambda a: np.maximum(a, 0)  # noqa: E731
+
+    def block(name, t, stride=1, transposed=False):
+        y = convT3d3s2(t, wt[name + ".conv.weight"]) if transposed else conv3d3(t, wt[name + ".conv.weight"], stride)
+        return relu(_bn_eval(y, wt, name + ".bn."))
+
+    c0 = block("conv0", _f32(x))
+    c2 = block("conv2", block("conv1", c0, 2))
+    c4 = block("conv4", block("conv3", c2, 2))
+    t = block("conv6", block("conv5", c4, 2))
+    t = c4 + block("conv7", t, transposed=True)
+    t = c2 + block("conv9", t, transposed=True)
+    t = c0 + block("conv11", t, transposed=True)
+    return conv3d3(t, wt["prob.weight"], 1)

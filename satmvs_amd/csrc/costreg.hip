@@ -1,0 +1,327 @@
+// costreg.hip -- native forward of the 3-D convolutional cost regulariser (eval mode).
+//
+// Replaces CostRegNet.forward (/root/reference/modules/module.py:546-577) with its Conv3d / Deconv3d
+// blocks (:324-410): conv0 (C->8), three [stride-2 conv, conv] pairs to 16/32/64 channels, three stride-2
+// transposed convolutions back with additive skips, and the final 3x3x3 `prob` convolution to one channel;
+// every block conv + BatchNorm3d + ReLU.  Used by CascadeMVSNet (networks/casmvs.py) and UCSNet
+// (networks/ucs.py).  BatchNorm runs in inference form (running statistics folded into a per-channel
+// scale/shift in the epilogue); training (batch statistics, autograd) stays on the PyTorch composite.
+//
+// Round-1 implementation: direct float32 convolutions with the same structure
+// as red.hip -- one lane per output voxel (x fastest), 8 output channels per lane, wave-uniform weights read
+// with scalar loads from a packed buffer [cout/8][cin][27][8], zero padding from the buffer range check,
+// BN scale/shift + ReLU + skip-add fused in the epilogue.  11 launches per volume.  The float32 MFMA
+// implicit-GEMM version of the 32/64-channel levels is the planned next step.
+#include "smvs_device.h"
+#include "smvs_host.h"
+
+namespace smvs {
+
+constexpr int CR_COT = 8;
+constexpr int CR_NL = 11;                    // conv0,1,2,3,4,5,6, conv7,9,11 (transposed), prob
+
+struct CrLayer { int cin, cout, stride, transposed, bn, relu; };
+
+static void cr_layers(int C, CrLayer L[CR_NL])
+{
+    const CrLayer t[CR_NL] = {
+        {C, 8, 1, 0, 1, 1}, {8, 16, 2, 0, 1, 1}, {16, 16, 1, 0, 1, 1}, {16, 32, 2, 0, 1, 1}, {32, 32, 1, 0, 1, 1},
+        {32, 64, 2, 0, 1, 1}, {64, 64, 1, 0, 1, 1}, {64, 32, 2, 1, 1, 1}, {32, 16, 2, 1, 1, 1}, {16, 8, 2, 1, 1, 1},
+        {8, 1, 1, 0, 0, 0}};
+    for (int i = 0; i < CR_NL; ++i) L[i] = t[i];
+}
+
+static inline size_t cr_packed_conv(int cin, int cout) { return (size_t)((cout + CR_COT - 1) / CR_COT) * cin * 27 * CR_COT; }
+
+struct CrLayout { size_t w[CR_NL], scale[CR_NL], shift[CR_NL], total; };
+
+static CrLayout cr_layout(int C)
+{
+    CrLayer L[CR_NL];
+    cr_layers(C, L);
+    CrLayout o{};
+    size_t p = 0;
+    for (int i = 0; i < CR_NL; ++i) {
+        o.w[i] = p; p += cr_packed_conv(L[i].cin, L[i].cout);
+        const int cp = ((L[i].cout + CR_COT - 1) / CR_COT) * CR_COT;
+        o.scale[i] = p; p += cp;
+        o.shift[i] = p; p += cp;
+    }
+    o.total = p;
+    return o;
+}
+
+__global__ void cr_pack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int cin, int cout, int transposed)
+{
+    const int ncog = (cout + CR_COT - 1) / CR_COT;
+    const int n = ncog * cin * 27 * CR_COT;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int j = i % CR_COT, k = (i / CR_COT) % 27, ci = (i / (CR_COT * 27)) % cin, cog = i / (CR_COT * 27 * cin);
+        const int co = cog * CR_COT + j;
+        float v = 0.0f;
+        if (co < cout) v = transposed ? src[((size_t)ci * cout + co) * 27 + k] : src[((size_t)co * cin + ci) * 27 + k];
+        dst[i] = v;
+    }
+}
+
+// BatchNorm3d in inference form: y = x*scale + shift, scale = gamma/sqrt(var+eps), shift = beta - mean*scale
+__global__ void cr_pack_bn_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                                  const float* __restrict__ var, float* __restrict__ scale, float* __restrict__ shift,
+                                  int cout, int cpad, int has_bn)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cpad) return;
+    float s = 1.0f, t = 0.0f;
+    if (has_bn && c < cout) {
+        s = gamma[c] / sqrtf(var[c] + 1e-5f);
+        t = beta[c] - mean[c] * s;
+    }
+    scale[c] = s;
+    shift[c] = t;
+}
+
+struct Conv3Args {
+    const float* in; const float* w; const float* scale; const float* shift;
+    const float* skip;                       // added after BN+ReLU (x = skip + block(x)), or null
+    float* out;
+    int Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, relu;
+};
+
+typedef const float __attribute__((address_space(4))) * cw3_t;
+
+// 3x3x3 correlation, pad 1, stride STRIDE; lane = one output voxel, CR_COT channels.
+template <int STRIDE>
+__global__ __launch_bounds__(256)
+void conv3d_kernel(const Conv3Args a)
+{
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int yz = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int oy = yz % a.Ho, od = yz / a.Ho;
+    const int ncog = (a.Cout + CR_COT - 1) / CR_COT;
+    const int cog = blockIdx.z % ncog, b = blockIdx.z / ncog;
+    const bool active = ox < a.Wo && od < a.Do;
+    const int HWi = a.Hi * a.Wi;
+    const size_t vol_i = (size_t)a.Di * HWi;
+
+    uint32_t off[27];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int id = od * STRIDE - 1 + kd, iy = oy * STRIDE - 1 + ky, ix = ox * STRIDE - 1 + kx;
+                const bool in = active && id >= 0 && id < a.Di && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+                off[(kd * 3 + ky) * 3 + kx] = in ? (uint32_t)((id * a.Hi + iy) * a.Wi + ix) * 4u : SMVS_OOB;
+            }
+    const BufRsrc rs = make_rsrc(a.in + (size_t)b * a.Cin * vol_i, (uint32_t)((size_t)a.Cin * vol_i * 4));
+    float acc[CR_COT];
+#pragma unroll
+    for (int j = 0; j < CR_COT; ++j) acc[j] = 0.0f;
+    const cw3_t wbase = (cw3_t)(uintptr_t)(a.w + (size_t)cog * a.Cin * 27 * CR_COT);
+    for (int ci = 0; ci < a.Cin; ++ci) {
+        const int choff = (int)((size_t)ci * vol_i * 4);
+        const cw3_t wc = wbase + (size_t)ci * 27 * CR_COT;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            float v[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) v[k] = llvm_raw_buffer_load_f32(rs.v, (int)off[kd * 9 + k], choff, 0);
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int j = 0; j < CR_COT; ++j) acc[j] = fmaf(v[k], wc[(kd * 9 + k) * CR_COT + j], acc[j]);
+        }
+    }
+    if (!active) return;
+    const size_t vol_o = (size_t)a.Do * a.Ho * a.Wo;
+    const size_t pos = ((size_t)od * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+    for (int j = 0; j < CR_COT; ++j) {
+        const int co = cog * CR_COT + j;
+        if (co < a.Cout) {
+            float r = fmaf(acc[j], a.scale[co], a.shift[co]);
+            if (a.relu) r = fmaxf(r, 0.0f);
+            const size_t o = ((size_t)b * a.Cout + co) * vol_o + pos;
+            if (a.skip) r = a.skip[o] + r;
+            a.out[o] = r;
+        }
+    }
+}
+
+// ConvTranspose3d(k=3, stride=2, pad=1, output_padding=1): lane = one INPUT voxel (d,y,x) -> the 2x2x2 output
+// block at (2d,2y,2x).  Per dimension an even output takes tap k=1 from input i; an odd output takes k=2 from
+// input i and k=0 from input i+1.
+__global__ __launch_bounds__(256)
+void convT3d_kernel(const Conv3Args a)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int yz = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = yz % a.Hi, d = yz / a.Hi;
+    const int ncog = (a.Cout + CR_COT - 1) / CR_COT;
+    const int cog = blockIdx.z % ncog, b = blockIdx.z / ncog;
+    const bool active = x < a.Wi && d < a.Di;
+    const int HWi = a.Hi * a.Wi;
+    const size_t vol_i = (size_t)a.Di * HWi;
+    uint32_t off[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int dd = d + (q >> 2), yy = y + ((q >> 1) & 1), xx = x + (q & 1);
+        off[q] = (active && dd < a.Di && yy < a.Hi && xx < a.Wi) ? (uint32_t)((dd * a.Hi + yy) * a.Wi + xx) * 4u : SMVS_OOB;
+    }
+    const BufRsrc rs = make_rsrc(a.in + (size_t)b * a.Cin * vol_i, (uint32_t)((size_t)a.Cin * vol_i * 4));
+    float acc[8][CR_COT];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int j = 0; j < CR_COT; ++j) acc[p][j] = 0.0f;
+    const cw3_t wbase = (cw3_t)(uintptr_t)(a.w + (size_t)cog * a.Cin * 27 * CR_COT);
+    for (int ci = 0; ci < a.Cin; ++ci) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = llvm_raw_buffer_load_f32(rs.v, (int)off[q], (int)((size_t)ci * vol_i * 4), 0);
+        const cw3_t wc = wbase + (size_t)ci * 27 * CR_COT;
+        // output parity p = (pd,py,px); per dimension: parity 0 -> (delta 0, k 1); parity 1 -> (delta 0, k 2), (delta 1, k 0)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int pd = p >> 2, py = (p >> 1) & 1, px = p & 1;
+#pragma unroll
+            for (int td = 0; td <= pd; ++td)
+#pragma unroll
+                for (int ty = 0; ty <= py; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx <= px; ++tx) {
+                        const int kd = pd ? (td ? 0 : 2) : 1, ky = py ? (ty ? 0 : 2) : 1, kx = px ? (tx ? 0 : 2) : 1;
+                        const int q = (td << 2) | (ty << 1) | tx;
+                        const int k = (kd * 3 + ky) * 3 + kx;
+#pragma unroll
+                        for (int j = 0; j < CR_COT; ++j) acc[p][j] = fmaf(v[q], wc[k * CR_COT + j], acc[p][j]);
+                    }
+        }
+    }
+    if (!active) return;
+    const size_t vol_o = (size_t)a.Do * a.Ho * a.Wo;
+#pragma unroll
+    for (int j = 0; j < CR_COT; ++j) {
+        const int co = cog * CR_COT + j;
+        if (co < a.Cout) {
+            const float sc = a.scale[co], sh = a.shift[co];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const size_t o = ((size_t)b * a.Cout + co) * vol_o +
+                                 ((size_t)(2 * d + (p >> 2)) * a.Ho + (2 * y + ((p >> 1) & 1))) * a.Wo + (2 * x + (p & 1));
+                float r = fmaf(acc[p][j], sc, sh);
+                if (a.relu) r = fmaxf(r, 0.0f);
+                if (a.skip) r = a.skip[o] + r;
+                a.out[o] = r;
+            }
+        }
+    }
+}
+
+struct CrWorkspace { size_t c0, t1, c2, t3, c4, t5, t6, x7, x9, x11, total; };
+
+static CrWorkspace cr_workspace(int B, int D, int H, int W)
+{
+    CrWorkspace w{};
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };
+    const size_t v1 = (size_t)D * H * W, v2 = v1 / 8, v4 = v1 / 64, v8 = v1 / 512;
+    w.c0 = take(B * 8 * v1);  w.t1 = take(B * 16 * v2); w.c2 = take(B * 16 * v2); w.t3 = take(B * 32 * v4);
+    w.c4 = take(B * 32 * v4); w.t5 = take(B * 64 * v8); w.t6 = take(B * 64 * v8);
+    w.x7 = take(B * 32 * v4); w.x9 = take(B * 16 * v2); w.x11 = take(B * 8 * v1);
+    w.total = o;
+    return w;
+}
+
+}  // namespace smvs
+
+extern "C" {
+
+SMVS_EXPORT size_t smvs_costreg_packed_floats(int C) { return C > 0 ? smvs::cr_layout(C).total : 0; }
+
+SMVS_EXPORT size_t smvs_costreg_workspace_bytes(int B, int C, int D, int H, int W)
+{
+    if (B < 1 || C < 1 || D < 8 || H < 8 || W < 8 || (D % 8) || (H % 8) || (W % 8)) return 0;
+    return smvs::cr_workspace(B, D, H, W).total * sizeof(float);
+}
+
+// params: HOST array of 51 device pointers: for conv0, conv1, conv2, conv3, conv4, conv5, conv6, conv7, conv9,
+// conv11: conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var; then prob.weight.
+SMVS_EXPORT int smvs_costreg_pack_weights(const float* const* params, int C, float* packed, void* stream)
+{
+    using namespace smvs;
+    if (!params || !packed) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (C < 1) return fail(SMVS_ERR_ARG, "non-positive channel count");
+    for (int i = 0; i < 51; ++i)
+        if (!params[i]) return fail(SMVS_ERR_ARG, "null parameter pointer %d", i);
+    CrLayer L[CR_NL];
+    cr_layers(C, L);
+    const CrLayout lay = cr_layout(C);
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < CR_NL; ++i) {
+        const float* const* q = params + (i < 10 ? i * 5 : 50);
+        const int n = (int)cr_packed_conv(L[i].cin, L[i].cout);
+        hipLaunchKernelGGL(cr_pack_conv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, q[0], packed + lay.w[i],
+                           L[i].cin, L[i].cout, L[i].transposed);
+        const int cp = ((L[i].cout + CR_COT - 1) / CR_COT) * CR_COT;
+        hipLaunchKernelGGL(cr_pack_bn_kernel, dim3(1), dim3(64), 0, st, i < 10 ? q[1] : q[0], i < 10 ? q[2] : q[0],
+                           i < 10 ? q[3] : q[0], i < 10 ? q[4] : q[0], packed + lay.scale[i], packed + lay.shift[i],
+                           L[i].cout, cp, L[i].bn);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "costreg_pack_weights launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
+}
+
+// vol (B,C,D,H,W) variance volume -> out (B,1,D,H,W) regularised cost.  D, H, W multiples of 8.
+SMVS_EXPORT int smvs_costreg_fwd(const float* packed, const float* vol, float* out, void* workspace,
+                                 size_t workspace_bytes, int B, int C, int D, int H, int W, void* stream)
+{
+    using namespace smvs;
+    if (!packed || !vol || !out || !workspace) return fail(SMVS_ERR_ARG, "null pointer argument");
+    const size_t need = smvs_costreg_workspace_bytes(B, C, D, H, W);
+    if (need == 0) return fail(SMVS_ERR_ARG, "volume %dx%dx%d must be a positive multiple of 8 in every dimension", D, H, W);
+    if (workspace_bytes < need) return fail(SMVS_ERR_ARG, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    if ((long long)D * H / 4 + 1 > 65535) return fail(SMVS_ERR_ARG, "volume too large for one launch grid");
+    CrLayer L[CR_NL];
+    cr_layers(C, L);
+    const CrLayout lay = cr_layout(C);
+    const CrWorkspace ws = cr_workspace(B, D, H, W);
+    float* f = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const int dims[4][3] = {{D, H, W}, {D / 2, H / 2, W / 2}, {D / 4, H / 4, W / 4}, {D / 8, H / 8, W / 8}};
+    struct Step { int layer; const float* in; float* out; const float* skip; int lin, lout; };
+    const Step steps[CR_NL] = {
+        {0, vol, f + ws.c0, nullptr, 0, 0},        {1, f + ws.c0, f + ws.t1, nullptr, 0, 1},
+        {2, f + ws.t1, f + ws.c2, nullptr, 1, 1},  {3, f + ws.c2, f + ws.t3, nullptr, 1, 2},
+        {4, f + ws.t3, f + ws.c4, nullptr, 2, 2},  {5, f + ws.c4, f + ws.t5, nullptr, 2, 3},
+        {6, f + ws.t5, f + ws.t6, nullptr, 3, 3},  {7, f + ws.t6, f + ws.x7, f + ws.c4, 3, 2},
+        {8, f + ws.x7, f + ws.x9, f + ws.c2, 2, 1}, {9, f + ws.x9, f + ws.x11, f + ws.c0, 1, 0},
+        {10, f + ws.x11, out, nullptr, 0, 0}};
+    for (int i = 0; i < CR_NL; ++i) {
+        const Step& s = steps[i];
+        const CrLayer& l = L[s.layer];
+        if ((long long)l.cin * dims[s.lin][0] * dims[s.lin][1] * dims[s.lin][2] * 4 >= (1ll << 32))
+            return fail(SMVS_ERR_ARG, "layer %d input larger than 4 GiB per batch item", i);
+        Conv3Args a{};
+        a.in = s.in; a.w = packed + lay.w[s.layer]; a.scale = packed + lay.scale[s.layer]; a.shift = packed + lay.shift[s.layer];
+        a.skip = s.skip; a.out = s.out; a.Cin = l.cin; a.Cout = l.cout; a.relu = l.relu;
+        a.Di = dims[s.lin][0]; a.Hi = dims[s.lin][1]; a.Wi = dims[s.lin][2];
+        a.Do = dims[s.lout][0]; a.Ho = dims[s.lout][1]; a.Wo = dims[s.lout][2];
+        const int ncog = (l.cout + CR_COT - 1) / CR_COT;
+        if (l.transposed) {
+            dim3 grd((a.Wi + 63) / 64, (a.Hi * a.Di + 3) / 4, B * ncog);
+            hipLaunchKernelGGL(convT3d_kernel, grd, dim3(256), 0, st, a);
+        } else {
+            dim3 grd((a.Wo + 63) / 64, (a.Ho * a.Do + 3) / 4, B * ncog);
+            if (l.stride == 1) hipLaunchKernelGGL(conv3d_kernel<1>, grd, dim3(256), 0, st, a);
+            else               hipLaunchKernelGGL(conv3d_kernel<2>, grd, dim3(256), 0, st, a);
+        }
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "costreg_fwd launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
+}
+
+}  // extern "C"

@@ -323,7 +323,57 @@ class CostRegNet(nn.Module):
         self.conv11 = Deconv3d(base_channels * 2, base_channels * 1, stride=2, padding=1, output_padding=1)
         self.prob = nn.Conv3d(base_channels, 1, 3, stride=1, padding=1, bias=False)
 
+    _LAYERS = ["conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11"]
+
+    def _packed_weights(self, device):
+        sd = dict(self.named_parameters())
+        sd.update(dict(self.named_buffers()))
+        names = [l + s for l in self._LAYERS for s in (".conv.weight", ".bn.weight", ".bn.bias", ".bn.running_mean",
+                                                       ".bn.running_var")] + ["prob.weight"]
+        tensors = [sd[n] for n in names]
+        key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
+        cache = getattr(self, "_packed_cache", None)
+        if cache is None or cache[0] != key:
+            in_ch = sd["conv0.conv.weight"].shape[1]
+            lib = _lib.load()
+            packed = torch.empty(lib.smvs_costreg_packed_floats(in_ch), dtype=torch.float32, device=device)
+            src = [t.detach().to(device=device, dtype=torch.float32).contiguous() for t in tensors]
+            with torch.cuda.device(device):
+                _lib.call("smvs_costreg_pack_weights", _lib.ptr_array(src), in_ch, _lib.ptr(packed),
+                          _lib.current_stream(device))
+            self._packed_cache = (key, packed, in_ch)
+        return self._packed_cache[1], self._packed_cache[2]
+
+    def _use_native(self, x):
+        if os.environ.get("SMVS_COSTREG_TORCH") == "1":     # A/B switch: force the stock PyTorch composite
+            return False
+        return (x.is_cuda and not self.training and not (torch.is_grad_enabled() and x.requires_grad)
+                and self.conv0.conv.out_channels == 8 and all(d % 8 == 0 for d in x.shape[2:]))
+
+    def native_forward(self, x):
+        """(B,C,D,H,W) -> (B,1,D,H,W) through smvs_costreg_fwd (HIP, inference-form BatchNorm)."""
+        dev = _lib.require_device(x)
+        packed, in_ch = self._packed_weights(dev)
+        x = x.detach().to(torch.float32).contiguous()
+        b, c, d, h, w = x.shape
+        if c != in_ch:
+            raise ValueError("volume has %d channels, regulariser expects %d" % (c, in_ch))
+        lib = _lib.load()
+        nbytes = lib.smvs_costreg_workspace_bytes(b, c, d, h, w)
+        if nbytes == 0:
+            raise ValueError("volume %s is not a positive multiple of 8 in D, H, W" % (tuple(x.shape),))
+        ws = getattr(self, "_workspace", None)
+        if ws is None or ws.numel() < nbytes or ws.device != dev:
+            ws = self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = torch.empty((b, 1, d, h, w), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("smvs_costreg_fwd", _lib.ptr(packed), _lib.ptr(x), _lib.ptr(out), _lib.ptr(ws), nbytes,
+                      b, c, d, h, w, _lib.current_stream(dev))
+        return out
+
     def forward(self, x):
+        if self._use_native(x):
+            return self.native_forward(x)
         c0 = self.conv0(x)
         c2 = self.conv2(self.conv1(c0))
         c4 = self.conv4(self.conv3(c2))

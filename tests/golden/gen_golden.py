@@ -383,10 +383,28 @@ def gen_cascade():
     save("cascade", **arrays)
 
 
+def gen_costreg():
+    """CostRegNet.forward (modules/module.py:546-577) in eval mode with non-trivial BatchNorm running
+    statistics; weights exported (1.2 MB)."""
+    torch.manual_seed(23)
+    net = ref_module.CostRegNet(8, 8).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.7, 1.3)
+            m.bias.data.normal_(0, 0.1)
+    x = torch.randn(1, 8, 8, 16, 24)
+    with torch.no_grad():
+        y = net(x)
+    arrays = {"w." + k: v for k, v in np_state(net).items() if "num_batches_tracked" not in k}
+    save("costreg", x=x.numpy(), y=y.numpy(), **arrays)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (gen_iccv, gen_project, gen_grid_sample, gen_rpc_warp, gen_qc, gen_homo, gen_costvol, gen_pred,
-               gen_regress, gen_depth_range, gen_cascade):
+               gen_regress, gen_depth_range, gen_cascade, gen_costreg):
         if only and fn.__name__[4:] not in only:
             continue
         fn()

@@ -7,6 +7,8 @@ weights, MIOpen convolutions on the GPU vs torch CPU convolutions differ at floa
 (~1e-6 relative on the regulariser output), which the softmax-weighted mean turns into <=1e-3 m on
 heights of a few hundred metres.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -106,6 +108,30 @@ def test_red_native_step_matches_reference(dev, golden, oracle):
     xg = x.clone().requires_grad_(True)
     t1 = reg(xg, *st2)
     np.testing.assert_allclose(t1[0].detach().cpu().numpy(), out1.cpu().numpy(), rtol=0, atol=2e-5)
+
+
+def test_costreg_native_matches_reference(dev, golden, oracle):
+    """smvs_costreg_fwd (3-D convolutions, folded BatchNorm, skips) vs the reference's CostRegNet output
+    (eval mode, non-trivial running statistics) and vs the oracle."""
+    from satmvs_amd.modules.module import CostRegNet
+    g = golden("costreg")
+    net = CostRegNet(8, 8).eval()
+    net.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}, strict=False)
+    net = net.to(dev)
+    x = torch.from_numpy(g["x"]).to(dev)
+    with torch.no_grad():
+        assert net._use_native(x)
+        y = net(x)
+    np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=0, atol=1e-5)
+    wt = {k[2:]: g[k] for k in g.files if k.startswith("w.")}
+    np.testing.assert_allclose(y.cpu().numpy(), oracle.costregnet(wt, g["x"]), rtol=0, atol=1e-5)
+    os.environ["SMVS_COSTREG_TORCH"] = "1"                 # the PyTorch composite of the same module agrees
+    try:
+        with torch.no_grad():
+            y2 = net(x)
+    finally:
+        del os.environ["SMVS_COSTREG_TORCH"]
+    np.testing.assert_allclose(y2.cpu().numpy(), y.cpu().numpy(), rtol=0, atol=1e-5)
 
 
 def test_pred_path_matches_reference(dev, golden):
