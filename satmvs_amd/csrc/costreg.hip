@@ -10,10 +10,13 @@
 // Round-1 implementation: direct float32 convolutions with the same structure
 // as red.hip -- one lane per output voxel (x fastest), 8 output channels per lane, wave-uniform weights read
 // with scalar loads from a packed buffer [cout/8][cin][27][8], zero padding from the buffer range check,
-// BN scale/shift + ReLU + skip-add fused in the epilogue.  11 launches per volume.  The float32 MFMA
-// implicit-GEMM version of the 32/64-channel levels is the planned next step.
+// BN scale/shift + ReLU + skip-add fused in the epilogue.  11 launches per volume.  The stride-1/2 convolutions
+// with >= 32 output channels (conv3..conv6) run on the float32 MFMA implicit-GEMM kernel of mfma_conv.h.
+#include <stdlib.h>
+
 #include "smvs_device.h"
 #include "smvs_host.h"
+#include "mfma_conv.h"
 
 namespace smvs {
 
@@ -33,7 +36,9 @@ static void cr_layers(int C, CrLayer L[CR_NL])
 
 static inline size_t cr_packed_conv(int cin, int cout) { return (size_t)((cout + CR_COT - 1) / CR_COT) * cin * 27 * CR_COT; }
 
-struct CrLayout { size_t w[CR_NL], scale[CR_NL], shift[CR_NL], total; };
+struct CrLayout { size_t w[CR_NL], scale[CR_NL], shift[CR_NL], wm[CR_NL], total; };   // wm: MFMA-order weights
+
+static bool cr_use_mfma(const CrLayer& l) { return !l.transposed && mfma_conv_ok(l.cin, 0, l.cout); }
 
 static CrLayout cr_layout(int C)
 {
@@ -46,6 +51,8 @@ static CrLayout cr_layout(int C)
         const int cp = ((L[i].cout + CR_COT - 1) / CR_COT) * CR_COT;
         o.scale[i] = p; p += cp;
         o.shift[i] = p; p += cp;
+        o.wm[i] = p;
+        if (cr_use_mfma(L[i])) p += mfma_packed_floats(L[i].cin, L[i].cout, 27);
     }
     o.total = p;
     return o;
@@ -264,6 +271,11 @@ SMVS_EXPORT int smvs_costreg_pack_weights(const float* const* params, int C, flo
         const int n = (int)cr_packed_conv(L[i].cin, L[i].cout);
         hipLaunchKernelGGL(cr_pack_conv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, q[0], packed + lay.w[i],
                            L[i].cin, L[i].cout, L[i].transposed);
+        if (cr_use_mfma(L[i])) {
+            const int nm = (int)mfma_packed_floats(L[i].cin, L[i].cout, 27);
+            hipLaunchKernelGGL(mfma_pack_kernel, dim3((nm + 255) / 256), dim3(256), 0, st, q[0], packed + lay.wm[i],
+                               L[i].cin, L[i].cout, 27);
+        }
         const int cp = ((L[i].cout + CR_COT - 1) / CR_COT) * CR_COT;
         hipLaunchKernelGGL(cr_pack_bn_kernel, dim3(1), dim3(64), 0, st, i < 10 ? q[1] : q[0], i < 10 ? q[2] : q[0],
                            i < 10 ? q[3] : q[0], i < 10 ? q[4] : q[0], packed + lay.scale[i], packed + lay.shift[i],
@@ -288,6 +300,8 @@ SMVS_EXPORT int smvs_costreg_fwd(const float* packed, const float* vol, float* o
     cr_layers(C, L);
     const CrLayout lay = cr_layout(C);
     const CrWorkspace ws = cr_workspace(B, D, H, W);
+    const char* env = getenv("SMVS_CONV_DIRECT");           // A/B switch: direct kernels only
+    const bool direct_only = env && env[0] == '1';
     float* f = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
     const int dims[4][3] = {{D, H, W}, {D / 2, H / 2, W / 2}, {D / 4, H / 4, W / 4}, {D / 8, H / 8, W / 8}};
@@ -310,7 +324,14 @@ SMVS_EXPORT int smvs_costreg_fwd(const float* packed, const float* vol, float* o
         a.Di = dims[s.lin][0]; a.Hi = dims[s.lin][1]; a.Wi = dims[s.lin][2];
         a.Do = dims[s.lout][0]; a.Ho = dims[s.lout][1]; a.Wo = dims[s.lout][2];
         const int ncog = (l.cout + CR_COT - 1) / CR_COT;
-        if (l.transposed) {
+        if (cr_use_mfma(l) && !direct_only) {
+            MfmaConvArgs m{};
+            m.inA = s.in; m.CA = l.cin; m.scaleA = 1.0f; m.w = packed + lay.wm[s.layer];
+            m.scale = a.scale; m.shift = a.shift; m.skip = s.skip; m.out = s.out;
+            m.Cout = l.cout; m.relu = l.relu; m.stride = l.stride;
+            m.Di = a.Di; m.Hi = a.Hi; m.Wi = a.Wi; m.Do = a.Do; m.Ho = a.Ho; m.Wo = a.Wo;
+            mfma_conv_launch<27>(m, B, st);
+        } else if (l.transposed) {
             dim3 grd((a.Wi + 63) / 64, (a.Hi * a.Di + 3) / 4, B * ncog);
             hipLaunchKernelGGL(convT3d_kernel, grd, dim3(256), 0, st, a);
         } else {
