@@ -37,7 +37,7 @@ struct MfmaConvArgs {
 
 // W pack kernel: src (Cout, Cin, TAPS) [conv] -> dst [cip][p][nt][h][32]
 // step p of channel pair cip covers kk = 2p + h in the 2*TAPS-long (ci0 taps..., ci1 taps...) list.
-__global__ void mfma_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int cin, int cout, int taps)
+static __global__ void mfma_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int cin, int cout, int taps)
 {
     const int nt = (cout + 31) / 32;
     const int n = (cin / 2) * taps * nt * 64;

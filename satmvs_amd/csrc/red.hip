@@ -12,9 +12,13 @@
 // pre-packed buffer ([cout/8][cin][tap][8]), inputs through the buffer range check (zero padding for free),
 // concat inputs (x,h) / (x,r*h) read from two tensors without materialising the concatenation, bias / ReLU /
 // GroupNorm statistics (float64 atomics) fused in the epilogue.  24 launches per plane instead of ~60 in
-// the stock PyTorch composite.  MFMA implicit-GEMM tiles for the 64/128-channel levels are the next step.
+// the stock PyTorch composite.  Layers with >= 32 output channels (gates of levels 2-4, candidates of levels
+// 3-4, encoder conv2/conv3) run on the float32 MFMA implicit-GEMM kernel of mfma_conv.h.
+#include <stdlib.h>
+
 #include "smvs_device.h"
 #include "smvs_host.h"
+#include "mfma_conv.h"
 
 namespace smvs {
 
@@ -33,6 +37,7 @@ struct RedLayout {
     size_t gate_w[4], gate_b[4], rn_w[4], rn_b[4], un_w[4], un_b[4], out_w[4], out_b[4], on_w[4], on_b[4];
     size_t up_w[3];                          // upconv1..3 (index i -> upconv{i+1})
     size_t up2d_w, up2d_b;
+    size_t conv_wm[3], gate_wm[4], out_wm[4]; // MFMA-order copies for the layers mfma_conv_ok() accepts
     size_t total;
 };
 
@@ -60,6 +65,12 @@ static RedLayout red_layout(int C)
     for (int i = 0; i < 3; ++i) { L.up_w[i] = o; o += packed_conv_floats(up_in[i], up_out[i]); }
     L.up2d_w = o; o += packed_conv_floats(8, 1);
     L.up2d_b = o; o += 8;
+    for (int i = 0; i < 3; ++i) { L.conv_wm[i] = o; if (mfma_conv_ok(enc_in[i], 0, enc_out[i])) o += mfma_packed_floats(enc_in[i], enc_out[i], 9); }
+    for (int i = 0; i < 4; ++i) {
+        const int hc = HID[i], cx = xin[i];
+        L.gate_wm[i] = o; if (mfma_conv_ok(cx, hc, 2 * hc)) o += mfma_packed_floats(cx + hc, 2 * hc, 9);
+        L.out_wm[i] = o;  if (mfma_conv_ok(cx, hc, hc)) o += mfma_packed_floats(cx + hc, hc, 9);
+    }
     L.total = o;
     return L;
 }
@@ -347,8 +358,24 @@ static RedWorkspace red_workspace(int B, int C, int H, int W)
     return w;
 }
 
-static void launch_conv(int stride, const ConvArgs& a, int B, hipStream_t st)
+static bool g_red_direct_only()
 {
+    const char* e = getenv("SMVS_CONV_DIRECT");             // A/B switch: direct kernels only
+    return e && e[0] == '1';
+}
+
+// `wm` = MFMA-order weights of the same layer (used when the layer qualifies)
+static void launch_conv(int stride, const ConvArgs& a, int B, hipStream_t st, const float* wm = nullptr)
+{
+    if (wm && mfma_conv_ok(a.CA, a.CB, a.Cout) && !g_red_direct_only()) {
+        MfmaConvArgs m{};
+        m.inA = a.inA; m.CA = a.CA; m.inB = a.inB; m.CB = a.CB; m.scaleA = a.scaleA; m.w = wm; m.bias = a.bias;
+        m.out = a.out; m.stats = a.stats; m.ngroups = a.ngroups; m.nslot = NSLOT;
+        m.Cout = a.Cout; m.relu = a.relu; m.stride = stride;
+        m.Di = m.Do = 1; m.Hi = a.Hi; m.Wi = a.Wi; m.Ho = a.Ho; m.Wo = a.Wo;
+        mfma_conv_launch<9>(m, B, st);
+        return;
+    }
     const int ncog = (a.Cout + COT - 1) / COT;
     dim3 grd((a.Wo + 63) / 64, (a.Ho + 3) / 4, B * ncog), blk(256);
     if (stride == 1) hipLaunchKernelGGL(conv3x3_kernel<1>, grd, blk, 0, st, a);
@@ -395,10 +422,16 @@ SMVS_EXPORT int smvs_red_pack_weights(const float* const* params, int C, float* 
     auto copy = [&](const float* src, size_t dst, int n) {
         hipLaunchKernelGGL(copy_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, packed + dst, n);
     };
+    auto packm = [&](const float* src, size_t dst, int cin, int cout) {
+        const int n = (int)mfma_packed_floats(cin, cout, 9);
+        hipLaunchKernelGGL(mfma_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, packed + dst, cin, cout, 9);
+    };
     const int xin[4] = {C, 16, 32, 64};
     for (int g = 0; g < 4; ++g) {
         const float* const* q = params + g * 10;
         const int hc = HID[g], cin = xin[g] + hc;
+        if (mfma_conv_ok(xin[g], hc, 2 * hc)) packm(q[0], L.gate_wm[g], cin, 2 * hc);
+        if (mfma_conv_ok(xin[g], hc, hc)) packm(q[6], L.out_wm[g], cin, hc);
         pack(q[0], L.gate_w[g], cin, 2 * hc, 0);  copy(q[1], L.gate_b[g], 2 * hc);
         copy(q[2], L.rn_w[g], hc);  copy(q[3], L.rn_b[g], hc);
         copy(q[4], L.un_w[g], hc);  copy(q[5], L.un_b[g], hc);
@@ -406,7 +439,10 @@ SMVS_EXPORT int smvs_red_pack_weights(const float* const* params, int C, float* 
         copy(q[8], L.on_w[g], hc);  copy(q[9], L.on_b[g], hc);
     }
     const int enc_in[3] = {C, 16, 32}, enc_out[3] = {16, 32, 64};
-    for (int i = 0; i < 3; ++i) pack(params[40 + i], L.conv_w[i], enc_in[i], enc_out[i], 0);
+    for (int i = 0; i < 3; ++i) {
+        pack(params[40 + i], L.conv_w[i], enc_in[i], enc_out[i], 0);
+        if (mfma_conv_ok(enc_in[i], 0, enc_out[i])) packm(params[40 + i], L.conv_wm[i], enc_in[i], enc_out[i]);
+    }
     const int up_in[3] = {16, 32, 64}, up_out[3] = {8, 16, 32};
     for (int i = 0; i < 3; ++i) pack(params[43 + i], L.up_w[i], up_in[i], up_out[i], 1);
     pack(params[46], L.up2d_w, 8, 1, 2);
@@ -446,7 +482,7 @@ SMVS_EXPORT int smvs_red_step_fwd(const float* packed, const float* cost, float*
         a.inA = i == 0 ? cost : wsf + ws.e[i - 1]; a.CA = enc_in[i]; a.scaleA = i == 0 ? -1.0f : 1.0f;
         a.w = packed + L.conv_w[i]; a.out = wsf + ws.e[i]; a.Cout = enc_out[i];
         a.Hi = hs[i]; a.Wi = wd[i]; a.Ho = hs[i + 1]; a.Wo = wd[i + 1]; a.relu = 1;
-        launch_conv(2, a, B, st);
+        launch_conv(2, a, B, st, packed + L.conv_wm[i]);
     }
     // four GRU levels, coarse to fine, interleaved with the decoder
     for (int g = 3; g >= 0; --g) {
@@ -460,7 +496,7 @@ SMVS_EXPORT int smvs_red_step_fwd(const float* packed, const float* cost, float*
         a.inA = x; a.CA = cx; a.scaleA = sx; a.inB = state[g]; a.CB = hc;
         a.w = packed + L.gate_w[g]; a.bias = packed + L.gate_b[g]; a.out = wsf + ws.gates[g]; a.stats = sg; a.ngroups = 2;
         a.Cout = 2 * hc; a.Hi = a.Ho = hs[g]; a.Wi = a.Wo = wd[g];
-        launch_conv(1, a, B, st);
+        launch_conv(1, a, B, st, packed + L.gate_wm[g]);
         const size_t n = (size_t)hc * hw;                                 // per sample; blockIdx.y = sample
         hipLaunchKernelGGL(gru_gate_apply_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, wsf + ws.gates[g], sg,
                            packed + L.rn_w[g], packed + L.rn_b[g], packed + L.un_w[g], packed + L.un_b[g], state[g],
@@ -469,7 +505,7 @@ SMVS_EXPORT int smvs_red_step_fwd(const float* packed, const float* cost, float*
         o.inA = x; o.CA = cx; o.scaleA = sx; o.inB = wsf + ws.rh[g]; o.CB = hc;
         o.w = packed + L.out_w[g]; o.bias = packed + L.out_b[g]; o.out = wsf + ws.cand[g]; o.stats = so; o.ngroups = 1;
         o.Cout = hc; o.Hi = o.Ho = hs[g]; o.Wi = o.Wo = wd[g];
-        launch_conv(1, o, B, st);
+        launch_conv(1, o, B, st, packed + L.out_wm[g]);
         const bool skip = g < 3;                                          // levels 3,2,1 add the upsampled coarser level
         hipLaunchKernelGGL(gru_combine_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, wsf + ws.cand[g], so,
                            packed + L.on_w[g], packed + L.on_b[g], wsf + ws.gates[g], state[g],
