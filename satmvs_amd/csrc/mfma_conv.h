@@ -50,12 +50,14 @@ static __global__ void mfma_pack_kernel(const float* __restrict__ src, float* __
     }
 }
 
-template <int TAPS, int NT>
-__global__ __launch_bounds__(256)
+// NT = cout tiles per workgroup (blockIdx.y walks the rest), NW = waves splitting K.
+template <int TAPS, int NT, int NW>
+__global__ __launch_bounds__(NW * 64)
 void mfma_conv_kernel(const MfmaConvArgs a)
 {
     constexpr int KD = TAPS == 27 ? 3 : 1;
-    __shared__ float red[3][NT * 16][64];    // partial accumulators of waves 1..3
+    __shared__ float red[NW - 1][NT * 16][64];   // partial accumulators of waves 1..NW-1
+    const int nt_all = (a.Cout + 31) / 32, nt0 = blockIdx.y * NT;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     // tile -> (b, od, oy, x0)
@@ -87,7 +89,7 @@ void mfma_conv_kernel(const MfmaConvArgs a)
     }
     const BufRsrc rA = make_rsrc(a.inA + (size_t)b * a.CA * vol_i, (uint32_t)((size_t)a.CA * vol_i * 4));
     const BufRsrc rB = make_rsrc(a.CB ? a.inB + (size_t)b * a.CB * vol_i : a.inA, (uint32_t)((size_t)a.CB * vol_i * 4));
-    const BufRsrc rW = make_rsrc(a.w, (uint32_t)((size_t)(Cin / 2) * TAPS * NT * 64 * 4));
+    const BufRsrc rW = make_rsrc(a.w, (uint32_t)((size_t)(Cin / 2) * TAPS * nt_all * 64 * 4));
 
     f32x16 acc[NT];
 #pragma unroll
@@ -101,7 +103,7 @@ void mfma_conv_kernel(const MfmaConvArgs a)
     // no occupancy to hide latency with -- the prefetch is what keeps the matrix pipe fed.
     constexpr int BS = (TAPS == 27) ? 9 : 9;               // steps per batch (TAPS is a multiple of 9)
     constexpr int NB = TAPS / BS;                          // batches per channel pair
-    const int ncip = Cin / 2, per = ncip / 4;
+    const int ncip = Cin / 2, per = ncip / NW;
     const int q_end = per * NB;
     struct Batch { float x[BS]; float w[NT][BS]; };
     // explicit variants so that every off[] / register index is a compile-time constant
@@ -117,7 +119,7 @@ void mfma_conv_kernel(const MfmaConvArgs a)
         _Pragma("unroll") for (int s_ = 0; s_ < BS; ++s_) {                                              \
             BT.x[s_] = llvm_raw_buffer_load_f32(rx_, (int)off[(G) * BS + s_], choff_, 0) * sx_;          \
             _Pragma("unroll") for (int n_ = 0; n_ < NT; ++n_)                                            \
-                BT.w[n_][s_] = llvm_raw_buffer_load_f32(rW.v, lane * 4, ((cip_ * TAPS + (G) * BS + s_) * NT + n_) * 256, 0); \
+                BT.w[n_][s_] = llvm_raw_buffer_load_f32(rW.v, lane * 4, ((cip_ * TAPS + (G) * BS + s_) * nt_all + nt0 + n_) * 256, 0); \
         }                                                                                                \
     }
 #define SMVS_MMA_BATCH(BT)                                                                               \
@@ -178,10 +180,12 @@ void mfma_conv_kernel(const MfmaConvArgs a)
     }
     __syncthreads();
     if (wave > 0) return;
+#pragma unroll 1
+    for (int k = 0; k < NW - 1; ++k)         // one partial at a time: 16*NT loads in flight, not 16*NT*(NW-1)
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] += red[0][n * 16 + r][lane] + red[1][n * 16 + r][lane] + red[2][n * 16 + r][lane];
+            for (int r = 0; r < 16; ++r) acc[n][r] += red[k][n * 16 + r][lane];
 
     // D layout of 32x32 MFMA: register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31
     const size_t vol_o = (size_t)a.Do * a.Ho * a.Wo;
@@ -191,7 +195,7 @@ void mfma_conv_kernel(const MfmaConvArgs a)
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = n * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int co = (nt0 + n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (co < a.Cout && pos_ok) {
                 float v = acc[n][r];
                 if (a.bias) v += a.bias[co];
@@ -239,10 +243,19 @@ template <int TAPS>
 inline void mfma_conv_launch(const MfmaConvArgs& a, int B, hipStream_t st)
 {
     const int tiles = ((a.Wo + 31) / 32) * a.Ho * a.Do * B;
-    const int nt = a.Cout / 32;
-    if (nt == 1)      hipLaunchKernelGGL((mfma_conv_kernel<TAPS, 1>), dim3(tiles), dim3(256), 0, st, a);
-    else if (nt == 2) hipLaunchKernelGGL((mfma_conv_kernel<TAPS, 2>), dim3(tiles), dim3(256), 0, st, a);
-    else              hipLaunchKernelGGL((mfma_conv_kernel<TAPS, 4>), dim3(tiles), dim3(256), 0, st, a);
+    const int nt = a.Cout / 32, ncip = (a.CA + a.CB) / 2;
+    // Few tiles (the coarse levels): latency, not throughput, sets the time -- one cout tile per workgroup
+    // and as many K-splitting waves as the channel count divides into.  Many tiles: one workgroup carries
+    // every cout tile so the X operand is loaded once.
+    static const int small = [] { const char* e = getenv("SMVS_MFMA_SMALL"); return e ? atoi(e) : 1024; }();
+    static const int maxw = [] { const char* e = getenv("SMVS_MFMA_WAVES"); return e ? atoi(e) : 8; }();
+    if (tiles < small) {
+        if (ncip % 16 == 0 && maxw >= 16)     hipLaunchKernelGGL((mfma_conv_kernel<TAPS, 1, 16>), dim3(tiles, nt), dim3(1024), 0, st, a);
+        else if (ncip % 8 == 0 && maxw >= 8) hipLaunchKernelGGL((mfma_conv_kernel<TAPS, 1, 8>), dim3(tiles, nt), dim3(512), 0, st, a);
+        else                    hipLaunchKernelGGL((mfma_conv_kernel<TAPS, 1, 4>), dim3(tiles, nt), dim3(256), 0, st, a);
+    } else if (nt == 1) hipLaunchKernelGGL((mfma_conv_kernel<TAPS, 1, 4>), dim3(tiles), dim3(256), 0, st, a);
+    else if (nt == 2)   hipLaunchKernelGGL((mfma_conv_kernel<TAPS, 2, 4>), dim3(tiles), dim3(256), 0, st, a);
+    else                hipLaunchKernelGGL((mfma_conv_kernel<TAPS, 4, 4>), dim3(tiles), dim3(256), 0, st, a);
 }
 
 }  // namespace smvs
