@@ -15,6 +15,7 @@
 // the stock PyTorch composite.  Layers with >= 32 output channels (gates of levels 2-4, candidates of levels
 // 3-4, encoder conv2/conv3) run on the float32 MFMA implicit-GEMM kernel of mfma_conv.h.
 #include <stdlib.h>
+#include <string.h>
 
 #include "smvs_device.h"
 #include "smvs_host.h"
@@ -122,12 +123,19 @@ __device__ __forceinline__ float wave_sum_f(float v)
 }
 
 // STRIDE 1 or 2 correlation with pad 1; lane = one output pixel, COT output channels.
-template <int STRIDE>
+// SPLIT = false: workgroup = 64x4 output pixels, every wave walks all input channels (large planes:
+//   throughput regime).
+// SPLIT = true : workgroup = 64x1 output pixels, its 4 waves split the input channels and reduce through
+//   LDS.  The coarse planes give a few dozen workgroups on a 256-CU part: there the time is one wave's
+//   serial channel loop (a load round trip per channel), so 4x shorter chains = ~3x shorter kernels.
+// Both: the taps of channel c+1 are in flight while channel c is multiplied.
+template <int STRIDE, bool SPLIT>
 __global__ __launch_bounds__(256)
 void conv3x3_kernel(const ConvArgs a)
 {
-    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int oy = (blockIdx.y * 4 + (threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ox = blockIdx.x * 64 + lane;
+    const int oy = SPLIT ? (int)blockIdx.y : (int)blockIdx.y * 4 + wave;
     const int ncog = (a.Cout + COT - 1) / COT;
     const int cog = blockIdx.z % ncog, b = blockIdx.z / ncog;
     const bool active = ox < a.Wo && oy < a.Ho;
@@ -151,25 +159,49 @@ void conv3x3_kernel(const ConvArgs a)
     for (int j = 0; j < COT; ++j) acc[j] = 0.0f;
     const cw_t wbase = (cw_t)(uintptr_t)(a.w + (size_t)cog * Cin * 9 * COT);
 
-    for (int ci = 0; ci < a.CA; ++ci) {
-        float v[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) v[k] = llvm_raw_buffer_load_f32(rA.v, (int)off[k], ci * HWi * 4, 0) * a.scaleA;
-        const cw_t wc = wbase + (size_t)ci * 9 * COT;
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-#pragma unroll
-            for (int j = 0; j < COT; ++j) acc[j] = fmaf(v[k], wc[k * COT + j], acc[j]);
+    const int per = SPLIT ? (Cin + 3) / 4 : Cin;
+    const int c0 = SPLIT ? wave * per : 0, c1 = SPLIT ? min(Cin, c0 + per) : Cin;
+#define SMVS_CONV_LOAD(V, CC)                                                                          \
+    {                                                                                                  \
+        const bool fa_ = (CC) < a.CA;                              /* wave-uniform: scalar selects */ \
+        i32x4 rx_;                                                                                     \
+        rx_.x = fa_ ? rA.v.x : rB.v.x; rx_.y = fa_ ? rA.v.y : rB.v.y;                                  \
+        rx_.z = fa_ ? rA.v.z : rB.v.z; rx_.w = rA.v.w;                                                 \
+        const int co_ = (fa_ ? (CC) : (CC) - a.CA) * HWi * 4;                                          \
+        const float sc_ = fa_ ? a.scaleA : 1.0f;                                                       \
+        _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_) V[k_] = llvm_raw_buffer_load_f32(rx_, (int)off[k_], co_, 0) * sc_; \
     }
-    for (int ci = 0; ci < a.CB; ++ci) {
-        float v[9];
+#define SMVS_CONV_FMA(V, CC)                                                                           \
+    {                                                                                                  \
+        const cw_t wc_ = wbase + (size_t)(CC) * 9 * COT;                                               \
+        _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_)                                               \
+            _Pragma("unroll") for (int j_ = 0; j_ < COT; ++j_) acc[j_] = fmaf(V[k_], wc_[k_ * COT + j_], acc[j_]); \
+    }
+    float v0[9], v1[9];
+    if (c0 < c1) SMVS_CONV_LOAD(v0, c0)
+    for (int cc = c0; cc < c1; cc += 2) {
+        if (cc + 1 < c1) SMVS_CONV_LOAD(v1, cc + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        SMVS_CONV_FMA(v0, cc)
+        __builtin_amdgcn_sched_barrier(0);
+        if (cc + 2 < c1) SMVS_CONV_LOAD(v0, cc + 2)
+        __builtin_amdgcn_sched_barrier(0);
+        if (cc + 1 < c1) SMVS_CONV_FMA(v1, cc + 1)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef SMVS_CONV_LOAD
+#undef SMVS_CONV_FMA
+
+    if (SPLIT) {
+        __shared__ float part[3][COT][64];
+        if (wave > 0) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) v[k] = llvm_raw_buffer_load_f32(rB.v, (int)off[k], ci * HWi * 4, 0);
-        const cw_t wc = wbase + (size_t)(a.CA + ci) * 9 * COT;
+            for (int j = 0; j < COT; ++j) part[wave - 1][j][lane] = acc[j];
+        }
+        __syncthreads();
+        if (wave > 0) return;
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
-#pragma unroll
-            for (int j = 0; j < COT; ++j) acc[j] = fmaf(v[k], wc[k * COT + j], acc[j]);
+        for (int j = 0; j < COT; ++j) acc[j] += part[0][j][lane] + part[1][j][lane] + part[2][j][lane];
     }
 
     float s1 = 0.0f, s2 = 0.0f;
@@ -191,14 +223,18 @@ void conv3x3_kernel(const ConvArgs a)
         __shared__ float red[2][4];
         s1 = wave_sum_f(s1);
         s2 = wave_sum_f(s2);
-        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int grp = (a.ngroups == 2 && cog * COT >= a.Cout / 2) ? 1 : 0;
-            const int slot = (blockIdx.x + blockIdx.y * 7 + cog * 13) % NSLOT;
-            double* st = a.stats + (((size_t)b * a.ngroups + grp) * NSLOT + slot) * 2;
-            atomicAdd(st, (double)red[0][0] + (double)red[0][1] + (double)red[0][2] + (double)red[0][3]);
-            atomicAdd(st + 1, (double)red[1][0] + (double)red[1][1] + (double)red[1][2] + (double)red[1][3]);
+        const int grp = (a.ngroups == 2 && cog * COT >= a.Cout / 2) ? 1 : 0;
+        const int slot = (blockIdx.x + blockIdx.y * 7 + cog * 13) % NSLOT;
+        double* st = a.stats + (((size_t)b * a.ngroups + grp) * NSLOT + slot) * 2;
+        if (SPLIT) {
+            if (lane == 0) { atomicAdd(st, (double)s1); atomicAdd(st + 1, (double)s2); }
+        } else {
+            if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                atomicAdd(st, (double)red[0][0] + (double)red[0][1] + (double)red[0][2] + (double)red[0][3]);
+                atomicAdd(st + 1, (double)red[1][0] + (double)red[1][1] + (double)red[1][2] + (double)red[1][3]);
+            }
         }
     }
 }
@@ -209,11 +245,14 @@ void conv3x3_kernel(const ConvArgs a)
 //   out(2y  ,2x+1) = in(y,x) w[1][2] + in(y,x+1) w[1][0]
 //   out(2y+1,2x  ) = in(y,x) w[2][1] + in(y+1,x) w[0][1]
 //   out(2y+1,2x+1) = in(y,x) w[2][2] + in(y,x+1) w[2][0] + in(y+1,x) w[0][2] + in(y+1,x+1) w[0][0]
+// SPLIT as in conv3x3_kernel (64x1 input positions per workgroup, 4 waves split the input channels).
+template <bool SPLIT>
 __global__ __launch_bounds__(256)
 void convT3x3s2_kernel(const ConvArgs a)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = blockIdx.x * 64 + lane;
+    const int y = SPLIT ? (int)blockIdx.y : (int)blockIdx.y * 4 + wave;
     const int ncog = (a.Cout + COT - 1) / COT;
     const int cog = blockIdx.z % ncog, b = blockIdx.z / ncog;
     const bool active = x < a.Wi && y < a.Hi;
@@ -231,19 +270,56 @@ void convT3x3s2_kernel(const ConvArgs a)
 #pragma unroll
         for (int j = 0; j < COT; ++j) acc[q][j] = 0.0f;
     const cw_t wbase = (cw_t)(uintptr_t)(a.w + (size_t)cog * a.CA * 9 * COT);
-    for (int ci = 0; ci < a.CA; ++ci) {
-        float v[4];
+    const int per = SPLIT ? (a.CA + 3) / 4 : a.CA;
+    const int c0 = SPLIT ? wave * per : 0, c1 = SPLIT ? min(a.CA, c0 + per) : a.CA;
+#define SMVS_CT_LOAD(V, CC) \
+    { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) V[k_] = llvm_raw_buffer_load_f32(rA.v, (int)off[k_], (CC) * HWi * 4, 0); }
+#define SMVS_CT_FMA(V, CC)                                                                             \
+    {                                                                                                  \
+        const cw_t wc = wbase + (size_t)(CC) * 9 * COT;                                                \
+        _Pragma("unroll") for (int j = 0; j < COT; ++j) {                                              \
+            acc[0][j] = fmaf(V[0], wc[4 * COT + j], acc[0][j]);                                        \
+            acc[1][j] = fmaf(V[0], wc[5 * COT + j], fmaf(V[1], wc[3 * COT + j], acc[1][j]));           \
+            acc[2][j] = fmaf(V[0], wc[7 * COT + j], fmaf(V[2], wc[1 * COT + j], acc[2][j]));           \
+            acc[3][j] = fmaf(V[0], wc[8 * COT + j], fmaf(V[1], wc[6 * COT + j],                        \
+                        fmaf(V[2], wc[2 * COT + j], fmaf(V[3], wc[0 * COT + j], acc[3][j]))));         \
+        }                                                                                              \
+    }
+    // three channels of taps in flight ahead of the multiply (4 loads per channel only)
+    float v0[4], v1[4], v2[4];
+    if (c0 < c1) SMVS_CT_LOAD(v0, c0)
+    if (c0 + 1 < c1) SMVS_CT_LOAD(v1, c0 + 1)
+    for (int cc = c0; cc < c1; cc += 3) {
+        if (cc + 2 < c1) SMVS_CT_LOAD(v2, cc + 2)
+        __builtin_amdgcn_sched_barrier(0);
+        SMVS_CT_FMA(v0, cc)
+        __builtin_amdgcn_sched_barrier(0);
+        if (cc + 3 < c1) SMVS_CT_LOAD(v0, cc + 3)
+        __builtin_amdgcn_sched_barrier(0);
+        if (cc + 1 < c1) SMVS_CT_FMA(v1, cc + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (cc + 4 < c1) SMVS_CT_LOAD(v1, cc + 4)
+        __builtin_amdgcn_sched_barrier(0);
+        if (cc + 2 < c1) SMVS_CT_FMA(v2, cc + 2)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef SMVS_CT_LOAD
+#undef SMVS_CT_FMA
+    if (SPLIT) {
+        __shared__ float part[3][4 * COT][64];
+        if (wave > 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = llvm_raw_buffer_load_f32(rA.v, (int)off[k], ci * HWi * 4, 0);
-        const cw_t wc = wbase + (size_t)ci * 9 * COT;
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int j = 0; j < COT; ++j) {
-            acc[0][j] = fmaf(v[0], wc[4 * COT + j], acc[0][j]);
-            acc[1][j] = fmaf(v[0], wc[5 * COT + j], fmaf(v[1], wc[3 * COT + j], acc[1][j]));
-            acc[2][j] = fmaf(v[0], wc[7 * COT + j], fmaf(v[2], wc[1 * COT + j], acc[2][j]));
-            acc[3][j] = fmaf(v[0], wc[8 * COT + j], fmaf(v[1], wc[6 * COT + j],
-                        fmaf(v[2], wc[2 * COT + j], fmaf(v[3], wc[0 * COT + j], acc[3][j]))));
+                for (int j = 0; j < COT; ++j) part[wave - 1][q * COT + j][lane] = acc[q][j];
         }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < COT; ++j)
+                acc[q][j] += part[0][q * COT + j][lane] + part[1][q * COT + j][lane] + part[2][q * COT + j][lane];
     }
     if (!active) return;
     const int HWo = a.Ho * a.Wo;
@@ -290,10 +366,16 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 __global__ __launch_bounds__(256)
 void gru_gate_apply_kernel(float* __restrict__ gates, const double* __restrict__ stats, const float* __restrict__ rn_w,
                            const float* __restrict__ rn_b, const float* __restrict__ un_w, const float* __restrict__ un_b,
-                           const float* __restrict__ h, float* __restrict__ rh, int B, int HC, int HW)
+                           const float* __restrict__ h, float* __restrict__ rh, int B, int HC, int HW,
+                           double* __restrict__ zero_next)
 {
     __shared__ float coef[2][2];
     const int b = blockIdx.y;
+    // the next plane's statistics of this level (other parity buffer) are cleared here: every reader of
+    // that buffer (the previous plane's gate/combine kernels) precedes this kernel on the level's stream,
+    // every writer (the next plane's convolutions) follows it.
+    if (zero_next && blockIdx.x == 0 && b == 0)
+        for (int i = threadIdx.x; i < B * 3 * NSLOT * 2; i += blockDim.x) zero_next[i] = 0.0;
     float mr, sr, mu, su;
     gn_coeffs(stats + ((size_t)b * 2 + 0) * NSLOT * 2, (double)HC * HW, 1e-5f, mr, sr, coef[0]);
     gn_coeffs(stats + ((size_t)b * 2 + 1) * NSLOT * 2, (double)HC * HW, 1e-5f, mu, su, coef[1]);
@@ -331,8 +413,11 @@ void gru_combine_kernel(const float* __restrict__ cand, const double* __restrict
 }
 
 // ---- host orchestration ----------------------------------------------------------------------------------------------
+constexpr int NBUF = 4;                      // planes in flight in the pred pipeline (ring of cross-stream buffers)
 struct RedWorkspace {                        // offsets in floats into the caller's workspace
-    size_t e[3], gates[4], rh[4], cand[4], up[3], sum[3], stats;   // stats: doubles, offset in floats (8-byte aligned)
+    // e / up / stats exist NBUF times: they cross streams, so plane k+1.. may be written while plane k is
+    // still being read (see red_run_planes).  gates / rh / cand / sum live on one stream each.
+    size_t e[NBUF][3], gates[4], rh[4], cand[4], up[NBUF][3], sum[3], stats[NBUF];   // stats: doubles, offset in floats (8-byte aligned)
     size_t total;
 };
 
@@ -343,17 +428,19 @@ static RedWorkspace red_workspace(int B, int C, int H, int W)
     auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };
     const int hs[4] = {H, H / 2, H / 4, H / 8}, ws[4] = {W, W / 2, W / 4, W / 8};
     const int ech[3] = {16, 32, 64};
-    for (int i = 0; i < 3; ++i) w.e[i] = take((size_t)B * ech[i] * hs[i + 1] * ws[i + 1]);
+    for (int p = 0; p < NBUF; ++p)
+        for (int i = 0; i < 3; ++i) w.e[p][i] = take((size_t)B * ech[i] * hs[i + 1] * ws[i + 1]);
     for (int i = 0; i < 4; ++i) {
         w.gates[i] = take((size_t)B * 2 * HID[i] * hs[i] * ws[i]);
         w.rh[i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
         w.cand[i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
     }
-    for (int i = 0; i < 3; ++i) {            // up[i]: output of upconv{i+1} at level i ; sum[i] = up[i] + state{i+1}'
-        w.up[i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
+    for (int i = 0; i < 3; ++i) {            // up[.][i]: output of upconv{i+1} at level i ; sum[i] = up[i] + state{i+1}'
+        for (int p = 0; p < NBUF; ++p) w.up[p][i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
         w.sum[i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
     }
-    w.stats = take((size_t)B * 4 * 3 * NSLOT * 2 * 2);   // 4 GRUs x (reset, update, output) x NSLOT x (sum, sumsq) doubles
+    for (int p = 0; p < NBUF; ++p)
+        w.stats[p] = take((size_t)B * 4 * 3 * NSLOT * 2 * 2);   // 4 GRUs x (reset, update, output) x NSLOT x (sum, sumsq) doubles
     w.total = o;
     return w;
 }
@@ -362,6 +449,12 @@ static bool g_red_direct_only()
 {
     const char* e = getenv("SMVS_CONV_DIRECT");             // A/B switch: direct kernels only
     return e && e[0] == '1';
+}
+
+static int g_split_below()
+{
+    static const int v = [] { const char* e = getenv("SMVS_CONV_SPLIT_BELOW"); return e ? atoi(e) : 1024; }();
+    return v;                                               // workgroups (unsplit) below which the channel-split kernels run
 }
 
 // `wm` = MFMA-order weights of the same layer (used when the layer qualifies)
@@ -377,16 +470,203 @@ static void launch_conv(int stride, const ConvArgs& a, int B, hipStream_t st, co
         return;
     }
     const int ncog = (a.Cout + COT - 1) / COT;
-    dim3 grd((a.Wo + 63) / 64, (a.Ho + 3) / 4, B * ncog), blk(256);
-    if (stride == 1) hipLaunchKernelGGL(conv3x3_kernel<1>, grd, blk, 0, st, a);
-    else             hipLaunchKernelGGL(conv3x3_kernel<2>, grd, blk, 0, st, a);
+    const int wx = (a.Wo + 63) / 64;
+    if (wx * ((a.Ho + 3) / 4) * B * ncog < g_split_below()) {          // coarse plane: latency regime
+        dim3 grd(wx, a.Ho, B * ncog), blk(256);
+        if (stride == 1) hipLaunchKernelGGL((conv3x3_kernel<1, true>), grd, blk, 0, st, a);
+        else             hipLaunchKernelGGL((conv3x3_kernel<2, true>), grd, blk, 0, st, a);
+        return;
+    }
+    dim3 grd(wx, (a.Ho + 3) / 4, B * ncog), blk(256);
+    if (stride == 1) hipLaunchKernelGGL((conv3x3_kernel<1, false>), grd, blk, 0, st, a);
+    else             hipLaunchKernelGGL((conv3x3_kernel<2, false>), grd, blk, 0, st, a);
 }
 
 static void launch_convT(const ConvArgs& a, int B, hipStream_t st)
 {
     const int ncog = (a.Cout + COT - 1) / COT;
-    dim3 grd((a.Wi + 63) / 64, (a.Hi + 3) / 4, B * ncog), blk(256);
-    hipLaunchKernelGGL(convT3x3s2_kernel, grd, blk, 0, st, a);
+    const int wx = (a.Wi + 63) / 64;
+    if (wx * ((a.Hi + 3) / 4) * B * ncog < g_split_below()) {
+        hipLaunchKernelGGL(convT3x3s2_kernel<true>, dim3(wx, a.Hi, B * ncog), dim3(256), 0, st, a);
+        return;
+    }
+    hipLaunchKernelGGL(convT3x3s2_kernel<false>, dim3(wx, (a.Hi + 3) / 4, B * ncog), dim3(256), 0, st, a);
+}
+
+// ---- plane pipeline ------------------------------------------------------------------------------------------
+// The 24 kernels of a plane are small (12..300 workgroups on a 256-CU part) and form a long dependency chain
+// when issued on one stream.  The data flow is wider than that:
+//   * the encoder (and, in the pred loop, the cost-volume plane) does not depend on the recurrent state;
+//   * the four ConvGRU levels only need their encoder level and their own previous state;
+//   * only the decoder chain (combine + upconv, coarse to fine) crosses levels.
+// So the GRU levels run on their own HIP streams (gates, gate apply, candidate, combine, upconv to the next
+// finer level), the caller's stream carries cost volume + encoder, and events carry exactly the edges above.
+// In the pred loop plane k+1's cost volume / encoder / coarse levels run under plane k's fine levels: buffers
+// that cross streams form a ring of NBUF planes and one back-pressure wait per plane keeps plane k off the
+// buffers of plane k-NBUF.  SMVS_RED_STREAMS = 0 (caller's stream only) | 2 (levels {4,3} and {2,1}; default:
+// the host enqueue rate, not the GPU, bounds the loop, and this needs the fewest event edges) | 4 (one per level).
+constexpr int RING = 2 * NBUF;
+struct RedPipe {
+    bool ready = false; int mode = 0;
+    hipStream_t lvl[4];
+    hipEvent_t enc[RING][4], up[RING][3], done[RING];
+};
+
+static RedPipe* red_pipe()
+{
+    static thread_local RedPipe pipes[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    RedPipe& p = pipes[dev];
+    if (p.ready) return &p;
+    const char* e = getenv("SMVS_RED_STREAMS");
+    p.mode = e ? atoi(e) : 2;
+    if (p.mode != 0 && p.mode != 2 && p.mode != 4) p.mode = 2;
+    if (p.mode) {
+        for (int g = 0; g < 4; ++g)
+            if (hipStreamCreateWithFlags(&p.lvl[g], hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (int r = 0; r < RING; ++r) {
+            for (int g = 0; g < 4; ++g)
+                if (hipEventCreateWithFlags(&p.enc[r][g], hipEventDisableTiming) != hipSuccess) return nullptr;
+            for (int g = 0; g < 3; ++g)
+                if (hipEventCreateWithFlags(&p.up[r][g], hipEventDisableTiming) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&p.done[r], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+    }
+    p.ready = true;
+    return &p;
+}
+
+struct RedRun {
+    const float* packed; float* state[4]; float* wsf; int B, C, H, W; hipStream_t main;
+    // single step: the caller's variance plane and output plane
+    const float* cost; float* reg_out;
+    // pred loop (pred = true): cost-volume plane built here, regression accumulators updated here
+    bool pred; int geo_kind; const float* ref_fea; const float* const* src_fea; int n_src; const double* geo;
+    const float* depth; int depth_is_4d; double* acc; int D;
+    float* plane[NBUF]; float* reg;
+};
+
+static int red_run_planes(const RedRun& r, int d_begin, int d_end)
+{
+    RedPipe* pp = red_pipe();
+    if (!pp) return fail(SMVS_ERR_LAUNCH, "could not create the regulariser's streams/events");
+    const RedPipe& P = *pp;
+    // one plane alone: the cross-stream hops cost more than they buy (measured) -> caller's stream only
+    const int mode = d_end - d_begin > 1 ? P.mode : 0;
+    const RedLayout L = red_layout(r.C);
+    const RedWorkspace ws = red_workspace(r.B, r.C, r.H, r.W);
+    const int B = r.B, C = r.C, H = r.H, W = r.W;
+    const float* packed = r.packed;
+    float* wsf = r.wsf;
+    const int hs[4] = {H, H / 2, H / 4, H / 8}, wd[4] = {W, W / 2, W / 4, W / 8};
+    const int enc_in[3] = {C, 16, 32}, enc_out[3] = {16, 32, 64};
+    const size_t npix = (size_t)B * H * W;
+    hipStream_t lv[4];                                      // level -> stream
+    for (int g = 0; g < 4; ++g) lv[g] = mode == 4 ? P.lvl[g] : mode == 2 ? P.lvl[g >> 1] : r.main;
+    const bool multi = mode != 0;
+    const size_t stat_doubles = (size_t)B * 4 * 3 * NSLOT * 2;
+    // the first plane's statistics are cleared here; afterwards each level clears the next plane's buffer itself
+    (void)hipMemsetAsync(wsf + ws.stats[0], 0, stat_doubles * sizeof(double), r.main);
+
+    for (int d = d_begin; d < d_end; ++d) {
+        const int k = d - d_begin, buf = k % NBUF, slot = k % RING;
+        // this ring entry was last used by plane k-NBUF; its finest level finishing implies all of it
+        if (multi && k >= NBUF) (void)hipStreamWaitEvent(r.main, P.done[(k - NBUF) % RING], 0);
+        double* stats = (double*)(wsf + ws.stats[buf]);
+        double* stats_next = d + 1 < d_end ? (double*)(wsf + ws.stats[(k + 1) % NBUF]) : nullptr;
+        const float* cost = r.cost;
+        if (r.pred) {
+            float* pl = r.plane[buf];
+            const int rc = r.geo_kind == 0
+                ? smvs_rpc_costvol_fwd(r.ref_fea, r.src_fea, r.n_src, r.geo, r.depth, r.depth_is_4d, pl, B, C, r.D, H, W, d, d + 1, 1, 0, r.main)
+                : smvs_homo_costvol_fwd(r.ref_fea, r.src_fea, r.n_src, r.geo, r.depth, r.depth_is_4d, pl, B, C, r.D, H, W, d, d + 1, 1, 0, r.main);
+            if (rc) return rc;
+            cost = pl;
+        }
+        // a level's stream waits for the encoder output of the COARSEST level it carries (the finer inputs
+        // are older on the caller's stream); head[g] = that level is the first of its stream
+        bool head[4];
+        for (int g = 0; g < 4; ++g) head[g] = multi && (g == 3 || lv[g + 1] != lv[g]);
+        if (head[0]) (void)hipEventRecord(P.enc[slot][0], r.main);
+        // encoder: e1 = relu(conv1(-cost)), e2 = relu(conv2(e1)), e3 = relu(conv3(e2))
+        for (int i = 0; i < 3; ++i) {
+            ConvArgs a{};
+            a.inA = i == 0 ? cost : wsf + ws.e[buf][i - 1]; a.CA = enc_in[i]; a.scaleA = i == 0 ? -1.0f : 1.0f;
+            a.w = packed + L.conv_w[i]; a.out = wsf + ws.e[buf][i]; a.Cout = enc_out[i];
+            a.Hi = hs[i]; a.Wi = wd[i]; a.Ho = hs[i + 1]; a.Wo = wd[i + 1]; a.relu = 1;
+            launch_conv(2, a, B, r.main, packed + L.conv_wm[i]);
+            if (head[i + 1]) (void)hipEventRecord(P.enc[slot][i + 1], r.main);
+        }
+        // GRU levels coarse to fine.  Per stream: first the state-only part of all its levels (gates, gate
+        // apply, candidate), then the decoder-coupled part (combine with the upsampled coarser level, upconv).
+        for (int ghi = 3; ghi >= 0;) {
+            int glo = ghi;
+            while (glo > 0 && lv[glo - 1] == lv[ghi]) --glo;
+            hipStream_t st = lv[ghi];
+            if (multi) (void)hipStreamWaitEvent(st, P.enc[slot][ghi], 0);
+            for (int g = ghi; g >= glo; --g) {
+                const int hc = HID[g], hw = hs[g] * wd[g];
+                const float* x = g == 0 ? cost : wsf + ws.e[buf][g - 1];
+                const int cx = g == 0 ? C : enc_out[g - 1];
+                const float sx = g == 0 ? -1.0f : 1.0f;
+                double* sg = stats + (size_t)g * B * 3 * NSLOT * 2;       // [b][reset,update][slot][2], then [b][slot][2] for the output norm
+                double* so = sg + (size_t)B * 2 * NSLOT * 2;
+                ConvArgs a{};
+                a.inA = x; a.CA = cx; a.scaleA = sx; a.inB = r.state[g]; a.CB = hc;
+                a.w = packed + L.gate_w[g]; a.bias = packed + L.gate_b[g]; a.out = wsf + ws.gates[g]; a.stats = sg; a.ngroups = 2;
+                a.Cout = 2 * hc; a.Hi = a.Ho = hs[g]; a.Wi = a.Wo = wd[g];
+                launch_conv(1, a, B, st, packed + L.gate_wm[g]);
+                const size_t n = (size_t)hc * hw;                         // per sample; blockIdx.y = sample
+                hipLaunchKernelGGL(gru_gate_apply_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, wsf + ws.gates[g], sg,
+                                   packed + L.rn_w[g], packed + L.rn_b[g], packed + L.un_w[g], packed + L.un_b[g], r.state[g],
+                                   wsf + ws.rh[g], B, hc, hw, stats_next ? stats_next + (size_t)g * B * 3 * NSLOT * 2 : nullptr);
+                ConvArgs o{};
+                o.inA = x; o.CA = cx; o.scaleA = sx; o.inB = wsf + ws.rh[g]; o.CB = hc;
+                o.w = packed + L.out_w[g]; o.bias = packed + L.out_b[g]; o.out = wsf + ws.cand[g]; o.stats = so; o.ngroups = 1;
+                o.Cout = hc; o.Hi = o.Ho = hs[g]; o.Wi = o.Wo = wd[g];
+                launch_conv(1, o, B, st, packed + L.out_wm[g]);
+            }
+            for (int g = ghi; g >= glo; --g) {
+                const int hc = HID[g], hw = hs[g] * wd[g];
+                const size_t n = (size_t)hc * hw;
+                double* so = stats + (size_t)g * B * 3 * NSLOT * 2 + (size_t)B * 2 * NSLOT * 2;
+                const bool skip = g < 3;                                  // levels 3,2,1 add the upsampled coarser level
+                if (multi && skip && lv[g + 1] != st) (void)hipStreamWaitEvent(st, P.up[slot][g], 0);
+                hipLaunchKernelGGL(gru_combine_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, wsf + ws.cand[g], so,
+                                   packed + L.on_w[g], packed + L.on_b[g], wsf + ws.gates[g], r.state[g],
+                                   skip ? wsf + ws.up[buf][g] : nullptr, skip ? wsf + ws.sum[g] : nullptr, B, hc, hw);
+                if (g > 0) {
+                    // decoder: up[g-1] = relu(upconv{g}(state4' or sum[g]))
+                    ConvArgs u{};
+                    u.inA = g == 3 ? r.state[3] : wsf + ws.sum[g]; u.CA = hc; u.scaleA = 1.0f;
+                    u.w = packed + L.up_w[g - 1]; u.out = wsf + ws.up[buf][g - 1]; u.Cout = HID[g - 1];
+                    u.Hi = hs[g]; u.Wi = wd[g]; u.Ho = hs[g - 1]; u.Wo = wd[g - 1]; u.relu = 1;
+                    launch_convT(u, B, st);
+                    if (multi && lv[g - 1] != st) (void)hipEventRecord(P.up[slot][g - 1], st);
+                } else {
+                    // reg = upconv2d(up1 + state1') : ConvTranspose2d stride 1 == correlation with flipped taps
+                    float* reg = r.pred ? r.reg : r.reg_out;
+                    ConvArgs f{};
+                    f.inA = wsf + ws.sum[0]; f.CA = 8; f.scaleA = 1.0f; f.w = packed + L.up2d_w; f.bias = packed + L.up2d_b;
+                    f.out = reg; f.Cout = 1; f.Hi = f.Ho = H; f.Wi = f.Wo = W;
+                    launch_conv(1, f, B, st);
+                    if (r.pred) {
+                        const int rc = smvs_stream_regress_step(reg, r.depth, r.depth_is_4d, r.acc, r.acc + npix, r.acc + 2 * npix,
+                                                                B, r.D, H, W, d, st);
+                        if (rc) return rc;
+                    }
+                    if (multi) (void)hipEventRecord(P.done[slot], st);
+                }
+            }
+            ghi = glo - 1;
+        }
+    }
+    // join: the caller's stream continues only after the last plane's finest level (which implies the rest)
+    if (multi && d_end > d_begin) (void)hipStreamWaitEvent(r.main, P.done[(d_end - d_begin - 1) % RING], 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "red planes launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
 }
 
 }  // namespace smvs
@@ -464,69 +744,14 @@ SMVS_EXPORT int smvs_red_step_fwd(const float* packed, const float* cost, float*
         return fail(SMVS_ERR_ARG, "null pointer argument");
     if (B < 1 || C < 1 || H < 8 || W < 8 || (H % 8) || (W % 8))
         return fail(SMVS_ERR_ARG, "plane %dx%d must be a positive multiple of 8 in both dimensions", H, W);
-    const RedLayout L = red_layout(C);
     const RedWorkspace ws = red_workspace(B, C, H, W);
     if (workspace_bytes < ws.total * sizeof(float)) return fail(SMVS_ERR_ARG, "workspace too small: %zu < %zu bytes", workspace_bytes, ws.total * sizeof(float));
     if ((long long)(C + 8) * H * W * 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "plane too large");
-    hipStream_t st = (hipStream_t)stream;
-    float* wsf = (float*)workspace;
-    double* stats = (double*)(wsf + ws.stats);
-    float* state[4] = {state1, state2, state3, state4};
-    const int hs[4] = {H, H / 2, H / 4, H / 8}, wd[4] = {W, W / 2, W / 4, W / 8};
-    hipMemsetAsync(stats, 0, (size_t)B * 4 * 3 * NSLOT * 2 * sizeof(double), st);
-
-    // encoder: e1 = relu(conv1(-cost)), e2 = relu(conv2(e1)), e3 = relu(conv3(e2))
-    const int enc_in[3] = {C, 16, 32}, enc_out[3] = {16, 32, 64};
-    for (int i = 0; i < 3; ++i) {
-        ConvArgs a{};
-        a.inA = i == 0 ? cost : wsf + ws.e[i - 1]; a.CA = enc_in[i]; a.scaleA = i == 0 ? -1.0f : 1.0f;
-        a.w = packed + L.conv_w[i]; a.out = wsf + ws.e[i]; a.Cout = enc_out[i];
-        a.Hi = hs[i]; a.Wi = wd[i]; a.Ho = hs[i + 1]; a.Wo = wd[i + 1]; a.relu = 1;
-        launch_conv(2, a, B, st, packed + L.conv_wm[i]);
-    }
-    // four GRU levels, coarse to fine, interleaved with the decoder
-    for (int g = 3; g >= 0; --g) {
-        const int hc = HID[g], hw = hs[g] * wd[g];
-        const float* x = g == 0 ? cost : wsf + ws.e[g - 1];
-        const int cx = g == 0 ? C : enc_out[g - 1];
-        const float sx = g == 0 ? -1.0f : 1.0f;
-        double* sg = stats + (size_t)g * B * 3 * NSLOT * 2;               // [b][reset,update][slot][2], then [b][slot][2] for the output norm
-        double* so = sg + (size_t)B * 2 * NSLOT * 2;
-        ConvArgs a{};
-        a.inA = x; a.CA = cx; a.scaleA = sx; a.inB = state[g]; a.CB = hc;
-        a.w = packed + L.gate_w[g]; a.bias = packed + L.gate_b[g]; a.out = wsf + ws.gates[g]; a.stats = sg; a.ngroups = 2;
-        a.Cout = 2 * hc; a.Hi = a.Ho = hs[g]; a.Wi = a.Wo = wd[g];
-        launch_conv(1, a, B, st, packed + L.gate_wm[g]);
-        const size_t n = (size_t)hc * hw;                                 // per sample; blockIdx.y = sample
-        hipLaunchKernelGGL(gru_gate_apply_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, wsf + ws.gates[g], sg,
-                           packed + L.rn_w[g], packed + L.rn_b[g], packed + L.un_w[g], packed + L.un_b[g], state[g],
-                           wsf + ws.rh[g], B, hc, hw);
-        ConvArgs o{};
-        o.inA = x; o.CA = cx; o.scaleA = sx; o.inB = wsf + ws.rh[g]; o.CB = hc;
-        o.w = packed + L.out_w[g]; o.bias = packed + L.out_b[g]; o.out = wsf + ws.cand[g]; o.stats = so; o.ngroups = 1;
-        o.Cout = hc; o.Hi = o.Ho = hs[g]; o.Wi = o.Wo = wd[g];
-        launch_conv(1, o, B, st, packed + L.out_wm[g]);
-        const bool skip = g < 3;                                          // levels 3,2,1 add the upsampled coarser level
-        hipLaunchKernelGGL(gru_combine_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, wsf + ws.cand[g], so,
-                           packed + L.on_w[g], packed + L.on_b[g], wsf + ws.gates[g], state[g],
-                           skip ? wsf + ws.up[g] : nullptr, skip ? wsf + ws.sum[g] : nullptr, B, hc, hw);
-        if (g > 0) {
-            // decoder: up[g-1] = relu(upconv{g}(state4' or sum[g]))
-            ConvArgs u{};
-            u.inA = g == 3 ? state[3] : wsf + ws.sum[g]; u.CA = hc; u.scaleA = 1.0f;
-            u.w = packed + L.up_w[g - 1]; u.out = wsf + ws.up[g - 1]; u.Cout = HID[g - 1];
-            u.Hi = hs[g]; u.Wi = wd[g]; u.Ho = hs[g - 1]; u.Wo = wd[g - 1]; u.relu = 1;
-            launch_convT(u, B, st);
-        }
-    }
-    // reg = upconv2d(up1 + state1') : ConvTranspose2d stride 1 == correlation with flipped taps
-    ConvArgs f{};
-    f.inA = wsf + ws.sum[0]; f.CA = 8; f.scaleA = 1.0f; f.w = packed + L.up2d_w; f.bias = packed + L.up2d_b;
-    f.out = reg_out; f.Cout = 1; f.Hi = f.Ho = H; f.Wi = f.Wo = W;
-    launch_conv(1, f, B, st);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "red_step launch: %s", hipGetErrorString(e));
-    return SMVS_OK;
+    RedRun r{};
+    r.packed = packed; r.state[0] = state1; r.state[1] = state2; r.state[2] = state3; r.state[3] = state4;
+    r.wsf = (float*)workspace; r.B = B; r.C = C; r.H = H; r.W = W; r.main = (hipStream_t)stream;
+    r.cost = cost; r.reg_out = reg_out; r.pred = false;
+    return red_run_planes(r, 0, 1);
 }
 
 // The whole plane loop of compute_depth_when_pred (networks/casred.py:191-231) for planes [d_begin,d_end)
@@ -539,7 +764,7 @@ SMVS_EXPORT size_t smvs_red_pred_workspace_bytes(int B, int C, int H, int W)
 {
     const size_t r = smvs_red_workspace_bytes(B, C, H, W);
     if (r == 0) return 0;
-    return r + ((size_t)B * C * H * W + (size_t)B * H * W) * sizeof(float) + 64;
+    return r + (smvs::NBUF * (size_t)B * C * H * W + (size_t)B * H * W) * sizeof(float) + 64;   // ring of variance planes + reg
 }
 
 SMVS_EXPORT int smvs_red_pred_planes(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
@@ -555,21 +780,18 @@ SMVS_EXPORT int smvs_red_pred_planes(int geo_kind, const float* ref_fea, const f
     if (need == 0) return fail(SMVS_ERR_ARG, "plane %dx%d must be a positive multiple of 8 in both dimensions", H, W);
     if (workspace_bytes < need) return fail(SMVS_ERR_ARG, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
     if (d_begin < 0 || d_end > D || d_begin > d_end) return fail(SMVS_ERR_ARG, "bad plane range [%d,%d) of %d", d_begin, d_end, D);
+    if (!packed || !state1 || !state2 || !state3 || !state4 || !ref_fea || !src_fea || !geo || !depth)
+        return fail(SMVS_ERR_ARG, "null pointer argument");
     const size_t red_bytes = smvs_red_workspace_bytes(B, C, H, W);
-    float* plane = (float*)((char*)workspace + ((red_bytes + 15) & ~(size_t)15));
-    float* reg = plane + (size_t)B * C * H * W;
-    const size_t n = (size_t)B * H * W;
-    for (int d = d_begin; d < d_end; ++d) {
-        int rc = geo_kind == 0
-            ? smvs_rpc_costvol_fwd(ref_fea, src_fea, n_src, geo, depth, depth_is_4d, plane, B, C, D, H, W, d, d + 1, 1, 0, stream)
-            : smvs_homo_costvol_fwd(ref_fea, src_fea, n_src, geo, depth, depth_is_4d, plane, B, C, D, H, W, d, d + 1, 1, 0, stream);
-        if (rc) return rc;
-        rc = smvs_red_step_fwd(packed, plane, state1, state2, state3, state4, reg, workspace, red_bytes, B, C, H, W, stream);
-        if (rc) return rc;
-        rc = smvs_stream_regress_step(reg, depth, depth_is_4d, acc, acc + n, acc + 2 * n, B, D, H, W, d, stream);
-        if (rc) return rc;
-    }
-    return SMVS_OK;
+    RedRun r{};
+    r.packed = packed; r.state[0] = state1; r.state[1] = state2; r.state[2] = state3; r.state[3] = state4;
+    r.wsf = (float*)workspace; r.B = B; r.C = C; r.H = H; r.W = W; r.main = (hipStream_t)stream;
+    r.pred = true; r.geo_kind = geo_kind; r.ref_fea = ref_fea; r.src_fea = src_fea; r.n_src = n_src; r.geo = geo;
+    r.depth = depth; r.depth_is_4d = depth_is_4d; r.acc = acc; r.D = D;
+    r.plane[0] = (float*)((char*)workspace + ((red_bytes + 15) & ~(size_t)15));
+    for (int p = 1; p < NBUF; ++p) r.plane[p] = r.plane[p - 1] + (size_t)B * C * H * W;
+    r.reg = r.plane[NBUF - 1] + (size_t)B * C * H * W;
+    return red_run_planes(r, d_begin, d_end);
 }
 
 }  // extern "C"
