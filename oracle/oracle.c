@@ -489,6 +489,33 @@ ORC_API void orc_conv2d3x3(const float *in, const float *w, const float *bias, f
                 }
 }
 
+/* nn.Conv2d(k=K, stride, padding=K/2) for the feature extractor (modules/module.py:442-543 uses K = 1, 3, 5). */
+ORC_API void orc_conv2d_k(const float *in, const float *w, const float *bias, float *out,
+                          int B, int Cin, int Cout, int H, int W, int K, int stride)
+{
+    const int pad = K / 2;
+    const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int co = 0; co < Cout; ++co)
+            for (int oy = 0; oy < Ho; ++oy)
+                for (int ox = 0; ox < Wo; ++ox) {
+                    double acc = bias ? (double)bias[co] : 0.0;
+                    for (int ci = 0; ci < Cin; ++ci)
+                        for (int ky = 0; ky < K; ++ky) {
+                            const int iy = oy * stride - pad + ky;
+                            if (iy < 0 || iy >= H) continue;
+                            for (int kx = 0; kx < K; ++kx) {
+                                const int ix = ox * stride - pad + kx;
+                                if (ix < 0 || ix >= W) continue;
+                                acc += (double)in[(((size_t)b * Cin + ci) * H + iy) * W + ix] *
+                                       (double)w[(((size_t)co * Cin + ci) * K + ky) * K + kx];
+                            }
+                        }
+                    out[(((size_t)b * Cout + co) * Ho + oy) * Wo + ox] = (float)acc;
+                }
+}
+
 /* nn.ConvTranspose2d(k=3, pad=1): weight (Cin, Cout, 3, 3); out size (H-1)*stride - 2 + 3 + out_pad */
 ORC_API void orc_convT2d3x3(const float *in, const float *w, const float *bias, float *out,
                             int B, int Cin, int Cout, int H, int W, int stride, int out_pad)

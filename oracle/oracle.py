@@ -290,3 +290,45 @@ def costregnet(wt, x):
     t = c2 + block("conv9", t, transposed=True)
     t = c0 + block("conv11", t, transposed=True)
     return conv3d3(t, wt["prob.weight"], 1)
+
+
+# ---- FeatureNet (modules/module.py:442-543), eval mode, arch_mode="unet" ----------------------------------------
+def conv2d_k(x, w, stride=1):
+    x, w = _f32(x), _f32(w)
+    B, Cin, H, W = x.shape
+    Cout, K = w.shape[0], w.shape[2]
+    pad = K // 2
+    out = np.empty((B, Cout, (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1), np.float32)
+    lib().orc_conv2d_k(_p(x), _p(w), None, _p(out), B, Cin, Cout, H, W, K, stride)
+    return out
+
+
+def _bn2d_eval(x, wt, prefix, eps=1e-5):
+    shp = (1, -1, 1, 1)
+    g, b = wt[prefix + "weight"].astype(np.float64), wt[prefix + "bias"].astype(np.float64)
+    m, v = wt[prefix + "running_mean"].astype(np.float64), wt[prefix + "running_var"].astype(np.float64)
+    y = (x.astype(np.float64) - m.reshape(shp)) / np.sqrt(v.reshape(shp) + eps) * g.reshape(shp) + b.reshape(shp)
+    return y.astype(np.float32)
+
+
+def featurenet(wt, img):
+    """FeatureNet.forward (unet, 3 stages) in eval mode.  wt: name -> array (state_dict incl. BN running stats).
+    Returns (stage1, stage2, stage3) = (B,4c,H/4,W/4), (B,2c,H/2,W/2), (B,c,H,W)."""
+    relu = lambda a: np.maximum(a, 0)  # noqa: E731
+
+    def cbr(name, t, stride=1):
+        return relu(_bn2d_eval(conv2d_k(t, wt[name + ".conv.weight"], stride), wt, name + ".bn."))
+
+    def fuse(name, pre, t):
+        up = relu(_bn2d_eval(convT2d3x3(t, wt[name + ".deconv.conv.weight"], None, 2, 1), wt, name + ".deconv.bn."))
+        return cbr(name + ".conv", np.concatenate([up, pre], 1))
+
+    c0 = cbr("conv0.1", cbr("conv0.0", _f32(img)))
+    c1 = cbr("conv1.2", cbr("conv1.1", cbr("conv1.0", c0, 2)))
+    c2 = cbr("conv2.2", cbr("conv2.1", cbr("conv2.0", c1, 2)))
+    s1 = conv2d_k(c2, wt["out1.weight"])
+    f = fuse("deconv1", c1, c2)
+    s2 = conv2d_k(f, wt["out2.weight"])
+    f = fuse("deconv2", c0, f)
+    s3 = conv2d_k(f, wt["out3.weight"])
+    return s1, s2, s3

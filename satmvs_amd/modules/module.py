@@ -424,7 +424,74 @@ class FeatureNet(nn.Module):
                 self.out2 = nn.Conv2d(final, c, 3, padding=1, bias=False)
                 self.out_channels.append(c)
 
+    # ---- native inference path (smvs_featnet_fwd) ---------------------------------------------------------
+    _NATIVE_BLOCKS = ("conv0.0", "conv0.1", "conv1.0", "conv1.1", "conv1.2", "conv2.0", "conv2.1", "conv2.2",
+                      "deconv1.deconv", "deconv1.conv", "deconv2.deconv", "deconv2.conv")
+
+    def _packed_weights(self, device):
+        """Parameters + BatchNorm running statistics repacked for the HIP kernels; cached until any of them
+        changes (load_state_dict / an optimiser step / a training-mode forward bump the tensor versions)."""
+        sd = dict(self.named_parameters())
+        sd.update(dict(self.named_buffers()))
+        names = [b + s for b in self._NATIVE_BLOCKS
+                 for s in (".conv.weight", ".bn.weight", ".bn.bias", ".bn.running_mean", ".bn.running_var")]
+        names += ["out1.weight", "out2.weight", "out3.weight"]
+        tensors = [sd[n] for n in names]
+        key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
+        cache = getattr(self, "_packed_cache", None)
+        if cache is None or cache[0] != key:
+            lib = _lib.load()
+            packed = torch.empty(lib.smvs_featnet_packed_floats(self.base_channels), dtype=torch.float32, device=device)
+            src = [t.detach().to(device=device, dtype=torch.float32).contiguous() for t in tensors]
+            with torch.cuda.device(device):
+                _lib.call("smvs_featnet_pack_weights", _lib.ptr_array(src), self.base_channels, _lib.ptr(packed),
+                          _lib.current_stream(device))
+            self._packed_cache = (key, packed)
+        return self._packed_cache[1]
+
+    def _use_native(self, x):
+        if os.environ.get("SMVS_FEATNET_TORCH") == "1":     # A/B switch: force the stock PyTorch composite
+            return False
+        return (x.is_cuda and not self.training and not torch.is_grad_enabled() and self.arch_mode == "unet"
+                and self.num_stage == 3 and self.base_channels <= 16 and x.shape[-1] % 4 == 0 and x.shape[-2] % 4 == 0)
+
+    def native_forward(self, x):
+        """(N,3,H,W) -> {"stage1": (N,4c,H/4,W/4), "stage2": (N,2c,H/2,W/2), "stage3": (N,c,H,W)} in one
+        native call (15 launches for all N images)."""
+        dev = _lib.require_device(x)
+        packed = self._packed_weights(dev)
+        x = x.detach().to(torch.float32).contiguous()
+        n, ch, h, w = x.shape
+        if ch != 3:
+            raise ValueError("FeatureNet expects 3-channel images, got %d" % ch)
+        c = self.base_channels
+        lib = _lib.load()
+        nbytes = lib.smvs_featnet_workspace_bytes(n, h, w, c)
+        if nbytes == 0:
+            raise ValueError("image %dx%d is not a positive multiple of 4 in both dimensions" % (h, w))
+        ws = getattr(self, "_workspace", None)
+        if ws is None or ws.numel() < nbytes or ws.device != dev:
+            ws = self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        s1 = torch.empty((n, 4 * c, h // 4, w // 4), dtype=torch.float32, device=dev)
+        s2 = torch.empty((n, 2 * c, h // 2, w // 2), dtype=torch.float32, device=dev)
+        s3 = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("smvs_featnet_fwd", _lib.ptr(packed), _lib.ptr(x), _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(s3),
+                      _lib.ptr(ws), nbytes, n, h, w, c, _lib.current_stream(dev))
+        return {"stage1": s1, "stage2": s2, "stage3": s3}
+
+    def forward_views(self, imgs):
+        """imgs (B,V,3,H,W) -> list over views of {"stageK": (B,C,h,w)} (what the networks' per-view loop
+        `[self.feature(imgs[:, v]) ...]` produces, casred.py:116-121).  Native path: all B*V images in one call."""
+        b, v = imgs.shape[:2]
+        if self._use_native(imgs):
+            out = self.native_forward(imgs.transpose(0, 1).reshape(v * b, *imgs.shape[2:]))
+            return [{k: t[i * b:(i + 1) * b] for k, t in out.items()} for i in range(v)]
+        return [self(imgs[:, i]) for i in range(v)]
+
     def forward(self, x):
+        if self._use_native(x):
+            return self.native_forward(x)
         c0 = self.conv0(x)
         c1 = self.conv1(c0)
         c2 = self.conv2(c1)

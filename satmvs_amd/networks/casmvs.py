@@ -63,7 +63,7 @@ class CascadeMVSNet(nn.Module):
         self.DepthNet = DepthNet()
 
     def forward(self, imgs, proj_matrices, depth_values):
-        features = [self.feature(imgs[:, v]) for v in range(imgs.size(1))]
+        features = self.feature.forward_views(imgs)
         h, w = int(imgs.shape[3]), int(imgs.shape[4])
         outputs = {}
         depth = None

@@ -90,7 +90,7 @@ class _CascadeRED(nn.Module):
 
     def forward(self, imgs, proj_matrices, depth_values):
         """imgs (B,V,3,H,W); proj_matrices {"stageK": (B,V,170)|(B,V,4,4)|QC dicts}; depth_values (B,2)."""
-        features = [self.feature(imgs[:, v]) for v in range(imgs.size(1))]
+        features = self.feature.forward_views(imgs)
         img_h, img_w = int(imgs.shape[3]), int(imgs.shape[4])
         outputs = {}
         depth = None

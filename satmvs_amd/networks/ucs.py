@@ -41,7 +41,7 @@ class UCSNet(nn.Module):
             for i in range(self.num_stage)])
 
     def forward(self, imgs, proj_matrices, depth_values):
-        features = [self.feature_extraction(imgs[:, v]) for v in range(imgs.shape[1])]
+        features = self.feature_extraction.forward_views(imgs)
         outputs = {}
         depth, exp_var = None, None
         depth_min, depth_max = depth_values[:, 0], depth_values[:, -1]

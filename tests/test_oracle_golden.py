@@ -120,3 +120,40 @@ def test_stream_regress(oracle, golden):
     depth, conf = st.final()
     np.testing.assert_allclose(depth, r["st_depth"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(conf, r["st_conf"], rtol=1e-6)
+
+
+# ---- regularisers and feature extractor (float32 convolutions: the oracle accumulates in double) ------------
+def _weights(g):
+    return {k[2:]: g[k] for k in g.files if k.startswith("w.")}
+
+
+def test_red_step_oracle_vs_reference(oracle, golden):
+    """oracle.red_step vs the reference's slice_RED_Regularization.forward (modules/module.py:672-693), two
+    consecutive planes with carried state.  Tolerance 1e-5 (torch accumulates its convolutions in float32)."""
+    g = golden("red_pred")
+    wt = _weights(g)
+    x = g["slice_x"]
+    B, _, H, W = x.shape
+    st = [np.zeros((B, 8, H, W), np.float32), np.zeros((B, 16, H // 2, W // 2), np.float32),
+          np.zeros((B, 32, H // 4, W // 4), np.float32), np.zeros((B, 64, H // 8, W // 8), np.float32)]
+    o1, st = oracle.red_step(wt, x, st)
+    np.testing.assert_allclose(o1, g["slice_out1"], rtol=0, atol=1e-5)
+    o2, st = oracle.red_step(wt, x * 0.5, st)
+    np.testing.assert_allclose(o2, g["slice_out2"], rtol=0, atol=1e-5)
+    for s, k in zip(st, ["slice_s1", "slice_s2", "slice_s3", "slice_s4"]):
+        np.testing.assert_allclose(s, g[k], rtol=0, atol=1e-5)
+
+
+def test_costregnet_oracle_vs_reference(oracle, golden):
+    """oracle.costregnet vs the reference's CostRegNet.forward (modules/module.py:546-577), eval mode."""
+    g = golden("costreg")
+    np.testing.assert_allclose(oracle.costregnet(_weights(g), g["x"]), g["y"], rtol=0, atol=1e-5)
+
+
+def test_featurenet_oracle_vs_reference(oracle, golden):
+    """oracle.featurenet vs the reference's FeatureNet.forward (modules/module.py:442-543), eval mode."""
+    g = golden("featnet")
+    s1, s2, s3 = oracle.featurenet(_weights(g), g["x"])
+    for got, want in ((s1, g["s1"]), (s2, g["s2"]), (s3, g["s3"])):
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
