@@ -17,6 +17,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 #include "smvs_device.h"
 #include "smvs_host.h"
 #include "mfma_conv.h"
@@ -547,62 +552,73 @@ struct RedRun {
     float* plane[NBUF]; float* reg;
 };
 
-static int red_run_planes(const RedRun& r, int d_begin, int d_end)
-{
-    RedPipe* pp = red_pipe();
-    if (!pp) return fail(SMVS_ERR_LAUNCH, "could not create the regulariser's streams/events");
-    const RedPipe& P = *pp;
-    // one plane alone: the cross-stream hops cost more than they buy (measured) -> caller's stream only
-    const int mode = d_end - d_begin > 1 ? P.mode : 0;
-    const RedLayout L = red_layout(r.C);
-    const RedWorkspace ws = red_workspace(r.B, r.C, r.H, r.W);
-    const int B = r.B, C = r.C, H = r.H, W = r.W;
-    const float* packed = r.packed;
-    float* wsf = r.wsf;
-    const int hs[4] = {H, H / 2, H / 4, H / 8}, wd[4] = {W, W / 2, W / 4, W / 8};
-    const int enc_in[3] = {C, 16, 32}, enc_out[3] = {16, 32, 64};
-    const size_t npix = (size_t)B * H * W;
-    hipStream_t lv[4];                                      // level -> stream
-    for (int g = 0; g < 4; ++g) lv[g] = mode == 4 ? P.lvl[g] : mode == 2 ? P.lvl[g >> 1] : r.main;
-    const bool multi = mode != 0;
-    const size_t stat_doubles = (size_t)B * 4 * 3 * NSLOT * 2;
-    // the first plane's statistics are cleared here; afterwards each level clears the next plane's buffer itself
-    (void)hipMemsetAsync(wsf + ws.stats[0], 0, stat_doubles * sizeof(double), r.main);
+// Everything one call needs to enqueue a plane; issue_front() = caller's stream (cost volume, encoder) + the
+// coarse GRU levels 4,3; issue_back() = the fine levels 2,1, the output convolution and the regression update.
+struct RedIssuer {
+    const RedRun& r; const RedPipe& P; int mode, d_begin, d_end;
+    RedLayout L; RedWorkspace ws;
+    hipStream_t lv[4]; bool multi;
+    int hs[4], wd[4];
 
-    for (int d = d_begin; d < d_end; ++d) {
-        const int k = d - d_begin, buf = k % NBUF, slot = k % RING;
-        // this ring entry was last used by plane k-NBUF; its finest level finishing implies all of it
-        if (multi && k >= NBUF) (void)hipStreamWaitEvent(r.main, P.done[(k - NBUF) % RING], 0);
-        double* stats = (double*)(wsf + ws.stats[buf]);
-        double* stats_next = d + 1 < d_end ? (double*)(wsf + ws.stats[(k + 1) % NBUF]) : nullptr;
-        const float* cost = r.cost;
+    RedIssuer(const RedRun& run, const RedPipe& pipe, int mode_, int d0, int d1)
+        : r(run), P(pipe), mode(mode_), d_begin(d0), d_end(d1), L(red_layout(run.C)), ws(red_workspace(run.B, run.C, run.H, run.W))
+    {
+        // level -> stream.  mode 4: one stream per level; mode 2: levels {3,2} and {1,0}; mode 0: caller's stream
+        for (int g = 0; g < 4; ++g) lv[g] = mode == 4 ? P.lvl[g] : mode == 2 ? P.lvl[g >> 1] : r.main;
+        multi = mode != 0;
+        for (int g = 0; g < 4; ++g) { hs[g] = r.H >> g; wd[g] = r.W >> g; }
+    }
+    bool head(int g) const { return multi && (g == 3 || lv[g + 1] != lv[g]); }   // first level of its stream
+    double* stats_of(int k) const { return (double*)(r.wsf + ws.stats[k % NBUF]); }
+    const float* cost_of(int k) const { return r.pred ? r.plane[k % NBUF] : r.cost; }
+
+    // cost-volume plane + encoder on the caller's stream, then GRU levels 3 and 2
+    int issue_front(int k)
+    {
+        const int d = d_begin + k, buf = k % NBUF, slot = k % RING;
+        const int B = r.B, C = r.C;
+        float* wsf = r.wsf;
+        const int enc_in[3] = {C, 16, 32}, enc_out[3] = {16, 32, 64};
         if (r.pred) {
             float* pl = r.plane[buf];
             const int rc = r.geo_kind == 0
-                ? smvs_rpc_costvol_fwd(r.ref_fea, r.src_fea, r.n_src, r.geo, r.depth, r.depth_is_4d, pl, B, C, r.D, H, W, d, d + 1, 1, 0, r.main)
-                : smvs_homo_costvol_fwd(r.ref_fea, r.src_fea, r.n_src, r.geo, r.depth, r.depth_is_4d, pl, B, C, r.D, H, W, d, d + 1, 1, 0, r.main);
+                ? smvs_rpc_costvol_fwd(r.ref_fea, r.src_fea, r.n_src, r.geo, r.depth, r.depth_is_4d, pl, B, C, r.D, r.H, r.W, d, d + 1, 1, 0, r.main)
+                : smvs_homo_costvol_fwd(r.ref_fea, r.src_fea, r.n_src, r.geo, r.depth, r.depth_is_4d, pl, B, C, r.D, r.H, r.W, d, d + 1, 1, 0, r.main);
             if (rc) return rc;
-            cost = pl;
         }
+        const float* cost = cost_of(k);
         // a level's stream waits for the encoder output of the COARSEST level it carries (the finer inputs
-        // are older on the caller's stream); head[g] = that level is the first of its stream
-        bool head[4];
-        for (int g = 0; g < 4; ++g) head[g] = multi && (g == 3 || lv[g + 1] != lv[g]);
-        if (head[0]) (void)hipEventRecord(P.enc[slot][0], r.main);
+        // are older on the caller's stream)
+        if (head(0)) (void)hipEventRecord(P.enc[slot][0], r.main);
         // encoder: e1 = relu(conv1(-cost)), e2 = relu(conv2(e1)), e3 = relu(conv3(e2))
         for (int i = 0; i < 3; ++i) {
             ConvArgs a{};
             a.inA = i == 0 ? cost : wsf + ws.e[buf][i - 1]; a.CA = enc_in[i]; a.scaleA = i == 0 ? -1.0f : 1.0f;
-            a.w = packed + L.conv_w[i]; a.out = wsf + ws.e[buf][i]; a.Cout = enc_out[i];
+            a.w = r.packed + L.conv_w[i]; a.out = wsf + ws.e[buf][i]; a.Cout = enc_out[i];
             a.Hi = hs[i]; a.Wi = wd[i]; a.Ho = hs[i + 1]; a.Wo = wd[i + 1]; a.relu = 1;
-            launch_conv(2, a, B, r.main, packed + L.conv_wm[i]);
-            if (head[i + 1]) (void)hipEventRecord(P.enc[slot][i + 1], r.main);
+            launch_conv(2, a, B, r.main, r.packed + L.conv_wm[i]);
+            if (head(i + 1)) (void)hipEventRecord(P.enc[slot][i + 1], r.main);
         }
-        // GRU levels coarse to fine.  Per stream: first the state-only part of all its levels (gates, gate
-        // apply, candidate), then the decoder-coupled part (combine with the upsampled coarser level, upconv).
-        for (int ghi = 3; ghi >= 0;) {
+        return issue_levels(k, 3, 2);
+    }
+    int issue_back(int k) { return issue_levels(k, 1, 0); }
+
+    // GRU levels g_hi..g_lo (coarse to fine).  Per stream: first the state-only part of all its levels (gates,
+    // gate apply, candidate), then the decoder-coupled part (combine with the upsampled coarser level, upconv).
+    int issue_levels(int k, int g_hi, int g_lo)
+    {
+        const int d = d_begin + k, buf = k % NBUF, slot = k % RING;
+        const int B = r.B, C = r.C;
+        float* wsf = r.wsf;
+        const float* packed = r.packed;
+        const int enc_out[3] = {16, 32, 64};
+        const float* cost = cost_of(k);
+        double* stats = stats_of(k);
+        double* stats_next = d + 1 < d_end ? stats_of(k + 1) : nullptr;
+        const size_t npix = (size_t)B * r.H * r.W;
+        for (int ghi = g_hi; ghi >= g_lo;) {
             int glo = ghi;
-            while (glo > 0 && lv[glo - 1] == lv[ghi]) --glo;
+            while (glo > g_lo && lv[glo - 1] == lv[ghi]) --glo;
             hipStream_t st = lv[ghi];
             if (multi) (void)hipStreamWaitEvent(st, P.enc[slot][ghi], 0);
             for (int g = ghi; g >= glo; --g) {
@@ -632,7 +648,10 @@ static int red_run_planes(const RedRun& r, int d_begin, int d_end)
                 const size_t n = (size_t)hc * hw;
                 double* so = stats + (size_t)g * B * 3 * NSLOT * 2 + (size_t)B * 2 * NSLOT * 2;
                 const bool skip = g < 3;                                  // levels 3,2,1 add the upsampled coarser level
-                if (multi && skip && lv[g + 1] != st) (void)hipStreamWaitEvent(st, P.up[slot][g], 0);
+                if (multi && skip && lv[g + 1] != st) {
+                    if (g == g_hi) wait_published(up_pub, k);             // recorded by the other host thread (if any)
+                    (void)hipStreamWaitEvent(st, P.up[slot][g], 0);
+                }
                 hipLaunchKernelGGL(gru_combine_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, wsf + ws.cand[g], so,
                                    packed + L.on_w[g], packed + L.on_b[g], wsf + ws.gates[g], r.state[g],
                                    skip ? wsf + ws.up[buf][g] : nullptr, skip ? wsf + ws.sum[g] : nullptr, B, hc, hw);
@@ -649,11 +668,11 @@ static int red_run_planes(const RedRun& r, int d_begin, int d_end)
                     float* reg = r.pred ? r.reg : r.reg_out;
                     ConvArgs f{};
                     f.inA = wsf + ws.sum[0]; f.CA = 8; f.scaleA = 1.0f; f.w = packed + L.up2d_w; f.bias = packed + L.up2d_b;
-                    f.out = reg; f.Cout = 1; f.Hi = f.Ho = H; f.Wi = f.Wo = W;
+                    f.out = reg; f.Cout = 1; f.Hi = f.Ho = r.H; f.Wi = f.Wo = r.W;
                     launch_conv(1, f, B, st);
                     if (r.pred) {
                         const int rc = smvs_stream_regress_step(reg, r.depth, r.depth_is_4d, r.acc, r.acc + npix, r.acc + 2 * npix,
-                                                                B, r.D, H, W, d, st);
+                                                                B, r.D, r.H, r.W, d, st);
                         if (rc) return rc;
                     }
                     if (multi) (void)hipEventRecord(P.done[slot], st);
@@ -661,9 +680,124 @@ static int red_run_planes(const RedRun& r, int d_begin, int d_end)
             }
             ghi = glo - 1;
         }
+        return SMVS_OK;
     }
+
+    // ---- two host threads: progress counters (planes whose event record has been ISSUED) -----------------
+    std::atomic<int>* front_pub = nullptr;                   // front of plane k issued (enc + up[.][1] records)
+    std::atomic<int>* up_pub = nullptr;                      // alias of front_pub for the back half's wait
+    std::atomic<int>* abort_flag = nullptr;
+    bool wait_published(std::atomic<int>* c, int k) const
+    {
+        if (!c) return true;
+        while (c->load(std::memory_order_acquire) <= k) {
+            if (abort_flag && abort_flag->load(std::memory_order_acquire)) return false;
+            __builtin_ia32_pause();
+        }
+        return true;
+    }
+};
+
+// A second host thread enqueues the fine levels while the caller's thread enqueues cost volume, encoder and
+// coarse levels: the pred loop is bound by the host's launch rate (~3 us per launch or event call, ~33 per
+// plane), not by the GPU.  One worker per process, parked on a condition variable between calls.
+struct RedWorker {
+    std::mutex call_mutex;                                   // one pred loop at a time uses the worker
+    std::mutex m; std::condition_variable cv;
+    RedIssuer* job = nullptr; int nplanes = 0, dev = 0;
+    std::atomic<int> front_pub{0}, back_pub{0}, abort_flag{0}, rc{0};
+    void loop()
+    {
+        for (;;) {
+            RedIssuer* is;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return job != nullptr; });
+                is = job;
+            }
+            (void)hipSetDevice(dev);
+            int err = SMVS_OK;
+            for (int k = 0; k < nplanes && !err; ++k) {
+                if (!is->wait_published(&front_pub, k)) { err = SMVS_ERR_LAUNCH; break; }
+                err = is->issue_back(k);
+                back_pub.store(k + 1, std::memory_order_release);
+            }
+            if (!err && hipGetLastError() != hipSuccess) err = SMVS_ERR_LAUNCH;
+            rc.store(err, std::memory_order_release);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                job = nullptr;
+            }
+            back_pub.store(nplanes + 1, std::memory_order_release);     // "finished issuing" marker
+        }
+    }
+};
+
+static RedWorker* red_worker()
+{
+    static RedWorker* w = [] {
+        const char* e = getenv("SMVS_RED_WORKER");
+        if (e && e[0] == '0') return (RedWorker*)nullptr;
+        RedWorker* p = new RedWorker;                        // lives for the process (the thread is detached)
+        std::thread([p] { p->loop(); }).detach();
+        return p;
+    }();
+    return w;
+}
+
+static int red_run_planes(const RedRun& r, int d_begin, int d_end)
+{
+    RedPipe* pp = red_pipe();
+    if (!pp) return fail(SMVS_ERR_LAUNCH, "could not create the regulariser's streams/events");
+    const int nplanes = d_end - d_begin;
+    if (nplanes <= 0) return SMVS_OK;
+    // one plane alone: the cross-stream hops cost more than they buy (measured) -> caller's stream only
+    const int mode = nplanes > 1 ? pp->mode : 0;
+    RedIssuer is(r, *pp, mode, d_begin, d_end);
+    const RedPipe& P = *pp;
+    // the first plane's statistics are cleared here; afterwards each level clears the next plane's buffer itself
+    (void)hipMemsetAsync(r.wsf + is.ws.stats[0], 0, (size_t)r.B * 4 * 3 * NSLOT * 2 * sizeof(double), r.main);
+
+    RedWorker* w = is.multi && nplanes >= 4 ? red_worker() : nullptr;
+    int rc = SMVS_OK;
+    if (!w) {
+        for (int k = 0; k < nplanes && !rc; ++k) {
+            // this ring entry was last used by plane k-NBUF; its finest level finishing implies all of it
+            if (is.multi && k >= NBUF) (void)hipStreamWaitEvent(r.main, P.done[(k - NBUF) % RING], 0);
+            rc = is.issue_front(k);
+            if (!rc) rc = is.issue_back(k);
+        }
+    } else {
+        std::lock_guard<std::mutex> call_lock(w->call_mutex);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        w->front_pub.store(0); w->back_pub.store(0); w->abort_flag.store(0); w->rc.store(0);
+        is.abort_flag = &w->abort_flag;
+        // the back half (worker) waits for front_pub before its cross-thread event waits: both the encoder
+        // events and up[.][1] of plane k are recorded inside issue_front(k)
+        is.up_pub = nullptr;                                 // covered by the front_pub wait at the top of the plane
+        {
+            std::lock_guard<std::mutex> lk(w->m);
+            w->nplanes = nplanes; w->dev = dev; w->job = &is;
+        }
+        w->cv.notify_one();
+        for (int k = 0; k < nplanes && !rc; ++k) {
+            if (k >= NBUF) {
+                // done[(k-NBUF)] is recorded by the worker: wait until that call has been made, then wait on it
+                while (w->back_pub.load(std::memory_order_acquire) < k - NBUF + 1) __builtin_ia32_pause();
+                (void)hipStreamWaitEvent(r.main, P.done[(k - NBUF) % RING], 0);
+            }
+            rc = is.issue_front(k);
+            w->front_pub.store(k + 1, std::memory_order_release);
+        }
+        if (rc) w->abort_flag.store(1, std::memory_order_release);
+        while (w->back_pub.load(std::memory_order_acquire) != nplanes + 1) __builtin_ia32_pause();   // worker done with `is`
+        const int wrc = w->rc.load(std::memory_order_acquire);
+        if (!rc && wrc) return fail(wrc, "the regulariser's second enqueue thread failed (code %d)", wrc);
+    }
+    if (rc) return rc;
     // join: the caller's stream continues only after the last plane's finest level (which implies the rest)
-    if (multi && d_end > d_begin) (void)hipStreamWaitEvent(r.main, P.done[(d_end - d_begin - 1) % RING], 0);
+    if (is.multi) (void)hipStreamWaitEvent(r.main, P.done[(nplanes - 1) % RING], 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "red planes launch: %s", hipGetErrorString(e));
     return SMVS_OK;
