@@ -105,7 +105,7 @@ void mfma_conv_kernel(const MfmaConvArgs a)
     constexpr int NB = TAPS / BS;                          // batches per channel pair
     const int ncip = Cin / 2, per = ncip / NW;
     const int q_end = per * NB;
-    struct Batch { float x[BS]; float w[NT][BS]; };
+    struct Batch { float x[BS]; float w[NT][BS]; float sx; };
     // explicit variants so that every off[] / register index is a compile-time constant
 #define SMVS_LOAD_BATCH(G, BT, Q)                                                                        \
     {                                                                                                    \
@@ -117,15 +117,16 @@ void mfma_conv_kernel(const MfmaConvArgs a)
         rx_.z = fromA_ ? rA.v.z : rB.v.z; rx_.w = rA.v.w;                                                \
         const float sx_ = fromA_ ? a.scaleA : 1.0f;                                                      \
         _Pragma("unroll") for (int s_ = 0; s_ < BS; ++s_) {                                              \
-            BT.x[s_] = llvm_raw_buffer_load_f32(rx_, (int)off[(G) * BS + s_], choff_, 0) * sx_;          \
+            BT.x[s_] = llvm_raw_buffer_load_f32(rx_, (int)off[(G) * BS + s_], choff_, 0);                \
             _Pragma("unroll") for (int n_ = 0; n_ < NT; ++n_)                                            \
                 BT.w[n_][s_] = llvm_raw_buffer_load_f32(rW.v, lane * 4, ((cip_ * TAPS + (G) * BS + s_) * nt_all + nt0 + n_) * 256, 0); \
         }                                                                                                \
+        BT.sx = sx_;                                              /* applied at MMA time: no wait on the loads here */ \
     }
 #define SMVS_MMA_BATCH(BT)                                                                               \
     _Pragma("unroll") for (int s_ = 0; s_ < BS; ++s_)                                                    \
         _Pragma("unroll") for (int n_ = 0; n_ < NT; ++n_)                                                \
-            acc[n_] = __builtin_amdgcn_mfma_f32_32x32x2f32(BT.w[n_][s_], BT.x[s_], acc[n_], 0, 0, 0);
+            acc[n_] = __builtin_amdgcn_mfma_f32_32x32x2f32(BT.w[n_][s_], BT.x[s_] * BT.sx, acc[n_], 0, 0, 0);
     static_assert(NB == 1 || NB == 3, "batching assumes 9 or 27 taps");
     Batch b0, b1;
     if (NB == 3) {
@@ -146,6 +147,7 @@ void mfma_conv_kernel(const MfmaConvArgs a)
             __builtin_amdgcn_sched_barrier(0);
             if (q + 3 < q_end) {
                 // rotate: the prefetched batch sits in b1, the loop expects it in b0
+                b0.sx = b1.sx;
 #pragma unroll
                 for (int s_ = 0; s_ < BS; ++s_) {
                     b0.x[s_] = b1.x[s_];

@@ -17,10 +17,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <atomic>
-#include <condition_variable>
-#include <mutex>
-#include <thread>
 
 #include "smvs_device.h"
 #include "smvs_host.h"
@@ -648,10 +644,7 @@ struct RedIssuer {
                 const size_t n = (size_t)hc * hw;
                 double* so = stats + (size_t)g * B * 3 * NSLOT * 2 + (size_t)B * 2 * NSLOT * 2;
                 const bool skip = g < 3;                                  // levels 3,2,1 add the upsampled coarser level
-                if (multi && skip && lv[g + 1] != st) {
-                    if (g == g_hi) wait_published(up_pub, k);             // recorded by the other host thread (if any)
-                    (void)hipStreamWaitEvent(st, P.up[slot][g], 0);
-                }
+                if (multi && skip && lv[g + 1] != st) (void)hipStreamWaitEvent(st, P.up[slot][g], 0);
                 hipLaunchKernelGGL(gru_combine_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, wsf + ws.cand[g], so,
                                    packed + L.on_w[g], packed + L.on_b[g], wsf + ws.gates[g], r.state[g],
                                    skip ? wsf + ws.up[buf][g] : nullptr, skip ? wsf + ws.sum[g] : nullptr, B, hc, hw);
@@ -682,68 +675,7 @@ struct RedIssuer {
         }
         return SMVS_OK;
     }
-
-    // ---- two host threads: progress counters (planes whose event record has been ISSUED) -----------------
-    std::atomic<int>* front_pub = nullptr;                   // front of plane k issued (enc + up[.][1] records)
-    std::atomic<int>* up_pub = nullptr;                      // alias of front_pub for the back half's wait
-    std::atomic<int>* abort_flag = nullptr;
-    bool wait_published(std::atomic<int>* c, int k) const
-    {
-        if (!c) return true;
-        while (c->load(std::memory_order_acquire) <= k) {
-            if (abort_flag && abort_flag->load(std::memory_order_acquire)) return false;
-            __builtin_ia32_pause();
-        }
-        return true;
-    }
 };
-
-// A second host thread enqueues the fine levels while the caller's thread enqueues cost volume, encoder and
-// coarse levels: the pred loop is bound by the host's launch rate (~3 us per launch or event call, ~33 per
-// plane), not by the GPU.  One worker per process, parked on a condition variable between calls.
-struct RedWorker {
-    std::mutex call_mutex;                                   // one pred loop at a time uses the worker
-    std::mutex m; std::condition_variable cv;
-    RedIssuer* job = nullptr; int nplanes = 0, dev = 0;
-    std::atomic<int> front_pub{0}, back_pub{0}, abort_flag{0}, rc{0};
-    void loop()
-    {
-        for (;;) {
-            RedIssuer* is;
-            {
-                std::unique_lock<std::mutex> lk(m);
-                cv.wait(lk, [&] { return job != nullptr; });
-                is = job;
-            }
-            (void)hipSetDevice(dev);
-            int err = SMVS_OK;
-            for (int k = 0; k < nplanes && !err; ++k) {
-                if (!is->wait_published(&front_pub, k)) { err = SMVS_ERR_LAUNCH; break; }
-                err = is->issue_back(k);
-                back_pub.store(k + 1, std::memory_order_release);
-            }
-            if (!err && hipGetLastError() != hipSuccess) err = SMVS_ERR_LAUNCH;
-            rc.store(err, std::memory_order_release);
-            {
-                std::lock_guard<std::mutex> lk(m);
-                job = nullptr;
-            }
-            back_pub.store(nplanes + 1, std::memory_order_release);     // "finished issuing" marker
-        }
-    }
-};
-
-static RedWorker* red_worker()
-{
-    static RedWorker* w = [] {
-        const char* e = getenv("SMVS_RED_WORKER");
-        if (e && e[0] == '0') return (RedWorker*)nullptr;
-        RedWorker* p = new RedWorker;                        // lives for the process (the thread is detached)
-        std::thread([p] { p->loop(); }).detach();
-        return p;
-    }();
-    return w;
-}
 
 static int red_run_planes(const RedRun& r, int d_begin, int d_end)
 {
@@ -758,42 +690,14 @@ static int red_run_planes(const RedRun& r, int d_begin, int d_end)
     // the first plane's statistics are cleared here; afterwards each level clears the next plane's buffer itself
     (void)hipMemsetAsync(r.wsf + is.ws.stats[0], 0, (size_t)r.B * 4 * 3 * NSLOT * 2 * sizeof(double), r.main);
 
-    RedWorker* w = is.multi && nplanes >= 4 ? red_worker() : nullptr;
+    // Host enqueue is not the limit: a second host thread issuing the fine levels was tried and left the
+    // GPU-complete time unchanged (stage 2) or worse (stage 1) -- the loop is bound by the busiest stream.
     int rc = SMVS_OK;
-    if (!w) {
-        for (int k = 0; k < nplanes && !rc; ++k) {
-            // this ring entry was last used by plane k-NBUF; its finest level finishing implies all of it
-            if (is.multi && k >= NBUF) (void)hipStreamWaitEvent(r.main, P.done[(k - NBUF) % RING], 0);
-            rc = is.issue_front(k);
-            if (!rc) rc = is.issue_back(k);
-        }
-    } else {
-        std::lock_guard<std::mutex> call_lock(w->call_mutex);
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        w->front_pub.store(0); w->back_pub.store(0); w->abort_flag.store(0); w->rc.store(0);
-        is.abort_flag = &w->abort_flag;
-        // the back half (worker) waits for front_pub before its cross-thread event waits: both the encoder
-        // events and up[.][1] of plane k are recorded inside issue_front(k)
-        is.up_pub = nullptr;                                 // covered by the front_pub wait at the top of the plane
-        {
-            std::lock_guard<std::mutex> lk(w->m);
-            w->nplanes = nplanes; w->dev = dev; w->job = &is;
-        }
-        w->cv.notify_one();
-        for (int k = 0; k < nplanes && !rc; ++k) {
-            if (k >= NBUF) {
-                // done[(k-NBUF)] is recorded by the worker: wait until that call has been made, then wait on it
-                while (w->back_pub.load(std::memory_order_acquire) < k - NBUF + 1) __builtin_ia32_pause();
-                (void)hipStreamWaitEvent(r.main, P.done[(k - NBUF) % RING], 0);
-            }
-            rc = is.issue_front(k);
-            w->front_pub.store(k + 1, std::memory_order_release);
-        }
-        if (rc) w->abort_flag.store(1, std::memory_order_release);
-        while (w->back_pub.load(std::memory_order_acquire) != nplanes + 1) __builtin_ia32_pause();   // worker done with `is`
-        const int wrc = w->rc.load(std::memory_order_acquire);
-        if (!rc && wrc) return fail(wrc, "the regulariser's second enqueue thread failed (code %d)", wrc);
+    for (int k = 0; k < nplanes && !rc; ++k) {
+        // this ring entry was last used by plane k-NBUF; its finest level finishing implies all of it
+        if (is.multi && k >= NBUF) (void)hipStreamWaitEvent(r.main, P.done[(k - NBUF) % RING], 0);
+        rc = is.issue_front(k);
+        if (!rc) rc = is.issue_back(k);
     }
     if (rc) return rc;
     // join: the caller's stream continues only after the last plane's finest level (which implies the rest)

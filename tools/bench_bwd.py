@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Forward + backward of the fused variance cost volume at the metric shape (training path)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from satmvs_amd import rpc_synth
+from satmvs_amd.modules.warping import variance_cost_volume
+
+dev = torch.device("cuda:0")
+for name, (C, H, W, D, s) in {"cfg2 C32 768x384x64": (32, 384, 768, 64, 1), "stage1 C32 192x96x48": (32, 96, 192, 48, 4),
+                              "stage3 C8 768x384x8": (8, 384, 768, 8, 1)}.items():
+    V = 3
+    torch.manual_seed(0)
+    feats = [torch.randn(1, C, H, W, device=dev, requires_grad=True) for _ in range(V)]
+    proj = torch.from_numpy(rpc_synth.rescale_rpc(rpc_synth.make_view_rpcs(V, 384, 768, seed=0)[None], s)).to(dev)
+    dv = torch.linspace(0, 400, D, device=dev).view(1, D, 1, 1).expand(1, D, H, W).contiguous()
+    vol = variance_cost_volume(feats, proj, dv, "rpc", False)
+    g = torch.randn_like(vol)
+    for _ in range(2):
+        vol = variance_cost_volume(feats, proj, dv, "rpc", False)
+        vol.backward(g)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        vol = variance_cost_volume(feats, proj, dv, "rpc", False)
+    torch.cuda.synchronize(); tf = (time.perf_counter() - t0) / n * 1e3
+    t0 = time.perf_counter()
+    for _ in range(n):
+        vol = variance_cost_volume(feats, proj, dv, "rpc", False)
+        vol.backward(g)
+    torch.cuda.synchronize(); tfb = (time.perf_counter() - t0) / n * 1e3
+    print("%-22s forward %.3f ms   forward+backward %.3f ms   (backward %.3f ms)" % (name, tf, tfb, tfb - tf))
