@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --workload $WL --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $BENCH --steps 20 --warmup 3 > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $BENCH --steps 100 --warmup 10 > "$OUT/trace.log" 2>&1
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
