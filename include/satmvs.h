@@ -153,6 +153,16 @@ int smvs_red_pred_planes(int geo_kind, const float* ref_fea, const float* const*
                          void* workspace, size_t workspace_bytes,
                          int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream);
 
+/* Same plane pipeline with the regularised planes written to reg_volume (B,D,H,W) instead of the regression
+ * accumulators: the whole-volume network's path (compute_depth_when_train under no_grad: networks/casred.py:22-62
+ * with RED_Regularization.forward, modules/module.py:625-647) without materialising the (B,C,D,H,W) variance
+ * volume; follow with smvs_softmax_regress_fwd. */
+int smvs_red_volume_planes(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
+                           const double* geo, const float* depth, int depth_is_4d, const float* packed,
+                           float* state1, float* state2, float* state3, float* state4, float* reg_volume,
+                           void* workspace, size_t workspace_bytes,
+                           int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream);
+
 /* ---- 3-D convolutional cost regulariser (CostRegNet), inference form ---------------------------------
  * Replaces CostRegNet.forward (modules/module.py:546-577; Conv3d :324, Deconv3d :369) for
  * CascadeMVSNet (networks/casmvs.py) and UCSNet (networks/ucs.py); base_channels = 8.  BatchNorm3d uses

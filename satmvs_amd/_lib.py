@@ -33,6 +33,7 @@ _SIGNATURES = {
     "smvs_red_pack_weights": [_vp, _i, _vp, _vp],
     "smvs_red_step_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 4 + [_vp],
     "smvs_red_pred_planes": [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 7 + [_vp],
+    "smvs_red_volume_planes": [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 7 + [_vp],
     "smvs_costreg_pack_weights": [_vp, _i, _vp, _vp],
     "smvs_costreg_fwd": [_vp, _vp, _vp, _vp, _sz] + [_i] * 5 + [_vp],
     "smvs_featnet_pack_weights": [_vp, _i, _vp, _vp],

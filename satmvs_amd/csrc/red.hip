@@ -112,6 +112,7 @@ struct ConvArgs {
     double* stats;                           // (B,ngroups,2) sum / sum of squares of the raw output, or null
     int ngroups;                             // 1, or 2 (gate conv: reset half / update half)
     int Cout, Hi, Wi, Ho, Wo, relu;
+    size_t out_bstride;                      // floats between samples of `out`; 0 = Cout*Ho*Wo (dense)
 };
 
 typedef const float __attribute__((address_space(4))) * cw_t;
@@ -214,7 +215,7 @@ void conv3x3_kernel(const ConvArgs a)
             float r = acc[j] + (a.bias ? a.bias[co] : 0.0f);
             if (active) { s1 += r; s2 = fmaf(r, r, s2); }
             if (a.relu) r = fmaxf(r, 0.0f);
-            if (active) a.out[((size_t)b * a.Cout + co) * HWo + (size_t)oy * a.Wo + ox] = r;
+            if (active) a.out[(a.out_bstride ? (size_t)b * a.out_bstride + (size_t)co * HWo : ((size_t)b * a.Cout + co) * HWo) + (size_t)oy * a.Wo + ox] = r;
         }
     }
     if (a.stats) {
@@ -545,6 +546,7 @@ struct RedRun {
     // pred loop (pred = true): cost-volume plane built here, regression accumulators updated here
     bool pred; int geo_kind; const float* ref_fea; const float* const* src_fea; int n_src; const double* geo;
     const float* depth; int depth_is_4d; double* acc; int D;
+    float* reg_volume;                       // pred with acc == null: regularised planes go to (B,D,H,W) instead
     float* plane[NBUF]; float* reg;
 };
 
@@ -658,12 +660,13 @@ struct RedIssuer {
                     if (multi && lv[g - 1] != st) (void)hipEventRecord(P.up[slot][g - 1], st);
                 } else {
                     // reg = upconv2d(up1 + state1') : ConvTranspose2d stride 1 == correlation with flipped taps
-                    float* reg = r.pred ? r.reg : r.reg_out;
+                    float* reg = !r.pred ? r.reg_out : r.reg_volume ? r.reg_volume + (size_t)d * r.H * r.W : r.reg;
                     ConvArgs f{};
                     f.inA = wsf + ws.sum[0]; f.CA = 8; f.scaleA = 1.0f; f.w = packed + L.up2d_w; f.bias = packed + L.up2d_b;
                     f.out = reg; f.Cout = 1; f.Hi = f.Ho = r.H; f.Wi = f.Wo = r.W;
+                    if (r.pred && r.reg_volume) f.out_bstride = (size_t)r.D * r.H * r.W;
                     launch_conv(1, f, B, st);
-                    if (r.pred) {
+                    if (r.pred && !r.reg_volume) {
                         const int rc = smvs_stream_regress_step(reg, r.depth, r.depth_is_4d, r.acc, r.acc + npix, r.acc + 2 * npix,
                                                                 B, r.D, r.H, r.W, d, st);
                         if (rc) return rc;
@@ -805,14 +808,14 @@ SMVS_EXPORT size_t smvs_red_pred_workspace_bytes(int B, int C, int H, int W)
     return r + (smvs::NBUF * (size_t)B * C * H * W + (size_t)B * H * W) * sizeof(float) + 64;   // ring of variance planes + reg
 }
 
-SMVS_EXPORT int smvs_red_pred_planes(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
-                                     const double* geo, const float* depth, int depth_is_4d, const float* packed,
-                                     float* state1, float* state2, float* state3, float* state4, double* acc,
-                                     void* workspace, size_t workspace_bytes,
-                                     int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream)
+static int red_planes_entry(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
+                            const double* geo, const float* depth, int depth_is_4d, const float* packed,
+                            float* state1, float* state2, float* state3, float* state4, double* acc, float* reg_volume,
+                            void* workspace, size_t workspace_bytes,
+                            int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream)
 {
     using namespace smvs;
-    if (!acc || !workspace) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if ((!acc && !reg_volume) || !workspace) return fail(SMVS_ERR_ARG, "null pointer argument");
     if (geo_kind != 0 && geo_kind != 1) return fail(SMVS_ERR_ARG, "geo_kind must be 0 (rpc) or 1 (homography)");
     const size_t need = smvs_red_pred_workspace_bytes(B, C, H, W);
     if (need == 0) return fail(SMVS_ERR_ARG, "plane %dx%d must be a positive multiple of 8 in both dimensions", H, W);
@@ -825,11 +828,37 @@ SMVS_EXPORT int smvs_red_pred_planes(int geo_kind, const float* ref_fea, const f
     r.packed = packed; r.state[0] = state1; r.state[1] = state2; r.state[2] = state3; r.state[3] = state4;
     r.wsf = (float*)workspace; r.B = B; r.C = C; r.H = H; r.W = W; r.main = (hipStream_t)stream;
     r.pred = true; r.geo_kind = geo_kind; r.ref_fea = ref_fea; r.src_fea = src_fea; r.n_src = n_src; r.geo = geo;
-    r.depth = depth; r.depth_is_4d = depth_is_4d; r.acc = acc; r.D = D;
+    r.depth = depth; r.depth_is_4d = depth_is_4d; r.acc = acc; r.reg_volume = reg_volume; r.D = D;
     r.plane[0] = (float*)((char*)workspace + ((red_bytes + 15) & ~(size_t)15));
     for (int p = 1; p < NBUF; ++p) r.plane[p] = r.plane[p - 1] + (size_t)B * C * H * W;
     r.reg = r.plane[NBUF - 1] + (size_t)B * C * H * W;
     return red_run_planes(r, d_begin, d_end);
+}
+
+SMVS_EXPORT int smvs_red_pred_planes(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
+                                     const double* geo, const float* depth, int depth_is_4d, const float* packed,
+                                     float* state1, float* state2, float* state3, float* state4, double* acc,
+                                     void* workspace, size_t workspace_bytes,
+                                     int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream)
+{
+    if (!acc) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
+    return red_planes_entry(geo_kind, ref_fea, src_fea, n_src, geo, depth, depth_is_4d, packed, state1, state2, state3, state4,
+                            acc, nullptr, workspace, workspace_bytes, B, C, D, H, W, d_begin, d_end, stream);
+}
+
+// Same plane pipeline, but the regularised planes are written to reg_volume (B,D,H,W) (planes [d_begin,d_end))
+// instead of being folded into the regression accumulators: RED_Regularization.forward of the whole-volume
+// network (networks/casred.py:22-62, modules/module.py:625-647) without ever materialising the (B,C,D,H,W)
+// variance volume.  The caller applies softmax + regression (smvs_softmax_regress_fwd) to reg_volume.
+SMVS_EXPORT int smvs_red_volume_planes(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
+                                       const double* geo, const float* depth, int depth_is_4d, const float* packed,
+                                       float* state1, float* state2, float* state3, float* state4, float* reg_volume,
+                                       void* workspace, size_t workspace_bytes,
+                                       int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream)
+{
+    if (!reg_volume) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
+    return red_planes_entry(geo_kind, ref_fea, src_fea, n_src, geo, depth, depth_is_4d, packed, state1, state2, state3, state4,
+                            nullptr, reg_volume, workspace, workspace_bytes, B, C, D, H, W, d_begin, d_end, stream);
 }
 
 }  // extern "C"

@@ -227,13 +227,13 @@ class _REDCore(nn.Module):
         return (out, *states)
 
     def native_pred_planes(self, features, proj_matrices, depth_values, geo_model, use_qc, states, acc_state,
-                           d_begin, d_end):
+                           d_begin, d_end, reg_volume=None):
         """Planes [d_begin,d_end) of the pred loop in one native call (smvs_red_pred_planes): per plane
         variance build -> RED step -> float64 regression update.  `states` (list of 4) and `acc_state`
         ((3,B,H,W) float64) are updated in place."""
         from .warping import _depth_arg, prepare_geometry
         ref = features[0]
-        dev = _lib.require_device(ref, acc_state, *states)
+        dev = _lib.require_device(ref, acc_state, reg_volume, *states)
         packed, in_ch = self._packed_weights(dev)
         feats = [f.detach().to(torch.float32).contiguous() for f in features]
         b, c, h, w = feats[0].shape
@@ -251,11 +251,25 @@ class _REDCore(nn.Module):
         for s in states:
             if s.dtype != torch.float32 or not s.is_contiguous():
                 raise ValueError("states must be contiguous float32")
+        target = acc_state if reg_volume is None else reg_volume
         with torch.cuda.device(dev):
-            _lib.call("smvs_red_pred_planes", kind, _lib.ptr(feats[0]), _lib.ptr_array(feats[1:]), len(feats) - 1,
+            _lib.call("smvs_red_pred_planes" if reg_volume is None else "smvs_red_volume_planes",
+                      kind, _lib.ptr(feats[0]), _lib.ptr_array(feats[1:]), len(feats) - 1,
                       _lib.ptr(geo), _lib.ptr(depth), is4d, _lib.ptr(packed), *[_lib.ptr(s) for s in states],
-                      _lib.ptr(acc_state), _lib.ptr(ws), nbytes, b, c, D, h, w, d_begin, d_end,
+                      _lib.ptr(target), _lib.ptr(ws), nbytes, b, c, D, h, w, d_begin, d_end,
                       _lib.current_stream(dev))
+
+    def native_volume(self, features, proj_matrices, depth_values, geo_model, use_qc):
+        """(B,D,H,W) regularised cost of the whole sweep without materialising the variance volume
+        (smvs_red_volume_planes): what RED_Regularization.forward(variance_cost_volume(...)) returns."""
+        ref = features[0]
+        b, _, h, w = ref.shape
+        d_num = depth_values.shape[1]
+        states = self.initial_states(b, h, w, ref.device)
+        reg = torch.empty((b, d_num, h, w), dtype=torch.float32, device=ref.device)
+        self.native_pred_planes(features, proj_matrices, depth_values, geo_model, use_qc, states, None, 0, d_num,
+                                reg_volume=reg)
+        return reg
 
     def _use_native(self, cost):
         if os.environ.get("SMVS_RED_TORCH") == "1":        # A/B switch: force the stock PyTorch composite

@@ -38,8 +38,15 @@ def compute_depth_when_train(features, proj_matrices, depth_values, num_depth, c
                              use_qc):
     """Whole-volume path: variance volume -> regulariser -> softmax -> expected height."""
     _check(features, proj_matrices, depth_values, num_depth, use_qc)
-    volume_variance = variance_cost_volume(features, proj_matrices, depth_values, geo_model, use_qc)
-    reg = cost_regularization(volume_variance)                     # (B,D,H,W)
+    if (not torch.is_grad_enabled() and hasattr(cost_regularization, "native_volume")
+            and cost_regularization._use_native(features[0])):
+        # inference: plane pipeline (variance plane -> RED step) straight into the (B,D,H,W) regularised cost;
+        # the (B,C,D,H,W) variance volume is never materialised
+        reg = cost_regularization.native_volume(features, proj_matrices, depth_values.detach().to(torch.float32).contiguous(),
+                                                geo_model, use_qc)
+    else:
+        volume_variance = variance_cost_volume(features, proj_matrices, depth_values, geo_model, use_qc)
+        reg = cost_regularization(volume_variance)                 # (B,D,H,W)
     depth, confidence = softmax_depth_regression(reg, depth_values)
     return {"depth": depth, "photometric_confidence": confidence}
 

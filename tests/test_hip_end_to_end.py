@@ -188,6 +188,28 @@ def test_train_path_matches_reference(dev, golden):
     np.testing.assert_allclose(out["photometric_confidence"].cpu().numpy(), g["train_conf"], rtol=1e-4, atol=1e-6)
 
 
+def test_red_volume_pipeline_equals_per_plane_steps(dev):
+    """smvs_red_volume_planes (stream-pipelined plane loop, variance volume never materialised, B = 2 to cover
+    the batch stride of the (B,D,H,W) output) against RED_Regularization.forward on the materialised volume
+    (one smvs_red_step_fwd per plane on one stream): same kernels, same per-plane order -> same bits."""
+    from satmvs_amd import rpc_synth
+    from satmvs_amd.modules.module import RED_Regularization
+    from satmvs_amd.modules.warping import variance_cost_volume
+    torch.manual_seed(5)
+    B, V, C, H, W, D = 2, 3, 8, 32, 40, 6
+    reg = RED_Regularization(C, 8).to(dev).eval()
+    feats = [torch.randn(B, C, H, W, device=dev) for _ in range(V)]
+    rpc = np.stack([rpc_synth.make_view_rpcs(V, H, W, seed=11 + b) for b in range(B)])
+    proj = torch.from_numpy(rpc).to(dev)
+    dv = (torch.linspace(50, 350, D, device=dev).view(1, D, 1, 1) + 3 * torch.rand(B, D, H, W, device=dev)).contiguous()
+    with torch.no_grad():
+        assert reg._use_native(feats[0])
+        a = reg.native_volume(feats, proj, dv, "rpc", False)
+        b = reg(variance_cost_volume(feats, proj, dv, "rpc", False))
+    assert a.shape == b.shape == (B, D, H, W)
+    assert torch.equal(a, b)
+
+
 def test_sharded_pred_equals_unsharded_on_one_gpu(dev, golden):
     """satmvs_amd.shard with no process group (world 1) is the plain pred path, bit for bit."""
     from satmvs_amd import shard
