@@ -383,6 +383,52 @@ def gen_cascade():
     save("cascade", **arrays)
 
 
+def gen_cascade_pinhole():
+    """BASELINE cfg5 family: full forwards with geo_model="pinhole" (homography warp, modules/warping.py:6-44)
+    at 3-view 64x128, ndepths 16/8/8: UCSNet (networks/ucs.py:79), CascadeREDNet and Infer_CascadeREDNet
+    (networks/casred.py:114,285; same weights).  Stage matrices = intrinsics rows scaled by 1/4, 1/2, 1 as
+    dataset/virdataset.py does.  Weights by seed + checksum as in gen_cascade."""
+    B, V, H, W = 1, 3, 64, 128
+    nd = [16, 8, 8]
+    torch.manual_seed(31)
+    imgs = torch.randn(B, V, 3, H, W)
+    full = _pinhole_mats(V, H, W, seed=9, batch=B)
+
+    def scaled(s):
+        m = full.copy()
+        m[:, :, :2, :] /= s
+        return torch.from_numpy(m)
+
+    proj = {"stage1": scaled(4), "stage2": scaled(2), "stage3": scaled(1)}
+    dv = torch.tensor([[420.0, 680.0]])
+    arrays = {"imgs": imgs.numpy(), "proj": full, "dv": dv.numpy(), "ndepths": np.array(nd)}
+
+    def record(tag, out):
+        for s in ("stage1", "stage2", "stage3"):
+            for k, v in out[s].items():
+                arrays["%s.%s.%s" % (tag, s, k)] = v.numpy()
+
+    def sums(tag, net):
+        arrays[tag + ".param_sums"] = np.array([[float(v.double().sum()), float((v.double() ** 2).sum())]
+                                                for k, v in net.state_dict().items() if "num_batches_tracked" not in k])
+
+    torch.manual_seed(33)
+    red = ref_casred.CascadeREDNet("pinhole", min_interval=2.5, ndepths=nd).eval()
+    arrays["red.seed"] = np.int64(33)
+    sums("red", red)
+    inf = ref_casred.Infer_CascadeREDNet("pinhole", min_interval=2.5, ndepths=nd).eval()
+    inf.load_state_dict(red.state_dict())
+    torch.manual_seed(34)
+    ucs = ref_ucs.UCSNet("pinhole", stage_configs=nd).eval()
+    arrays["ucs.seed"] = np.int64(34)
+    sums("ucs", ucs)
+    with torch.no_grad():
+        record("red", red(imgs, proj, dv))
+        record("redinf", inf(imgs, proj, dv))
+        record("ucs", ucs(imgs, proj, dv))
+    save("cascade_pinhole", **arrays)
+
+
 def gen_costreg():
     """CostRegNet.forward (modules/module.py:546-577) in eval mode with non-trivial BatchNorm running
     statistics; weights exported (1.2 MB)."""
@@ -422,7 +468,7 @@ def gen_featnet():
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (gen_iccv, gen_project, gen_grid_sample, gen_rpc_warp, gen_qc, gen_homo, gen_costvol, gen_pred,
-               gen_regress, gen_depth_range, gen_cascade, gen_costreg, gen_featnet):
+               gen_regress, gen_depth_range, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet):
         if only and fn.__name__[4:] not in only:
             continue
         fn()

@@ -70,6 +70,46 @@ def test_cascade_forward_matches_reference(dev, golden, tag):
         np.testing.assert_allclose(out[s]["photometric_confidence"].cpu().numpy(), wc, rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("tag", ["red", "redinf", "ucs"])
+def test_cascade_forward_pinhole_matches_reference(dev, golden, tag):
+    """BASELINE cfg5 family: geo_model="pinhole" end to end (homography cost volume; for the RED networks the
+    native plane pipeline with geo_kind 1) against the reference's outputs, heights within 1e-3."""
+    from satmvs_amd.networks import casred, ucs
+    g = golden("cascade_pinhole")
+    nd = [int(v) for v in g["ndepths"]]
+    seed_tag = "red" if tag == "redinf" else tag
+    torch.manual_seed(int(g[seed_tag + ".seed"]))
+    if tag == "red":
+        net = casred.CascadeREDNet("pinhole", min_interval=2.5, ndepths=nd)
+    elif tag == "redinf":
+        net = casred.Infer_CascadeREDNet("pinhole", min_interval=2.5, ndepths=nd)
+    else:
+        net = ucs.UCSNet("pinhole", stage_configs=nd)
+    sd = {k: v for k, v in net.state_dict().items() if "num_batches_tracked" not in k}
+    sums = np.array([[float(v.double().sum()), float((v.double() ** 2).sum())] for v in sd.values()])
+    np.testing.assert_allclose(sums, g[seed_tag + ".param_sums"], rtol=1e-12, atol=1e-12)
+    net = net.to(dev).eval()
+    imgs = torch.from_numpy(g["imgs"]).to(dev)
+    full = g["proj"]
+
+    def scaled(s):
+        m = full.copy()
+        m[:, :, :2, :] /= s
+        return torch.from_numpy(m).to(dev)
+
+    proj = {"stage1": scaled(4), "stage2": scaled(2), "stage3": scaled(1)}
+    with torch.no_grad():
+        out = net(imgs, proj, torch.from_numpy(g["dv"]).to(dev))
+    for s in ("stage1", "stage2", "stage3"):
+        want = g["%s.%s.depth" % (tag, s)]
+        got = out[s]["depth"].cpu().numpy()
+        assert got.shape == want.shape
+        err = np.abs(got - want).max()
+        assert err <= H_TOL, "%s %s: max depth error %.3g" % (tag, s, err)
+        np.testing.assert_allclose(out[s]["photometric_confidence"].cpu().numpy(),
+                                   g["%s.%s.photometric_confidence" % (tag, s)], rtol=1e-3, atol=1e-5)
+
+
 def _red_pred_setup(g, dev, cls):
     reg = cls(8, 8).eval()
     reg.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")})
