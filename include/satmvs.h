@@ -179,21 +179,25 @@ int smvs_costreg_fwd(const float* packed, const float* vol, float* out, void* wo
                      int B, int C, int D, int H, int W, void* stream);
 
 /* ---- feature extractor (FeatureNet), inference form ---------------------------------------------------
- * Replaces FeatureNet.forward (modules/module.py:442-543; arch_mode "unet", num_stage 3; Conv2d :19-60,
- * Deconv2d :62-114, DeConv2dFuse :117-140) applied to every view (networks/casred.py:116-121): all views
- * of all samples in one call (N = B*V images).  BatchNorm2d uses its running statistics, folded into a
- * per-channel scale/shift.
- * smvs_featnet_pack_weights: params = HOST array of 63 device pointers -- for conv0.0, conv0.1, conv1.0,
- * conv1.1, conv1.2, conv2.0, conv2.1, conv2.2, deconv1.deconv, deconv1.conv, deconv2.deconv,
- * deconv2.conv: conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var; then out1.weight,
- * out2.weight, out3.weight.  packed: smvs_featnet_packed_floats(base_channels) floats owned by the caller.
+ * Replaces FeatureNet.forward (modules/module.py:442-543; num_stage 3; Conv2d :19-60, Deconv2d :62-114,
+ * DeConv2dFuse :117-140) applied to every view (networks/casred.py:116-121): all views of all samples in one
+ * call (N = B*V images).  arch 0 = arch_mode "unet" (casred, ucs), arch 1 = arch_mode "fpn" (casmvs: 1x1
+ * laterals added to the nearest-upsampled coarser level, module.py:527-536).  BatchNorm2d uses its running
+ * statistics, folded into a per-channel scale/shift.
+ * smvs_featnet_pack_weights: params = HOST array of device pointers.  Both variants: for conv0.0, conv0.1,
+ * conv1.0, conv1.1, conv1.2, conv2.0, conv2.1, conv2.2: conv.weight, bn.weight, bn.bias, bn.running_mean,
+ * bn.running_var (40).  arch 0 continues with the same five for deconv1.deconv, deconv1.conv, deconv2.deconv,
+ * deconv2.conv, then out1.weight, out2.weight, out3.weight (63 in all); arch 1 with out1.weight,
+ * inner1.weight, inner1.bias, out2.weight, inner2.weight, inner2.bias, out3.weight (47 in all).
+ * packed: smvs_featnet_packed_floats(base_channels, arch) floats owned by the caller.
  * smvs_featnet_fwd: imgs (N,3,H,W) -> stage1 (N,4c,H/4,W/4), stage2 (N,2c,H/2,W/2), stage3 (N,c,H,W);
  * H, W multiples of 4; workspace of smvs_featnet_workspace_bytes bytes. */
-size_t smvs_featnet_packed_floats(int base_channels);
-size_t smvs_featnet_workspace_bytes(int N, int H, int W, int base_channels);
-int smvs_featnet_pack_weights(const float* const* params, int base_channels, float* packed, void* stream);
+size_t smvs_featnet_packed_floats(int base_channels, int arch);
+size_t smvs_featnet_workspace_bytes(int N, int H, int W, int base_channels, int arch);
+int smvs_featnet_pack_weights(const float* const* params, int base_channels, int arch, float* packed, void* stream);
 int smvs_featnet_fwd(const float* packed, const float* imgs, float* stage1, float* stage2, float* stage3,
-                     void* workspace, size_t workspace_bytes, int N, int H, int W, int base_channels, void* stream);
+                     void* workspace, size_t workspace_bytes, int N, int H, int W, int base_channels, int arch,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -311,9 +311,9 @@ def _bn2d_eval(x, wt, prefix, eps=1e-5):
     return y.astype(np.float32)
 
 
-def featurenet(wt, img):
-    """FeatureNet.forward (unet, 3 stages) in eval mode.  wt: name -> array (state_dict incl. BN running stats).
-    Returns (stage1, stage2, stage3) = (B,4c,H/4,W/4), (B,2c,H/2,W/2), (B,c,H,W)."""
+def featurenet(wt, img, arch_mode="unet"):
+    """FeatureNet.forward (3 stages, arch_mode "unet" or "fpn") in eval mode.  wt: name -> array (state_dict incl.
+    BN running stats).  Returns (stage1, stage2, stage3) = (B,4c,H/4,W/4), (B,2c,H/2,W/2), (B,c,H,W)."""
     relu = lambda a: np.maximum(a, 0)  # noqa: E731
 
     def cbr(name, t, stride=1):
@@ -323,12 +323,22 @@ def featurenet(wt, img):
         up = relu(_bn2d_eval(convT2d3x3(t, wt[name + ".deconv.conv.weight"], None, 2, 1), wt, name + ".deconv.bn."))
         return cbr(name + ".conv", np.concatenate([up, pre], 1))
 
+    def lateral(name, pre, t):                             # F.interpolate(t, 2, "nearest") + innerK(pre), module.py:527-536
+        up = np.repeat(np.repeat(t, 2, axis=2), 2, axis=3)
+        return up + (conv2d_k(pre, wt[name + ".weight"]) + _f32(wt[name + ".bias"]).reshape(1, -1, 1, 1))
+
     c0 = cbr("conv0.1", cbr("conv0.0", _f32(img)))
     c1 = cbr("conv1.2", cbr("conv1.1", cbr("conv1.0", c0, 2)))
     c2 = cbr("conv2.2", cbr("conv2.1", cbr("conv2.0", c1, 2)))
     s1 = conv2d_k(c2, wt["out1.weight"])
-    f = fuse("deconv1", c1, c2)
-    s2 = conv2d_k(f, wt["out2.weight"])
-    f = fuse("deconv2", c0, f)
-    s3 = conv2d_k(f, wt["out3.weight"])
+    if arch_mode == "unet":
+        f = fuse("deconv1", c1, c2)
+        s2 = conv2d_k(f, wt["out2.weight"])
+        f = fuse("deconv2", c0, f)
+        s3 = conv2d_k(f, wt["out3.weight"])
+    else:
+        f = lateral("inner1", c1, c2)
+        s2 = conv2d_k(f, wt["out2.weight"])
+        f = lateral("inner2", c0, f)
+        s3 = conv2d_k(f, wt["out3.weight"])
     return s1, s2, s3

@@ -36,13 +36,13 @@ _SIGNATURES = {
     "smvs_red_volume_planes": [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 7 + [_vp],
     "smvs_costreg_pack_weights": [_vp, _i, _vp, _vp],
     "smvs_costreg_fwd": [_vp, _vp, _vp, _vp, _sz] + [_i] * 5 + [_vp],
-    "smvs_featnet_pack_weights": [_vp, _i, _vp, _vp],
-    "smvs_featnet_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 4 + [_vp],
+    "smvs_featnet_pack_weights": [_vp, _i, _i, _vp, _vp],
+    "smvs_featnet_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 5 + [_vp],
 }
 _SIZE_FUNCS = {"smvs_red_packed_floats": [_i], "smvs_red_workspace_bytes": [_i] * 4,
                "smvs_red_pred_workspace_bytes": [_i] * 4, "smvs_costreg_packed_floats": [_i],
-               "smvs_costreg_workspace_bytes": [_i] * 5, "smvs_featnet_packed_floats": [_i],
-               "smvs_featnet_workspace_bytes": [_i] * 4}
+               "smvs_costreg_workspace_bytes": [_i] * 5, "smvs_featnet_packed_floats": [_i] * 2,
+               "smvs_featnet_workspace_bytes": [_i] * 5}
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SIZE_FUNCS) + ["smvs_version", "smvs_last_error"])
 
 _lib = None

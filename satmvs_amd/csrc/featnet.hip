@@ -1,6 +1,7 @@
 // featnet.hip -- native inference forward of the feature extractor.
 //
-// Replaces FeatureNet.forward (/root/reference/modules/module.py:442-543, arch_mode "unet", 3 stages) in
+// Replaces FeatureNet.forward (/root/reference/modules/module.py:442-543, 3 stages; arch_mode "unet" = arch 0,
+// arch_mode "fpn" = arch 1: 1x1 lateral convolutions added to the nearest-upsampled coarser level) in
 // eval mode: 3x3 / 5x5 / 1x1 convolutions with BatchNorm folded to a per-channel scale/shift + ReLU
 // (Conv2d :19-60), two stride-2 transposed convolutions fused with their skip concatenation
 // (DeConv2dFuse :117-140) and the three 1x1 output heads.  All views of a sample go through ONE call
@@ -20,36 +21,47 @@
 namespace smvs {
 
 constexpr int FN_COT = 8;
-constexpr int FN_NL = 15;
+constexpr int FN_NL = 15;                   // layers of the unet variant (the fpn variant has 13)
 
-struct FnLayer { int cin, cout, k, stride, transposed, bn, relu; };
+struct FnLayer { int cin, cout, k, stride, transposed, bn, relu, bias; };
 
-// layer list in execution order; c = base channels
-static void fn_layers(int c, FnLayer* L)
+// layer list in execution order; c = base channels.  Returns the number of layers.
+static int fn_layers(int c, int arch, FnLayer* L)
 {
-    const FnLayer l[FN_NL] = {
-        {3, c, 3, 1, 0, 1, 1},          {c, c, 3, 1, 0, 1, 1},                                     // conv0.0, conv0.1
-        {c, 2 * c, 5, 2, 0, 1, 1},      {2 * c, 2 * c, 3, 1, 0, 1, 1}, {2 * c, 2 * c, 3, 1, 0, 1, 1},  // conv1.0..2
-        {2 * c, 4 * c, 5, 2, 0, 1, 1},  {4 * c, 4 * c, 3, 1, 0, 1, 1}, {4 * c, 4 * c, 3, 1, 0, 1, 1},  // conv2.0..2
-        {4 * c, 4 * c, 1, 1, 0, 0, 0},                                                               // out1
-        {4 * c, 2 * c, 3, 2, 1, 1, 1},  {4 * c, 2 * c, 3, 1, 0, 1, 1},                               // deconv1.deconv, deconv1.conv
-        {2 * c, 2 * c, 1, 1, 0, 0, 0},                                                               // out2
-        {2 * c, c, 3, 2, 1, 1, 1},      {2 * c, c, 3, 1, 0, 1, 1},                                   // deconv2.deconv, deconv2.conv
-        {c, c, 1, 1, 0, 0, 0}};                                                                      // out3
-    for (int i = 0; i < FN_NL; ++i) L[i] = l[i];
+    const FnLayer trunk[8] = {
+        {3, c, 3, 1, 0, 1, 1, 0},          {c, c, 3, 1, 0, 1, 1, 0},                                         // conv0.0, conv0.1
+        {c, 2 * c, 5, 2, 0, 1, 1, 0},      {2 * c, 2 * c, 3, 1, 0, 1, 1, 0}, {2 * c, 2 * c, 3, 1, 0, 1, 1, 0},  // conv1.0..2
+        {2 * c, 4 * c, 5, 2, 0, 1, 1, 0},  {4 * c, 4 * c, 3, 1, 0, 1, 1, 0}, {4 * c, 4 * c, 3, 1, 0, 1, 1, 0}};  // conv2.0..2
+    for (int i = 0; i < 8; ++i) L[i] = trunk[i];
+    if (arch == 0) {
+        const FnLayer head[7] = {
+            {4 * c, 4 * c, 1, 1, 0, 0, 0, 0},                                                                   // out1
+            {4 * c, 2 * c, 3, 2, 1, 1, 1, 0},  {4 * c, 2 * c, 3, 1, 0, 1, 1, 0},                                // deconv1.deconv, deconv1.conv
+            {2 * c, 2 * c, 1, 1, 0, 0, 0, 0},                                                                   // out2
+            {2 * c, c, 3, 2, 1, 1, 1, 0},      {2 * c, c, 3, 1, 0, 1, 1, 0},                                    // deconv2.deconv, deconv2.conv
+            {c, c, 1, 1, 0, 0, 0, 0}};                                                                          // out3
+        for (int i = 0; i < 7; ++i) L[8 + i] = head[i];
+        return 15;
+    }
+    const FnLayer head[5] = {
+        {4 * c, 4 * c, 1, 1, 0, 0, 0, 0},                                                                       // out1
+        {2 * c, 4 * c, 1, 1, 0, 0, 0, 1},  {4 * c, 2 * c, 3, 1, 0, 0, 0, 0},                                    // inner1 (+ up(c2)), out2
+        {c, 4 * c, 1, 1, 0, 0, 0, 1},      {4 * c, c, 3, 1, 0, 0, 0, 0}};                                       // inner2 (+ up(f1)), out3
+    for (int i = 0; i < 5; ++i) L[8 + i] = head[i];
+    return 13;
 }
 
 __host__ __device__ inline size_t fn_packed_conv(int cin, int cout, int k) { return (size_t)((cout + FN_COT - 1) / FN_COT) * cin * k * k * FN_COT; }
 
 struct FnLayout { size_t w[FN_NL], scale[FN_NL], shift[FN_NL], total; };
 
-static FnLayout fn_layout(int c)
+static FnLayout fn_layout(int c, int arch)
 {
     FnLayer L[FN_NL];
-    fn_layers(c, L);
+    const int nl = fn_layers(c, arch, L);
     FnLayout lay{};
     size_t o = 0;
-    for (int i = 0; i < FN_NL; ++i) {
+    for (int i = 0; i < nl; ++i) {
         const size_t cp = (size_t)((L[i].cout + FN_COT - 1) / FN_COT) * FN_COT;
         lay.w[i] = o; o += fn_packed_conv(L[i].cin, L[i].cout, L[i].k);
         lay.scale[i] = o; o += cp;
@@ -78,10 +90,12 @@ __global__ void fn_pack_bn_kernel(const float* __restrict__ gamma, const float* 
                                   const float* __restrict__ var, float* __restrict__ scale, float* __restrict__ shift,
                                   int cout, int cp, int bn)
 {
+    // bn == 1: fold the BatchNorm; bn == 2: `gamma` is a plain convolution bias (scale 1); bn == 0: identity
     const int i = threadIdx.x;
     if (i >= cp) return;
     float s = 1.0f, t = 0.0f;
-    if (bn && i < cout) {
+    if (bn == 2 && i < cout) t = gamma[i];
+    if (bn == 1 && i < cout) {
         const double sd = (double)gamma[i] / sqrt((double)var[i] + 1e-5);
         s = (float)sd;
         t = (float)((double)beta[i] - (double)mean[i] * sd);
@@ -96,6 +110,7 @@ struct FnConvArgs {
     const float* w;                          // packed [cog][CA+CB][K*K][8]
     const float* scale; const float* shift;  // (>= Cout, padded to 8)
     float* out;                              // (N,Cout,Ho,Wo)
+    const float* up;                         // (N,Cout,Ho/2,Wo/2) added after nearest x2 upsampling, or null (fpn lateral)
     int Cout, Hi, Wi, Ho, Wo, relu;
 };
 
@@ -169,6 +184,7 @@ void fn_conv_kernel(const FnConvArgs a)
         if (co < a.Cout) {
             float r = fmaf(acc[j], a.scale[co], a.shift[co]);
             if (a.relu) r = fmaxf(r, 0.0f);
+            if (a.up) r = a.up[((size_t)n * a.Cout + co) * (HWo / 4) + (size_t)(oy >> 1) * (a.Wo >> 1) + (ox >> 1)] + r;
             a.out[((size_t)n * a.Cout + co) * HWo + (size_t)oy * a.Wo + ox] = r;
         }
     }
@@ -249,7 +265,7 @@ void fn_convT_kernel(const FnConvArgs a)
 
 struct FnWorkspace { size_t t0, c0, t1a, t1b, c1, t2a, t2b, c2, up1, f1, up2, f2, total; };
 
-static FnWorkspace fn_workspace(int N, int H, int W, int c)
+static FnWorkspace fn_workspace(int N, int H, int W, int c, int arch)
 {
     FnWorkspace w{};
     size_t o = 0;
@@ -258,8 +274,13 @@ static FnWorkspace fn_workspace(int N, int H, int W, int c)
     w.t0 = take(c * p0); w.c0 = take(c * p0);
     w.t1a = take(2 * c * p1); w.t1b = take(2 * c * p1); w.c1 = take(2 * c * p1);
     w.t2a = take(4 * c * p2); w.t2b = take(4 * c * p2); w.c2 = take(4 * c * p2);
-    w.up1 = take(2 * c * p1); w.f1 = take(2 * c * p1);
-    w.up2 = take(c * p0); w.f2 = take(c * p0);
+    if (arch == 0) {
+        w.up1 = take(2 * c * p1); w.f1 = take(2 * c * p1);
+        w.up2 = take(c * p0); w.f2 = take(c * p0);
+    } else {                                               // fpn: the merged levels carry 4c channels
+        w.f1 = take(4 * c * p1);
+        w.f2 = take(4 * c * p0);
+    }
     w.total = o;
     return w;
 }
@@ -273,7 +294,7 @@ static void fn_launch(const FnLayer& l, const FnConvArgs& a, int N, hipStream_t 
     }
     const dim3 grd((a.Wo + 63) / 64, (a.Ho + 3) / 4, N * ncog), blk(256);
     if (l.k == 1)                       hipLaunchKernelGGL((fn_conv_kernel<1, 1>), grd, blk, 0, st, a);
-    else if (l.k == 3 && l.stride == 1) hipLaunchKernelGGL((fn_conv_kernel<3, 1>), grd, blk, 0, st, a);
+    else if (l.k == 3)                  hipLaunchKernelGGL((fn_conv_kernel<3, 1>), grd, blk, 0, st, a);
     else                                hipLaunchKernelGGL((fn_conv_kernel<5, 2>), grd, blk, 0, st, a);
 }
 
@@ -281,46 +302,51 @@ static void fn_launch(const FnLayer& l, const FnConvArgs& a, int N, hipStream_t 
 
 extern "C" {
 
-SMVS_EXPORT size_t smvs_featnet_packed_floats(int base_channels)
+SMVS_EXPORT size_t smvs_featnet_packed_floats(int base_channels, int arch)
 {
-    return base_channels > 0 ? smvs::fn_layout(base_channels).total : 0;
+    return base_channels > 0 && (arch == 0 || arch == 1) ? smvs::fn_layout(base_channels, arch).total : 0;
 }
 
-SMVS_EXPORT size_t smvs_featnet_workspace_bytes(int N, int H, int W, int base_channels)
+SMVS_EXPORT size_t smvs_featnet_workspace_bytes(int N, int H, int W, int base_channels, int arch)
 {
-    if (N < 1 || base_channels < 1 || H < 4 || W < 4 || (H % 4) || (W % 4)) return 0;
-    return smvs::fn_workspace(N, H, W, base_channels).total * sizeof(float);
+    if (N < 1 || base_channels < 1 || H < 4 || W < 4 || (H % 4) || (W % 4) || (arch != 0 && arch != 1)) return 0;
+    return smvs::fn_workspace(N, H, W, base_channels, arch).total * sizeof(float);
 }
 
-// params: HOST array of 63 device pointers in the module's own order:
-//   for each of conv0.0, conv0.1, conv1.0, conv1.1, conv1.2, conv2.0, conv2.1, conv2.2,
-//               deconv1.deconv, deconv1.conv, deconv2.deconv, deconv2.conv:
-//       conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var          (12 x 5)
-//   out1.weight, out2.weight, out3.weight                                         (+ 3)
-SMVS_EXPORT int smvs_featnet_pack_weights(const float* const* params, int base_channels, float* packed, void* stream)
+// params: HOST array of device pointers in the module's own order.  Both variants start with
+//   for each of conv0.0, conv0.1, conv1.0, conv1.1, conv1.2, conv2.0, conv2.1, conv2.2:
+//       conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var                       (8 x 5 = 40)
+// arch 0 (unet, 63 pointers): the same 5 for deconv1.deconv, deconv1.conv, deconv2.deconv, deconv2.conv (+20),
+//   then out1.weight, out2.weight, out3.weight.
+// arch 1 (fpn, 47 pointers): out1.weight, inner1.weight, inner1.bias, out2.weight, inner2.weight, inner2.bias,
+//   out3.weight.
+SMVS_EXPORT int smvs_featnet_pack_weights(const float* const* params, int base_channels, int arch, float* packed, void* stream)
 {
     using namespace smvs;
     if (!params || !packed) return fail(SMVS_ERR_ARG, "null pointer argument");
     if (base_channels < 1) return fail(SMVS_ERR_ARG, "non-positive channel count");
-    for (int i = 0; i < 63; ++i)
+    if (arch != 0 && arch != 1) return fail(SMVS_ERR_ARG, "arch must be 0 (unet) or 1 (fpn)");
+    const int nparams = arch == 0 ? 63 : 47;
+    for (int i = 0; i < nparams; ++i)
         if (!params[i]) return fail(SMVS_ERR_ARG, "null parameter pointer %d", i);
     FnLayer L[FN_NL];
-    fn_layers(base_channels, L);
-    const FnLayout lay = fn_layout(base_channels);
-    // execution-order layer -> index of its 5-pointer block (or, for the heads, of its single weight)
-    const int block[FN_NL] = {0, 1, 2, 3, 4, 5, 6, 7, -60, 8, 9, -61, 10, 11, -62};
+    const int nl = fn_layers(base_channels, arch, L);
+    const FnLayout lay = fn_layout(base_channels, arch);
+    // execution-order layer -> index of its first pointer
+    const int first_unet[15] = {0, 5, 10, 15, 20, 25, 30, 35, 60, 40, 45, 61, 50, 55, 62};
+    const int first_fpn[13] = {0, 5, 10, 15, 20, 25, 30, 35, 40, 41, 43, 44, 46};
     hipStream_t st = (hipStream_t)stream;
-    for (int i = 0; i < FN_NL; ++i) {
-        const bool head = block[i] < 0;
-        const float* const* q = params + (head ? -block[i] : block[i] * 5);
+    for (int i = 0; i < nl; ++i) {
+        const float* const* q = params + (arch == 0 ? first_unet[i] : first_fpn[i]);
         if (L[i].cout > 64) return fail(SMVS_ERR_UNSUPPORTED, "base_channels %d too large for the BatchNorm fold kernel", base_channels);
         const int n = (int)fn_packed_conv(L[i].cin, L[i].cout, L[i].k);
         hipLaunchKernelGGL(fn_pack_conv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, q[0], packed + lay.w[i],
                            L[i].cin, L[i].cout, L[i].k, L[i].transposed);
         const int cp = ((L[i].cout + FN_COT - 1) / FN_COT) * FN_COT;
-        hipLaunchKernelGGL(fn_pack_bn_kernel, dim3(1), dim3(64), 0, st, head ? q[0] : q[1], head ? q[0] : q[2],
-                           head ? q[0] : q[3], head ? q[0] : q[4], packed + lay.scale[i], packed + lay.shift[i],
-                           L[i].cout, cp, L[i].bn);
+        const int mode = L[i].bn ? 1 : L[i].bias ? 2 : 0;
+        hipLaunchKernelGGL(fn_pack_bn_kernel, dim3(1), dim3(64), 0, st, mode ? q[1] : q[0], mode == 1 ? q[2] : q[0],
+                           mode == 1 ? q[3] : q[0], mode == 1 ? q[4] : q[0], packed + lay.scale[i], packed + lay.shift[i],
+                           L[i].cout, cp, mode);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "featnet_pack_weights launch: %s", hipGetErrorString(e));
@@ -330,38 +356,45 @@ SMVS_EXPORT int smvs_featnet_pack_weights(const float* const* params, int base_c
 // imgs (N,3,H,W) -> stage1 (N,4c,H/4,W/4), stage2 (N,2c,H/2,W/2), stage3 (N,c,H,W).  N = samples x views;
 // H and W multiples of 4.
 SMVS_EXPORT int smvs_featnet_fwd(const float* packed, const float* imgs, float* stage1, float* stage2, float* stage3,
-                                 void* workspace, size_t workspace_bytes, int N, int H, int W, int base_channels, void* stream)
+                                 void* workspace, size_t workspace_bytes, int N, int H, int W, int base_channels, int arch,
+                                 void* stream)
 {
     using namespace smvs;
     if (!packed || !imgs || !stage1 || !stage2 || !stage3 || !workspace) return fail(SMVS_ERR_ARG, "null pointer argument");
-    const size_t need = smvs_featnet_workspace_bytes(N, H, W, base_channels);
+    if (arch != 0 && arch != 1) return fail(SMVS_ERR_ARG, "arch must be 0 (unet) or 1 (fpn)");
+    const size_t need = smvs_featnet_workspace_bytes(N, H, W, base_channels, arch);
     if (need == 0) return fail(SMVS_ERR_ARG, "image %dx%d must be a positive multiple of 4 in both dimensions", H, W);
     if (workspace_bytes < need) return fail(SMVS_ERR_ARG, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
     const int c = base_channels;
     if ((long long)4 * c * H * W * 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "image too large");
     if ((long long)N * ((4 * c + FN_COT - 1) / FN_COT) > 65535) return fail(SMVS_ERR_ARG, "too many views for one launch grid");
     FnLayer L[FN_NL];
-    fn_layers(c, L);
-    const FnLayout lay = fn_layout(c);
-    const FnWorkspace ws = fn_workspace(N, H, W, c);
+    const int nl = fn_layers(c, arch, L);
+    const FnLayout lay = fn_layout(c, arch);
+    const FnWorkspace ws = fn_workspace(N, H, W, c, arch);
     float* f = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    struct Step { const float* inA; const float* inB; int CB; float* out; int lin, lout; };   // lin / lout: 0 full, 1 half, 2 quarter
-    const Step steps[FN_NL] = {
-        {imgs, nullptr, 0, f + ws.t0, 0, 0},          {f + ws.t0, nullptr, 0, f + ws.c0, 0, 0},
-        {f + ws.c0, nullptr, 0, f + ws.t1a, 0, 1},    {f + ws.t1a, nullptr, 0, f + ws.t1b, 1, 1},  {f + ws.t1b, nullptr, 0, f + ws.c1, 1, 1},
-        {f + ws.c1, nullptr, 0, f + ws.t2a, 1, 2},    {f + ws.t2a, nullptr, 0, f + ws.t2b, 2, 2},  {f + ws.t2b, nullptr, 0, f + ws.c2, 2, 2},
-        {f + ws.c2, nullptr, 0, stage1, 2, 2},
-        {f + ws.c2, nullptr, 0, f + ws.up1, 2, 1},    {f + ws.up1, f + ws.c1, 2 * c, f + ws.f1, 1, 1},
-        {f + ws.f1, nullptr, 0, stage2, 1, 1},
-        {f + ws.f1, nullptr, 0, f + ws.up2, 1, 0},    {f + ws.up2, f + ws.c0, c, f + ws.f2, 0, 0},
-        {f + ws.f2, nullptr, 0, stage3, 0, 0}};
-    for (int i = 0; i < FN_NL; ++i) {
-        const Step& s = steps[i];
+    struct Step { const float* inA; const float* inB; int CB; float* out; int lin, lout; const float* up; };   // lin / lout: 0 full, 1 half, 2 quarter
+    const Step trunk[8] = {
+        {imgs, nullptr, 0, f + ws.t0, 0, 0, nullptr},          {f + ws.t0, nullptr, 0, f + ws.c0, 0, 0, nullptr},
+        {f + ws.c0, nullptr, 0, f + ws.t1a, 0, 1, nullptr},    {f + ws.t1a, nullptr, 0, f + ws.t1b, 1, 1, nullptr},  {f + ws.t1b, nullptr, 0, f + ws.c1, 1, 1, nullptr},
+        {f + ws.c1, nullptr, 0, f + ws.t2a, 1, 2, nullptr},    {f + ws.t2a, nullptr, 0, f + ws.t2b, 2, 2, nullptr},  {f + ws.t2b, nullptr, 0, f + ws.c2, 2, 2, nullptr}};
+    const Step head_unet[7] = {
+        {f + ws.c2, nullptr, 0, stage1, 2, 2, nullptr},
+        {f + ws.c2, nullptr, 0, f + ws.up1, 2, 1, nullptr},    {f + ws.up1, f + ws.c1, 2 * c, f + ws.f1, 1, 1, nullptr},
+        {f + ws.f1, nullptr, 0, stage2, 1, 1, nullptr},
+        {f + ws.f1, nullptr, 0, f + ws.up2, 1, 0, nullptr},    {f + ws.up2, f + ws.c0, c, f + ws.f2, 0, 0, nullptr},
+        {f + ws.f2, nullptr, 0, stage3, 0, 0, nullptr}};
+    const Step head_fpn[5] = {
+        {f + ws.c2, nullptr, 0, stage1, 2, 2, nullptr},
+        {f + ws.c1, nullptr, 0, f + ws.f1, 1, 1, f + ws.c2},   {f + ws.f1, nullptr, 0, stage2, 1, 1, nullptr},
+        {f + ws.c0, nullptr, 0, f + ws.f2, 0, 0, f + ws.f1},   {f + ws.f2, nullptr, 0, stage3, 0, 0, nullptr}};
+    for (int i = 0; i < nl; ++i) {
+        const Step& s = i < 8 ? trunk[i] : arch == 0 ? head_unet[i - 8] : head_fpn[i - 8];
         FnConvArgs a{};
         a.inA = s.inA; a.CA = L[i].cin - s.CB; a.inB = s.inB; a.CB = s.CB;
         a.w = packed + lay.w[i]; a.scale = packed + lay.scale[i]; a.shift = packed + lay.shift[i];
-        a.out = s.out; a.Cout = L[i].cout; a.relu = L[i].relu;
+        a.out = s.out; a.up = s.up; a.Cout = L[i].cout; a.relu = L[i].relu;
         a.Hi = H >> s.lin; a.Wi = W >> s.lin; a.Ho = H >> s.lout; a.Wo = W >> s.lout;
         fn_launch(L[i], a, N, st);
     }

@@ -439,34 +439,42 @@ class FeatureNet(nn.Module):
                 self.out_channels.append(c)
 
     # ---- native inference path (smvs_featnet_fwd) ---------------------------------------------------------
-    _NATIVE_BLOCKS = ("conv0.0", "conv0.1", "conv1.0", "conv1.1", "conv1.2", "conv2.0", "conv2.1", "conv2.2",
-                      "deconv1.deconv", "deconv1.conv", "deconv2.deconv", "deconv2.conv")
+    _TRUNK = ("conv0.0", "conv0.1", "conv1.0", "conv1.1", "conv1.2", "conv2.0", "conv2.1", "conv2.2")
+    _UNET_BLOCKS = ("deconv1.deconv", "deconv1.conv", "deconv2.deconv", "deconv2.conv")
+    _BN5 = (".conv.weight", ".bn.weight", ".bn.bias", ".bn.running_mean", ".bn.running_var")
+
+    def _arch(self):
+        return 0 if self.arch_mode == "unet" else 1
 
     def _packed_weights(self, device):
         """Parameters + BatchNorm running statistics repacked for the HIP kernels; cached until any of them
         changes (load_state_dict / an optimiser step / a training-mode forward bump the tensor versions)."""
         sd = dict(self.named_parameters())
         sd.update(dict(self.named_buffers()))
-        names = [b + s for b in self._NATIVE_BLOCKS
-                 for s in (".conv.weight", ".bn.weight", ".bn.bias", ".bn.running_mean", ".bn.running_var")]
-        names += ["out1.weight", "out2.weight", "out3.weight"]
+        names = [b + s for b in self._TRUNK for s in self._BN5]
+        if self.arch_mode == "unet":
+            names += [b + s for b in self._UNET_BLOCKS for s in self._BN5] + ["out1.weight", "out2.weight", "out3.weight"]
+        else:
+            names += ["out1.weight", "inner1.weight", "inner1.bias", "out2.weight", "inner2.weight", "inner2.bias",
+                      "out3.weight"]
         tensors = [sd[n] for n in names]
         key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
         cache = getattr(self, "_packed_cache", None)
         if cache is None or cache[0] != key:
             lib = _lib.load()
-            packed = torch.empty(lib.smvs_featnet_packed_floats(self.base_channels), dtype=torch.float32, device=device)
+            packed = torch.empty(lib.smvs_featnet_packed_floats(self.base_channels, self._arch()), dtype=torch.float32,
+                                 device=device)
             src = [t.detach().to(device=device, dtype=torch.float32).contiguous() for t in tensors]
             with torch.cuda.device(device):
-                _lib.call("smvs_featnet_pack_weights", _lib.ptr_array(src), self.base_channels, _lib.ptr(packed),
-                          _lib.current_stream(device))
+                _lib.call("smvs_featnet_pack_weights", _lib.ptr_array(src), self.base_channels, self._arch(),
+                          _lib.ptr(packed), _lib.current_stream(device))
             self._packed_cache = (key, packed)
         return self._packed_cache[1]
 
     def _use_native(self, x):
         if os.environ.get("SMVS_FEATNET_TORCH") == "1":     # A/B switch: force the stock PyTorch composite
             return False
-        return (x.is_cuda and not self.training and not torch.is_grad_enabled() and self.arch_mode == "unet"
+        return (x.is_cuda and not self.training and not torch.is_grad_enabled()
                 and self.num_stage == 3 and self.base_channels <= 16 and x.shape[-1] % 4 == 0 and x.shape[-2] % 4 == 0)
 
     def native_forward(self, x):
@@ -480,7 +488,7 @@ class FeatureNet(nn.Module):
             raise ValueError("FeatureNet expects 3-channel images, got %d" % ch)
         c = self.base_channels
         lib = _lib.load()
-        nbytes = lib.smvs_featnet_workspace_bytes(n, h, w, c)
+        nbytes = lib.smvs_featnet_workspace_bytes(n, h, w, c, self._arch())
         if nbytes == 0:
             raise ValueError("image %dx%d is not a positive multiple of 4 in both dimensions" % (h, w))
         ws = getattr(self, "_workspace", None)
@@ -491,7 +499,7 @@ class FeatureNet(nn.Module):
         s3 = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.call("smvs_featnet_fwd", _lib.ptr(packed), _lib.ptr(x), _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(s3),
-                      _lib.ptr(ws), nbytes, n, h, w, c, _lib.current_stream(dev))
+                      _lib.ptr(ws), nbytes, n, h, w, c, self._arch(), _lib.current_stream(dev))
         return {"stage1": s1, "stage2": s2, "stage3": s3}
 
     def forward_views(self, imgs):

@@ -448,21 +448,24 @@ def gen_costreg():
 
 
 def gen_featnet():
-    """FeatureNet.forward (modules/module.py:442-543; base 8, 3 stages, unet) in eval mode with non-trivial
-    BatchNorm running statistics, two views of 40x56 (ragged against the 64-wide tiles); weights exported."""
-    torch.manual_seed(29)
-    net = ref_module.FeatureNet(base_channels=8, stride=4, num_stage=3, arch_mode="unet").eval()
-    for m in net.modules():
-        if isinstance(m, torch.nn.BatchNorm2d):
-            m.running_mean.normal_(0, 0.2)
-            m.running_var.uniform_(0.5, 1.5)
-            m.weight.data.uniform_(0.7, 1.3)
-            m.bias.data.normal_(0, 0.1)
-    x = torch.randn(2, 3, 40, 56)
-    with torch.no_grad():
-        y = net(x)
-    arrays = {"w." + k: v for k, v in np_state(net).items() if "num_batches_tracked" not in k}
-    save("featnet", x=x.numpy(), s1=y["stage1"].numpy(), s2=y["stage2"].numpy(), s3=y["stage3"].numpy(), **arrays)
+    """FeatureNet.forward (modules/module.py:442-543; base 8, 3 stages) in eval mode with non-trivial BatchNorm
+    running statistics, two views of 40x56 (ragged against the 64-wide tiles), both arch modes ("unet" used by
+    casred / ucs, "fpn" by casmvs); weights exported."""
+    for arch, seed in (("unet", 29), ("fpn", 30)):
+        torch.manual_seed(seed)
+        net = ref_module.FeatureNet(base_channels=8, stride=4, num_stage=3, arch_mode=arch).eval()
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.7, 1.3)
+                m.bias.data.normal_(0, 0.1)
+        x = torch.randn(2, 3, 40, 56)
+        with torch.no_grad():
+            y = net(x)
+        arrays = {"w." + k: v for k, v in np_state(net).items() if "num_batches_tracked" not in k}
+        save("featnet" if arch == "unet" else "featnet_fpn", x=x.numpy(), s1=y["stage1"].numpy(), s2=y["stage2"].numpy(),
+             s3=y["stage3"].numpy(), **arrays)
 
 
 if __name__ == "__main__":

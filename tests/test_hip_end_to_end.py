@@ -174,13 +174,15 @@ def test_costreg_native_matches_reference(dev, golden, oracle):
     np.testing.assert_allclose(y2.cpu().numpy(), y.cpu().numpy(), rtol=0, atol=1e-5)
 
 
-def test_featnet_native_matches_reference(dev, golden, oracle):
+@pytest.mark.parametrize("arch", ["unet", "fpn"])
+def test_featnet_native_matches_reference(dev, golden, oracle, arch):
     """smvs_featnet_fwd (all views in one call; 3x3/5x5/1x1 convolutions, folded BatchNorm, fused skip
-    concatenation) vs the reference's FeatureNet outputs (eval mode, non-trivial running statistics), vs the
-    oracle, and vs the PyTorch composite of the same module.  Tolerance 2e-6 on values of magnitude <= 0.4."""
+    concatenation / upsample-add laterals) vs the reference's FeatureNet outputs (eval mode, non-trivial running
+    statistics), vs the oracle, and vs the PyTorch composite of the same module.  Tolerance 2e-6 on values of
+    magnitude <= 0.4."""
     from satmvs_amd.modules.module import FeatureNet
-    g = golden("featnet")
-    net = FeatureNet(base_channels=8, stride=4, num_stage=3, arch_mode="unet").eval()
+    g = golden("featnet" if arch == "unet" else "featnet_fpn")
+    net = FeatureNet(base_channels=8, stride=4, num_stage=3, arch_mode=arch).eval()
     net.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}, strict=False)
     net = net.to(dev)
     x = torch.from_numpy(g["x"]).to(dev)
@@ -189,7 +191,7 @@ def test_featnet_native_matches_reference(dev, golden, oracle):
         y = net(x)
         views = net.forward_views(x[None])                # (B=1, V=2, 3, H, W): the networks' entry point
     wt = {k[2:]: g[k] for k in g.files if k.startswith("w.")}
-    o = oracle.featurenet(wt, g["x"])
+    o = oracle.featurenet(wt, g["x"], arch)
     for i, k in enumerate(["stage1", "stage2", "stage3"]):
         np.testing.assert_allclose(y[k].cpu().numpy(), g["s%d" % (i + 1)], rtol=0, atol=2e-6)
         np.testing.assert_allclose(y[k].cpu().numpy(), o[i], rtol=0, atol=2e-6)

@@ -150,10 +150,11 @@ def test_costregnet_oracle_vs_reference(oracle, golden):
     np.testing.assert_allclose(oracle.costregnet(_weights(g), g["x"]), g["y"], rtol=0, atol=1e-5)
 
 
-def test_featurenet_oracle_vs_reference(oracle, golden):
+@pytest.mark.parametrize("arch", ["unet", "fpn"])
+def test_featurenet_oracle_vs_reference(oracle, golden, arch):
     """oracle.featurenet vs the reference's FeatureNet.forward (modules/module.py:442-543), eval mode."""
-    g = golden("featnet")
-    s1, s2, s3 = oracle.featurenet(_weights(g), g["x"])
+    g = golden("featnet" if arch == "unet" else "featnet_fpn")
+    s1, s2, s3 = oracle.featurenet(_weights(g), g["x"], arch)
     for got, want in ((s1, g["s1"]), (s2, g["s2"]), (s3, g["s3"])):
         assert got.shape == want.shape
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
