@@ -156,6 +156,85 @@ void conv3d_kernel(const Conv3Args a)
     }
 }
 
+// Stride-1 3x3x3 correlation for the full-resolution layers (conv0, prob): the direct kernel above is bound by the
+// texture-address path -- 27 gathers per channel, the +-1 x-taps unaligned (8 clocks each on this part).  Here a
+// wave owns 64 consecutive x of one (d,y) row: per input row ONE aligned coalesced load gives the centre taps,
+// the x-1 / x+1 taps come from the neighbouring lanes (DPP wave shift), and a second, two-lane load supplies
+// the halo for lanes 0 and 63.  Row validity is wave-uniform, so the row offset rides in the scalar offset and
+// the 27-entry per-lane offset table disappears.  With the loads cheap the kernel turns VALU-bound, so the 8
+// output channels are 4 register pairs on v_pk_fma_f32 (weight pairs straight from SGPRs).
+__global__ __launch_bounds__(256)
+void conv3d_s1_kernel(const Conv3Args a)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0 = blockIdx.x * 64, ox = x0 + lane;
+    const int yz = blockIdx.y * 4 + wave;
+    const int oy = yz % a.Ho, od = yz / a.Ho;
+    const int ncog = (a.Cout + CR_COT - 1) / CR_COT;
+    const int cog = blockIdx.z % ncog, b = blockIdx.z / ncog;
+    if (od >= a.Do) return;                                  // wave-uniform
+    const bool active = ox < a.Wo;
+    const int HWi = a.Hi * a.Wi;
+    const size_t vol_i = (size_t)a.Di * HWi;
+    const uint32_t vc = active ? (uint32_t)ox * 4u : SMVS_OOB;
+    const uint32_t vh = lane == 0 ? (x0 > 0 ? (uint32_t)(x0 - 1) * 4u : SMVS_OOB)
+                      : lane == 63 ? (x0 + 64 < a.Wi ? (uint32_t)(x0 + 64) * 4u : SMVS_OOB) : SMVS_OOB;
+    int rowoff[9];                                           // (kd,ky) -> byte offset of the input row, wave-uniform
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int id = od - 1 + kd, iy = oy - 1 + ky;
+            rowoff[kd * 3 + ky] = (id >= 0 && id < a.Di && iy >= 0 && iy < a.Hi) ? (id * a.Hi + iy) * a.Wi * 4 : -1;
+        }
+    const BufRsrc rs = make_rsrc(a.in + (size_t)b * a.Cin * vol_i, (uint32_t)((size_t)a.Cin * vol_i * 4));
+    typedef const f32x2 __attribute__((address_space(4))) * cw3p_t;
+    f32x2 acc2[CR_COT / 2];
+#pragma unroll
+    for (int j = 0; j < CR_COT / 2; ++j) acc2[j] = (f32x2)(0.0f);
+    const cw3_t wbase = (cw3_t)(uintptr_t)(a.w + (size_t)cog * a.Cin * 27 * CR_COT);
+    for (int ci = 0; ci < a.Cin; ++ci) {
+        const int choff = (int)((size_t)ci * vol_i * 4);
+        const cw3p_t wc = (cw3p_t)(wbase + (size_t)ci * 27 * CR_COT);
+        float c[9], h[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int so = rowoff[r] >= 0 ? choff + rowoff[r] : (int)SMVS_OOB;      // scalar select
+            c[r] = llvm_raw_buffer_load_f32(rs.v, (int)vc, so, 0);
+            h[r] = llvm_raw_buffer_load_f32(rs.v, (int)vh, so, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            // lane i <- lane i-1 (wave_shr:1, lane 0 keeps its halo) ; lane i <- lane i+1 (wave_shl:1, lane 63 keeps its halo)
+            const float l = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, h[r]), __builtin_bit_cast(int, c[r]), 0x138, 0xf, 0xf, false));
+            const float rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, h[r]), __builtin_bit_cast(int, c[r]), 0x130, 0xf, 0xf, false));
+            const f32x2 t0 = {l, c[r]};
+            const f32x2 t1 = {rr, rr};
+#pragma unroll
+            for (int j = 0; j < CR_COT / 2; ++j) {
+                acc2[j] = __builtin_elementwise_fma(__builtin_shufflevector(t0, t0, 0, 0), wc[(r * 3 + 0) * (CR_COT / 2) + j], acc2[j]);
+                acc2[j] = __builtin_elementwise_fma(__builtin_shufflevector(t0, t0, 1, 1), wc[(r * 3 + 1) * (CR_COT / 2) + j], acc2[j]);
+                acc2[j] = __builtin_elementwise_fma(__builtin_shufflevector(t1, t1, 0, 0), wc[(r * 3 + 2) * (CR_COT / 2) + j], acc2[j]);
+            }
+        }
+    }
+    if (!active) return;
+    const size_t vol_o = (size_t)a.Do * a.Ho * a.Wo;
+    const size_t pos = ((size_t)od * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+    for (int j = 0; j < CR_COT; ++j) {
+        const int co = cog * CR_COT + j;
+        if (co < a.Cout) {
+            const float av = (j & 1) ? acc2[j >> 1].y : acc2[j >> 1].x;
+            float r = fmaf(av, a.scale[co], a.shift[co]);
+            if (a.relu) r = fmaxf(r, 0.0f);
+            const size_t o = ((size_t)b * a.Cout + co) * vol_o + pos;
+            if (a.skip) r = a.skip[o] + r;
+            a.out[o] = r;
+        }
+    }
+}
+
 // ConvTranspose3d(k=3, stride=2, pad=1, output_padding=1): lane = one INPUT voxel (d,y,x) -> the 2x2x2 output
 // block at (2d,2y,2x).  Per dimension an even output takes tap k=1 from input i; an odd output takes k=2 from
 // input i and k=0 from input i+1.
@@ -218,6 +297,97 @@ void convT3d_kernel(const Conv3Args a)
                 const size_t o = ((size_t)b * a.Cout + co) * vol_o +
                                  ((size_t)(2 * d + (p >> 2)) * a.Ho + (2 * y + ((p >> 1) & 1))) * a.Wo + (2 * x + (p & 1));
                 float r = fmaf(acc[p][j], sc, sh);
+                if (a.relu) r = fmaxf(r, 0.0f);
+                if (a.skip) r = a.skip[o] + r;
+                a.out[o] = r;
+            }
+        }
+    }
+}
+
+// Transposed convolution on the COARSE levels (a few thousand input voxels: 27..600 tiles on a 256-CU part).
+// The kernel above wastes most lanes there (rows of 12..48 voxels in 64-lane tiles) and its time is one wave's
+// serial walk over the input channels.  Here lanes are consecutive LINEAR input voxels (every lane busy), the 4
+// waves of a workgroup split the input channels and reduce through LDS, and the 8 corner loads of the next
+// channel are in flight while the current one is multiplied.
+__global__ __launch_bounds__(256)
+void convT3d_split_kernel(const Conv3Args a)
+{
+    __shared__ float part[3][64][64 + 1];                    // [wave-1][parity*8 + cout][lane]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int HWi = a.Hi * a.Wi;
+    const int vol = a.Di * HWi;
+    const int v = blockIdx.x * 64 + lane;
+    const bool active = v < vol;
+    const int d = v / HWi, y = (v % HWi) / a.Wi, x = v % a.Wi;
+    const int ncog = (a.Cout + CR_COT - 1) / CR_COT;
+    const int cog = blockIdx.z % ncog, b = blockIdx.z / ncog;
+    const size_t vol_i = (size_t)vol;
+    uint32_t off[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int dd = d + (q >> 2), yy = y + ((q >> 1) & 1), xx = x + (q & 1);
+        off[q] = (active && dd < a.Di && yy < a.Hi && xx < a.Wi) ? (uint32_t)((dd * a.Hi + yy) * a.Wi + xx) * 4u : SMVS_OOB;
+    }
+    const BufRsrc rs = make_rsrc(a.in + (size_t)b * a.Cin * vol_i, (uint32_t)((size_t)a.Cin * vol_i * 4));
+    float acc[8][CR_COT];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int j = 0; j < CR_COT; ++j) acc[p][j] = 0.0f;
+    const cw3_t wbase = (cw3_t)(uintptr_t)(a.w + (size_t)cog * a.Cin * 27 * CR_COT);
+    const int per = (a.Cin + 3) / 4, c0 = wave * per, c1 = min(a.Cin, c0 + per);
+#define SMVS_T3_LOAD(V, CC) \
+    { _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) V[q_] = llvm_raw_buffer_load_f32(rs.v, (int)off[q_], (int)((size_t)(CC) * vol_i * 4), 0); }
+#define SMVS_T3_FMA(V, CC)                                                                             \
+    {                                                                                                  \
+        const cw3_t wc = wbase + (size_t)(CC) * 27 * CR_COT;                                           \
+        _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                \
+            const int pd = p >> 2, py = (p >> 1) & 1, px = p & 1;                                      \
+            _Pragma("unroll") for (int td = 0; td <= pd; ++td)                                         \
+                _Pragma("unroll") for (int ty = 0; ty <= py; ++ty)                                     \
+                    _Pragma("unroll") for (int tx = 0; tx <= px; ++tx) {                               \
+                        const int kd = pd ? (td ? 0 : 2) : 1, ky = py ? (ty ? 0 : 2) : 1, kx = px ? (tx ? 0 : 2) : 1; \
+                        const int q = (td << 2) | (ty << 1) | tx;                                      \
+                        const int k = (kd * 3 + ky) * 3 + kx;                                          \
+                        _Pragma("unroll") for (int j = 0; j < CR_COT; ++j) acc[p][j] = fmaf(V[q], wc[k * CR_COT + j], acc[p][j]); \
+                    }                                                                                  \
+        }                                                                                              \
+    }
+    float v0[8], v1[8];
+    if (c0 < c1) SMVS_T3_LOAD(v0, c0)
+    for (int cc = c0; cc < c1; cc += 2) {
+        if (cc + 1 < c1) SMVS_T3_LOAD(v1, cc + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        SMVS_T3_FMA(v0, cc)
+        __builtin_amdgcn_sched_barrier(0);
+        if (cc + 2 < c1) SMVS_T3_LOAD(v0, cc + 2)
+        __builtin_amdgcn_sched_barrier(0);
+        if (cc + 1 < c1) SMVS_T3_FMA(v1, cc + 1)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef SMVS_T3_LOAD
+#undef SMVS_T3_FMA
+    if (wave > 0) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int j = 0; j < CR_COT; ++j) part[wave - 1][p * CR_COT + j][lane] = acc[p][j];
+    }
+    __syncthreads();
+    if (wave > 0 || !active) return;
+    const size_t vol_o = (size_t)a.Do * a.Ho * a.Wo;
+#pragma unroll
+    for (int j = 0; j < CR_COT; ++j) {
+        const int co = cog * CR_COT + j;
+        if (co < a.Cout) {
+            const float sc = a.scale[co], sh = a.shift[co];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const float s = acc[p][j] + part[0][p * CR_COT + j][lane] + part[1][p * CR_COT + j][lane] + part[2][p * CR_COT + j][lane];
+                const size_t o = ((size_t)b * a.Cout + co) * vol_o +
+                                 ((size_t)(2 * d + (p >> 2)) * a.Ho + (2 * y + ((p >> 1) & 1))) * a.Wo + (2 * x + (p & 1));
+                float r = fmaf(s, sc, sh);
                 if (a.relu) r = fmaxf(r, 0.0f);
                 if (a.skip) r = a.skip[o] + r;
                 a.out[o] = r;
@@ -333,10 +503,16 @@ SMVS_EXPORT int smvs_costreg_fwd(const float* packed, const float* vol, float* o
             mfma_conv_launch<27>(m, B, st);
         } else if (l.transposed) {
             dim3 grd((a.Wi + 63) / 64, (a.Hi * a.Di + 3) / 4, B * ncog);
-            hipLaunchKernelGGL(convT3d_kernel, grd, dim3(256), 0, st, a);
+            static const int split_below = [] { const char* e = getenv("SMVS_CONV_SPLIT_BELOW"); return e ? atoi(e) : 1024; }();
+            if ((long long)((a.Di * a.Hi * a.Wi + 63) / 64) * B * ncog < split_below / 2 && !direct_only)
+                hipLaunchKernelGGL(convT3d_split_kernel, dim3((a.Di * a.Hi * a.Wi + 63) / 64, 1, B * ncog), dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL(convT3d_kernel, grd, dim3(256), 0, st, a);
         } else {
             dim3 grd((a.Wo + 63) / 64, (a.Ho * a.Do + 3) / 4, B * ncog);
-            if (l.stride == 1) hipLaunchKernelGGL(conv3d_kernel<1>, grd, dim3(256), 0, st, a);
+            static const bool gather = [] { const char* e = getenv("SMVS_CONV3D_GATHER"); return e && e[0] == '1'; }();
+            if (l.stride == 1 && !gather) hipLaunchKernelGGL(conv3d_s1_kernel, grd, dim3(256), 0, st, a);
+            else if (l.stride == 1)       hipLaunchKernelGGL(conv3d_kernel<1>, grd, dim3(256), 0, st, a);
             else               hipLaunchKernelGGL(conv3d_kernel<2>, grd, dim3(256), 0, st, a);
         }
     }
