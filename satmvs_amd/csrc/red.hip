@@ -718,7 +718,7 @@ SMVS_EXPORT size_t smvs_red_packed_floats(int C) { return C > 0 ? smvs::red_layo
 
 SMVS_EXPORT size_t smvs_red_workspace_bytes(int B, int C, int H, int W)
 {
-    if (B < 1 || C < 1 || H < 8 || W < 8) return 0;
+    if (B < 1 || C < 1 || H < 8 || W < 8 || (H % 8) || (W % 8)) return 0;
     return smvs::red_workspace(B, C, H, W).total * sizeof(float);
 }
 

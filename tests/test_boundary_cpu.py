@@ -56,6 +56,47 @@ def test_argument_errors_do_not_touch_the_gpu(lib):
         _lib.call("smvs_rpc_project", dummy, dummy, dummy, dummy, dummy, dummy, 4, 7, None)
 
 
+def test_regulariser_entry_points_validate_arguments(lib):
+    """The widened entry points (RED / CostRegNet / FeatureNet) reject bad shapes and null pointers before any
+    HIP call, and their size queries return 0 for shapes they do not serve."""
+    from satmvs_amd import _lib
+    dummy = C.c_void_p(16)
+    arr = (C.c_void_p * 2)(16, 16)
+    assert lib.smvs_red_workspace_bytes(1, 8, 30, 40) == 0                 # H not a multiple of 8
+    assert lib.smvs_red_workspace_bytes(1, 8, 32, 40) > 0
+    assert lib.smvs_red_pred_workspace_bytes(1, 8, 32, 40) > lib.smvs_red_workspace_bytes(1, 8, 32, 40)
+    assert lib.smvs_costreg_workspace_bytes(1, 8, 8, 16, 20) == 0          # W not a multiple of 8
+    assert lib.smvs_costreg_workspace_bytes(1, 8, 8, 16, 24) > 0
+    assert lib.smvs_featnet_workspace_bytes(2, 40, 54, 8, 0) == 0          # W not a multiple of 4
+    assert lib.smvs_featnet_workspace_bytes(2, 40, 56, 8, 0) > 0
+    assert lib.smvs_featnet_workspace_bytes(2, 40, 56, 8, 1) > lib.smvs_featnet_workspace_bytes(2, 40, 56, 8, 0)
+    assert lib.smvs_featnet_workspace_bytes(2, 40, 56, 8, 2) == 0          # unknown arch
+    assert lib.smvs_featnet_packed_floats(8, 0) > 0 and lib.smvs_featnet_packed_floats(8, 1) > 0
+    with pytest.raises(_lib.SatMVSNativeError, match="null pointer"):
+        _lib.call("smvs_red_step_fwd", None, dummy, dummy, dummy, dummy, dummy, dummy, dummy, 1 << 30, 1, 8, 32, 40, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="multiple of 8"):
+        _lib.call("smvs_red_step_fwd", dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, 1 << 30, 1, 8, 30, 40, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="workspace too small"):
+        _lib.call("smvs_red_step_fwd", dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, 16, 1, 8, 32, 40, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="null pointer"):
+        _lib.call("smvs_red_volume_planes", 0, dummy, arr, 2, dummy, dummy, 1, dummy, dummy, dummy, dummy, dummy, None,
+                  dummy, 1 << 30, 1, 8, 4, 32, 40, 0, 4, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="bad plane range"):
+        _lib.call("smvs_red_pred_planes", 0, dummy, arr, 2, dummy, dummy, 1, dummy, dummy, dummy, dummy, dummy, dummy,
+                  dummy, 1 << 30, 1, 8, 4, 32, 40, 2, 6, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="geo_kind"):
+        _lib.call("smvs_red_pred_planes", 3, dummy, arr, 2, dummy, dummy, 1, dummy, dummy, dummy, dummy, dummy, dummy,
+                  dummy, 1 << 30, 1, 8, 4, 32, 40, 0, 4, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="multiple of 8"):
+        _lib.call("smvs_costreg_fwd", dummy, dummy, dummy, dummy, 1 << 30, 1, 8, 8, 16, 20, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="arch must be"):
+        _lib.call("smvs_featnet_fwd", dummy, dummy, dummy, dummy, dummy, dummy, 1 << 30, 2, 40, 56, 8, 5, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="multiple of 4"):
+        _lib.call("smvs_featnet_fwd", dummy, dummy, dummy, dummy, dummy, dummy, 1 << 30, 2, 40, 54, 8, 0, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="null parameter pointer"):
+        _lib.call("smvs_featnet_pack_weights", (C.c_void_p * 63)(), 8, 0, dummy, None)
+
+
 def test_product_path_has_no_cpu_fallback():
     from satmvs_amd import _lib
     from satmvs_amd.modules import warping
