@@ -7,11 +7,15 @@
 // (networks/ucs.py).  BatchNorm runs in inference form (running statistics folded into a per-channel
 // scale/shift in the epilogue); training (batch statistics, autograd) stays on the PyTorch composite.
 //
-// Round-1 implementation: direct float32 convolutions with the same structure
-// as red.hip -- one lane per output voxel (x fastest), 8 output channels per lane, wave-uniform weights read
-// with scalar loads from a packed buffer [cout/8][cin][27][8], zero padding from the buffer range check,
-// BN scale/shift + ReLU + skip-add fused in the epilogue.  11 launches per volume.  The stride-1/2 convolutions
-// with >= 32 output channels (conv3..conv6) run on the float32 MFMA implicit-GEMM kernel of mfma_conv.h.
+// Kernels, 11 launches per volume:
+//   * conv3..conv6 (>= 32 output channels): float32 MFMA implicit GEMM (mfma_conv.h, 27 taps);
+//   * stride-1 8/16-channel layers (conv0, conv2, prob): conv3d_s1_kernel -- one aligned row load per input
+//     row, x+-1 taps by DPP wave shifts, channel pairs on v_pk_fma_f32;
+//   * stride-2 conv1: conv3d_kernel<2>, direct gathers (one lane per output voxel, 8 output channels per lane,
+//     wave-uniform weights from a packed buffer [cout/8][cin][27][8], zero padding from the buffer range check);
+//   * transposed conv7/conv9/conv11: convT3d_kernel (one lane per input voxel -> 2x2x2 outputs), and on the
+//     coarse levels convT3d_split_kernel (linear voxel -> lane mapping, input channels split over 4 waves).
+// BN scale/shift + ReLU + skip-add are fused in every epilogue.
 #include <stdlib.h>
 
 #include "smvs_device.h"

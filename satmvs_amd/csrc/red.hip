@@ -1,22 +1,25 @@
-// red.hip -- native forward of the recurrent encoder-decoder regulariser, one height plane per call.
+// red.hip -- native inference forward of the recurrent encoder-decoder (RED) regulariser.
 //
 // Replaces slice_RED_Regularization.forward (/root/reference/modules/module.py:672-693) and, called
 // once per plane, the loop body of RED_Regularization.forward (:625-644) with its ConvGRUCell2 cells
 // (:6-58): three stride-2 3x3 convolutions (encoder), a 3x3 ConvGRU with GroupNorm(1,.) on every gate
 // at each of the four scales, three stride-2 transposed convolutions with additive skips (decoder) and
 // a final 3x3 transposed convolution to one channel.  Hidden sizes 8/16/32/64 as hard-coded in the
-// reference (module.py:617-620).
+// reference (module.py:617-620).  SURVEY.md section 8 rows a10, a11, a14.
 //
-// Round-1 implementation: direct float32 convolutions -- one lane per output
-// pixel, 8 output channels per lane in registers, weights wave-uniform and read with scalar loads from a
-// pre-packed buffer ([cout/8][cin][tap][8]), inputs through the buffer range check (zero padding for free),
-// concat inputs (x,h) / (x,r*h) read from two tensors without materialising the concatenation, bias / ReLU /
-// GroupNorm statistics (float64 atomics) fused in the epilogue.  24 launches per plane instead of ~60 in
-// the stock PyTorch composite.  Layers with >= 32 output channels (gates of levels 2-4, candidates of levels
-// 3-4, encoder conv2/conv3) run on the float32 MFMA implicit-GEMM kernel of mfma_conv.h.
+// Kernels: direct float32 convolutions for the < 32-channel layers -- one lane per output pixel, 8 output
+// channels per lane in registers, weights wave-uniform and read with scalar loads from a pre-packed buffer
+// ([cout/8][cin][tap][8]), inputs through the buffer range check (zero padding for free), concat inputs
+// (x,h) / (x,r*h) read from two tensors without materialising the concatenation, bias / ReLU / GroupNorm
+// statistics (float64 atomics into 64 slots) fused in the epilogue; a channel-split variant for the coarse
+// planes.  Layers with >= 32 output channels (gates of levels 2-4, candidates of levels 3-4, encoder
+// conv2/conv3) run on the float32 MFMA implicit-GEMM kernel of mfma_conv.h.  24 launches per plane instead
+// of ~60 in the stock PyTorch composite.
+//
+// Entry points: smvs_red_step_fwd (one plane, caller's stream), smvs_red_pred_planes / smvs_red_volume_planes
+// (the whole plane loop incl. the cost-volume plane, as a 3-stream pipeline: see red_run_planes).
 #include <stdlib.h>
 #include <string.h>
-
 
 #include "smvs_device.h"
 #include "smvs_host.h"
@@ -27,7 +30,7 @@ namespace smvs {
 constexpr int COT = 8;                       // output channels per lane
 constexpr int NSLOT = 64;                    // GroupNorm statistics are accumulated in 64 partial slots per
                                              // (sample, norm group): ~36 same-address float64 atomics per slot
-                                             // instead of ~18000 on one address (measured: 237 -> see profile)
+                                             // instead of ~18000 on one address (measured: 237 us -> 25 us for the full-resolution gate convolution)
 constexpr int HID[4] = {8, 16, 32, 64};      // hidden sizes of conv_gru1..4
 
 // ---- packed parameter buffer -------------------------------------------------------------------------------
