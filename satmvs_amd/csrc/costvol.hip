@@ -448,6 +448,19 @@ void costvol_dma_kernel(const CostVolParams p)
                     const int gyp = by0[s] + er;
                     rowoff[s][er] = (gyp >= 0 && gyp < H) ? gyp * W * 4 : (int)SMVS_OOB;
                 }
+            // (s, er) are unrolled loop indices but not constant expressions: dispatch to the immediate-offset variant
+            auto dma_at = [&](auto half_tag, int s, int er, uint32_t buf, uint32_t voff, int so) {
+                constexpr int HALF = decltype(half_tag)::value;
+#define SMVS_DMA_CASE(S, ER) \
+    case (S) * R + (ER): dma_dword_to_lds_at<((S) * SRC_STRIDE + (ER) * BW) * 8 + HALF>(rs[(S) < NSRC ? (S) : 0], buf, voff, so); break;
+                switch (s * R + er) {
+                    SMVS_DMA_CASE(0, 0) SMVS_DMA_CASE(0, 1) SMVS_DMA_CASE(0, 2) SMVS_DMA_CASE(0, 3) SMVS_DMA_CASE(0, 4)
+                    SMVS_DMA_CASE(1, 0) SMVS_DMA_CASE(1, 1) SMVS_DMA_CASE(1, 2) SMVS_DMA_CASE(1, 3) SMVS_DMA_CASE(1, 4)
+                    SMVS_DMA_CASE(2, 0) SMVS_DMA_CASE(2, 1) SMVS_DMA_CASE(2, 2) SMVS_DMA_CASE(2, 3) SMVS_DMA_CASE(2, 4)
+                    default: break;
+                }
+#undef SMVS_DMA_CASE
+            };
             auto issue_dma = [&](int st) {
                 if (p.ablate & 2) return;
                 const uint32_t buf = tile_lds + (uint32_t)((st & 1) * BUF_STRIDE * 8);
@@ -458,9 +471,9 @@ void costvol_dma_kernel(const CostVolParams p)
                     for (int er = 0; er < R; ++er) {
                         if (er < bh[s]) {                                         // wave-uniform
                             const int so = (rowoff[s][er] != (int)SMVS_OOB) ? rowoff[s][er] + choff : (int)SMVS_OOB;
-                            const uint32_t dst = buf + (uint32_t)((s * SRC_STRIDE + er * BW) * 8);
-                            dma_dword_to_lds(rs[s], dst, vo[s][0], so);
-                            dma_dword_to_lds(rs[s], dst + 256u, vo[s][1], so);
+                            // destination = buf + a compile-time offset, formed inside the asm by one s_add into M0
+                            dma_at(std::integral_constant<int, 0>(), s, er, buf, vo[s][0], so);
+                            dma_at(std::integral_constant<int, 256>(), s, er, buf, vo[s][1], so);
                         }
                     }
                 }

@@ -229,6 +229,17 @@ __device__ __forceinline__ void dma_dword_to_lds(const BufRsrc& rs, uint32_t lds
                  :: "s"(lds_byte_addr), "v"(voffset), "s"(rs.v), "s"(soffset) : "memory", "m0");
 }
 
+// Same, with the LDS destination = lds_base (SGPR) + a compile-time byte offset formed by ONE scalar add into
+// M0.  Passing precomputed destinations instead makes the compiler keep every (source,row,half) address as a
+// loop-invariant SGPR; there are more of them than SGPRs, so they end up spilled to VGPR lanes and each use
+// costs a v_readlane on the VALU (measured: 20 per channel pair in the cost-volume kernel).
+template <int OFF>
+__device__ __forceinline__ void dma_dword_to_lds_at(const BufRsrc& rs, uint32_t lds_base, uint32_t voffset, int soffset)
+{
+    asm volatile("s_add_u32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(lds_base), "v"(voffset), "s"(rs.v), "s"(soffset), "n"(OFF) : "memory", "m0", "scc");
+}
+
 // The four corners of one tap for a channel pair, as four ds_read_b64 (256 B/clk) rather than the
 // two ds_read2_b64 (128 B/clk) hipcc merges them into.  Issued from inline asm, so completion is
 // tracked by hand: LDS reads of a wave return in order, lds_wait<N>() = s_waitcnt lgkmcnt(N) and
