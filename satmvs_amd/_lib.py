@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsatmvs_hip.so")
+# SMVS_LIB_PATH: load another build of the same library (A/B timing of kernel variants in one process-level run)
+LIB_PATH = os.environ.get("SMVS_LIB_PATH") or os.path.join(_HERE, "lib", "libsatmvs_hip.so")
 
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 
