@@ -186,7 +186,8 @@ def main():
                        "planes_total": D_total, "H": H, "W": W, "depth_values": "per-voxel (B,D,H,W)",
                        "sharding": "height planes, %d per GPU" % D},
             "roofline": {"bound": "hbm", "kernel": "%s<rpc,%d,%d>" % (
-                             "costvol_fwd_kernel" if os.environ.get("SMVS_COSTVOL_KERNEL", "").startswith("di")
+                             "costvol_fwd_kernel" if (os.environ.get("SMVS_COSTVOL_KERNEL", "").startswith("di")
+                                                      or V - 1 > 2 or C not in (16, 32))      # dispatch rule of costvol.hip
                              else "costvol_dma_kernel", V - 1, C),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
