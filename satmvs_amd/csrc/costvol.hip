@@ -45,7 +45,6 @@ struct CostVolParams {
     int D_out, d_out_off;           // plane d lands at index d - d_begin + d_out_off of `out`
     int depth_is_4d;
     int xt, yt, dct, dch;           // tiles in x, y; plane chunks; planes per chunk
-    int ablate;                     // profiling only (SMVS_ABLATE): 1 no stores, 2 no staging loads, 4 no float64 chain
 };
 
 template <int GEO, int NSRC, int CT>
@@ -263,7 +262,8 @@ void costvol_dma_kernel(const CostVolParams p)
     constexpr int NSTEP = CT / 2;
     static_assert(CT % 2 == 0 && 2 * DP <= 63 && DP % 2 == 0, "steps / vmcnt bookkeeping");
     __shared__ f32x2 tile_all[WV_WAVES][DM_NBUF * BUF_STRIDE];
-
+    // one wave = one 32 x 2 pixel patch x ONE group of DP planes (p.dch == DP): no loop over groups, so
+    // nothing of the geometry phase stays live across the channel-pair loop
     uint32_t L = xcd_remap(blockIdx.x, gridDim.x);
     const int xtile = L % p.xt; L /= p.xt;
     const int dchunk = L % p.dct; L /= p.dct;
@@ -280,15 +280,146 @@ void costvol_dma_kernel(const CostVolParams p)
     const int y = (ytile * WV_WAVES + wave) * WV_TY + (lane >> 5);
     const bool active = (x < W) && (y < H);
     const int pix = min(y, H - 1) * W + min(x, W - 1);
-    const int d0 = p.d_begin + dchunk * p.dch;
-    const int d1 = min(d0 + p.dch, p.d_end);
+    const int dg = p.d_begin + dchunk * DP;
+    const int np = min(DP, p.d_end - dg);
+
     if ((ytile * WV_WAVES + wave) * WV_TY >= H) return;      // whole wave below the image (no barriers used)
 
     // zero cells behind each buffer: a tap whose footprint misses the image reads these, so it
-    // contributes 0 * weight exactly like four masked gathers (never stale LDS bits)
+    // contributes 0 * weight exactly like four masked gathers (0, or NaN for a NaN coordinate)
     for (int i = lane; i < ZPAD; i += 64) {
         tile[NSRC * SRC_STRIDE + i] = (f32x2)(0.0f);
         tile[BUF_STRIDE + NSRC * SRC_STRIDE + i] = (f32x2)(0.0f);
+    }
+
+    const float fV = (float)p.V;
+    const float rV = __fdiv_rn(1.0f, fV);
+    const float half_wm1 = (float)((W - 1) * 0.5);
+    const float half_hm1 = (float)((H - 1) * 0.5);
+    const float r_half_wm1 = __fdiv_rn(1.0f, half_wm1), r_half_hm1 = __fdiv_rn(1.0f, half_hm1);
+
+    const cgeo_t geo_b = as_cgeo((GEO == 0) ? p.geo + (size_t)b * p.V * RPC_LEN
+                                            : p.geo + (size_t)b * (p.V - 1) * 16);
+    const double fx = (double)min(x, W - 1), fy = (double)min(y, H - 1);
+    const uint32_t pix4 = (uint32_t)pix * 4u;
+
+    // heights of the group's planes (tail planes shadow the last one; they are never stored)
+    float hf[DP];
+#pragma unroll
+    for (int pl = 0; pl < DP; ++pl) {
+        const int d = min(dg + pl, p.d_end - 1);
+        hf[pl] = p.depth_is_4d ? p.depth[((size_t)b * p.D + d) * HW + pix] : p.depth[(size_t)b * p.D + d];
+    }
+
+    // ---- A: taps of the group's planes -----------------------------------------------------------
+    TapD tap[DP][NSRC];
+    uint32_t txy[DP][NSRC];
+    uint32_t okmask = 0;
+    int lo_x[NSRC], hi_x[NSRC], lo_y[NSRC], hi_y[NSRC];
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s) { lo_x[s] = lo_y[s] = INT_MAX; hi_x[s] = hi_y[s] = INT_MIN; }
+
+    double lat[DP], lon[DP];
+#pragma unroll
+    for (int pl = 0; pl < DP; ++pl) lat[pl] = lon[pl] = 0.0;
+    RpcInv ref_n, src_n[NSRC];
+    ref_n.a = ref_n.b = ref_n.h = 0.0;
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s) src_n[s].a = src_n[s].b = src_n[s].h = 0.0;
+    if (GEO == 0) {
+        // The 3 reciprocal scales of every view, correctly rounded, at one IEEE division per WAVE: lane 3v+k
+        // divides for (view v, scale k); the quotients travel through the wave's own LDS tile (not yet in use)
+        // and come back as broadcast reads, i.e. in VGPRs (18 SGPRs would not survive the coefficient loads).
+        {
+            const int v = lane / 3, k = lane - 3 * v;
+            const int idx = (v == 0) ? (k == 0 ? I_SAMP_SCALE : k == 1 ? I_LINE_SCALE : I_H_SCALE)
+                                     : (k == 0 ? I_LAT_SCALE : k == 1 ? I_LON_SCALE : I_H_SCALE);
+            double* slot = reinterpret_cast<double*>(tile);
+            if (lane < 3 * (NSRC + 1)) slot[lane] = 1.0 / p.geo[((size_t)b * p.V + v) * RPC_LEN + idx];
+            ref_n.a = slot[0]; ref_n.b = slot[1]; ref_n.h = slot[2];
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s) { src_n[s].a = slot[3 * s + 3]; src_n[s].b = slot[3 * s + 4]; src_n[s].h = slot[3 * s + 5]; }
+        }
+        // ref view, image -> ground: plane-invariant part once per pixel, Horner in the height per plane
+        P2OPix px;
+        p2o_pixel(geo_b, ref_n, fx, fy, px);
+#pragma unroll
+        for (int pl = 0; pl < DP; ++pl) {
+            p2o_plane(launder(geo_b), ref_n, px, (double)hf[pl], lat[pl], lon[pl]);
+            pin(lat[pl]); pin(lon[pl]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // two planes per pass: every coefficient is fetched into SGPRs once for both
+#pragma unroll
+    for (int pq = 0; pq < DP; pq += 2) {
+        const cgeo_t geo_d = launder(geo_b);
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) {
+            float gxs[2], gys[2];
+            if (GEO == 0) {
+                double samp[2], line[2];
+                const double hh[2] = {(double)hf[pq], (double)hf[pq + 1]};
+                o2p_xn<2>(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat + pq, lon + pq, hh, samp, line);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    gxs[u] = div_half_int((float)samp[u], half_wm1, r_half_wm1) - 1.0f;
+                    gys[u] = div_half_int((float)line[u], half_hm1, r_half_hm1) - 1.0f;
+                }
+            } else {
+                const cgeo_t P = geo_d + s * 16;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const double hh = (double)hf[pq + u];
+                    const double rx = fma(P[1], fy, P[0] * fx) + P[2];
+                    const double ry = fma(P[5], fy, P[4] * fx) + P[6];
+                    const double rz = fma(P[9], fy, P[8] * fx) + P[10];
+                    const double X = fma(rx, hh, P[3]), Y = fma(ry, hh, P[7]), Z = fma(rz, hh, P[11]);
+                    gxs[u] = (float)((X / Z) / ((W - 1) * 0.5) - 1.0);
+                    gys[u] = (float)((Y / Z) / ((H - 1) * 0.5) - 1.0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pl = pq + u;
+                // same arithmetic as tap_from_grid (ATen unnormalise, floor, weights)
+                const float px = fmaf(gxs[u] + 1.0f, (float)W * 0.5f, -0.5f);
+                const float py = fmaf(gys[u] + 1.0f, (float)H * 0.5f, -0.5f);
+                const float xw = floorf(px), yn = floorf(py);
+                const float w = px - xw, e = 1.0f - w, n = py - yn, so = 1.0f - n;
+                // A footprint that misses the image reads the zero cells: 0 * weight = 0 for any finite
+                // weight, NaN for the NaN weights of a NaN / infinite coordinate -- what four masked
+                // gathers contribute.  v_cvt_i32_f32 saturates and maps NaN to 0, so the unsigned tests
+                // reject every far-away coordinate (a NaN one passes with NaN weights: NaN either way).
+                tap[pl][s].wn.x = so * e; tap[pl][s].wn.y = so * w;
+                tap[pl][s].ws.x = n * e;  tap[pl][s].ws.y = n * w;
+                const int ix0 = cvt_i32_sat(xw), iy0 = cvt_i32_sat(yn);
+                const bool ok = ((uint32_t)(ix0 + 1) <= (uint32_t)W) && ((uint32_t)(iy0 + 1) <= (uint32_t)H);
+                txy[pl][s] = ((uint32_t)(iy0 + 1) << 16) | (uint32_t)((ix0 + 1) & 0xffff);
+                if (ok) okmask |= 1u << (pl * NSRC + s);
+                if (ok && active && pl < np) {
+                    lo_x[s] = min(lo_x[s], ix0); hi_x[s] = max(hi_x[s], ix0);
+                    lo_y[s] = min(lo_y[s], iy0); hi_y[s] = max(hi_y[s], iy0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- B: the wave's bounding box per source -------------------------------------------------------
+    int bx0[NSRC], by0[NSRC], bw[NSRC], bh[NSRC];
+    bool fits = true;
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s) {
+        const int a0 = wave_min_i32(lo_x[s]);
+        const int a1 = wave_max_i32(hi_x[s]);
+        const int b0 = wave_min_i32(lo_y[s]);
+        const int b1 = wave_max_i32(hi_y[s]);
+        const bool empty = a1 < a0;
+        bx0[s] = empty ? 0 : a0; by0[s] = empty ? 0 : b0;
+        bw[s] = empty ? 0 : a1 - a0 + 2;
+        bh[s] = empty ? 0 : b1 - b0 + 2;
+        fits = fits && (bw[s] <= BW) && (bh[s] <= R);
     }
 
     BufRsrc rs[NSRC];
@@ -296,331 +427,212 @@ void costvol_dma_kernel(const CostVolParams p)
     for (int s = 0; s < NSRC; ++s)
         rs[s] = make_rsrc(p.src[s] + (size_t)b * CT * HW, (uint32_t)CT * (uint32_t)HW * 4u);
     const BufRsrc rref = make_rsrc(p.ref + (size_t)b * CT * HW, (uint32_t)CT * (uint32_t)HW * 4u);
-
-    const float fV = (float)p.V;
-    const float rV = __fdiv_rn(1.0f, fV);
-    const float half_wm1 = (float)((W - 1) * 0.5);
-    const float half_hm1 = (float)((H - 1) * 0.5);
-
-    const cgeo_t geo_b = as_cgeo((GEO == 0) ? p.geo + (size_t)b * p.V * RPC_LEN
-                                            : p.geo + (size_t)b * (p.V - 1) * 16);
-    const double fx = (double)min(x, W - 1), fy = (double)min(y, H - 1);
     const size_t ostride = (size_t)p.D_out * HW;             // floats between channels of the output
-    const uint32_t pix4 = (uint32_t)pix * 4u;
 
-    for (int dg = d0; dg < d1; dg += DP) {
-        const int np = min(DP, d1 - dg);
-        // reciprocal scales are recomputed per plane group (9 divisions) instead of being held in
-        // 18 SGPRs across the step loop below
-        RpcInv ref_n;
-        RpcInv src_n[NSRC];
-        if (GEO == 0) {
-            const cgeo_t gl = launder(geo_b);
-            ref_n = rpc_inv_image(gl);
+    if (fits) {
+        // DMA lane map: lane -> (column lane>>1 of a 32-column half row, channel lane&1 of the pair)
+        uint32_t vo[NSRC][2];
 #pragma unroll
-            for (int s = 0; s < NSRC; ++s) src_n[s] = rpc_inv_ground(gl + (size_t)(s + 1) * RPC_LEN);
-        }
-
-        // ---- A: taps of the group's planes -----------------------------------------------------
-        TapD tap[DP][NSRC];
-        uint32_t txy[DP][NSRC];
-        uint32_t okmask = 0;
-        int lo_x[NSRC], hi_x[NSRC], lo_y[NSRC], hi_y[NSRC];
+        for (int s = 0; s < NSRC; ++s)
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) { lo_x[s] = lo_y[s] = INT_MAX; hi_x[s] = hi_y[s] = INT_MIN; }
-        // two planes per pass: each RPC coefficient is fetched into SGPRs once for both (cubic4x2)
-#pragma unroll
-        for (int pq = 0; pq < DP; pq += 2) {
-            float hf[2];
-            double hh[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int d = min(dg + pq + u, d1 - 1);       // tail planes shadow the last one (never stored)
-                hf[u] = p.depth_is_4d ? p.depth[((size_t)b * p.D + d) * HW + pix] : p.depth[(size_t)b * p.D + d];
-                hh[u] = (double)hf[u];
+            for (int hh = 0; hh < 2; ++hh) {
+                const int col = hh * 32 + (lane >> 1), c0 = bx0[s] + col;
+                vo[s][hh] = (col < bw[s] && c0 >= 0 && c0 < W) ? (uint32_t)(c0 * 4 + (lane & 1) * HW * 4) : SMVS_OOB;
             }
-            const cgeo_t geo_d = launder(geo_b);
-            double lat[2] = {0.0, 0.0}, lon[2] = {0.0, 0.0};
-            if (GEO == 0 && !(p.ablate & 4))
-                rpc_photo2obj_x2(geo_d, ref_n, fx, fy, hh[0], hh[1], lat[0], lon[0], lat[1], lon[1]);
+#pragma unroll
+        for (int pl = 0; pl < DP; ++pl)
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) {
-                float gxs[2], gys[2];
-                if (p.ablate & 4) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        gxs[u] = ((float)fx + 0.37f + 0.011f * hf[u] * (float)(s + 1)) / half_wm1 - 1.0f;
-                        gys[u] = ((float)fy + 0.21f) / half_hm1 - 1.0f;
-                    }
-                } else if (GEO == 0) {
-                    double samp[2], line[2];
-                    rpc_obj2photo_x2(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat[0], lon[0], hh[0],
-                                     lat[1], lon[1], hh[1], samp[0], line[0], samp[1], line[1]);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        gxs[u] = (float)samp[u] / half_wm1 - 1.0f;
-                        gys[u] = (float)line[u] / half_hm1 - 1.0f;
-                    }
-                } else {
-                    const cgeo_t P = geo_d + s * 16;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const double rx = fma(P[1], fy, P[0] * fx) + P[2];
-                        const double ry = fma(P[5], fy, P[4] * fx) + P[6];
-                        const double rz = fma(P[9], fy, P[8] * fx) + P[10];
-                        const double X = fma(rx, hh[u], P[3]), Y = fma(ry, hh[u], P[7]), Z = fma(rz, hh[u], P[11]);
-                        gxs[u] = (float)((X / Z) / ((W - 1) * 0.5) - 1.0);
-                        gys[u] = (float)((Y / Z) / ((H - 1) * 0.5) - 1.0);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int pl = pq + u;
-                    // same arithmetic as tap_from_grid (ATen unnormalise, floor, weights)
-                    const float px = fmaf(gxs[u] + 1.0f, (float)W * 0.5f, -0.5f);
-                    const float py = fmaf(gys[u] + 1.0f, (float)H * 0.5f, -0.5f);
-                    const float xw = floorf(px), yn = floorf(py);
-                    const float w = px - xw, e = 1.0f - w, n = py - yn, so = 1.0f - n;
-                    const bool ok = (xw >= -1.0f) && (xw <= (float)(W - 1)) && (yn >= -1.0f) && (yn <= (float)(H - 1));
-                    // a footprint that misses the image keeps (NaN-propagating) zero weights: it then
-                    // contributes what four masked gathers contribute -- 0, or NaN for a NaN coordinate
-                    const float okf = ok ? 1.0f : 0.0f;
-                    tap[pl][s].wn.x = (so * e) * okf; tap[pl][s].wn.y = (so * w) * okf;
-                    tap[pl][s].ws.x = (n * e) * okf;  tap[pl][s].ws.y = (n * w) * okf;
-                    const int ix0 = ok ? (int)xw : 0, iy0 = ok ? (int)yn : 0;
-                    txy[pl][s] = ((uint32_t)(iy0 + 1) << 16) | (uint32_t)(ix0 + 1);
-                    if (ok) okmask |= 1u << (pl * NSRC + s);
-                    if (ok && active && pl < np) {
-                        lo_x[s] = min(lo_x[s], ix0); hi_x[s] = max(hi_x[s], ix0);
-                        lo_y[s] = min(lo_y[s], iy0); hi_y[s] = max(hi_y[s], iy0);
-                    }
-                }
+                const bool ok = (okmask >> (pl * NSRC + s)) & 1u;
+                const int iy0 = (int)(txy[pl][s] >> 16) - 1, ix0 = (int)(txy[pl][s] & 0xffffu) - 1;
+                tap[pl][s].base = tile_lds + 8u * (uint32_t)(ok ? s * SRC_STRIDE + (iy0 - by0[s]) * BW + (ix0 - bx0[s])
+                                                                  : NSRC * SRC_STRIDE);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        uint32_t ovo[DP];                                 // per-plane byte offset of this pixel inside one channel volume
+#pragma unroll
+        for (int pl = 0; pl < DP; ++pl)
+            ovo[pl] = (active && pl < np) ? (uint32_t)(dg + pl - p.d_begin + p.d_out_off) * (uint32_t)HW * 4u + pix4
+                                          : SMVS_OOB;       // inactive lanes / tail planes: store dropped by the range check
 
-        // ---- B: the wave's bounding box per source ----------------------------------------------
-        int bx0[NSRC], by0[NSRC], bw[NSRC], bh[NSRC];
-        bool fits = true;
+        // byte offset of each box row inside one channel plane; rows outside the image carry 2^31, which
+        // stays out of range after the channel offset (< 2^31, one batch item is < 2 GiB) is added
+        uint32_t rowoff[NSRC][R];
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) {
-            const int a0 = __builtin_amdgcn_readfirstlane(wave_min(lo_x[s]));
-            const int a1 = __builtin_amdgcn_readfirstlane(wave_max(hi_x[s]));
-            const int b0 = __builtin_amdgcn_readfirstlane(wave_min(lo_y[s]));
-            const int b1 = __builtin_amdgcn_readfirstlane(wave_max(hi_y[s]));
-            const bool empty = a1 < a0;
-            bx0[s] = empty ? 0 : a0; by0[s] = empty ? 0 : b0;
-            bw[s] = empty ? 0 : a1 - a0 + 2;
-            bh[s] = empty ? 0 : b1 - b0 + 2;
-            fits = fits && (bw[s] <= BW) && (bh[s] <= R);
-        }
-
-        if (fits) {
-            // DMA lane map: lane -> (column lane>>1 of a 32-column half row, channel lane&1 of the pair)
-            uint32_t vo[NSRC][2];
+        for (int s = 0; s < NSRC; ++s)
 #pragma unroll
-            for (int s = 0; s < NSRC; ++s)
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int col = hh * 32 + (lane >> 1), c0 = bx0[s] + col;
-                    vo[s][hh] = (col < bw[s] && c0 >= 0 && c0 < W) ? (uint32_t)(c0 * 4 + (lane & 1) * HW * 4) : SMVS_OOB;
-                }
-#pragma unroll
-            for (int pl = 0; pl < DP; ++pl)
-#pragma unroll
-                for (int s = 0; s < NSRC; ++s) {
-                    const bool ok = (okmask >> (pl * NSRC + s)) & 1u;
-                    const int iy0 = (int)(txy[pl][s] >> 16) - 1, ix0 = (int)(txy[pl][s] & 0xffffu) - 1;
-                    tap[pl][s].base = tile_lds + 8u * (uint32_t)(ok ? s * SRC_STRIDE + (iy0 - by0[s]) * BW + (ix0 - bx0[s])
-                                                                      : NSRC * SRC_STRIDE);
-                }
-            uint32_t ovo[DP];                                 // per-plane byte offset of this pixel inside one channel volume
-#pragma unroll
-            for (int pl = 0; pl < DP; ++pl)
-                ovo[pl] = (active && pl < np && !(p.ablate & 1)) ? (uint32_t)(dg + pl - p.d_begin + p.d_out_off) * (uint32_t)HW * 4u + pix4
-                                              : SMVS_OOB;       // inactive lanes / tail planes: store dropped by the range check
-
-            int rowoff[NSRC][R];                               // byte offset of each box row inside one channel plane
-#pragma unroll
-            for (int s = 0; s < NSRC; ++s)
-#pragma unroll
-                for (int er = 0; er < R; ++er) {
-                    const int gyp = by0[s] + er;
-                    rowoff[s][er] = (gyp >= 0 && gyp < H) ? gyp * W * 4 : (int)SMVS_OOB;
-                }
-            // (s, er) are unrolled loop indices but not constant expressions: dispatch to the immediate-offset variant
-            auto dma_at = [&](auto half_tag, int s, int er, uint32_t buf, uint32_t voff, int so) {
-                constexpr int HALF = decltype(half_tag)::value;
+            for (int er = 0; er < R; ++er) {
+                const int gyp = by0[s] + er;
+                rowoff[s][er] = (gyp >= 0 && gyp < H) ? (uint32_t)(gyp * W * 4) : SMVS_OOB;
+            }
+        // (s, er) are unrolled loop indices but not constant expressions: dispatch to the immediate-offset variant
+        auto dma_at = [&](auto half_tag, int s, int er, uint32_t buf, uint32_t voff, int so) {
+            constexpr int HALF = decltype(half_tag)::value;
 #define SMVS_DMA_CASE(S, ER) \
     case (S) * R + (ER): dma_dword_to_lds_at<((S) * SRC_STRIDE + (ER) * BW) * 8 + HALF>(rs[(S) < NSRC ? (S) : 0], buf, voff, so); break;
-                switch (s * R + er) {
-                    SMVS_DMA_CASE(0, 0) SMVS_DMA_CASE(0, 1) SMVS_DMA_CASE(0, 2) SMVS_DMA_CASE(0, 3) SMVS_DMA_CASE(0, 4)
-                    SMVS_DMA_CASE(1, 0) SMVS_DMA_CASE(1, 1) SMVS_DMA_CASE(1, 2) SMVS_DMA_CASE(1, 3) SMVS_DMA_CASE(1, 4)
-                    SMVS_DMA_CASE(2, 0) SMVS_DMA_CASE(2, 1) SMVS_DMA_CASE(2, 2) SMVS_DMA_CASE(2, 3) SMVS_DMA_CASE(2, 4)
-                    default: break;
-                }
+            switch (s * R + er) {
+                SMVS_DMA_CASE(0, 0) SMVS_DMA_CASE(0, 1) SMVS_DMA_CASE(0, 2) SMVS_DMA_CASE(0, 3) SMVS_DMA_CASE(0, 4)
+                SMVS_DMA_CASE(1, 0) SMVS_DMA_CASE(1, 1) SMVS_DMA_CASE(1, 2) SMVS_DMA_CASE(1, 3) SMVS_DMA_CASE(1, 4)
+                SMVS_DMA_CASE(2, 0) SMVS_DMA_CASE(2, 1) SMVS_DMA_CASE(2, 2) SMVS_DMA_CASE(2, 3) SMVS_DMA_CASE(2, 4)
+                default: break;
+            }
 #undef SMVS_DMA_CASE
+        };
+        auto issue_dma = [&](int st) {
+            const uint32_t buf = tile_lds + (uint32_t)((st & 1) * BUF_STRIDE * 8);
+            const uint32_t choff = (uint32_t)(2 * st * HW * 4);
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s) {
+#pragma unroll
+                for (int er = 0; er < R; ++er) {
+                    if (er < bh[s]) {                                         // wave-uniform
+                        const int so = (int)(rowoff[s][er] + choff);
+                        // destination = buf + a compile-time offset, formed inside the asm by one s_add into M0
+                        dma_at(std::integral_constant<int, 0>(), s, er, buf, vo[s][0], so);
+                        dma_at(std::integral_constant<int, 256>(), s, er, buf, vo[s][1], so);
+                    }
+                }
+            }
+        };
+
+        // prologue: pair 0
+        // ref feature pairs run two steps ahead of their use, in registers
+        f32x2 ref0, ref1;
+        ref0.x = llvm_raw_buffer_load_f32(rref.v, (int)pix4, 0, 0);
+        ref0.y = llvm_raw_buffer_load_f32(rref.v, (int)pix4, HW * 4, 0);
+        ref1.x = llvm_raw_buffer_load_f32(rref.v, (int)pix4, (NSTEP > 1 ? 2 : 0) * HW * 4, 0);
+        ref1.y = llvm_raw_buffer_load_f32(rref.v, (int)pix4, (NSTEP > 1 ? 3 : 1) * HW * 4, 0);
+        issue_dma(0);
+
+        // One step = one channel pair.  PAR (buffer parity) is a compile-time constant so that the
+        // staging buffer enters every LDS read as an immediate offset.
+        auto step = [&](int st, auto par_tag) {
+            constexpr int PAR = decltype(par_tag)::value;
+            // Issue order behind DMA(st): the two ref loads of step st+1 and the 2*DP stores of step
+            // st-1 (every step issues all of them; lanes/planes without output carry an out-of-range
+            // offset).  vmcnt retires in order, so DMA(st) has landed once at most that many
+            // operations are outstanding.
+            const f32x2 refc = ref0;
+            if (st == 0) wait_vmcnt<0>();
+            else if (st + 1 < NSTEP) wait_vmcnt<2 * DP + 2>();
+            else wait_vmcnt<2 * DP>();
+            ref0 = ref1;
+            if (st + 1 < NSTEP) {
+                issue_dma(st + 1);
+                const int nx = (st + 2 < NSTEP) ? 2 * st + 4 : 0;   // dummy reload keeps the count constant
+                ref1.x = llvm_raw_buffer_load_f32(rref.v, (int)pix4, nx * HW * 4, 0);
+                ref1.y = llvm_raw_buffer_load_f32(rref.v, (int)pix4, (nx + 1) * HW * 4, 0);
+            }
+            const f32x2 refsq = refc * refc;
+            // one descriptor per channel pair: base = channel 2*st of the output, second channel
+            // through the scalar offset
+            const BufRsrc ro = make_rsrc(p.out + ((size_t)b * CT + 2 * st) * ostride, (uint32_t)(2 * ostride * 4));
+            const int och1 = (int)(ostride * 4);
+            // Software pipeline over the planes: the taps of plane pl+1 are in flight (ds_read_b64 from
+            // inline asm, in-order return, counted lgkmcnt) while plane pl is being computed.
+            f32x2 cv[DP][NSRC][4];
+            auto read_plane = [&](int pl) {
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s)
+                    lds_read_tap<PAR * BUF_STRIDE * 8, BW * 8>(tap[pl][s].base, cv[pl][s][0], cv[pl][s][1],
+                                                               cv[pl][s][2], cv[pl][s][3]);
             };
-            auto issue_dma = [&](int st) {
-                if (p.ablate & 2) return;
-                const uint32_t buf = tile_lds + (uint32_t)((st & 1) * BUF_STRIDE * 8);
-                const int choff = 2 * st * HW * 4;
+            auto compute_plane = [&](int pl) {
+                f32x2 sum = refc, sq = refsq;
 #pragma unroll
                 for (int s = 0; s < NSRC; ++s) {
-#pragma unroll
-                    for (int er = 0; er < R; ++er) {
-                        if (er < bh[s]) {                                         // wave-uniform
-                            const int so = (rowoff[s][er] != (int)SMVS_OOB) ? rowoff[s][er] + choff : (int)SMVS_OOB;
-                            // destination = buf + a compile-time offset, formed inside the asm by one s_add into M0
-                            dma_at(std::integral_constant<int, 0>(), s, er, buf, vo[s][0], so);
-                            dma_at(std::integral_constant<int, 256>(), s, er, buf, vo[s][1], so);
-                        }
-                    }
+                    const TapD& t = tap[pl][s];
+                    f32x2 wv = cv[pl][s][0] * __builtin_shufflevector(t.wn, t.wn, 0, 0);
+                    wv = __builtin_elementwise_fma(cv[pl][s][1], __builtin_shufflevector(t.wn, t.wn, 1, 1), wv);
+                    wv = __builtin_elementwise_fma(cv[pl][s][2], __builtin_shufflevector(t.ws, t.ws, 0, 0), wv);
+                    wv = __builtin_elementwise_fma(cv[pl][s][3], __builtin_shufflevector(t.ws, t.ws, 1, 1), wv);
+                    sum = sum + wv;
+                    sq = sq + wv * wv;
                 }
+                const f32x2 m = div_by_views2(sum, fV, rV);
+                const f32x2 q = div_by_views2(sq, fV, rV);
+                const f32x2 var = q - m * m;
+                llvm_raw_buffer_store_f32(var.x, ro.v, (int)ovo[pl], 0, STORE_AUX);
+                llvm_raw_buffer_store_f32(var.y, ro.v, (int)ovo[pl], och1, STORE_AUX);
             };
-
-            // prologue: pair 0
-            // ref feature pairs run two steps ahead of their use, in registers
-            f32x2 ref0, ref1;
-            ref0.x = llvm_raw_buffer_load_f32(rref.v, (int)pix4, 0, 0);
-            ref0.y = llvm_raw_buffer_load_f32(rref.v, (int)pix4, HW * 4, 0);
-            ref1.x = llvm_raw_buffer_load_f32(rref.v, (int)pix4, (NSTEP > 1 ? 2 : 0) * HW * 4, 0);
-            ref1.y = llvm_raw_buffer_load_f32(rref.v, (int)pix4, (NSTEP > 1 ? 3 : 1) * HW * 4, 0);
-            wait_vmcnt<0>();                                  // also: nothing of the previous group is still in flight
-            issue_dma(0);
-
-            // One step = one channel pair.  PAR (buffer parity) is a compile-time constant so that the
-            // staging buffer enters every LDS read as an immediate offset.
-            auto step = [&](int st, auto par_tag) {
-                constexpr int PAR = decltype(par_tag)::value;
-                // Issue order behind DMA(st): the two ref loads of step st+1 and the 2*DP stores of step
-                // st-1 (every step issues all of them; lanes/planes without output carry an out-of-range
-                // offset).  vmcnt retires in order, so DMA(st) has landed once at most that many
-                // operations are outstanding.
-                const f32x2 refc = ref0;
-                if (st == 0) wait_vmcnt<0>();
-                else if (st + 1 < NSTEP) wait_vmcnt<2 * DP + 2>();
-                else wait_vmcnt<2 * DP>();
-                ref0 = ref1;
-                if (st + 1 < NSTEP) {
-                    issue_dma(st + 1);
-                    const int nx = (st + 2 < NSTEP) ? 2 * st + 4 : 0;   // dummy reload keeps the count constant
-                    ref1.x = llvm_raw_buffer_load_f32(rref.v, (int)pix4, nx * HW * 4, 0);
-                    ref1.y = llvm_raw_buffer_load_f32(rref.v, (int)pix4, (nx + 1) * HW * 4, 0);
-                }
-                const f32x2 refsq = refc * refc;
-                // one descriptor per channel pair: base = channel 2*st of the output, second channel
-                // through the scalar offset
-                const BufRsrc ro = make_rsrc(p.out + ((size_t)b * CT + 2 * st) * ostride, (uint32_t)(2 * ostride * 4));
-                const int och1 = (int)(ostride * 4);
-                // Software pipeline over the planes: the taps of plane pl+1 are in flight (ds_read_b64 from
-                // inline asm, in-order return, counted lgkmcnt) while plane pl is being computed.
-                f32x2 cv[DP][NSRC][4];
-                auto read_plane = [&](int pl) {
+            read_plane(0);
 #pragma unroll
-                    for (int s = 0; s < NSRC; ++s)
-                        lds_read_tap<PAR * BUF_STRIDE * 8, BW * 8>(tap[pl][s].base, cv[pl][s][0], cv[pl][s][1],
-                                                                   cv[pl][s][2], cv[pl][s][3]);
-                };
-                auto compute_plane = [&](int pl) {
-                    f32x2 sum = refc, sq = refsq;
+            for (int pl = 0; pl < DP; ++pl) {
+                if (pl + 1 < DP) read_plane(pl + 1);
+                // reads per plane = 4*NSRC; everything older than the next plane's reads has returned
+                if constexpr (NSRC == 1) {
+                    f32x2 d0, d1, d2, d3;
+                    d0 = d1 = d2 = d3 = (f32x2)(0.0f);
+                    if (pl + 1 < DP) lds_wait<4>(cv[pl][0][0], cv[pl][0][1], cv[pl][0][2], cv[pl][0][3], d0, d1, d2, d3);
+                    else             lds_wait<0>(cv[pl][0][0], cv[pl][0][1], cv[pl][0][2], cv[pl][0][3], d0, d1, d2, d3);
+                } else {
 #pragma unroll
-                    for (int s = 0; s < NSRC; ++s) {
-                        const TapD& t = tap[pl][s];
-                        f32x2 wv = cv[pl][s][0] * __builtin_shufflevector(t.wn, t.wn, 0, 0);
-                        wv = __builtin_elementwise_fma(cv[pl][s][1], __builtin_shufflevector(t.wn, t.wn, 1, 1), wv);
-                        wv = __builtin_elementwise_fma(cv[pl][s][2], __builtin_shufflevector(t.ws, t.ws, 0, 0), wv);
-                        wv = __builtin_elementwise_fma(cv[pl][s][3], __builtin_shufflevector(t.ws, t.ws, 1, 1), wv);
-                        sum = sum + wv;
-                        sq = sq + wv * wv;
+                    for (int s = 0; s + 1 < NSRC; s += 2) {
+                        if (pl + 1 < DP) lds_wait<(4 * NSRC <= 15 ? 4 * NSRC : 15)>(cv[pl][s][0], cv[pl][s][1], cv[pl][s][2], cv[pl][s][3],
+                                                       cv[pl][s + 1][0], cv[pl][s + 1][1], cv[pl][s + 1][2], cv[pl][s + 1][3]);
+                        else             lds_wait<0>(cv[pl][s][0], cv[pl][s][1], cv[pl][s][2], cv[pl][s][3],
+                                                     cv[pl][s + 1][0], cv[pl][s + 1][1], cv[pl][s + 1][2], cv[pl][s + 1][3]);
                     }
-                    const f32x2 m = div_by_views2(sum, fV, rV);
-                    const f32x2 q = div_by_views2(sq, fV, rV);
-                    const f32x2 var = q - m * m;
-                    llvm_raw_buffer_store_f32(var.x, ro.v, (int)ovo[pl], 0, STORE_AUX);
-                    llvm_raw_buffer_store_f32(var.y, ro.v, (int)ovo[pl], och1, STORE_AUX);
-                };
-                read_plane(0);
-#pragma unroll
-                for (int pl = 0; pl < DP; ++pl) {
-                    if (pl + 1 < DP) read_plane(pl + 1);
-                    // reads per plane = 4*NSRC; everything older than the next plane's reads has returned
-                    if constexpr (NSRC == 1) {
+                    if constexpr (NSRC == 3) {
                         f32x2 d0, d1, d2, d3;
                         d0 = d1 = d2 = d3 = (f32x2)(0.0f);
-                        if (pl + 1 < DP) lds_wait<4>(cv[pl][0][0], cv[pl][0][1], cv[pl][0][2], cv[pl][0][3], d0, d1, d2, d3);
-                        else             lds_wait<0>(cv[pl][0][0], cv[pl][0][1], cv[pl][0][2], cv[pl][0][3], d0, d1, d2, d3);
-                    } else {
-#pragma unroll
-                        for (int s = 0; s + 1 < NSRC; s += 2) {
-                            if (pl + 1 < DP) lds_wait<(4 * NSRC <= 15 ? 4 * NSRC : 15)>(cv[pl][s][0], cv[pl][s][1], cv[pl][s][2], cv[pl][s][3],
-                                                           cv[pl][s + 1][0], cv[pl][s + 1][1], cv[pl][s + 1][2], cv[pl][s + 1][3]);
-                            else             lds_wait<0>(cv[pl][s][0], cv[pl][s][1], cv[pl][s][2], cv[pl][s][3],
-                                                         cv[pl][s + 1][0], cv[pl][s + 1][1], cv[pl][s + 1][2], cv[pl][s + 1][3]);
-                        }
-                        if constexpr (NSRC == 3) {
-                            f32x2 d0, d1, d2, d3;
-                            d0 = d1 = d2 = d3 = (f32x2)(0.0f);
-                            if (pl + 1 < DP) lds_wait<12>(cv[pl][2][0], cv[pl][2][1], cv[pl][2][2], cv[pl][2][3], d0, d1, d2, d3);
-                            else             lds_wait<0>(cv[pl][2][0], cv[pl][2][1], cv[pl][2][2], cv[pl][2][3], d0, d1, d2, d3);
-                        }
+                        if (pl + 1 < DP) lds_wait<12>(cv[pl][2][0], cv[pl][2][1], cv[pl][2][2], cv[pl][2][3], d0, d1, d2, d3);
+                        else             lds_wait<0>(cv[pl][2][0], cv[pl][2][1], cv[pl][2][2], cv[pl][2][3], d0, d1, d2, d3);
                     }
-                    compute_plane(pl);
                 }
-            };
-            static_assert(NSTEP % 2 == 0, "two steps per loop iteration");
-            for (int st = 0; st < NSTEP; st += 2) {
-                step(st, std::integral_constant<int, 0>());
-                step(st + 1, std::integral_constant<int, 1>());
+                compute_plane(pl);
             }
-        } else {
-            // ---- fallback: direct gathers for this plane group (box larger than the staged tile).
-            //      Rare and wave-uniform; the taps are recomputed plane by plane in a rolled loop so
-            //      that this path adds no register pressure to the staged one.
-            const float* refp = p.ref + (size_t)b * CT * HW + pix;
-            float* outp = p.out + (size_t)b * CT * p.D_out * HW + pix;
+        };
+        static_assert(NSTEP % 2 == 0, "two steps per loop iteration");
+        for (int st = 0; st < NSTEP; st += 2) {
+            step(st, std::integral_constant<int, 0>());
+            step(st + 1, std::integral_constant<int, 1>());
+        }
+    } else {
+        // ---- fallback: direct gathers for this plane group (box larger than the staged tile).
+        //      Rare and wave-uniform; the source taps are rebuilt plane by plane from the ground point
+        //      of phase A in a rolled loop (same float64 values as the staged path would have used).
+        const float* refp = p.ref + (size_t)b * CT * HW + pix;
+        float* outp = p.out + (size_t)b * CT * p.D_out * HW + pix;
 #pragma unroll 1
-            for (int pl = 0; pl < np; ++pl) {
-                const int d = dg + pl;
-                const float hf = p.depth_is_4d ? p.depth[((size_t)b * p.D + d) * HW + pix]
-                                               : p.depth[(size_t)b * p.D + d];
-                const double h = (double)hf;
-                const cgeo_t geo_d = launder(geo_b);
-                Tap tp[NSRC];
-                double lat = 0.0, lon = 0.0;
-                if (GEO == 0) rpc_photo2obj(geo_d, ref_n, fx, fy, h, lat, lon);
+        for (int pl = 0; pl < np; ++pl) {
+            const int d = dg + pl;
+            float hfp = hf[0]; double latp = lat[0], lonp = lon[0];
+#pragma unroll
+            for (int k = 1; k < DP; ++k) if (pl == k) { hfp = hf[k]; latp = lat[k]; lonp = lon[k]; }
+            const double h = (double)hfp;
+            const cgeo_t geo_d = launder(geo_b);
+            Tap tp[NSRC];
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s) {
+                if (GEO == 0) {
+                    double samp, line;
+                    o2p_xn<1>(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], &latp, &lonp, &h, &samp, &line);
+                    tp[s] = tap_from_pixel((float)samp, (float)line, H, W, half_wm1, half_hm1);
+                } else {
+                    const cgeo_t P = geo_d + s * 16;
+                    const double rx = fma(P[1], fy, P[0] * fx) + P[2];
+                    const double ry = fma(P[5], fy, P[4] * fx) + P[6];
+                    const double rz = fma(P[9], fy, P[8] * fx) + P[10];
+                    const double X = fma(rx, h, P[3]), Y = fma(ry, h, P[7]), Z = fma(rz, h, P[11]);
+                    tp[s] = tap_from_grid((float)((X / Z) / ((W - 1) * 0.5) - 1.0),
+                                          (float)((Y / Z) / ((H - 1) * 0.5) - 1.0), H, W);
+                }
+            }
+            float* od = outp + (size_t)(d - p.d_begin + p.d_out_off) * HW;
+#pragma unroll 1
+            for (int c = 0; c < CT; ++c) {
+                const float r = refp[(size_t)c * HW];
+                float sum = r;
+                float sq = r * r;
 #pragma unroll
                 for (int s = 0; s < NSRC; ++s) {
-                    if (GEO == 0) {
-                        double samp, line;
-                        rpc_obj2photo(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat, lon, h, samp, line);
-                        tp[s] = tap_from_pixel((float)samp, (float)line, H, W, half_wm1, half_hm1);
-                    } else {
-                        const cgeo_t P = geo_d + s * 16;
-                        const double rx = fma(P[1], fy, P[0] * fx) + P[2];
-                        const double ry = fma(P[5], fy, P[4] * fx) + P[6];
-                        const double rz = fma(P[9], fy, P[8] * fx) + P[10];
-                        const double X = fma(rx, h, P[3]), Y = fma(ry, h, P[7]), Z = fma(rz, h, P[11]);
-                        tp[s] = tap_from_grid((float)((X / Z) / ((W - 1) * 0.5) - 1.0),
-                                              (float)((Y / Z) / ((H - 1) * 0.5) - 1.0), H, W);
-                    }
+                    const float wv = tap_fetch(rs[s], tp[s], c * HW * 4);
+                    sum = sum + wv;
+                    sq = sq + wv * wv;
                 }
-                float* od = outp + (size_t)(d - p.d_begin + p.d_out_off) * HW;
-#pragma unroll 1
-                for (int c = 0; c < CT; ++c) {
-                    const float r = refp[(size_t)c * HW];
-                    float sum = r;
-                    float sq = r * r;
-#pragma unroll
-                    for (int s = 0; s < NSRC; ++s) {
-                        const float wv = tap_fetch(rs[s], tp[s], c * HW * 4);
-                        sum = sum + wv;
-                        sq = sq + wv * wv;
-                    }
-                    const float m = div_by_views(sum, fV, rV);
-                    const float q = div_by_views(sq, fV, rV);
-                    if (active) od[(size_t)c * ostride] = q - m * m;
-                }
+                const float m = div_by_views(sum, fV, rV);
+                const float q = div_by_views(sq, fV, rV);
+                if (active) od[(size_t)c * ostride] = q - m * m;
             }
         }
     }
@@ -652,10 +664,8 @@ static hipError_t launch_ct(CostVolParams p, hipStream_t st)
         if (kc != K_DIRECT && staged_ok) {
             p.xt = (p.W + WV_TX - 1) / WV_TX;
             p.yt = (p.H + WV_TY * WV_WAVES - 1) / (WV_TY * WV_WAVES);
-            int dpg = DM_DP;                                  // planes per wave: one staged group (measured: 4 -> 0.865, 8 -> 0.873, 16 -> 0.90 ms)
-            if (const char* e = getenv("SMVS_PLANES_PER_WAVE")) dpg = atoi(e) > 0 ? atoi(e) : dpg;   // tuning knob
-            p.dch = nd < dpg ? nd : dpg;
-            p.dct = (nd + p.dch - 1) / p.dch;
+            p.dch = DM_DP;                                    // one staged plane group per wave (measured: 4 -> 0.865, 8 -> 0.873, 16 -> 0.90 ms)
+            p.dct = (nd + DM_DP - 1) / DM_DP;
             const long long nb = (long long)p.xt * p.yt * p.dct * p.B;
             if (nb >= (1ll << 31)) return hipErrorInvalidValue;
             dim3 blk(64 * WV_WAVES), grd((unsigned)nb);
@@ -719,7 +729,6 @@ static int costvol_fwd(int geo_kind, const float* ref_fea, const float* const* s
     p.B = B; p.V = n_src + 1; p.C = C; p.D = D; p.H = H; p.W = W;
     p.d_begin = d_begin; p.d_end = d_end; p.D_out = D_out; p.d_out_off = d_out_off;
     p.depth_is_4d = depth_is_4d;
-    { const char* ab = getenv("SMVS_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = (geo_kind == 0) ? launch_nsrc<0>(p, st) : launch_nsrc<1>(p, st);
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "costvol_fwd launch: %s", hipGetErrorString(e));

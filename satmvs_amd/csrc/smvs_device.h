@@ -190,6 +190,170 @@ __device__ __forceinline__ void rpc_obj2photo_x2(cgeo_t r, const RpcInv& n,
     line_b = fma(fast_div(qb.n1, qb.d1), r[I_LINE_SCALE], r[I_LINE_OFF]);
 }
 
+// ---- rational cubics in nested (Horner) form, coefficients in SGPRs -------------------------------------
+//   poly = A + H*(B + H*(C + H*c19))
+//   A = (c0 + P(c2 + P(c8 + P c15))) + L((c1 + P(c4 + P c12)) + L((c7 + P c14) + L c11))
+//   B = (c3 + P(c6 + P c18)) + L((c5 + P c10) + L c17)        C = c9 + L c13 + P c16
+// (monomial order 1,L,P,H,LP,LH,PH,LL,PP,HH,PLH,LLL,LPP,LHH,LLP,PPP,PHH,LLH,PPH,HHH, warping.py:183-207):
+// 19 FMAs per cubic and no monomial products (the flat form costs 16 products + 76 FMAs per four cubics).
+// A VALU instruction reads at most one SGPR operand, and the six innermost steps (c8 + P c15, ...) combine two
+// coefficients: one of each pair is copied to a VGPR first (v_mov_b64), shared by the N points evaluated
+// together.  N points = N planes of one pixel: every scalar-loaded coefficient then feeds N FMAs.
+// Same polynomial as the reference's sum of 20 products, different summation order: the results differ by
+// rounding only (~1e-16 relative; tolerance 1e-12 deg / 1e-8 px, tests/test_hip_parity.py).
+__device__ __forceinline__ double to_vgpr(double s)
+{
+    double v;
+    asm("v_mov_b64 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+
+// A(P,L), B(P,L), C(P,L) of one cubic at N points
+template <int N>
+__device__ __forceinline__ void cubic_abc_xn(cgeo_t k, const double* P, const double* L, double* A, double* B, double* C)
+{
+    const double v4 = to_vgpr(k[4]), v5 = to_vgpr(k[5]), v6 = to_vgpr(k[6]);
+    const double v7 = to_vgpr(k[7]), v8 = to_vgpr(k[8]), v9 = to_vgpr(k[9]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        double t = fma(L[u], k[11], fma(P[u], k[14], v7));
+        t = fma(L[u], t, fma(P[u], fma(P[u], k[12], v4), k[1]));
+        A[u] = fma(L[u], t, fma(P[u], fma(P[u], fma(P[u], k[15], v8), k[2]), k[0]));
+        t = fma(L[u], k[17], fma(P[u], k[10], v5));
+        B[u] = fma(L[u], t, fma(P[u], fma(P[u], k[18], v6), k[3]));
+        C[u] = fma(P[u], k[16], fma(L[u], k[13], v9));
+    }
+}
+
+// Pin a value at this point of the program: it must be computed before, and cannot be re-derived after.  Stops
+// the optimiser from sinking a finished computation down to its first use (which keeps its operands alive
+// all the way there).
+__device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+
+// RPC_Photo2Obj (warping.py:255-307) of one ref pixel, split into its plane-invariant part (A, B, C of the
+// four cubics in the normalised (samp, line): 64 FMAs per pixel) and the per-plane part (Horner in the
+// normalised height: 12 FMAs + two quotients).  inv = {1/SAMP_SCALE, 1/LINE_SCALE, 1/HEIGHT_SCALE}.
+struct P2OPix { double A[4], B[4], C[4]; };
+
+__device__ __forceinline__ void p2o_pixel(cgeo_t r, const RpcInv& n, double samp, double line, P2OPix& o)
+{
+    const double P = (samp - r[I_SAMP_OFF]) * n.a;
+    const double L = (line - r[I_LINE_OFF]) * n.b;
+    // one cubic at a time: the pointer is re-materialised so that only 20 coefficients are in SGPRs at once
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        cubic_abc_xn<1>(launder(r) + I_LATNUM + 20 * i, &P, &L, &o.A[i], &o.B[i], &o.C[i]);
+        pin(o.A[i]); pin(o.B[i]); pin(o.C[i]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ void p2o_plane(cgeo_t r, const RpcInv& n, const P2OPix& o, double hei, double& lat, double& lon)
+{
+    const double z = (hei - r[I_H_OFF]) * n.h;
+    double q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = fma(z, fma(z, fma(z, r[I_LATNUM + 20 * i + 19], o.C[i]), o.B[i]), o.A[i]);
+    lat = fma(fast_div(q[0], q[1]), r[I_LAT_SCALE], r[I_LAT_OFF]);
+    lon = fma(fast_div(q[2], q[3]), r[I_LON_SCALE], r[I_LON_OFF]);
+}
+
+// RPC_Obj2Photo (warping.py:218-252) at N ground points at once (N planes of one pixel), one cubic at a time.
+// n = {1/LAT_SCALE, 1/LONG_SCALE, 1/HEIGHT_SCALE}.
+template <int N>
+__device__ __forceinline__ void o2p_xn(cgeo_t r, const RpcInv& n, const double* lat, const double* lon, const double* hei,
+                                       double* samp, double* line)
+{
+    double P[N], L[N], H[N], q[4][N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        P[u] = (lat[u] - r[I_LAT_OFF]) * n.a;
+        L[u] = (lon[u] - r[I_LON_OFF]) * n.b;
+        H[u] = (hei[u] - r[I_H_OFF]) * n.h;
+    }
+    constexpr int base[4] = {I_SNUM, I_SDEN, I_LNUM, I_LDEN};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        const cgeo_t k = launder(r) + base[i];
+        double A[N], B[N], C[N];
+        cubic_abc_xn<N>(k, P, L, A, B, C);
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            q[i][u] = fma(H[u], fma(H[u], fma(H[u], k[19], C[u]), B[u]), A[u]);
+            pin(q[i][u]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const cgeo_t rr = launder(r);
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        samp[u] = fma(fast_div(q[0][u], q[1][u]), rr[I_SAMP_SCALE], rr[I_SAMP_OFF]);
+        line[u] = fma(fast_div(q[2][u], q[3][u]), rr[I_LINE_SCALE], rr[I_LINE_OFF]);
+    }
+}
+
+// x / d in float32, correctly rounded, for a wave-uniform d = k/2 with integer 1 <= k < 2^16 (the
+// reference divides pixel coordinates by the python float (W-1)/2, warping.py:350-351): q0 = x*rd,
+// r = fma(-q0, d, x) (exact), q = fma(r, rd, q0), rd = RN(1/d).  q0 + r*rd = x/d * (1 + e), |e| <
+// 2^-47, while a quotient of a float by such a d is either representable or at least 2^-41
+// (relative) away from every rounding boundary, so the final rounding is the IEEE one; inf/NaN
+// inputs give NaN where the true quotient is inf/NaN, and both end as NaN taps.  3 instructions
+// instead of the ~11 of the IEEE sequence (v_div_scale / v_rcp / v_div_fmas / v_div_fixup).
+__device__ __forceinline__ float div_half_int(float x, float d, float rd)
+{
+    const float q0 = x * rd;
+    const float r = fmaf(-q0, d, x);
+    return fmaf(r, rd, q0);
+}
+
+// float -> int32 with the hardware's saturating conversion (NaN -> 0): defined for every input, unlike a C cast
+__device__ __forceinline__ int cvt_i32_sat(float x)
+{
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// ---- wave reductions on the DPP network (no LDS traffic, unlike ds_bpermute shuffles) ------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int old, int v)
+{
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+// result valid in lane 63 (returned as a wave-uniform value)
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    v = min(v, dpp_i32<0x111, 0xf>(v, v));      // row_shr:1
+    v = min(v, dpp_i32<0x112, 0xf>(v, v));      // row_shr:2
+    v = min(v, dpp_i32<0x114, 0xf>(v, v));      // row_shr:4
+    v = min(v, dpp_i32<0x118, 0xf>(v, v));      // row_shr:8   -> lane 15 of each row = row minimum
+    v = min(v, dpp_i32<0x142, 0xa>(v, v));      // row_bcast:15 into rows 1 and 3
+    v = min(v, dpp_i32<0x143, 0xc>(v, v));      // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    v = max(v, dpp_i32<0x111, 0xf>(v, v));
+    v = max(v, dpp_i32<0x112, 0xf>(v, v));
+    v = max(v, dpp_i32<0x114, 0xf>(v, v));
+    v = max(v, dpp_i32<0x118, 0xf>(v, v));
+    v = max(v, dpp_i32<0x142, 0xa>(v, v));
+    v = max(v, dpp_i32<0x143, 0xc>(v, v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), lane);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
 // ---- raw buffer access -------------------------------------------------------------------------
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
