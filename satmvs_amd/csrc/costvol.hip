@@ -45,6 +45,7 @@ struct CostVolParams {
     int D_out, d_out_off;           // plane d lands at index d - d_begin + d_out_off of `out`
     int depth_is_4d;
     int xt, yt, dct, dch;           // tiles in x, y; plane chunks; planes per chunk
+    float rV, r_half_wm1, r_half_hm1;   // RN(1/V), RN(1/((W-1)/2)), RN(1/((H-1)/2)) in float32, divided once on the host
 };
 
 template <int GEO, int NSRC, int CT>
@@ -227,13 +228,39 @@ __device__ __forceinline__ int wave_max(int v)
 // the oracle.
 // =====================================================================================================
 constexpr int DM_DP = 4;       // planes per group
-constexpr int DM_BW = 64;      // staged box width (columns)
-constexpr int DM_R = 5;        // staged box rows: 2 pixel rows + south tap + parallax/rotation slack
+#ifndef SMVS_BOX_W
+#define SMVS_BOX_W 40
+#endif
+#ifndef SMVS_WAVES_PER_SIMD
+#define SMVS_WAVES_PER_SIMD 3
+#endif
+constexpr int DM_BW = SMVS_BOX_W;      // staged box width (columns)
+#ifndef SMVS_BOX_R
+#define SMVS_BOX_R 5
+#endif
+constexpr int DM_R = SMVS_BOX_R;        // staged box rows: 2 pixel rows + south tap + parallax/rotation slack
 constexpr int DM_NBUF = 2;
+#ifndef SMVS_ABLATE
+#define SMVS_ABLATE 0                 // profiling builds only (tools/ab_build.sh x -DSMVS_ABLATE=n): 1 stores dropped, 2 no staging DMA, 4 no float64 chain -- results are WRONG
+#endif
+#ifndef SMVS_O2P_PLANES
+#define SMVS_O2P_PLANES 4          // planes per evaluation pass of a source view's cubics
+#endif
 #ifndef SMVS_STORE_AUX
 #define SMVS_STORE_AUX 2              // nt: the variance volume streams out once, keep it from evicting feature rows in L2
 #endif
 constexpr int STORE_AUX = SMVS_STORE_AUX;
+
+#ifdef SMVS_TIMING
+// profiling builds only (tools/ab_build.sh x -DSMVS_TIMING): per-wave phase stamps in shader clocks, read back through
+// smvs_debug_timing().  [0] geometry phase, [1] box + setup, [2] channel-pair loop, [3] of which spent in the vmcnt waits,
+// [4] of which in the lgkmcnt waits of the last plane, [5] DMA issue
+__device__ unsigned long long smvs_timing[8];
+__device__ __forceinline__ unsigned long long now() { unsigned long long t = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return t; }
+#define SMVS_T(...) __VA_ARGS__
+#else
+#define SMVS_T(...)
+#endif
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
@@ -252,16 +279,21 @@ __device__ __forceinline__ void wait_vmcnt_upto8(int n)
 struct TapD { uint32_t base; f32x2 wn, ws; };       // wn = {nw, ne}, ws = {sw, se}
 
 template <int GEO, int NSRC, int CT>
-__global__ __launch_bounds__(64 * WV_WAVES, 3)
+__global__ __launch_bounds__(64 * WV_WAVES, SMVS_WAVES_PER_SIMD)
 void costvol_dma_kernel(const CostVolParams p)
 {
     constexpr int DP = DM_DP, BW = DM_BW, R = DM_R;
-    constexpr int SRC_STRIDE = R * BW;                       // float2 elements per source box
+    constexpr int NI = (R * BW * 2 + 63) / 64;               // DMA instructions per source box and channel pair
+    constexpr int SRC_STRIDE = NI * 32;                      // float2 cells per source box, padded to whole DMA instructions
     constexpr int ZPAD = BW + 2;                             // always-zero cells a dropped tap reads (NW..SE span)
     constexpr int BUF_STRIDE = NSRC * SRC_STRIDE + ZPAD;
     constexpr int NSTEP = CT / 2;
     static_assert(CT % 2 == 0 && 2 * DP <= 63 && DP % 2 == 0, "steps / vmcnt bookkeeping");
     __shared__ f32x2 tile_all[WV_WAVES][DM_NBUF * BUF_STRIDE];
+#ifdef SMVS_LDS_PAD
+    __shared__ float lds_pad[SMVS_LDS_PAD / 4];            // profiling builds only: caps the workgroups per CU
+    if (p.B < 0) lds_pad[threadIdx.x] = 0.0f;
+#endif
     // one wave = one 32 x 2 pixel patch x ONE group of DP planes (p.dch == DP): no loop over groups, so
     // nothing of the geometry phase stays live across the channel-pair loop
     uint32_t L = xcd_remap(blockIdx.x, gridDim.x);
@@ -293,16 +325,17 @@ void costvol_dma_kernel(const CostVolParams p)
     }
 
     const float fV = (float)p.V;
-    const float rV = __fdiv_rn(1.0f, fV);
+    const float rV = p.rV;
     const float half_wm1 = (float)((W - 1) * 0.5);
     const float half_hm1 = (float)((H - 1) * 0.5);
-    const float r_half_wm1 = __fdiv_rn(1.0f, half_wm1), r_half_hm1 = __fdiv_rn(1.0f, half_hm1);
+    const float r_half_wm1 = p.r_half_wm1, r_half_hm1 = p.r_half_hm1;
 
     const cgeo_t geo_b = as_cgeo((GEO == 0) ? p.geo + (size_t)b * p.V * RPC_LEN
                                             : p.geo + (size_t)b * (p.V - 1) * 16);
     const double fx = (double)min(x, W - 1), fy = (double)min(y, H - 1);
     const uint32_t pix4 = (uint32_t)pix * 4u;
 
+    SMVS_T(const unsigned long long t_start = now(); unsigned long long t_vm = 0, t_dma = 0, t_st = 0;)
     // heights of the group's planes (tail planes shadow the last one; they are never stored)
     float hf[DP];
 #pragma unroll
@@ -326,7 +359,7 @@ void costvol_dma_kernel(const CostVolParams p)
     ref_n.a = ref_n.b = ref_n.h = 0.0;
 #pragma unroll
     for (int s = 0; s < NSRC; ++s) src_n[s].a = src_n[s].b = src_n[s].h = 0.0;
-    if (GEO == 0) {
+    if (GEO == 0 && !(SMVS_ABLATE & 4)) {
         // The 3 reciprocal scales of every view, correctly rounded, at one IEEE division per WAVE: lane 3v+k
         // divides for (view v, scale k); the quotients travel through the wave's own LDS tile (not yet in use)
         // and come back as broadcast reads, i.e. in VGPRs (18 SGPRs would not survive the coefficient loads).
@@ -350,26 +383,36 @@ void costvol_dma_kernel(const CostVolParams p)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // two planes per pass: every coefficient is fetched into SGPRs once for both
+    // PQ planes per pass: every source coefficient is fetched into SGPRs once for all of them
+    constexpr int PQ = SMVS_O2P_PLANES;
+    static_assert(DP % PQ == 0, "planes per pass");
 #pragma unroll
-    for (int pq = 0; pq < DP; pq += 2) {
+    for (int pq = 0; pq < DP; pq += PQ) {
         const cgeo_t geo_d = launder(geo_b);
 #pragma unroll
         for (int s = 0; s < NSRC; ++s) {
-            float gxs[2], gys[2];
-            if (GEO == 0) {
-                double samp[2], line[2];
-                const double hh[2] = {(double)hf[pq], (double)hf[pq + 1]};
-                o2p_xn<2>(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat + pq, lon + pq, hh, samp, line);
+            float gxs[PQ], gys[PQ];
+            if (SMVS_ABLATE & 4) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < PQ; ++u) {
+                    gxs[u] = ((float)fx + 0.37f + 0.011f * hf[pq + u] * (float)(s + 1)) / half_wm1 - 1.0f;
+                    gys[u] = ((float)fy + 0.21f) / half_hm1 - 1.0f;
+                }
+            } else if (GEO == 0) {
+                double samp[PQ], line[PQ];
+                double hh[PQ];
+#pragma unroll
+                for (int u = 0; u < PQ; ++u) hh[u] = (double)hf[pq + u];
+                o2p_xn<PQ>(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat + pq, lon + pq, hh, samp, line);
+#pragma unroll
+                for (int u = 0; u < PQ; ++u) {
                     gxs[u] = div_half_int((float)samp[u], half_wm1, r_half_wm1) - 1.0f;
                     gys[u] = div_half_int((float)line[u], half_hm1, r_half_hm1) - 1.0f;
                 }
             } else {
                 const cgeo_t P = geo_d + s * 16;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < PQ; ++u) {
                     const double hh = (double)hf[pq + u];
                     const double rx = fma(P[1], fy, P[0] * fx) + P[2];
                     const double ry = fma(P[5], fy, P[4] * fx) + P[6];
@@ -380,7 +423,7 @@ void costvol_dma_kernel(const CostVolParams p)
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < PQ; ++u) {
                 const int pl = pq + u;
                 // same arithmetic as tap_from_grid (ATen unnormalise, floor, weights)
                 const float px = fmaf(gxs[u] + 1.0f, (float)W * 0.5f, -0.5f);
@@ -406,15 +449,14 @@ void costvol_dma_kernel(const CostVolParams p)
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    SMVS_T(const unsigned long long t_geo = now();)
     // ---- B: the wave's bounding box per source -------------------------------------------------------
     int bx0[NSRC], by0[NSRC], bw[NSRC], bh[NSRC];
     bool fits = true;
 #pragma unroll
     for (int s = 0; s < NSRC; ++s) {
-        const int a0 = wave_min_i32(lo_x[s]);
-        const int a1 = wave_max_i32(hi_x[s]);
-        const int b0 = wave_min_i32(lo_y[s]);
-        const int b1 = wave_max_i32(hi_y[s]);
+        int a0 = lo_x[s], a1 = hi_x[s], b0 = lo_y[s], b1 = hi_y[s];
+        wave_minmax4(a0, a1, b0, b1);
         const bool empty = a1 < a0;
         bx0[s] = empty ? 0 : a0; by0[s] = empty ? 0 : b0;
         bw[s] = empty ? 0 : a1 - a0 + 2;
@@ -430,15 +472,34 @@ void costvol_dma_kernel(const CostVolParams p)
     const size_t ostride = (size_t)p.D_out * HW;             // floats between channels of the output
 
     if (fits) {
-        // DMA lane map: lane -> (column lane>>1 of a 32-column half row, channel lane&1 of the pair)
-        uint32_t vo[NSRC][2];
+        // DMA lane map.  A source box is R rows x BW columns x 2 channels = R*BW*2 dwords laid out row-major in LDS with the
+        // channel pair innermost; DMA instruction j of a source deposits dwords [64 j, 64 j + 64) of that block, so lane l of
+        // instruction j carries box cell (row, col, ch) of dword 64 j + l -- rows are packed back to back and no instruction
+        // is spent on the empty tail of a row (a vector-memory instruction costs the texture path ~8 clocks whatever
+        // its active lanes: tools/ubench_dma.hip).  Cells outside the box or the image get an out-of-range offset = 0.
+        uint32_t vo[NSRC][NI];
+        {
+            int rlo[NSRC], rn[NSRC], clo[NSRC], cn[NSRC], boxbase[NSRC];
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int col = hh * 32 + (lane >> 1), c0 = bx0[s] + col;
-                vo[s][hh] = (col < bw[s] && c0 >= 0 && c0 < W) ? (uint32_t)(c0 * 4 + (lane & 1) * HW * 4) : SMVS_OOB;
+            for (int s = 0; s < NSRC; ++s) {
+                rlo[s] = max(0, -by0[s]); rn[s] = min(bh[s], H - by0[s]) - rlo[s];     // valid box rows [rlo, rlo + rn)
+                clo[s] = max(0, -bx0[s]); cn[s] = min(bw[s], W - bx0[s]) - clo[s];     // valid box columns
+                rn[s] = max(rn[s], 0); cn[s] = max(cn[s], 0);
+                boxbase[s] = (by0[s] * W + bx0[s]) * 4;
             }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int slot = 64 * j + lane;
+                const int row = slot / (2 * BW), rem = slot - row * (2 * BW);
+                const int col = rem >> 1;
+                const int rel = (row * W + col) * 4 + (rem & 1) * HW * 4;
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s) {
+                    const bool valid = ((uint32_t)(row - rlo[s]) < (uint32_t)rn[s]) && ((uint32_t)(col - clo[s]) < (uint32_t)cn[s]);
+                    vo[s][j] = valid ? (uint32_t)(rel + boxbase[s]) : SMVS_OOB;
+                }
+            }
+        }
 #pragma unroll
         for (int pl = 0; pl < DP; ++pl)
 #pragma unroll
@@ -451,49 +512,40 @@ void costvol_dma_kernel(const CostVolParams p)
         uint32_t ovo[DP];                                 // per-plane byte offset of this pixel inside one channel volume
 #pragma unroll
         for (int pl = 0; pl < DP; ++pl)
-            ovo[pl] = (active && pl < np) ? (uint32_t)(dg + pl - p.d_begin + p.d_out_off) * (uint32_t)HW * 4u + pix4
+            ovo[pl] = (active && pl < np && !(SMVS_ABLATE & 1)) ? (uint32_t)((SMVS_ABLATE & 16) ? ((dg + pl) & 3) : (dg + pl - p.d_begin + p.d_out_off)) * (uint32_t)HW * 4u + pix4
                                           : SMVS_OOB;       // inactive lanes / tail planes: store dropped by the range check
 
-        // byte offset of each box row inside one channel plane; rows outside the image carry 2^31, which
-        // stays out of range after the channel offset (< 2^31, one batch item is < 2 GiB) is added
-        uint32_t rowoff[NSRC][R];
-#pragma unroll
-        for (int s = 0; s < NSRC; ++s)
-#pragma unroll
-            for (int er = 0; er < R; ++er) {
-                const int gyp = by0[s] + er;
-                rowoff[s][er] = (gyp >= 0 && gyp < H) ? (uint32_t)(gyp * W * 4) : SMVS_OOB;
-            }
-        // (s, er) are unrolled loop indices but not constant expressions: dispatch to the immediate-offset variant
-        auto dma_at = [&](auto half_tag, int s, int er, uint32_t buf, uint32_t voff, int so) {
-            constexpr int HALF = decltype(half_tag)::value;
-#define SMVS_DMA_CASE(S, ER) \
-    case (S) * R + (ER): dma_dword_to_lds_at<((S) * SRC_STRIDE + (ER) * BW) * 8 + HALF>(rs[(S) < NSRC ? (S) : 0], buf, voff, so); break;
-            switch (s * R + er) {
-                SMVS_DMA_CASE(0, 0) SMVS_DMA_CASE(0, 1) SMVS_DMA_CASE(0, 2) SMVS_DMA_CASE(0, 3) SMVS_DMA_CASE(0, 4)
-                SMVS_DMA_CASE(1, 0) SMVS_DMA_CASE(1, 1) SMVS_DMA_CASE(1, 2) SMVS_DMA_CASE(1, 3) SMVS_DMA_CASE(1, 4)
-                SMVS_DMA_CASE(2, 0) SMVS_DMA_CASE(2, 1) SMVS_DMA_CASE(2, 2) SMVS_DMA_CASE(2, 3) SMVS_DMA_CASE(2, 4)
+        // (s, j) are unrolled loop indices but not constant expressions: dispatch to the immediate-offset variant
+        auto dma_at = [&](int s, int j, uint32_t buf, uint32_t voff, int so) {
+#define SMVS_DMA_CASE(S, J) \
+    case (S) * 8 + (J): dma_dword_to_lds_at<((S) * SRC_STRIDE * 8 + (J) * 256)>(rs[(S) < NSRC ? (S) : 0], buf, voff, so); break;
+            static_assert(NI <= 8, "instruction dispatch");
+            switch (s * 8 + j) {
+                SMVS_DMA_CASE(0, 0) SMVS_DMA_CASE(0, 1) SMVS_DMA_CASE(0, 2) SMVS_DMA_CASE(0, 3) SMVS_DMA_CASE(0, 4) SMVS_DMA_CASE(0, 5) SMVS_DMA_CASE(0, 6) SMVS_DMA_CASE(0, 7)
+                SMVS_DMA_CASE(1, 0) SMVS_DMA_CASE(1, 1) SMVS_DMA_CASE(1, 2) SMVS_DMA_CASE(1, 3) SMVS_DMA_CASE(1, 4) SMVS_DMA_CASE(1, 5) SMVS_DMA_CASE(1, 6) SMVS_DMA_CASE(1, 7)
+                SMVS_DMA_CASE(2, 0) SMVS_DMA_CASE(2, 1) SMVS_DMA_CASE(2, 2) SMVS_DMA_CASE(2, 3) SMVS_DMA_CASE(2, 4) SMVS_DMA_CASE(2, 5) SMVS_DMA_CASE(2, 6) SMVS_DMA_CASE(2, 7)
                 default: break;
             }
 #undef SMVS_DMA_CASE
         };
+        int ni[NSRC];                                      // instructions that carry rows of the box (wave-uniform)
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) ni[s] = (bh[s] * 2 * BW + 63) >> 6;
         auto issue_dma = [&](int st) {
+            if (SMVS_ABLATE & 2) return;
             const uint32_t buf = tile_lds + (uint32_t)((st & 1) * BUF_STRIDE * 8);
-            const uint32_t choff = (uint32_t)(2 * st * HW * 4);
+            const int choff = 2 * st * HW * 4;
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) {
 #pragma unroll
-                for (int er = 0; er < R; ++er) {
-                    if (er < bh[s]) {                                         // wave-uniform
-                        const int so = (int)(rowoff[s][er] + choff);
-                        // destination = buf + a compile-time offset, formed inside the asm by one s_add into M0
-                        dma_at(std::integral_constant<int, 0>(), s, er, buf, vo[s][0], so);
-                        dma_at(std::integral_constant<int, 256>(), s, er, buf, vo[s][1], so);
-                    }
+                for (int j = 0; j < NI; ++j) {
+                    // destination = buf + a compile-time offset, formed inside the asm by one s_add into M0
+                    if (j < ni[s]) dma_at(s, j, buf, vo[s][j], choff);        // wave-uniform
                 }
             }
         };
 
+        SMVS_T(const unsigned long long t_setup = now();)
         // prologue: pair 0
         // ref feature pairs run two steps ahead of their use, in registers
         f32x2 ref0, ref1;
@@ -512,12 +564,15 @@ void costvol_dma_kernel(const CostVolParams p)
             // offset).  vmcnt retires in order, so DMA(st) has landed once at most that many
             // operations are outstanding.
             const f32x2 refc = ref0;
+            SMVS_T(const unsigned long long tw0 = now();)
             if (st == 0) wait_vmcnt<0>();
             else if (st + 1 < NSTEP) wait_vmcnt<2 * DP + 2>();
             else wait_vmcnt<2 * DP>();
+            SMVS_T(const unsigned long long tw1 = now(); t_vm += tw1 - tw0;)
             ref0 = ref1;
             if (st + 1 < NSTEP) {
                 issue_dma(st + 1);
+                SMVS_T(t_dma += now() - tw1;)
                 const int nx = (st + 2 < NSTEP) ? 2 * st + 4 : 0;   // dummy reload keeps the count constant
                 ref1.x = llvm_raw_buffer_load_f32(rref.v, (int)pix4, nx * HW * 4, 0);
                 ref1.y = llvm_raw_buffer_load_f32(rref.v, (int)pix4, (nx + 1) * HW * 4, 0);
@@ -551,8 +606,10 @@ void costvol_dma_kernel(const CostVolParams p)
                 const f32x2 m = div_by_views2(sum, fV, rV);
                 const f32x2 q = div_by_views2(sq, fV, rV);
                 const f32x2 var = q - m * m;
+                SMVS_T(const unsigned long long ts0 = now();)
                 llvm_raw_buffer_store_f32(var.x, ro.v, (int)ovo[pl], 0, STORE_AUX);
                 llvm_raw_buffer_store_f32(var.y, ro.v, (int)ovo[pl], och1, STORE_AUX);
+                SMVS_T(t_st += now() - ts0;)
             };
             read_plane(0);
 #pragma unroll
@@ -587,6 +644,16 @@ void costvol_dma_kernel(const CostVolParams p)
             step(st, std::integral_constant<int, 0>());
             step(st + 1, std::integral_constant<int, 1>());
         }
+#ifdef SMVS_TIMING
+        {
+            const unsigned long long t_end = now();
+            if (lane == 0) {
+                atomicAdd(&smvs_timing[0], t_geo - t_start); atomicAdd(&smvs_timing[1], t_setup - t_geo);
+                atomicAdd(&smvs_timing[2], t_end - t_setup); atomicAdd(&smvs_timing[3], t_vm);
+                atomicAdd(&smvs_timing[5], t_dma); atomicAdd(&smvs_timing[4], t_st); atomicAdd(&smvs_timing[7], 1ull);
+            }
+        }
+#endif
     } else {
         // ---- fallback: direct gathers for this plane group (box larger than the staged tile).
         //      Rare and wave-uniform; the source taps are rebuilt plane by plane from the ground point
@@ -659,8 +726,11 @@ static hipError_t launch_ct(CostVolParams p, hipStream_t st)
         // the float64 chain dominates and the direct kernel is 8 % faster; with 4+ sources two staging
         // buffers no longer fit 3 workgroups per CU and the direct kernel is 2x faster.
         const int kc = kernel_choice();
-        const bool staged_ok = (p.C == 16 || p.C == 32) && p.W < 65535 && p.H < 65535 &&
-                               (long long)p.D_out * p.H * p.W * 4 < (1ll << 32);
+        // one channel volume of the output < 2 GiB: the store descriptor spans two of them (num_records is 32-bit)
+        // and 2^31 is the offset that marks a dropped store; 2 <= W,H < 65535: packed tap coordinates and the
+        // exact-division argument of div_half_int
+        const bool staged_ok = (p.C == 16 || p.C == 32) && p.W >= 2 && p.H >= 2 && p.W < 65535 && p.H < 65535 &&
+                               (long long)p.D_out * p.H * p.W * 4 < (1ll << 31);
         if (kc != K_DIRECT && staged_ok) {
             p.xt = (p.W + WV_TX - 1) / WV_TX;
             p.yt = (p.H + WV_TY * WV_WAVES - 1) / (WV_TY * WV_WAVES);
@@ -729,6 +799,9 @@ static int costvol_fwd(int geo_kind, const float* ref_fea, const float* const* s
     p.B = B; p.V = n_src + 1; p.C = C; p.D = D; p.H = H; p.W = W;
     p.d_begin = d_begin; p.d_end = d_end; p.D_out = D_out; p.d_out_off = d_out_off;
     p.depth_is_4d = depth_is_4d;
+    p.rV = 1.0f / (float)(n_src + 1);
+    p.r_half_wm1 = 1.0f / (float)((W - 1) * 0.5);
+    p.r_half_hm1 = 1.0f / (float)((H - 1) * 0.5);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = (geo_kind == 0) ? launch_nsrc<0>(p, st) : launch_nsrc<1>(p, st);
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "costvol_fwd launch: %s", hipGetErrorString(e));
@@ -738,6 +811,16 @@ static int costvol_fwd(int geo_kind, const float* ref_fea, const float* const* s
 }  // namespace smvs
 
 extern "C" {
+
+#ifdef SMVS_TIMING
+SMVS_EXPORT int smvs_debug_timing(unsigned long long* out8, int reset)
+{
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(smvs::smvs_timing), 64) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(smvs::smvs_timing), z, 64) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 SMVS_EXPORT int smvs_rpc_costvol_fwd(const float* ref_fea, const float* const* src_fea, int n_src,
                                      const double* rpc, const float* depth, int depth_is_4d, float* out_var,

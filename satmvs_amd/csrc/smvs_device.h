@@ -287,10 +287,11 @@ __device__ __forceinline__ void o2p_xn(cgeo_t r, const RpcInv& n, const double* 
     }
     __builtin_amdgcn_sched_barrier(0);
     const cgeo_t rr = launder(r);
+    const double so = to_vgpr(rr[I_SAMP_OFF]), lo = to_vgpr(rr[I_LINE_OFF]);     // one copy for the N points
 #pragma unroll
     for (int u = 0; u < N; ++u) {
-        samp[u] = fma(fast_div(q[0][u], q[1][u]), rr[I_SAMP_SCALE], rr[I_SAMP_OFF]);
-        line[u] = fma(fast_div(q[2][u], q[3][u]), rr[I_LINE_SCALE], rr[I_LINE_OFF]);
+        samp[u] = fma(fast_div(q[0][u], q[1][u]), rr[I_SAMP_SCALE], so);
+        line[u] = fma(fast_div(q[2][u], q[3][u]), rr[I_LINE_SCALE], lo);
     }
 }
 
@@ -317,33 +318,32 @@ __device__ __forceinline__ int cvt_i32_sat(float x)
 }
 
 // ---- wave reductions on the DPP network (no LDS traffic, unlike ds_bpermute shuffles) ------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_i32(int old, int v)
+// min(a), max(b), min(c), max(d) over the 64 lanes, the four reductions interleaved so that every DPP
+// instruction is three instructions away from the write it reads (the DPP read-after-VALU-write hazard needs two
+// wait states; the compiler's own lowering spends a v_mov and an s_nop per step).  row_shr 1,2,4,8 leave the row
+// result in lane 15 of each 16-lane row (a lane whose source falls outside its row is left untouched),
+// row_bcast:15 / row_bcast:31 fold the rows; the wave result ends in lane 63.
+__device__ __forceinline__ void wave_minmax4(int& a, int& b, int& c, int& d)
 {
-    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
-}
-
-// result valid in lane 63 (returned as a wave-uniform value)
-__device__ __forceinline__ int wave_min_i32(int v)
-{
-    v = min(v, dpp_i32<0x111, 0xf>(v, v));      // row_shr:1
-    v = min(v, dpp_i32<0x112, 0xf>(v, v));      // row_shr:2
-    v = min(v, dpp_i32<0x114, 0xf>(v, v));      // row_shr:4
-    v = min(v, dpp_i32<0x118, 0xf>(v, v));      // row_shr:8   -> lane 15 of each row = row minimum
-    v = min(v, dpp_i32<0x142, 0xa>(v, v));      // row_bcast:15 into rows 1 and 3
-    v = min(v, dpp_i32<0x143, 0xc>(v, v));      // row_bcast:31 into rows 2 and 3
-    return __builtin_amdgcn_readlane(v, 63);
-}
-
-__device__ __forceinline__ int wave_max_i32(int v)
-{
-    v = max(v, dpp_i32<0x111, 0xf>(v, v));
-    v = max(v, dpp_i32<0x112, 0xf>(v, v));
-    v = max(v, dpp_i32<0x114, 0xf>(v, v));
-    v = max(v, dpp_i32<0x118, 0xf>(v, v));
-    v = max(v, dpp_i32<0x142, 0xa>(v, v));
-    v = max(v, dpp_i32<0x143, 0xc>(v, v));
-    return __builtin_amdgcn_readlane(v, 63);
+#define SMVS_DPP_STEP(ctrl)                       \
+    "v_min_i32_dpp %0, %0, %0 " ctrl "\n\t"       \
+    "v_max_i32_dpp %1, %1, %1 " ctrl "\n\t"       \
+    "v_min_i32_dpp %2, %2, %2 " ctrl "\n\t"       \
+    "v_max_i32_dpp %3, %3, %3 " ctrl "\n\t"
+    asm("s_nop 1\n\t"
+        SMVS_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+        SMVS_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+        SMVS_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+        SMVS_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+        SMVS_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        SMVS_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        "s_nop 0"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef SMVS_DPP_STEP
+    a = __builtin_amdgcn_readlane(a, 63);
+    b = __builtin_amdgcn_readlane(b, 63);
+    c = __builtin_amdgcn_readlane(c, 63);
+    d = __builtin_amdgcn_readlane(d, 63);
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int lane)

@@ -116,10 +116,12 @@ int main()
     setvbuf(stdout, NULL, _IONBF, 0);
     const int nblk = 256;
     unsigned long long* out; double* sink;
-    hipMalloc(&out, nblk * 16 * sizeof(*out));
-    hipMalloc(&sink, nblk * 1024 * sizeof(*sink));
+    hipMalloc(&out, 2 * nblk * 16 * sizeof(*out));
+    hipMalloc(&sink, 2 * nblk * 1024 * sizeof(*sink));
     unsigned long long* h = (unsigned long long*)malloc(nblk * 16 * sizeof(*h));
     printf("%-22s %10s %10s %10s   (shader cycles per wave-instruction, mean over waves; waves/SIMD = 1, 2, 4)\n", "instruction", "1w", "2w", "4w");
+    hipEvent_t ea, eb;
+    hipEventCreate(&ea); hipEventCreate(&eb);
     for (auto& e : es) {
         printf("%-22s", e.name);
         for (int wps : {1, 2, 4}) {
@@ -129,10 +131,17 @@ int main()
             hipMemcpy(h, out, nblk * (threads / 64) * sizeof(*h), hipMemcpyDeviceToHost);
             double s = 0; int n = nblk * (threads / 64);
             for (int i = 0; i < n; ++i) s += (double)h[i];
-            // per wave: REP*32 instructions; with wps waves sharing a SIMD the per-SIMD cost = cycles / (REP*32*wps) * ... report per-instruction wall per wave / wps
             printf(" %10.2f", s / n / (REP * 32.0) / wps);
         }
-        printf("\n");
+        // wall clock: 8 waves/SIMD (two 1024-thread workgroups per CU), ns per wave-instruction per SIMD
+        hipEventRecord(ea);
+        const int reps = 20;
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(e.k, dim3(2 * nblk), dim3(1024), 0, 0, out, sink);
+        hipEventRecord(eb);
+        hipEventSynchronize(eb);
+        float ms = 0;
+        hipEventElapsedTime(&ms, ea, eb);
+        printf("   wall @8w: %6.3f ns/instr/SIMD\n", ms * 1e6 / reps / (REP * 32.0 * 8));
     }
     return 0;
 }

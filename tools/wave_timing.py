@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""Per-wave phase times of the staged cost-volume kernel (library built with -DSMVS_TIMING):
+    SMVS_LIB_PATH=gpurun_ab/timing.so python tools/wave_timing.py"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from satmvs_amd import _lib
+import bench
+_lib.load()
+lib = ctypes.CDLL(os.environ["SMVS_LIB_PATH"])
+dev = torch.device("cuda:0")
+V, C, D, H, W = bench.WORKLOADS["cfg2_rpc_3view_768x384x64_c32"]
+feats, rpc, depth = bench.make_inputs(V, C, D, D, 0, H, W, dev)
+out = torch.empty((1, C, D, H, W), dtype=torch.float32, device=dev)
+srcs = _lib.ptr_array(feats[1:])
+st = _lib.current_stream(dev)
+def step():
+    _lib.call("smvs_rpc_costvol_fwd", _lib.ptr(feats[0]), srcs, V - 1, _lib.ptr(rpc), _lib.ptr(depth), 1, _lib.ptr(out), 1, C, D, H, W, 0, D, D, 0, st)
+for _ in range(20): step()
+buf = (ctypes.c_ulonglong * 8)()
+lib.smvs_debug_timing(buf, 1)
+n = 20
+for _ in range(n): step()
+lib.smvs_debug_timing(buf, 1)
+w = buf[7]
+names = ["geometry", "box+setup", "pair loop", " vmcnt waits", " store issue", " dma issue"]
+print("waves %d (%d launches)" % (w, n))
+for i in (0, 1, 2, 3, 4, 5):
+    print("%-14s %9.0f clocks per wave" % (names[i], buf[i] / w))
