@@ -11,11 +11,15 @@ metric is quoted on).  One "step" = one pass of the hot path over one synthetic 
 of smvs_rpc_costvol_fwd that writes the whole (1,32,64,384,768) variance volume, inputs already
 resident in HBM.
 
-Multi-GPU (one process per GPU): the height-hypothesis axis is sharded -- rank r builds planes
-[64 r, 64 (r+1)) of a 64*N-hypothesis sweep over the same tile (per-GPU work fixed => "weak").
-The build has no exchange step; the only exchange on the path is the all-reduce of the (3,H,W)
-float64 regression partials after the regulariser (satmvs_amd/shard.py), which is exercised and
-timed once outside the timed region and reported as "exchange".
+Multi-GPU (one process per GPU): the height-hypothesis axis of the SAME tile is sharded -- rank r
+builds planes plane_range(64, r, N) with replicated features / RPCs (fixed total work => "strong"),
+and every step ends with the path's one exchange, the all-reduce of the (3,1,H,W) float64 regression
+partials (satmvs_amd/shard.py), inside the timed region; its stand-alone time is reported as
+"exchange".  `value` is always the whole tile's voxels / step time.
+
+Before anything is timed the kernel is launched for --prewarm-seconds of wall clock (default 0.6 s)
+so that a short --warmup still measures steady clocks.  "extra" carries short runs of the other
+BASELINE shapes (cfg4 5-view shard, stage-3 C=8 planes, cfg5 homography volume, cfg3 cascade forward).
 
 The JSON line also carries
   roofline     HBM roofline of the dominant kernel: algorithmic bytes (138.25 B/voxel: 4*C write +
@@ -84,6 +88,129 @@ def cpu_baseline(V, C, D, H, W, budget_s=12.0):
                 passes, W, H, D, V, C, dt)}
 
 
+def kernel_source_hash():
+    """sha256 over the sources of the dominant kernel: ties profiles/pmc_traffic.json to the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("costvol.hip", "smvs_device.h"):
+        with open(os.path.join(ROOT, "satmvs_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(workload):
+    """HBM bytes per launch from the committed PMC passes -- only if they were taken on the current kernel sources."""
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(tf)).get(workload)
+        if isinstance(rec, dict) and rec.get("source_sha256") == kernel_source_hash():
+            return int(rec["bytes"])
+    except Exception:
+        pass
+    return None
+
+
+def prewarm(step, seconds):
+    """Untimed launches for `seconds` of wall clock: the timed region then runs at steady (power-limited) clocks
+    whatever --warmup says; a cold MI355X ramps for ~0.2 s and would charge that to the first launches."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+
+
+def time_steps(step, steps, barrier=lambda: None):
+    """(wall seconds for `steps` launches, mean HIP-event ms of one launch); events live on the launch stream."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    return elapsed, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+
+def kernel_name(V, C):
+    direct = os.environ.get("SMVS_COSTVOL_KERNEL", "").startswith("di") or V - 1 > 2 or C not in (16, 32)   # dispatch rule of costvol.hip
+    return "%s<rpc,%d,%d>" % ("costvol_fwd_kernel" if direct else "costvol_dma_kernel", V - 1, C)
+
+
+def side_workloads(dev, stream):
+    """Other BASELINE shapes, a few launches each (reported under "extra", never as `value`): the 5-view 1536x768 shard of
+    cfg4, a stage-3 C=8 plane group, the cfg5 homography volume, and one cfg3 inference cascade forward."""
+    from satmvs_amd import _lib
+    extra = {}
+    for name in ("cfg4_rpc_5view_1536x768x8_c32", "stage3_rpc_3view_768x384x8_c8"):
+        V, C, D, H, W = WORKLOADS[name]
+        feats, rpc, depth = make_inputs(V, C, D, D, 0, H, W, dev)
+        out = torch.empty((1, C, D, H, W), dtype=torch.float32, device=dev)
+        srcs = _lib.ptr_array(feats[1:])
+
+        def step():
+            _lib.call("smvs_rpc_costvol_fwd", _lib.ptr(feats[0]), srcs, V - 1, _lib.ptr(rpc), _lib.ptr(depth), 1,
+                      _lib.ptr(out), 1, C, D, H, W, 0, D, D, 0, stream)
+        for _ in range(10):
+            step()
+        _, ms = time_steps(step, 30)
+        bpv = algorithmic_bytes_per_voxel(V, C, D)
+        extra[name] = {"kernel": kernel_name(V, C), "ms": round(ms, 4), "Mvox/s": round(D * H * W / ms / 1e3, 1),
+                       "roofline_frac": round(bpv * D * H * W / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del feats, out
+    # cfg5: pinhole (homography) volume, 3-view 768x384x64, C=32
+    V, C, D, H, W = 3, 32, 64, 384, 768
+    g = torch.Generator(device="cpu").manual_seed(0)
+    feats = [torch.randn((1, C, H, W), generator=g, dtype=torch.float32).to(dev) for _ in range(V)]
+    proj = np.zeros((1, V, 4, 4))
+    for v in range(V):
+        f = 1.1 * W
+        K = np.array([[f, 0, W / 2.0, 0], [0, f, H / 2.0, 0], [0, 0, 1.0, 0], [0, 0, 0, 1]])
+        E = np.eye(4)
+        E[:3, 3] = [25.0 * v * (-1) ** v, 3.0 * v, 0.5 * v]
+        proj[0, v] = K @ E
+    from satmvs_amd.modules import warping
+    projt = torch.from_numpy(proj).to(dev)
+    depth = torch.linspace(400.0, 700.0, D).view(1, D, 1, 1).expand(1, D, H, W).contiguous().to(dev)
+
+    def step5():
+        return warping.variance_cost_volume(feats, projt, depth, "pinhole")
+    for _ in range(5):
+        step5()
+    _, ms = time_steps(step5, 20)
+    extra["cfg5_pinhole_3view_768x384x64_c32"] = {"ms": round(ms, 4), "Mvox/s": round(D * H * W / ms / 1e3, 1),
+                                                  "note": "through the Python surface (compose + volume allocation included)"}
+    del feats, depth
+    # cfg3: one inference cascade forward (FeatureNet + three stages of variance / RED / regression), 48/32/8 planes
+    try:
+        from satmvs_amd import rpc_synth
+        from satmvs_amd.networks.casred import Infer_CascadeREDNet
+        torch.manual_seed(0)
+        net = Infer_CascadeREDNet("rpc", ndepths=[48, 32, 8]).to(dev).eval()
+        imgs = torch.randn(1, 3, 3, H, W, device=dev)
+        rpc = rpc_synth.make_view_rpcs(3, H, W, seed=0)[None]
+        pm = {"stage1": torch.from_numpy(rpc_synth.rescale_rpc(rpc, 4)).to(dev),
+              "stage2": torch.from_numpy(rpc_synth.rescale_rpc(rpc, 2)).to(dev), "stage3": torch.from_numpy(rpc).to(dev)}
+        dv = torch.tensor([[0.0, 400.0]], device=dev)
+        with torch.no_grad():
+            for _ in range(2):
+                net(imgs, pm, dv)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                net(imgs, pm, dv)
+            torch.cuda.synchronize()
+        extra["cfg3_casred_cascade_48_32_8_768x384"] = {"ms_per_forward": round((time.perf_counter() - t0) / 5 * 1e3, 2),
+                                                       "note": "Infer_CascadeREDNet, random weights, B=1"}
+    except Exception as e:                                  # a side figure must never take the headline down
+        extra["cfg3_casred_cascade_48_32_8_768x384"] = {"error": repr(e)[:200]}
+    return extra
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +218,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="cfg2_rpc_3view_768x384x64_c32", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side workloads reported under \"extra\"")
+    ap.add_argument("--prewarm-seconds", type=float, default=0.6)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,88 +242,76 @@ def main():
         dist.init_process_group(os.environ.get("SMVS_BENCH_BACKEND", "nccl"),    # "nccl" is RCCL on ROCm
                                 rank=rank, world_size=world)
 
-    from satmvs_amd import _lib
+    from satmvs_amd import _lib, shard
     _lib.load()
     V, C, D, H, W = WORKLOADS[args.workload]
-    D_total = D * world
-    feats, rpc, depth = make_inputs(V, C, D, D_total, rank * D, H, W, dev)
-    out = torch.empty((1, C, D, H, W), dtype=torch.float32, device=dev)
+    # Strong scaling: the D planes of the BASELINE tile are split over the ranks (plane_range), every rank holds the
+    # replicated features / RPCs, builds its planes, and the step ends with the path's one exchange: the all-reduce
+    # of the (3,1,H,W) float64 regression partials (satmvs_amd/shard.py).  N = 1: the whole volume, no exchange.
+    lo, hi = shard.plane_range(D, rank, world)
+    D_local = hi - lo
+    feats, rpc, depth = make_inputs(V, C, D_local, D, lo, H, W, dev)
+    out = torch.empty((1, C, max(D_local, 1), H, W), dtype=torch.float32, device=dev)
     srcs = _lib.ptr_array(feats[1:])
     stream = _lib.current_stream(dev)
+    state = torch.rand((3, 1, H, W), dtype=torch.float64, device=dev) if world > 1 else None
+
+    def launch():
+        if D_local > 0:
+            _lib.call("smvs_rpc_costvol_fwd", _lib.ptr(feats[0]), srcs, V - 1, _lib.ptr(rpc), _lib.ptr(depth), 1,
+                      _lib.ptr(out), 1, C, D_local, H, W, 0, D_local, D_local, 0, stream)
 
     def step():
-        _lib.call("smvs_rpc_costvol_fwd", _lib.ptr(feats[0]), srcs, V - 1, _lib.ptr(rpc), _lib.ptr(depth), 1,
-                  _lib.ptr(out), 1, C, D, H, W, 0, D, D, 0, stream)
+        launch()
+        if state is not None:
+            shard.allreduce_regression_state(state)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
+    prewarm(launch, args.prewarm_seconds)
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for a, b in ev:                      # events live on the launch stream (torch's current stream)
-        a.record()
-        step()
-        b.record()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    elapsed, _ = time_steps(step, args.steps, barrier)
+    # the kernel alone (no exchange) for the roofline: same launches, HIP events around each
+    _, kern_ms = time_steps(launch, min(args.steps, 100))
 
     exchange = None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        from satmvs_amd import shard
-        state = torch.rand((3, 1, H, W), dtype=torch.float64, device=dev)
-        shard.allreduce_regression_state(state)             # warm-up (communicator setup)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t1 = time.perf_counter()
-        shard.allreduce_regression_state(state)
-        torch.cuda.synchronize()
-        exchange = {"op": "all_reduce(sum,sum,max) of (3,1,%d,%d) f64 regression partials" % (H, W),
-                    "bytes": int(state.numel() * 8), "ms": round((time.perf_counter() - t1) * 1e3, 3)}
+        _, ex_ms = time_steps(lambda: shard.allreduce_regression_state(state), 20, barrier)
+        exchange = {"op": "all_reduce(sum,sum,max) of (3,1,%d,%d) f64 regression partials, inside the timed step" % (H, W),
+                    "bytes": int(state.numel() * 8), "ms": round(ex_ms, 4)}
 
     if rank == 0:
-        vox_per_step = D * H * W * world
+        vox_per_step = D * H * W                              # the whole tile, whatever the rank count
         ms_per_step = elapsed / args.steps * 1e3
         bpv = algorithmic_bytes_per_voxel(V, C, D)
-        achieved = bpv * D * H * W / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(args.workload)
-            except Exception:
-                traffic = None
+        achieved = bpv * D_local * H * W / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "cost-volume Mvoxels/s (fused RPC warp + variance build)",
             "value": round(vox_per_step / (elapsed / args.steps) / 1e6, 1),
             "unit": "Mvox/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 features / f64 RPC geometry", "data": "synthetic",
-            "config": {"workload": args.workload, "views": V, "channels": C, "planes_per_gpu": D,
-                       "planes_total": D_total, "H": H, "W": W, "depth_values": "per-voxel (B,D,H,W)",
-                       "sharding": "height planes, %d per GPU" % D},
-            "roofline": {"bound": "hbm", "kernel": "%s<rpc,%d,%d>" % (
-                             "costvol_fwd_kernel" if (os.environ.get("SMVS_COSTVOL_KERNEL", "").startswith("di")
-                                                      or V - 1 > 2 or C not in (16, 32))      # dispatch rule of costvol.hip
-                             else "costvol_dma_kernel", V - 1, C),
+            "config": {"workload": args.workload, "views": V, "channels": C, "planes_per_gpu": D_local,
+                       "planes_total": D, "H": H, "W": W, "depth_values": "per-voxel (B,D,H,W)",
+                       "sharding": "height planes of one tile split over the ranks, regression partials all-reduced each step",
+                       "prewarm_seconds": args.prewarm_seconds},
+            "roofline": {"bound": "hbm", "kernel": kernel_name(V, C),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload) if world == 1 else None,
                          "bytes_per_voxel": bpv, "kernel_ms": round(kern_ms, 4)},
         }
         if exchange is not None:
             line["exchange"] = exchange
+        if world == 1 and not args.no_extra:
+            line["extra"] = side_workloads(dev, stream)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(V, C, D, H, W)
         print(json.dumps(line))
