@@ -137,7 +137,7 @@ def time_steps(step, steps, barrier=lambda: None):
 
 
 def kernel_name(V, C):
-    direct = os.environ.get("SMVS_COSTVOL_KERNEL", "").startswith("di") or V - 1 > 2 or C not in (16, 32)   # dispatch rule of costvol.hip
+    direct = V - 1 > 2 or C not in (16, 32)                 # dispatch rule of costvol.hip (launch_ct)
     return "%s<rpc,%d,%d>" % ("costvol_fwd_kernel" if direct else "costvol_dma_kernel", V - 1, C)
 
 

@@ -15,8 +15,17 @@
  *     on it and the call returns without synchronising.
  *   - Return value: SMVS_OK (0) or an SMVS_ERR_* code; smvs_last_error() then returns a
  *     thread-local message.  Nothing is written on an argument error.
- *   - Re-entrant; no per-process device/stream cache.  The caller selects the device
- *     (hipSetDevice / torch.cuda.device) before calling.
+ *   - Re-entrant.  The caller selects the device (hipSetDevice / torch.cuda.device) before
+ *     calling; nothing is cached per thread.  The only process-wide state is a mutex-guarded,
+ *     per-device pool of helper streams/events that smvs_red_pred_planes / smvs_red_volume_planes
+ *     borrow for the duration of a call (bounded by the peak number of concurrent calls on a device).
+ *   - The shipped library never reads the environment: tuning / A/B switches exist only in builds
+ *     made with -DSMVS_TUNING (tools/ab_build.sh).
+ *   - Deliberate differences from SURVEY.md section 8b's sketch: the Python binding is ctypes over
+ *     this header (satmvs_amd/_lib.py), not a torch.utils.cpp_extension shim -- no torch types or
+ *     headers are needed to build or call the library; and there is no smvs_shard_allreduce(ncclComm_t):
+ *     the one exchange of the path (a (3,B,H,W) float64 slab, 7 MB at 768x384) goes through
+ *     torch.distributed (backend "nccl" = RCCL), satmvs_amd/shard.py, DESIGN.md section 5.
  *   - depth_is_4d: 1 = per-voxel heights (B,D,H,W); 0 = per-plane heights (B,D) -- both forms
  *     of `depth_values` accepted by modules/warping.py:329-332.
  */
@@ -108,6 +117,13 @@ int smvs_rpc_project(const double* rpc170, const double* a, const double* b, con
  * reg (B,D,H,W) float32 regulariser output; out_depth, out_conf (B,H,W). */
 int smvs_softmax_regress_fwd(const float* reg, const float* depth, int depth_is_4d,
                              float* out_depth, float* out_conf, int B, int D, int H, int W, void* stream);
+/* CascadeMVSNet / UCSNet flavour: softmax over D + expected height + the probability mass of the four hypotheses
+ * around the expected index (networks/casmvs.py:66-74: F.pad(.,(1,2)) + 4*avg_pool3d((4,1,1)) gathered at
+ * clamp(trunc(E[index]))), and, when out_var is not NULL, UCSNet's lamb * sqrt(sum p*(h - depth)^2)
+ * (networks/ucs.py:73-74).  reg (B,D,H,W); out_depth, out_conf, out_var (B,H,W). */
+int smvs_window_regress_fwd(const float* reg, const float* depth, int depth_is_4d,
+                            float* out_depth, float* out_conf, float* out_var, float lamb,
+                            int B, int D, int H, int W, void* stream);
 /* Pred path, one plane d: prob = exp(double(reg)); max_prob = max(.,prob); depth_img += h*prob;
  * exp_sum += prob (networks/casred.py:218-231).  Accumulators (B,H,W) float64, zeroed by the
  * caller before plane 0.  reg_plane (B,H,W). */

@@ -416,6 +416,52 @@ ORC_API void orc_softmax_regress(const float *reg, const float *depth, int depth
         }
 }
 
+/* CascadeMVSNet / UCSNet regression (networks/casmvs.py:66-74, networks/ucs.py:60-74): softmax over D, expected
+ * height, photometric confidence = probability mass of the four hypotheses [idx-1, idx+2] around
+ * idx = clamp(trunc(E[index]), 0, D-1) -- F.pad(prob,(0,0,0,0,1,2)) + 4*avg_pool3d((4,1,1)) + gather -- and UCSNet's
+ * variance = lamb * sqrt(sum prob * (h - depth)^2).  float32, term by term like the torch composite. */
+ORC_API void orc_window_regress(const float *reg, const float *depth, int depth_is_4d,
+                                float *out_depth, float *out_conf, float *out_var, float lamb,
+                                int B, int D, int H, int W)
+{
+    size_t HW = (size_t)H * W;
+    for (int b = 0; b < B; ++b)
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < HW; ++i) {
+            const float *r = reg + (size_t)b * D * HW + i;
+            float mx = r[0];
+            for (int d = 1; d < D; ++d) mx = fmaxf(mx, r[d * HW]);
+            float den = 0.0f;
+            for (int d = 0; d < D; ++d) den = den + expf(r[d * HW] - mx);
+            float acc = 0.0f, fidx = 0.0f;
+            for (int d = 0; d < D; ++d) {
+                float p = expf(r[d * HW] - mx) / den;
+                float hv = depth_is_4d ? depth[((size_t)b * D + d) * HW + i] : depth[(size_t)b * D + d];
+                acc = acc + p * hv;
+                fidx = fidx + p * (float)d;
+            }
+            int idx = (int)fidx;
+            idx = idx < 0 ? 0 : (idx > D - 1 ? D - 1 : idx);
+            float conf = 0.0f;
+            for (int k = -1; k <= 2; ++k) {
+                int d = idx + k;
+                conf = conf + ((d >= 0 && d < D) ? expf(r[d * HW] - mx) / den : 0.0f);
+            }
+            out_depth[(size_t)b * HW + i] = acc;
+            out_conf[(size_t)b * HW + i] = conf;
+            if (out_var) {
+                float v = 0.0f;
+                for (int d = 0; d < D; ++d) {
+                    float p = expf(r[d * HW] - mx) / den;
+                    float hv = depth_is_4d ? depth[((size_t)b * D + d) * HW + i] : depth[(size_t)b * D + d];
+                    float dh = hv - acc;
+                    v = v + (dh * dh) * p;
+                }
+                out_var[(size_t)b * HW + i] = lamb * sqrtf(v);
+            }
+        }
+}
+
 /* Pred path, one plane (networks/casred.py:218-231): prob = exp(double(reg)) with no
  * max-subtraction; running max, sum of h*prob, sum of prob -- all float64. */
 ORC_API void orc_stream_regress_step(const float *reg_plane, const float *depth_plane, int depth_is_plane,

@@ -157,6 +157,21 @@ def softmax_regress(reg, depth):
     return od, oc
 
 
+def window_regress(reg, depth, lamb=None):
+    """casmvs / ucs regression: (depth, window-4 confidence[, lamb * std-dev]) -- orc_window_regress."""
+    reg = _f32(reg)
+    B, D, H, W = reg.shape
+    depth, is4 = _depth_args(depth, B, D, H, W)
+    od = np.empty((B, H, W), np.float32)
+    oc = np.empty((B, H, W), np.float32)
+    ov = np.empty((B, H, W), np.float32) if lamb is not None else None
+    import ctypes
+    f = lib().orc_window_regress
+    f.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_float] + [ctypes.c_int] * 4
+    f(_p(reg), _p(depth), is4, _p(od), _p(oc), _p(ov) if ov is not None else None, float(lamb or 0.0), B, D, H, W)
+    return (od, oc, ov) if lamb is not None else (od, oc)
+
+
 class StreamRegress:
     """The three float64 accumulators of networks/casred.py:182-184 and their updates."""
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SMVS_LIB_PATH: load another build of the same library (A/B timing of kernel variants in one process-level run)
 LIB_PATH = os.environ.get("SMVS_LIB_PATH") or os.path.join(_HERE, "lib", "libsatmvs_hip.so")
 
-_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+_vp, _i, _sz, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 
 # name -> argtypes; mirrors include/satmvs.h one to one
 _SIGNATURES = {
@@ -29,6 +29,7 @@ _SIGNATURES = {
     "smvs_costvol_bwd": [_i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp] + [_i] * 5 + [_vp],
     "smvs_rpc_project": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
     "smvs_softmax_regress_fwd": [_vp, _vp, _i, _vp, _vp] + [_i] * 4 + [_vp],
+    "smvs_window_regress_fwd": [_vp, _vp, _i, _vp, _vp, _vp, _f] + [_i] * 4 + [_vp],
     "smvs_stream_regress_step": [_vp, _vp, _i, _vp, _vp, _vp] + [_i] * 5 + [_vp],
     "smvs_stream_regress_final": [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "smvs_red_pack_weights": [_vp, _i, _vp, _vp],

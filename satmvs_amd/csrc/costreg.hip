@@ -424,6 +424,7 @@ SMVS_EXPORT size_t smvs_costreg_packed_floats(int C) { return C > 0 ? smvs::cr_l
 SMVS_EXPORT size_t smvs_costreg_workspace_bytes(int B, int C, int D, int H, int W)
 {
     if (B < 1 || C < 1 || D < 8 || H < 8 || W < 8 || (D % 8) || (H % 8) || (W % 8)) return 0;
+    if ((long long)D * H / 4 + 1 > 65535) return 0;         // beyond one launch grid: unsupported (callers fall back)
     return smvs::cr_workspace(B, D, H, W).total * sizeof(float);
 }
 
@@ -474,8 +475,7 @@ SMVS_EXPORT int smvs_costreg_fwd(const float* packed, const float* vol, float* o
     cr_layers(C, L);
     const CrLayout lay = cr_layout(C);
     const CrWorkspace ws = cr_workspace(B, D, H, W);
-    const char* env = getenv("SMVS_CONV_DIRECT");           // A/B switch: direct kernels only
-    const bool direct_only = env && env[0] == '1';
+    const bool direct_only = tune_int("SMVS_CONV_DIRECT", 0) == 1;      // A/B switch (tuning builds): direct kernels only
     float* f = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
     const int dims[4][3] = {{D, H, W}, {D / 2, H / 2, W / 2}, {D / 4, H / 4, W / 4}, {D / 8, H / 8, W / 8}};
@@ -507,14 +507,14 @@ SMVS_EXPORT int smvs_costreg_fwd(const float* packed, const float* vol, float* o
             mfma_conv_launch<27>(m, B, st);
         } else if (l.transposed) {
             dim3 grd((a.Wi + 63) / 64, (a.Hi * a.Di + 3) / 4, B * ncog);
-            static const int split_below = [] { const char* e = getenv("SMVS_CONV_SPLIT_BELOW"); return e ? atoi(e) : 1024; }();
+            static const int split_below = tune_int("SMVS_CONV_SPLIT_BELOW", 1024);
             if ((long long)((a.Di * a.Hi * a.Wi + 63) / 64) * B * ncog < split_below / 2 && !direct_only)
                 hipLaunchKernelGGL(convT3d_split_kernel, dim3((a.Di * a.Hi * a.Wi + 63) / 64, 1, B * ncog), dim3(256), 0, st, a);
             else
                 hipLaunchKernelGGL(convT3d_kernel, grd, dim3(256), 0, st, a);
         } else {
             dim3 grd((a.Wo + 63) / 64, (a.Ho * a.Do + 3) / 4, B * ncog);
-            static const bool gather = [] { const char* e = getenv("SMVS_CONV3D_GATHER"); return e && e[0] == '1'; }();
+            static const bool gather = tune_int("SMVS_CONV3D_GATHER", 0) == 1;
             if (l.stride == 1 && !gather) hipLaunchKernelGGL(conv3d_s1_kernel, grd, dim3(256), 0, st, a);
             else if (l.stride == 1)       hipLaunchKernelGGL(conv3d_kernel<1>, grd, dim3(256), 0, st, a);
             else               hipLaunchKernelGGL(conv3d_kernel<2>, grd, dim3(256), 0, st, a);

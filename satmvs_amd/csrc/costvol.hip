@@ -706,15 +706,13 @@ void costvol_dma_kernel(const CostVolParams p)
 }
 
 // Kernel choice.  The staged kernel serves 2-3 views at C = 16/32 (one channel volume < 4 GiB);
-// everything else, and SMVS_COSTVOL_KERNEL=direct (A/B switch for profiling), takes the direct-gather
+// everything else (and SMVS_COSTVOL_DIRECT=1 in tuning builds) takes the direct-gather
 // kernel.  Both produce identical bits.
 enum { K_DIRECT = 0, K_DMA = 2 };
 
 static int kernel_choice()
 {
-    const char* e = getenv("SMVS_COSTVOL_KERNEL");         // "direct" | "staged" (A/B switch for profiling)
-    if (e && e[0] == 'd' && e[1] == 'i') return K_DIRECT;
-    return K_DMA;
+    return tune_int("SMVS_COSTVOL_DIRECT", 0) == 1 ? K_DIRECT : K_DMA;      // A/B switch (tuning builds only)
 }
 
 template <int GEO, int NSRC>

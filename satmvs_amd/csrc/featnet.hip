@@ -310,6 +310,8 @@ SMVS_EXPORT size_t smvs_featnet_packed_floats(int base_channels, int arch)
 SMVS_EXPORT size_t smvs_featnet_workspace_bytes(int N, int H, int W, int base_channels, int arch)
 {
     if (N < 1 || base_channels < 1 || H < 4 || W < 4 || (H % 4) || (W % 4) || (arch != 0 && arch != 1)) return 0;
+    if ((long long)4 * base_channels * H * W * 4 >= (1ll << 31)) return 0;                       // unsupported sizes: 0
+    if ((long long)N * ((4 * base_channels + smvs::FN_COT - 1) / smvs::FN_COT) > 65535) return 0;
     return smvs::fn_workspace(N, H, W, base_channels, arch).total * sizeof(float);
 }
 

@@ -249,8 +249,8 @@ inline void mfma_conv_launch(const MfmaConvArgs& a, int B, hipStream_t st)
     // Few tiles (the coarse levels): latency, not throughput, sets the time -- one cout tile per workgroup
     // and as many K-splitting waves as the channel count divides into.  Many tiles: one workgroup carries
     // every cout tile so the X operand is loaded once.
-    static const int small = [] { const char* e = getenv("SMVS_MFMA_SMALL"); return e ? atoi(e) : 1024; }();
-    static const int maxw = [] { const char* e = getenv("SMVS_MFMA_WAVES"); return e ? atoi(e) : 8; }();
+    static const int small = tune_int("SMVS_MFMA_SMALL", 1024);
+    static const int maxw = tune_int("SMVS_MFMA_WAVES", 8);
     if (tiles < small) {
         if (ncip % 16 == 0 && maxw >= 16)     hipLaunchKernelGGL((mfma_conv_kernel<TAPS, 1, 16>), dim3(tiles, nt), dim3(1024), 0, st, a);
         else if (ncip % 8 == 0 && maxw >= 8) hipLaunchKernelGGL((mfma_conv_kernel<TAPS, 1, 8>), dim3(tiles, nt), dim3(512), 0, st, a);

@@ -21,6 +21,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "smvs_device.h"
 #include "smvs_host.h"
 #include "mfma_conv.h"
@@ -452,13 +455,12 @@ static RedWorkspace red_workspace(int B, int C, int H, int W)
 
 static bool g_red_direct_only()
 {
-    const char* e = getenv("SMVS_CONV_DIRECT");             // A/B switch: direct kernels only
-    return e && e[0] == '1';
+    return tune_int("SMVS_CONV_DIRECT", 0) == 1;            // A/B switch (tuning builds): direct kernels only
 }
 
 static int g_split_below()
 {
-    static const int v = [] { const char* e = getenv("SMVS_CONV_SPLIT_BELOW"); return e ? atoi(e) : 1024; }();
+    static const int v = tune_int("SMVS_CONV_SPLIT_BELOW", 1024);
     return v;                                               // workgroups (unsplit) below which the channel-split kernels run
 }
 
@@ -512,35 +514,54 @@ static void launch_convT(const ConvArgs& a, int B, hipStream_t st)
 // the host enqueue rate, not the GPU, bounds the loop, and this needs the fewest event edges) | 4 (one per level).
 constexpr int RING = 2 * NBUF;
 struct RedPipe {
-    bool ready = false; int mode = 0;
+    int mode = 0;
     hipStream_t lvl[4];
     hipEvent_t enc[RING][4], up[RING][3], done[RING];
 };
 
-static RedPipe* red_pipe()
+static RedPipe* red_pipe_create()
 {
-    static thread_local RedPipe pipes[16];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    RedPipe& p = pipes[dev];
-    if (p.ready) return &p;
-    const char* e = getenv("SMVS_RED_STREAMS");
-    p.mode = e ? atoi(e) : 2;
-    if (p.mode != 0 && p.mode != 2 && p.mode != 4) p.mode = 2;
-    if (p.mode) {
-        for (int g = 0; g < 4; ++g)
-            if (hipStreamCreateWithFlags(&p.lvl[g], hipStreamNonBlocking) != hipSuccess) return nullptr;
-        for (int r = 0; r < RING; ++r) {
-            for (int g = 0; g < 4; ++g)
-                if (hipEventCreateWithFlags(&p.enc[r][g], hipEventDisableTiming) != hipSuccess) return nullptr;
-            for (int g = 0; g < 3; ++g)
-                if (hipEventCreateWithFlags(&p.up[r][g], hipEventDisableTiming) != hipSuccess) return nullptr;
-            if (hipEventCreateWithFlags(&p.done[r], hipEventDisableTiming) != hipSuccess) return nullptr;
-        }
+    RedPipe* p = new RedPipe();
+    p->mode = tune_int("SMVS_RED_STREAMS", 2);
+    if (p->mode != 0 && p->mode != 2 && p->mode != 4) p->mode = 2;
+    bool ok = true;
+    for (int g = 0; g < 4 && ok; ++g) ok = hipStreamCreateWithFlags(&p->lvl[g], hipStreamNonBlocking) == hipSuccess;
+    for (int r = 0; r < RING && ok; ++r) {
+        for (int g = 0; g < 4 && ok; ++g) ok = hipEventCreateWithFlags(&p->enc[r][g], hipEventDisableTiming) == hipSuccess;
+        for (int g = 0; g < 3 && ok; ++g) ok = hipEventCreateWithFlags(&p->up[r][g], hipEventDisableTiming) == hipSuccess;
+        if (ok) ok = hipEventCreateWithFlags(&p->done[r], hipEventDisableTiming) == hipSuccess;
     }
-    p.ready = true;
-    return &p;
+    if (!ok) { delete p; return nullptr; }        // (the few objects created before the failure are abandoned: the device is unusable anyway)
+    return p;
 }
+
+// The helper streams / events of the plane pipeline come from a per-device pool guarded by a mutex: a call borrows one
+// set for its duration and returns it, so the number of sets ever created is the peak number of CONCURRENT calls on a
+// device (one per nn.DataParallel replica thread), not the number of threads that ever called -- DataParallel starts
+// fresh threads for every forward, which made a thread_local cache leak 4 streams + 44 events per forward.
+struct RedPipeLease {
+    RedPipe* p = nullptr; int dev = -1;
+    static std::mutex& mu() { static std::mutex m; return m; }
+    static std::vector<RedPipe*>& pool(int dev) { static std::vector<RedPipe*> v[64]; return v[dev]; }
+    RedPipeLease()
+    {
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { dev = -1; return; }
+        {
+            std::lock_guard<std::mutex> g(mu());
+            auto& v = pool(dev);
+            if (!v.empty()) { p = v.back(); v.pop_back(); }
+        }
+        if (!p) p = red_pipe_create();
+    }
+    ~RedPipeLease()
+    {
+        if (!p) return;
+        std::lock_guard<std::mutex> g(mu());
+        pool(dev).push_back(p);                     // work enqueued on its streams is ordered behind the caller's stream by the final join
+    }
+    RedPipeLease(const RedPipeLease&) = delete;
+    RedPipeLease& operator=(const RedPipeLease&) = delete;
+};
 
 struct RedRun {
     const float* packed; float* state[4]; float* wsf; int B, C, H, W; hipStream_t main;
@@ -685,7 +706,8 @@ struct RedIssuer {
 
 static int red_run_planes(const RedRun& r, int d_begin, int d_end)
 {
-    RedPipe* pp = red_pipe();
+    RedPipeLease lease;
+    RedPipe* pp = lease.p;
     if (!pp) return fail(SMVS_ERR_LAUNCH, "could not create the regulariser's streams/events");
     const int nplanes = d_end - d_begin;
     if (nplanes <= 0) return SMVS_OK;
@@ -722,6 +744,7 @@ SMVS_EXPORT size_t smvs_red_packed_floats(int C) { return C > 0 ? smvs::red_layo
 SMVS_EXPORT size_t smvs_red_workspace_bytes(int B, int C, int H, int W)
 {
     if (B < 1 || C < 1 || H < 8 || W < 8 || (H % 8) || (W % 8)) return 0;
+    if ((long long)(C + 8) * H * W * 4 >= (1ll << 31)) return 0;       // plane beyond 32-bit offsets: unsupported
     return smvs::red_workspace(B, C, H, W).total * sizeof(float);
 }
 

@@ -41,6 +41,56 @@ void softmax_regress_kernel(const float* __restrict__ reg, const float* __restri
     out_conf[i] = best;
 }
 
+// ---- casmvs / ucs flavour: softmax + expected height + window-4 confidence (+ ucs standard deviation) ------
+// networks/casmvs.py:66-74 and networks/ucs.py:60-74 in one pass structure over (B,D,H,W):
+//   p = softmax_D(reg); depth = sum p*h; idx = clamp(trunc(sum p*d), 0, D-1);
+//   conf = p[idx-1] + p[idx] + p[idx+1] + p[idx+2] (planes outside [0,D) count 0: F.pad(.,(1,2)) + 4*avg_pool3d(4,1,1));
+//   variance = lamb * sqrt(sum p * (h - depth)^2)                      (ucs only, out_var may be null)
+// One lane per pixel; the D regulariser values of a pixel are re-read per pass (they sit in L2: a stage volume is
+// 3.5 - 9.4 MB).  float32 throughout, same operation order as the torch composite the reference runs.
+__global__ __launch_bounds__(256)
+void window_regress_kernel(const float* __restrict__ reg, const float* __restrict__ depth, int depth_is_4d,
+                           float* __restrict__ out_depth, float* __restrict__ out_conf, float* __restrict__ out_var,
+                           float lamb, int B, int D, int HW)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * HW) return;
+    const int b = (int)(i / HW);
+    const int pix = (int)(i % HW);
+    const float* r = reg + (size_t)b * D * HW + pix;
+    const float* hp = depth_is_4d ? depth + (size_t)b * D * HW + pix : depth + (size_t)b * D;
+    const size_t hs = depth_is_4d ? (size_t)HW : 1;
+    float mx = r[0];
+    for (int d = 1; d < D; ++d) mx = fmaxf(mx, r[(size_t)d * HW]);
+    float den = 0.0f;
+    for (int d = 0; d < D; ++d) den = den + expf(r[(size_t)d * HW] - mx);
+    float acc = 0.0f, fidx = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        const float pr = __fdiv_rn(expf(r[(size_t)d * HW] - mx), den);
+        acc = acc + pr * hp[d * hs];
+        fidx = fidx + pr * (float)d;
+    }
+    int idx = (int)fidx;                                   // .long(): truncation (the value is >= 0)
+    idx = idx < 0 ? 0 : (idx > D - 1 ? D - 1 : idx);
+    float conf = 0.0f;
+    for (int k = -1; k <= 2; ++k) {                        // pooling window [idx-1, idx+2], summed front to back
+        const int d = idx + k;
+        const float pr = (d >= 0 && d < D) ? __fdiv_rn(expf(r[(size_t)d * HW] - mx), den) : 0.0f;
+        conf = conf + pr;
+    }
+    out_depth[i] = acc;
+    out_conf[i] = conf;
+    if (out_var) {
+        float v = 0.0f;
+        for (int d = 0; d < D; ++d) {
+            const float pr = __fdiv_rn(expf(r[(size_t)d * HW] - mx), den);
+            const float dh = hp[d * hs] - acc;
+            v = v + (dh * dh) * pr;
+        }
+        out_var[i] = lamb * sqrtf(v);
+    }
+}
+
 // ---- pred path, one plane: float64 accumulators, no max-subtraction (casred.py:218-231) -----------
 __global__ __launch_bounds__(256)
 void stream_regress_step_kernel(const float* __restrict__ reg_plane, const float* __restrict__ depth,
@@ -117,6 +167,18 @@ SMVS_EXPORT int smvs_softmax_regress_fwd(const float* reg, const float* depth, i
     hipLaunchKernelGGL(smvs::softmax_regress_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, reg, depth, depth_is_4d, out_depth, out_conf, B, D, H * W);
     return smvs::check_launch("softmax_regress");
+}
+
+SMVS_EXPORT int smvs_window_regress_fwd(const float* reg, const float* depth, int depth_is_4d,
+                                        float* out_depth, float* out_conf, float* out_var, float lamb,
+                                        int B, int D, int H, int W, void* stream)
+{
+    if (!reg || !depth || !out_depth || !out_conf) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
+    if (B < 1 || D < 1 || H < 1 || W < 1) return smvs::fail(SMVS_ERR_ARG, "non-positive dimension");
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(smvs::window_regress_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, reg, depth, depth_is_4d, out_depth, out_conf, out_var, lamb, B, D, H * W);
+    return smvs::check_launch("window_regress");
 }
 
 SMVS_EXPORT int smvs_stream_regress_step(const float* reg_plane, const float* depth, int depth_is_4d,

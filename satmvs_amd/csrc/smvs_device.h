@@ -382,6 +382,12 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* base, uint32_t bytes)
 __device__ void llvm_raw_buffer_store_f32(float v, i32x4 rsrc, int voffset, int soffset, int aux)
     __asm("llvm.amdgcn.raw.buffer.store.f32");
 
+// The two helpers below write M0 (the LDS-DMA destination register) inside the asm and list it as clobbered, which is
+// the correct declaration: the compiler never keeps a value in M0 across a statement that clobbers it (its own M0 users
+// -- LDS-DMA intrinsics, s_sendmsg, s_movrel -- set M0 immediately before each use).  clang's generic "reserved register
+// in the clobber list" warning does not apply to that use, so it is switched off for exactly these definitions.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 // LDS-DMA: one dword per lane from a buffer straight into LDS at lds_byte_addr + 4*lane, no VGPR
 // round trip; out-of-range lanes deposit 0.  Issued from inline asm so that hipcc does not drain
 // vmcnt(0) before every LDS read (it cannot tell the two staging buffers apart): completion is
@@ -403,6 +409,8 @@ __device__ __forceinline__ void dma_dword_to_lds_at(const BufRsrc& rs, uint32_t 
     asm volatile("s_add_u32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
                  :: "s"(lds_base), "v"(voffset), "s"(rs.v), "s"(soffset), "n"(OFF) : "memory", "m0", "scc");
 }
+
+#pragma clang diagnostic pop
 
 // The four corners of one tap for a channel pair, as four ds_read_b64 (256 B/clk) rather than the
 // two ds_read2_b64 (128 B/clk) hipcc merges them into.  Issued from inline asm, so completion is

@@ -25,4 +25,13 @@ inline int fail(int code, const char* fmt, ...)
     return code;
 }
 
+// A/B and tuning switches exist only in tuning builds (tools/ab_build.sh x -DSMVS_TUNING); the shipped library
+// never reads the environment: every switch folds to its default at compile time.
+#ifdef SMVS_TUNING
+#include <stdlib.h>
+inline int tune_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+constexpr int tune_int(const char*, int dflt) { return dflt; }
+#endif
+
 }  // namespace smvs

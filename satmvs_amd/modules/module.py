@@ -8,11 +8,12 @@ Mirror of the parts of /root/reference/modules/module.py that the cascade networ
     Conv2d (:78) Deconv2d (:120) DeConv2dFuse (:303) Conv3d (:324) Deconv3d (:369)
     FeatureNet (:442)            depth_regression (:433)
 
-What is native here: the height regression (softmax_depth_regression -> smvs_softmax_regress_fwd,
-StreamingRegression -> smvs_stream_regress_*).  The convolutions inside the regularisers and the
-feature extractor are stock PyTorch modules (MIOpen on ROCm) in this round; their MFMA kernels are
-the next rows of SURVEY.md section 8 (a11/a12).  Sub-modules are created in the same order as the
-reference so that a given torch.manual_seed yields the same initial parameters.
+What is native here (inference; autograd keeps the PyTorch composites on the same parameters): the RED plane
+step and pred loop (smvs_red_step_fwd / smvs_red_pred_planes / smvs_red_volume_planes), CostRegNet
+(smvs_costreg_fwd), FeatureNet (smvs_featnet_fwd) and the height regressions (smvs_softmax_regress_fwd,
+smvs_window_regress_fwd, smvs_stream_regress_*).  The nn.Module trees only hold the parameters and the
+differentiable fallback; sub-modules are created in the same order as the reference so that a given
+torch.manual_seed yields the same initial parameters.
 """
 from __future__ import annotations
 
@@ -23,6 +24,60 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
+
+
+# ---- native-path plumbing shared by the three modules with HIP kernels ---------------------------------
+def _tensors_by_path(module, names):
+    """Parameters / buffers by dotted attribute path.  Unlike named_parameters() this also works on the
+    replicas nn.DataParallel makes for every forward (train.py:129, predict.py:85): torch.nn.parallel.replicate
+    empties `_parameters` and sets the broadcast copies as plain tensor attributes."""
+    out = []
+    for n in names:
+        obj = module
+        for part in n.split("."):
+            obj = getattr(obj, part)
+        out.append(obj)
+    return out
+
+
+_PACK_CACHE = {}        # key -> (packed tensor, weak references to the source storages); module-level so that it survives
+_PACK_CACHE_MAX = 16    # DataParallel's per-forward replicas (the device-0 replica shares the parent's storages)
+
+
+def _packed(kind, device, tensors, build):
+    """Kernel-layout copy of `tensors`, rebuilt only when a parameter's storage or version changed.
+
+    The key is (address, version) of every source tensor; an entry is only trusted while all the storages it was
+    packed from are still alive (weak references), because the caching allocator hands a freed parameter's address
+    to the next model's parameters."""
+    from torch.multiprocessing.reductions import StorageWeakRef
+    key = (kind, str(device)) + tuple((t.data_ptr(), t._version) for t in tensors)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and any(r.expired() for r in hit[1]):
+        hit = None
+    if hit is None:
+        for k in [k for k, v in _PACK_CACHE.items() if any(r.expired() for r in v[1])]:
+            del _PACK_CACHE[k]
+        if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
+            _PACK_CACHE.pop(next(iter(_PACK_CACHE)))
+        hit = (build(), [StorageWeakRef(t.untyped_storage()) for t in tensors])
+        _PACK_CACHE[key] = hit
+    return hit[0]
+
+
+def _workspace(module, attr, nbytes, dev):
+    """Scratch buffer kept on the module; a DataParallel replica (re-created per forward) gets a fresh one
+    from torch's caching allocator, which costs no device allocation after the first forward."""
+    ws = module.__dict__.get(attr)
+    if ws is None or ws.numel() < nbytes or ws.device != dev:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        module.__dict__[attr] = ws
+    return ws
+
+
+def _autograd_needed(x, tensors):
+    """True when a gradient could be asked of this call: the native kernels are forward-only."""
+    return torch.is_grad_enabled() and (x.requires_grad or any(t.requires_grad for t in tensors))
 
 
 # ---- small conv wrappers (parameter names: .conv / .bn) ----------------------------------------------
@@ -190,19 +245,17 @@ class _REDCore(nn.Module):
 
     def _packed_weights(self, device):
         """Device buffer in the kernel's layout; rebuilt when any parameter changed (optimizer step, load)."""
-        params = dict(self.named_parameters())
-        tensors = [params[n] for n in self._PARAM_ORDER]
-        key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
-        cache = getattr(self, "_packed_cache", None)
-        if cache is None or cache[0] != key:
-            in_ch = params["conv1.conv.weight"].shape[1]
+        tensors = _tensors_by_path(self, self._PARAM_ORDER)
+        in_ch = tensors[self._PARAM_ORDER.index("conv1.conv.weight")].shape[1]
+
+        def build():
             lib = _lib.load()
             packed = torch.empty(lib.smvs_red_packed_floats(in_ch), dtype=torch.float32, device=device)
             src = [t.detach().to(device=device, dtype=torch.float32).contiguous() for t in tensors]
             with torch.cuda.device(device):
                 _lib.call("smvs_red_pack_weights", _lib.ptr_array(src), in_ch, _lib.ptr(packed), _lib.current_stream(device))
-            self._packed_cache = (key, packed, in_ch)
-        return self._packed_cache[1], self._packed_cache[2]
+            return packed
+        return _packed("red", device, tensors, build), in_ch
 
     def native_step(self, cost, s1, s2, s3, s4):
         """One plane through smvs_red_step_fwd (HIP).  States are updated in place and returned."""
@@ -217,9 +270,7 @@ class _REDCore(nn.Module):
         nbytes = lib.smvs_red_workspace_bytes(b, c, h, w)
         if nbytes == 0:
             raise ValueError("plane %dx%d is not a positive multiple of 8" % (h, w))
-        ws = getattr(self, "_workspace", None)
-        if ws is None or ws.numel() < nbytes or ws.device != dev:
-            ws = self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = _workspace(self, "_ws_step", nbytes, dev)
         out = torch.empty((b, 1, h, w), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.call("smvs_red_step_fwd", _lib.ptr(packed), _lib.ptr(cost), *[_lib.ptr(s) for s in states],
@@ -245,9 +296,7 @@ class _REDCore(nn.Module):
         nbytes = lib.smvs_red_pred_workspace_bytes(b, c, h, w)
         if nbytes == 0:
             raise ValueError("plane %dx%d is not a positive multiple of 8" % (h, w))
-        ws = getattr(self, "_pred_workspace", None)
-        if ws is None or ws.numel() < nbytes or ws.device != dev:
-            ws = self._pred_workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = _workspace(self, "_ws_pred", nbytes, dev)
         for s in states:
             if s.dtype != torch.float32 or not s.is_contiguous():
                 raise ValueError("states must be contiguous float32")
@@ -272,11 +321,16 @@ class _REDCore(nn.Module):
         return reg
 
     def _use_native(self, cost):
+        """Native kernels: GPU tensors, no gradient wanted (whatever train()/eval() says -- the ConvGRU has no
+        mode-dependent layers), and a plane the kernels support; anything else takes the PyTorch composite."""
         if os.environ.get("SMVS_RED_TORCH") == "1":        # A/B switch: force the stock PyTorch composite
             return False
-        return (cost.is_cuda and not (torch.is_grad_enabled() and (cost.requires_grad or any(
-            p.requires_grad for p in self.parameters()) and self.training)) and cost.shape[2] % 8 == 0
-            and cost.shape[3] % 8 == 0 and self.base_channels == 8)
+        if not cost.is_cuda or self.base_channels != 8 or cost.dim() != 4:
+            return False
+        if _autograd_needed(cost, _tensors_by_path(self, self._PARAM_ORDER)):
+            return False
+        b, c, h, w = cost.shape
+        return _lib.load().smvs_red_workspace_bytes(b, c, h, w) != 0      # 0: not a multiple of 8, or beyond the kernels' limits
 
     def step(self, cost, s1, s2, s3, s4):
         """One plane: 2-D encoder/decoder with a ConvGRU at each of the 4 scales (module.py:625-644).
@@ -339,30 +393,35 @@ class CostRegNet(nn.Module):
 
     _LAYERS = ["conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11"]
 
+    def _names(self):
+        return [l + s for l in self._LAYERS for s in (".conv.weight", ".bn.weight", ".bn.bias", ".bn.running_mean",
+                                                      ".bn.running_var")] + ["prob.weight"]
+
     def _packed_weights(self, device):
-        sd = dict(self.named_parameters())
-        sd.update(dict(self.named_buffers()))
-        names = [l + s for l in self._LAYERS for s in (".conv.weight", ".bn.weight", ".bn.bias", ".bn.running_mean",
-                                                       ".bn.running_var")] + ["prob.weight"]
-        tensors = [sd[n] for n in names]
-        key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
-        cache = getattr(self, "_packed_cache", None)
-        if cache is None or cache[0] != key:
-            in_ch = sd["conv0.conv.weight"].shape[1]
+        tensors = _tensors_by_path(self, self._names())
+        in_ch = tensors[0].shape[1]
+
+        def build():
             lib = _lib.load()
             packed = torch.empty(lib.smvs_costreg_packed_floats(in_ch), dtype=torch.float32, device=device)
             src = [t.detach().to(device=device, dtype=torch.float32).contiguous() for t in tensors]
             with torch.cuda.device(device):
                 _lib.call("smvs_costreg_pack_weights", _lib.ptr_array(src), in_ch, _lib.ptr(packed),
                           _lib.current_stream(device))
-            self._packed_cache = (key, packed, in_ch)
-        return self._packed_cache[1], self._packed_cache[2]
+            return packed
+        return _packed("costreg", device, tensors, build), in_ch
 
     def _use_native(self, x):
+        """Native kernels: GPU, eval mode (BatchNorm3d folded from its running statistics), no gradient wanted,
+        and a volume the kernels support; anything else takes the PyTorch composite below."""
         if os.environ.get("SMVS_COSTREG_TORCH") == "1":     # A/B switch: force the stock PyTorch composite
             return False
-        return (x.is_cuda and not self.training and not (torch.is_grad_enabled() and x.requires_grad)
-                and self.conv0.conv.out_channels == 8 and all(d % 8 == 0 for d in x.shape[2:]))
+        if not x.is_cuda or self.training or x.dim() != 5 or self.conv0.conv.out_channels != 8:
+            return False
+        if _autograd_needed(x, _tensors_by_path(self, self._names())):
+            return False
+        b, c, d, h, w = x.shape
+        return _lib.load().smvs_costreg_workspace_bytes(b, c, d, h, w) != 0
 
     def native_forward(self, x):
         """(B,C,D,H,W) -> (B,1,D,H,W) through smvs_costreg_fwd (HIP, inference-form BatchNorm)."""
@@ -376,9 +435,7 @@ class CostRegNet(nn.Module):
         nbytes = lib.smvs_costreg_workspace_bytes(b, c, d, h, w)
         if nbytes == 0:
             raise ValueError("volume %s is not a positive multiple of 8 in D, H, W" % (tuple(x.shape),))
-        ws = getattr(self, "_workspace", None)
-        if ws is None or ws.numel() < nbytes or ws.device != dev:
-            ws = self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = _workspace(self, "_ws", nbytes, dev)
         out = torch.empty((b, 1, d, h, w), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.call("smvs_costreg_fwd", _lib.ptr(packed), _lib.ptr(x), _lib.ptr(out), _lib.ptr(ws), nbytes,
@@ -446,21 +503,19 @@ class FeatureNet(nn.Module):
     def _arch(self):
         return 0 if self.arch_mode == "unet" else 1
 
+    def _names(self):
+        names = [b + s for b in self._TRUNK for s in self._BN5]
+        if self.arch_mode == "unet":
+            return names + [b + s for b in self._UNET_BLOCKS for s in self._BN5] + ["out1.weight", "out2.weight", "out3.weight"]
+        return names + ["out1.weight", "inner1.weight", "inner1.bias", "out2.weight", "inner2.weight", "inner2.bias",
+                        "out3.weight"]
+
     def _packed_weights(self, device):
         """Parameters + BatchNorm running statistics repacked for the HIP kernels; cached until any of them
         changes (load_state_dict / an optimiser step / a training-mode forward bump the tensor versions)."""
-        sd = dict(self.named_parameters())
-        sd.update(dict(self.named_buffers()))
-        names = [b + s for b in self._TRUNK for s in self._BN5]
-        if self.arch_mode == "unet":
-            names += [b + s for b in self._UNET_BLOCKS for s in self._BN5] + ["out1.weight", "out2.weight", "out3.weight"]
-        else:
-            names += ["out1.weight", "inner1.weight", "inner1.bias", "out2.weight", "inner2.weight", "inner2.bias",
-                      "out3.weight"]
-        tensors = [sd[n] for n in names]
-        key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
-        cache = getattr(self, "_packed_cache", None)
-        if cache is None or cache[0] != key:
+        tensors = _tensors_by_path(self, self._names())
+
+        def build():
             lib = _lib.load()
             packed = torch.empty(lib.smvs_featnet_packed_floats(self.base_channels, self._arch()), dtype=torch.float32,
                                  device=device)
@@ -468,14 +523,22 @@ class FeatureNet(nn.Module):
             with torch.cuda.device(device):
                 _lib.call("smvs_featnet_pack_weights", _lib.ptr_array(src), self.base_channels, self._arch(),
                           _lib.ptr(packed), _lib.current_stream(device))
-            self._packed_cache = (key, packed)
-        return self._packed_cache[1]
+            return packed
+        return _packed("featnet%d" % self._arch(), device, tensors, build)
 
     def _use_native(self, x):
+        """Native kernels: GPU, eval mode (BatchNorm folded from running statistics), no gradient wanted, and
+        an image size the kernels support; anything else takes the PyTorch composite."""
         if os.environ.get("SMVS_FEATNET_TORCH") == "1":     # A/B switch: force the stock PyTorch composite
             return False
-        return (x.is_cuda and not self.training and not torch.is_grad_enabled()
-                and self.num_stage == 3 and self.base_channels <= 16 and x.shape[-1] % 4 == 0 and x.shape[-2] % 4 == 0)
+        if not x.is_cuda or self.training or self.num_stage != 3 or self.base_channels > 16 or x.dim() < 4:
+            return False
+        if _autograd_needed(x, _tensors_by_path(self, self._names())):
+            return False
+        n = 1
+        for d in x.shape[:-3]:
+            n *= d
+        return _lib.load().smvs_featnet_workspace_bytes(n, x.shape[-2], x.shape[-1], self.base_channels, self._arch()) != 0
 
     def native_forward(self, x):
         """(N,3,H,W) -> {"stage1": (N,4c,H/4,W/4), "stage2": (N,2c,H/2,W/2), "stage3": (N,c,H,W)} in one
@@ -491,9 +554,7 @@ class FeatureNet(nn.Module):
         nbytes = lib.smvs_featnet_workspace_bytes(n, h, w, c, self._arch())
         if nbytes == 0:
             raise ValueError("image %dx%d is not a positive multiple of 4 in both dimensions" % (h, w))
-        ws = getattr(self, "_workspace", None)
-        if ws is None or ws.numel() < nbytes or ws.device != dev:
-            ws = self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = _workspace(self, "_ws", nbytes, dev)
         s1 = torch.empty((n, 4 * c, h // 4, w // 4), dtype=torch.float32, device=dev)
         s2 = torch.empty((n, 2 * c, h // 2, w // 2), dtype=torch.float32, device=dev)
         s3 = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
@@ -569,6 +630,43 @@ def softmax_depth_regression(reg, depth_values):
         _lib.call("smvs_softmax_regress_fwd", _lib.ptr(r), _lib.ptr(dv), is4d, _lib.ptr(depth), _lib.ptr(conf),
                   B, D, H, W, _lib.current_stream(dev))
     return depth, conf
+
+
+def window_depth_regression(reg, depth_values, lamb=None):
+    """CascadeMVSNet / UCSNet regression in one HIP kernel (no_grad paths): softmax over D, expected height,
+    photometric confidence = probability mass of the 4 hypotheses around the expected index
+    (networks/casmvs.py:66-74) and, with `lamb`, UCSNet's lamb * sqrt(sum p (h - depth)^2) (networks/ucs.py:73-74).
+
+    reg (B,D,H,W); depth_values (B,D) or (B,D,H,W).  Returns (depth, confidence) or (depth, confidence, variance).
+    With autograd enabled on `reg` the torch composite runs instead (differentiable, same operations)."""
+    if (torch.is_grad_enabled() and reg.requires_grad) or not reg.is_cuda:
+        p = F.softmax(reg, dim=1)
+        num_depth = reg.shape[1]
+        dv = depth_values
+        depth = depth_regression(p, depth_values=dv)
+        with torch.no_grad():
+            sum4 = 4 * F.avg_pool3d(F.pad(p.unsqueeze(1), pad=(0, 0, 0, 0, 1, 2)), (4, 1, 1), stride=1, padding=0).squeeze(1)
+            idx = depth_regression(p, depth_values=torch.arange(num_depth, device=p.device, dtype=torch.float)).long()
+            conf = torch.gather(sum4, 1, idx.clamp(min=0, max=num_depth - 1).unsqueeze(1)).squeeze(1)
+        if lamb is None:
+            return depth, conf
+        if dv.dim() == 2:
+            dv = dv.view(*dv.shape, 1, 1)
+        return depth, conf, lamb * torch.sum((dv - depth.unsqueeze(1)) ** 2 * p, dim=1) ** 0.5
+    dev = _lib.require_device(reg, depth_values)
+    r = reg.detach().to(torch.float32).contiguous()
+    B, D, H, W = r.shape
+    dv = depth_values.detach().to(torch.float32).contiguous()
+    is4d = 1 if dv.dim() == 4 else 0
+    if is4d and tuple(dv.shape) != (B, D, H, W):
+        dv = F.interpolate(dv, [H, W], mode="bilinear", align_corners=False).contiguous()
+    depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    conf = torch.empty_like(depth)
+    var = torch.empty_like(depth) if lamb is not None else None
+    with torch.cuda.device(dev):
+        _lib.call("smvs_window_regress_fwd", _lib.ptr(r), _lib.ptr(dv), is4d, _lib.ptr(depth), _lib.ptr(conf),
+                  _lib.ptr(var) if var is not None else None, float(lamb or 0.0), B, D, H, W, _lib.current_stream(dev))
+    return (depth, conf) if lamb is None else (depth, conf, var)
 
 
 class StreamingRegression:

@@ -1,8 +1,9 @@
 """Cascade MVSNet (3-D conv regulariser) on the native cost-volume engine.
 
 Same public surface as /root/reference/networks/casmvs.py: DepthNet (:11), CascadeMVSNet (:79).
-The per-source warp + variance accumulation is the fused HIP launch; CostRegNet's 3-D convolutions
-are stock PyTorch (MIOpen) in this round.
+The per-source warp + variance accumulation is the fused HIP launch; in inference CostRegNet runs on its native
+kernels (smvs_costreg_fwd) and softmax + expected height + window-4 confidence are one kernel
+(smvs_window_regress_fwd); training keeps the differentiable torch composites on the same parameters.
 """
 from __future__ import annotations
 
@@ -11,21 +12,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..modules.depth_range import get_depth_range_samples
-from ..modules.module import CostRegNet, FeatureNet, depth_regression
+from ..modules.module import CostRegNet, FeatureNet, depth_regression, window_depth_regression
 from ..modules.warping import variance_cost_volume
 
 Align_Corners_Range = False
-
-
-def window4_confidence(prob_volume, num_depth):
-    """Probability mass of the 4 hypotheses around the expected index (casmvs.py:69-74)."""
-    with torch.no_grad():
-        sum4 = 4 * F.avg_pool3d(F.pad(prob_volume.unsqueeze(1), pad=(0, 0, 0, 0, 1, 2)), (4, 1, 1), stride=1,
-                                padding=0).squeeze(1)
-        idx = depth_regression(prob_volume, depth_values=torch.arange(num_depth, device=prob_volume.device,
-                                                                      dtype=torch.float)).long()
-        idx = idx.clamp(min=0, max=num_depth - 1)
-        return torch.gather(sum4, 1, idx.unsqueeze(1)).squeeze(1)
 
 
 class DepthNet(nn.Module):
@@ -35,9 +25,9 @@ class DepthNet(nn.Module):
         assert depth_values.shape[1] == num_depth, "depth_values.shape[1]:{}  num_depth:{}".format(
             depth_values.shape[1], num_depth)
         volume_variance = variance_cost_volume(features, proj_matrices, depth_values, geo_model, use_qc)
-        prob_volume = F.softmax(cost_regularization(volume_variance).squeeze(1), dim=1)
-        depth = depth_regression(prob_volume, depth_values=depth_values)
-        return {"depth": depth, "photometric_confidence": window4_confidence(prob_volume, num_depth)}
+        reg = cost_regularization(volume_variance).squeeze(1)
+        depth, conf = window_depth_regression(reg, depth_values)      # casmvs.py:66-74; native when no gradient is wanted
+        return {"depth": depth, "photometric_confidence": conf}
 
 
 class CascadeMVSNet(nn.Module):

@@ -9,9 +9,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..modules.depth_range import uncertainty_aware_samples
-from ..modules.module import CostRegNet, FeatureNet, depth_regression
+from ..modules.module import CostRegNet, FeatureNet, window_depth_regression
 from ..modules.warping import variance_cost_volume
-from .casmvs import window4_confidence
 
 
 def compute_depth(feats, proj_mats, depth_samps, cost_reg, lamb, geo_model, is_training=False, use_qc=False):
@@ -19,11 +18,8 @@ def compute_depth(feats, proj_mats, depth_samps, cost_reg, lamb, geo_model, is_t
     n_proj = len(proj_mats) if use_qc else proj_mats.shape[1]
     assert n_proj == len(feats), "Different number of images and projection matrices"
     volume_variance = variance_cost_volume(feats, proj_mats, depth_samps, geo_model, use_qc)
-    prob_volume = F.softmax(cost_reg(volume_variance).squeeze(1), dim=1)
-    depth = depth_regression(prob_volume, depth_values=depth_samps)
-    prob_conf = window4_confidence(prob_volume, num_depth)
-    samp_variance = (depth_samps - depth.unsqueeze(1)) ** 2
-    exp_variance = lamb * torch.sum(samp_variance * prob_volume, dim=1, keepdim=False) ** 0.5
+    reg = cost_reg(volume_variance).squeeze(1)
+    depth, prob_conf, exp_variance = window_depth_regression(reg, depth_samps, lamb=lamb)      # ucs.py:60-74
     return {"depth": depth, "photometric_confidence": prob_conf, "variance": exp_variance}
 
 

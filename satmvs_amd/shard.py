@@ -10,9 +10,10 @@ The only exchange on the path is the regression: the pred loop's accumulators
 variance volume is never gathered (2.4 GB at the metric shape vs 7 MB for the slab).
 
 Caveat kept explicit: the RED regulariser is recurrent over planes (modules/module.py:625-644), so
-for exact parity its four hidden states are handed from shard g to shard g+1
-(`recurrent_handoff=True`, point-to-point, sequential within one tile); plane-local regularisers
-shard with no hand-off.
+for exact parity its four hidden states -- and, with them, the regression accumulators -- are handed
+from shard g to shard g+1 (`recurrent_handoff=True`, point-to-point, sequential within one tile; the
+last shard broadcasts the finished sums, which equal the single-GPU ones bit for bit); plane-local
+regularisers shard with no hand-off and one all-reduce.
 """
 from __future__ import annotations
 
@@ -61,11 +62,15 @@ def sharded_compute_depth_when_pred(features, proj_matrices, depth_values, num_d
     ref = features[0]
     b, _, h, w = ref.shape
     recurrent = hasattr(cost_regularization, "initial_states")
+    chain = recurrent and recurrent_handoff and world > 1
     states = cost_regularization.initial_states(b, h, w, ref.device) if recurrent else []
-    if recurrent and recurrent_handoff and world > 1 and rank > 0:
-        for s in states:
-            dist.recv(s, src=_global_rank(group, rank - 1), group=group)
     acc = StreamingRegression(b, h, w, ref.device)
+    if chain and rank > 0:
+        # The recurrence serialises the shards of one tile anyway, so the regression accumulators travel with the four
+        # hidden states: rank g continues the float64 sums exactly where rank g-1 stopped and the result is the
+        # single-GPU one bit for bit (a tree reduction would re-associate the float64 additions).
+        for s in states + [acc.state]:
+            _recv(s, _global_rank(group, rank - 1), group)
     dv = depth_values.detach().to(torch.float32).contiguous()
     if recurrent and hasattr(cost_regularization, "native_pred_planes") and cost_regularization._use_native(ref):
         cost_regularization.native_pred_planes(features, proj_matrices, dv, geo_model, use_qc, states, acc.state, lo, hi)
@@ -77,12 +82,33 @@ def sharded_compute_depth_when_pred(features, proj_matrices, depth_values, num_d
             else:
                 reg = cost_regularization(plane.squeeze(2))
             acc.step(reg, dv, d)
-    if recurrent and recurrent_handoff and world > 1 and rank < world - 1:
-        for s in states:
-            dist.send(s.contiguous(), dst=_global_rank(group, rank + 1), group=group)
-    allreduce_regression_state(acc.state, group)
+    if chain:
+        if rank < world - 1:
+            for s in states + [acc.state]:
+                _send(s.contiguous(), _global_rank(group, rank + 1), group)
+        dist.broadcast(acc.state, src=_global_rank(group, world - 1), group=group)    # the last shard holds the whole sum
+    else:
+        allreduce_regression_state(acc.state, group)
     depth, confidence = acc.result()
     return {"depth": depth, "photometric_confidence": confidence}
+
+
+def _host_staged(t, group):
+    """gloo moves only host memory point to point; RCCL ("nccl") takes device tensors as they are."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _send(t, dst, group):
+    dist.send(t.cpu() if _host_staged(t, group) else t, dst=dst, group=group)
+
+
+def _recv(t, src, group):
+    if _host_staged(t, group):
+        h = torch.empty(t.shape, dtype=t.dtype)
+        dist.recv(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.recv(t, src=src, group=group)
 
 
 def _global_rank(group, group_rank):

@@ -310,9 +310,22 @@ def gen_regress():
         dimg = dv[:, d:d + 1].double() * prob + dimg
         exp_sum = exp_sum + prob
     fes = exp_sum + 1e-10
+    # casmvs / ucs flavour (window-4 confidence, casmvs.py:69-74; ucs standard deviation, ucs.py:73-74): the reference's
+    # own DepthNet.forward / compute_depth run on a small pinhole problem whose "regulariser" ignores the volume and
+    # returns the seeded `reg`, so everything after the regulariser is the reference's code, not a transcription.
+    C = 4
+    feats = [torch.randn(B, C, H, W) for _ in range(2)]
+    proj = torch.eye(4, dtype=torch.double).repeat(B, 2, 1, 1)
+    fake_reg = lambda vol: reg.unsqueeze(1)                                   # noqa: E731
+    with torch.no_grad():
+        cas = ref_casmvs.DepthNet()(feats, proj, dv, D, fake_reg, "pinhole")
+        ucs = ref_ucs.compute_depth(feats, proj, dv, fake_reg, 1.5, "pinhole", False)
+    assert torch.equal(cas["depth"], depth) and torch.equal(ucs["depth"], depth)
+    assert torch.equal(cas["photometric_confidence"], ucs["photometric_confidence"])
     save("regress", reg=reg.numpy(), depth_values=dv.numpy(), sm_depth=depth.numpy(), sm_conf=conf.numpy(),
          st_exp_sum=exp_sum.numpy(), st_depth_img=dimg.numpy(), st_max=mx.numpy(),
-         st_depth=(dimg / fes).squeeze(1).float().numpy(), st_conf=(mx / fes).squeeze(1).float().numpy())
+         st_depth=(dimg / fes).squeeze(1).float().numpy(), st_conf=(mx / fes).squeeze(1).float().numpy(),
+         w4_conf=cas["photometric_confidence"].numpy(), ucs_variance=ucs["variance"].numpy(), ucs_lamb=np.float32(1.5))
 
 
 def gen_depth_range():

@@ -68,6 +68,8 @@ def test_cascade_forward_matches_reference(dev, golden, tag):
         assert err <= H_TOL, "%s %s: max height error %.3g m" % (tag, s, err)
         wc = g["%s.%s.photometric_confidence" % (tag, s)]
         np.testing.assert_allclose(out[s]["photometric_confidence"].cpu().numpy(), wc, rtol=1e-3, atol=1e-5)
+        if tag == "ucs":                                       # lamb * std-dev of the height distribution (ucs.py:73-74)
+            np.testing.assert_allclose(out[s]["variance"].cpu().numpy(), g["ucs.%s.variance" % s], rtol=1e-3, atol=1e-3)
 
 
 @pytest.mark.parametrize("tag", ["red", "redinf", "ucs"])
@@ -378,3 +380,25 @@ def test_native_modules_match_composites_at_ragged_shapes(dev):
                 a, b = two_planes(), composite("SMVS_RED_TORCH", two_planes)
                 for p_, q_ in zip(a, b):
                     assert float((p_ - q_).abs().max()) <= 2e-5, (c, bsz, h, w)
+
+
+def test_native_paths_run_on_dataparallel_replicas(dev, golden):
+    """torch.nn.parallel.replicate (what nn.DataParallel does for every forward with >= 2 devices; here both
+    replicas on cuda:0) leaves modules whose named_parameters() is empty: the native RED / CostRegNet / FeatureNet
+    paths must still find their weights and reproduce the parent's outputs bit for bit."""
+    from satmvs_amd.networks import casmvs, casred
+    g = golden("cascade")
+    nd = [int(v) for v in g["ndepths"]]
+    imgs, proj, dv = _inputs(g, dev)
+    for make in (lambda: casred.Infer_CascadeREDNet("rpc", min_interval=2.5, ndepths=nd),
+                 lambda: casmvs.CascadeMVSNet("rpc", min_interval=2.5, ndepths=nd)):
+        torch.manual_seed(5)
+        net = make().to(dev).eval()
+        with torch.no_grad():
+            want = net(imgs, proj, dv)
+            reps = torch.nn.parallel.replicate(net, [0, 0], detach=True)
+            assert len(dict(reps[1].named_parameters())) == 0
+            got = reps[1](imgs, proj, dv)
+        for s in ("stage1", "stage2", "stage3"):
+            assert torch.equal(got[s]["depth"], want[s]["depth"]), s
+            assert torch.equal(got[s]["photometric_confidence"], want[s]["photometric_confidence"]), s

@@ -224,6 +224,38 @@ def test_regression_golden(dev, golden, oracle):
     np.testing.assert_allclose(depth.cpu().numpy(), c["depth_rpc"], rtol=0, atol=1e-3)
 
 
+def test_window_regression_golden(dev, golden, oracle):
+    """smvs_window_regress_fwd (casmvs / ucs flavour) vs the reference's outputs and vs the oracle, and the torch
+    composite of the same function (what runs under autograd) vs the kernel."""
+    from satmvs_amd.modules import module as M
+    g = golden("regress")
+    reg, dv, lamb = _t(g["reg"], dev), _t(g["depth_values"], dev), float(g["ucs_lamb"])
+    with torch.no_grad():
+        depth, conf, var = M.window_depth_regression(reg, dv, lamb=lamb)
+        d2, c2 = M.window_depth_regression(reg, dv)
+    assert torch.equal(d2, depth) and torch.equal(c2, conf)
+    np.testing.assert_allclose(depth.cpu().numpy(), g["sm_depth"], rtol=0, atol=1e-3)
+    assert (np.abs(conf.cpu().numpy() - g["w4_conf"]) > 1e-5).mean() <= 0.01
+    np.testing.assert_allclose(var.cpu().numpy(), g["ucs_variance"], rtol=2e-5, atol=1e-3)
+    od, oc, ov = oracle.window_regress(g["reg"], g["depth_values"], lamb=lamb)
+    np.testing.assert_allclose(depth.cpu().numpy(), od, rtol=0, atol=1e-4)
+    assert (np.abs(conf.cpu().numpy() - oc) > 1e-6).mean() <= 0.005
+    np.testing.assert_allclose(var.cpu().numpy(), ov, rtol=1e-5, atol=1e-4)
+    # the differentiable composite (autograd path) computes the same numbers
+    rg = reg.clone().requires_grad_(True)
+    dc, cc, vc = M.window_depth_regression(rg, dv, lamb=lamb)
+    np.testing.assert_allclose(dc.detach().cpu().numpy(), depth.cpu().numpy(), rtol=0, atol=1e-3)
+    assert (np.abs(cc.detach().cpu().numpy() - conf.cpu().numpy()) > 1e-5).mean() <= 0.01
+    np.testing.assert_allclose(vc.detach().cpu().numpy(), var.cpu().numpy(), rtol=1e-4, atol=1e-3)
+    # (B,D) heights
+    planes = torch.linspace(0, 300, reg.shape[1], device=dev).repeat(reg.shape[0], 1)
+    with torch.no_grad():
+        dp, cp, vp = M.window_depth_regression(reg, planes, lamb=lamb)
+    od, oc, ov = oracle.window_regress(g["reg"], planes.cpu().numpy(), lamb=lamb)
+    np.testing.assert_allclose(dp.cpu().numpy(), od, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(vp.cpu().numpy(), ov, rtol=1e-5, atol=1e-4)
+
+
 def test_warp_backward_matches_torch(dev, oracle):
     """grad w.r.t. src_fea == autograd of F.grid_sample on the same (oracle-built) grid."""
     from satmvs_amd.modules import warping

@@ -53,3 +53,70 @@ def test_red_slice_step_matches_golden(golden):
     np.testing.assert_allclose(r2[0].numpy(), g["slice_out2"], rtol=1e-5, atol=1e-6)
     for i, k in enumerate(["slice_s1", "slice_s2", "slice_s3", "slice_s4"]):
         np.testing.assert_allclose(r2[1 + i].numpy(), g[k], rtol=1e-5, atol=1e-6)
+
+
+def _fake_replicate(m):
+    """What torch.nn.parallel.replicate leaves behind (no GPU needed): `_parameters` emptied, the broadcast copies
+    set as plain tensor attributes, buffers and sub-modules re-linked."""
+    rep = {mod: mod._replicate_for_data_parallel() for mod in m.modules()}
+    for mod, r in rep.items():
+        for k, child in mod._modules.items():
+            r._modules[k] = rep[child] if child is not None else None
+        for k, p in mod._parameters.items():
+            if p is not None:
+                setattr(r, k, p.detach().clone())
+        for k, b in mod._buffers.items():
+            r._buffers[k] = b
+    return rep[m]
+
+
+@pytest.mark.parametrize("kind", ["red", "costreg", "featnet_unet", "featnet_fpn"])
+def test_native_weight_lookup_works_on_dataparallel_replicas(kind):
+    """nn.DataParallel (train.py:129, predict.py:85) calls replicas whose named_parameters() is EMPTY; the native
+    paths must find their tensors by attribute path (KeyError 'conv_gru1.gate_conv.weight')."""
+    from satmvs_amd.modules import module as M
+    torch.manual_seed(3)
+    if kind == "red":
+        m, names = M.slice_RED_Regularization(32, 8), M._REDCore._PARAM_ORDER
+    elif kind == "costreg":
+        m = M.CostRegNet(32, 8)
+        names = m._names()
+    else:
+        m = M.FeatureNet(base_channels=8, num_stage=3, arch_mode=kind.split("_")[1])
+        names = m._names()
+    r = _fake_replicate(m)
+    assert len(dict(r.named_parameters())) == 0
+    got = M._tensors_by_path(r, names)
+    sd = dict(m.named_parameters())
+    sd.update(dict(m.named_buffers()))
+    for n, t in zip(names, got):
+        assert torch.equal(t, sd[n]), n
+    # decision helper: no gradient wanted under no_grad even though the parent's parameters require grad
+    with torch.no_grad():
+        assert not M._autograd_needed(torch.zeros(1), M._tensors_by_path(m, names))
+    assert M._autograd_needed(torch.zeros(1), M._tensors_by_path(m, names))
+
+
+def test_pack_cache_never_serves_a_freed_models_weights():
+    """The packed-weight cache is keyed by (address, version); an entry must die with the storages it was packed from,
+    because the allocator reuses a freed parameter's address for the next model."""
+    from satmvs_amd.modules import module as M
+    M._PACK_CACHE.clear()
+    built = []
+
+    def build_for(t):
+        def build():
+            built.append(float(t.sum()))
+            return t.clone()
+        return build
+    a = torch.ones(8)
+    p1 = M._packed("k", "cpu", [a], build_for(a))
+    assert M._packed("k", "cpu", [a], build_for(a)) is p1 and len(built) == 1          # hit
+    view = a.detach()                                                                  # DataParallel's device-0 replica
+    assert M._packed("k", "cpu", [view], build_for(view)) is p1 and len(built) == 1    # same storage: hit
+    key = next(iter(M._PACK_CACHE))
+    del a, view                                                                        # model freed
+    b = torch.full((8,), 2.0)
+    M._PACK_CACHE[(key[0], key[1], (b.data_ptr(), b._version))] = M._PACK_CACHE.pop(key)   # simulate address reuse
+    p2 = M._packed("k", "cpu", [b], build_for(b))
+    assert len(built) == 2 and float(p2.sum()) == 16.0

@@ -108,6 +108,20 @@ def test_softmax_regress(oracle, golden):
     np.testing.assert_allclose(conf, r["sm_conf"], rtol=1e-5, atol=1e-6)
 
 
+def test_window_regress(oracle, golden):
+    """casmvs / ucs regression (window-4 confidence, ucs std-dev) against the reference's own DepthNet / compute_depth
+    outputs (tests/golden/gen_golden.py::gen_regress).  A pixel whose expected index sits within float rounding of an
+    integer may pick the neighbouring window: at most 1 % of the pixels may differ by more than 1e-5."""
+    r = golden("regress")
+    depth, conf, var = oracle.window_regress(r["reg"], r["depth_values"], lamb=float(r["ucs_lamb"]))
+    np.testing.assert_allclose(depth, r["sm_depth"], rtol=0, atol=1e-3)
+    bad = np.abs(conf - r["w4_conf"]) > 1e-5
+    assert bad.mean() <= 0.01, bad.mean()
+    np.testing.assert_allclose(var, r["ucs_variance"], rtol=2e-5, atol=1e-3)
+    d2, c2 = oracle.window_regress(r["reg"], r["depth_values"])
+    assert np.array_equal(d2, depth) and np.array_equal(c2, conf)
+
+
 def test_stream_regress(oracle, golden):
     r = golden("regress")
     B, D, H, W = r["reg"].shape

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ-only look: tools/profile_sq.sh <tag>   (env is inherited: SMVS_COSTVOL_KERNEL, SMVS_ABLATE)
+# SQ-only look: tools/profile_sq.sh <tag>   (SMVS_LIB_PATH selects the build under test)
 set -u
 TAG=${1:-sq}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
