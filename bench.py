@@ -47,6 +47,11 @@ WORKLOADS = {
     "stage3_rpc_3view_768x384x8_c8": (3, 8, 8, 384, 768),
     "cfg4_rpc_5view_1536x768x8_c32": (5, 32, 8, 768, 1536),
 }
+# height hypotheses of the side workloads (metres): the planes a real run would hand to that launch
+SIDE_HEIGHTS = {
+    "stage3_rpc_3view_768x384x8_c8": (190.0, 207.5),        # stage 3 of the cascade: 8 planes 2.5 m apart around the surface
+    "cfg4_rpc_5view_1536x768x8_c32": (0.0, 400.0 * 7 / 63),  # one GPU's shard: the first 8 of 64 planes over 0..400 m
+}
 
 
 def algorithmic_bytes_per_voxel(V, C, D):
@@ -136,9 +141,11 @@ def time_steps(step, steps, barrier=lambda: None):
     return elapsed, float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
 
-def kernel_name(V, C):
-    direct = V - 1 > 2 or C not in (16, 32)                 # dispatch rule of costvol.hip (launch_ct)
-    return "%s<rpc,%d,%d>" % ("costvol_fwd_kernel" if direct else "costvol_dma_kernel", V - 1, C)
+def kernel_name(V, C, planes=4):
+    direct = V - 1 > 4 or C not in (8, 16, 32)              # dispatch rule of costvol.hip (launch_ct)
+    if direct:
+        return "costvol_fwd_kernel<rpc,%d,%d>" % (V - 1, C)
+    return "costvol_dma_kernel<rpc,%d,%d,%d>" % (V - 1, C, 1 if planes == 1 else 2 if planes == 2 else 4)
 
 
 def side_workloads(dev, stream):
@@ -149,6 +156,8 @@ def side_workloads(dev, stream):
     for name in ("cfg4_rpc_5view_1536x768x8_c32", "stage3_rpc_3view_768x384x8_c8"):
         V, C, D, H, W = WORKLOADS[name]
         feats, rpc, depth = make_inputs(V, C, D, D, 0, H, W, dev)
+        lo, hi = SIDE_HEIGHTS[name]
+        depth = torch.linspace(lo, hi, D, dtype=torch.float32).view(1, D, 1, 1).expand(1, D, H, W).contiguous().to(dev)
         out = torch.empty((1, C, D, H, W), dtype=torch.float32, device=dev)
         srcs = _lib.ptr_array(feats[1:])
 

@@ -227,7 +227,6 @@ __device__ __forceinline__ int wave_max(int v)
 // group, so results never depend on which path ran.  Bits are identical to the direct kernel and to
 // the oracle.
 // =====================================================================================================
-constexpr int DM_DP = 4;       // planes per group
 #ifndef SMVS_BOX_W
 #define SMVS_BOX_W 40
 #endif
@@ -278,17 +277,17 @@ __device__ __forceinline__ void wait_vmcnt_upto8(int n)
 // register pairs so that v_pk_* can broadcast either half through op_sel (no v_mov to build {w,w}).
 struct TapD { uint32_t base; f32x2 wn, ws; };       // wn = {nw, ne}, ws = {sw, se}
 
-template <int GEO, int NSRC, int CT>
-__global__ __launch_bounds__(64 * WV_WAVES, SMVS_WAVES_PER_SIMD)
+template <int GEO, int NSRC, int CT, int DP>
+__global__ __launch_bounds__(64 * WV_WAVES, (NSRC <= 2 ? SMVS_WAVES_PER_SIMD : 2))
 void costvol_dma_kernel(const CostVolParams p)
 {
-    constexpr int DP = DM_DP, BW = DM_BW, R = DM_R;
+    constexpr int BW = DM_BW, R = DM_R;
     constexpr int NI = (R * BW * 2 + 63) / 64;               // DMA instructions per source box and channel pair
     constexpr int SRC_STRIDE = NI * 32;                      // float2 cells per source box, padded to whole DMA instructions
     constexpr int ZPAD = BW + 2;                             // always-zero cells a dropped tap reads (NW..SE span)
     constexpr int BUF_STRIDE = NSRC * SRC_STRIDE + ZPAD;
     constexpr int NSTEP = CT / 2;
-    static_assert(CT % 2 == 0 && 2 * DP <= 63 && DP % 2 == 0, "steps / vmcnt bookkeeping");
+    static_assert(CT % 2 == 0 && 2 * DP + 2 <= 63 && DP * NSRC <= 32, "steps / vmcnt bookkeeping / tap mask");
     __shared__ f32x2 tile_all[WV_WAVES][DM_NBUF * BUF_STRIDE];
 #ifdef SMVS_LDS_PAD
     __shared__ float lds_pad[SMVS_LDS_PAD / 4];            // profiling builds only: caps the workgroups per CU
@@ -384,7 +383,7 @@ void costvol_dma_kernel(const CostVolParams p)
         }
     }
     // PQ planes per pass: every source coefficient is fetched into SGPRs once for all of them
-    constexpr int PQ = SMVS_O2P_PLANES;
+    constexpr int PQ = DP < SMVS_O2P_PLANES ? DP : SMVS_O2P_PLANES;
     static_assert(DP % PQ == 0, "planes per pass");
 #pragma unroll
     for (int pq = 0; pq < DP; pq += PQ) {
@@ -519,11 +518,12 @@ void costvol_dma_kernel(const CostVolParams p)
         auto dma_at = [&](int s, int j, uint32_t buf, uint32_t voff, int so) {
 #define SMVS_DMA_CASE(S, J) \
     case (S) * 8 + (J): dma_dword_to_lds_at<((S) * SRC_STRIDE * 8 + (J) * 256)>(rs[(S) < NSRC ? (S) : 0], buf, voff, so); break;
-            static_assert(NI <= 8, "instruction dispatch");
+            static_assert(NI <= 8 && NSRC <= 4, "instruction dispatch");
             switch (s * 8 + j) {
                 SMVS_DMA_CASE(0, 0) SMVS_DMA_CASE(0, 1) SMVS_DMA_CASE(0, 2) SMVS_DMA_CASE(0, 3) SMVS_DMA_CASE(0, 4) SMVS_DMA_CASE(0, 5) SMVS_DMA_CASE(0, 6) SMVS_DMA_CASE(0, 7)
                 SMVS_DMA_CASE(1, 0) SMVS_DMA_CASE(1, 1) SMVS_DMA_CASE(1, 2) SMVS_DMA_CASE(1, 3) SMVS_DMA_CASE(1, 4) SMVS_DMA_CASE(1, 5) SMVS_DMA_CASE(1, 6) SMVS_DMA_CASE(1, 7)
                 SMVS_DMA_CASE(2, 0) SMVS_DMA_CASE(2, 1) SMVS_DMA_CASE(2, 2) SMVS_DMA_CASE(2, 3) SMVS_DMA_CASE(2, 4) SMVS_DMA_CASE(2, 5) SMVS_DMA_CASE(2, 6) SMVS_DMA_CASE(2, 7)
+                SMVS_DMA_CASE(3, 0) SMVS_DMA_CASE(3, 1) SMVS_DMA_CASE(3, 2) SMVS_DMA_CASE(3, 3) SMVS_DMA_CASE(3, 4) SMVS_DMA_CASE(3, 5) SMVS_DMA_CASE(3, 6) SMVS_DMA_CASE(3, 7)
                 default: break;
             }
 #undef SMVS_DMA_CASE
@@ -582,61 +582,59 @@ void costvol_dma_kernel(const CostVolParams p)
             // through the scalar offset
             const BufRsrc ro = make_rsrc(p.out + ((size_t)b * CT + 2 * st) * ostride, (uint32_t)(2 * ostride * 4));
             const int och1 = (int)(ostride * 4);
-            // Software pipeline over the planes: the taps of plane pl+1 are in flight (ds_read_b64 from
-            // inline asm, in-order return, counted lgkmcnt) while plane pl is being computed.
-            f32x2 cv[DP][NSRC][4];
-            auto read_plane = [&](int pl) {
+            // Software pipeline over UNITS = (plane, group of US sources): the taps of unit u+1 are in flight (ds_read_b64
+            // from inline asm, in-order return, counted lgkmcnt) while unit u is being accumulated.  Two sources per unit
+            // when the source count is even, one otherwise; a plane's sum / sum of squares run across its units.
+            constexpr int US = (NSRC % 2 == 0) ? 2 : 1, UPP = NSRC / US, NU = DP * UPP;
+            f32x2 cv[2][US][4];
+            f32x2 sum = refc, sq = refsq;
+            auto read_unit = [&](int u) {
+                const int pl = u / UPP, s0 = (u % UPP) * US;
 #pragma unroll
-                for (int s = 0; s < NSRC; ++s)
-                    lds_read_tap<PAR * BUF_STRIDE * 8, BW * 8>(tap[pl][s].base, cv[pl][s][0], cv[pl][s][1],
-                                                               cv[pl][s][2], cv[pl][s][3]);
+                for (int k = 0; k < US; ++k)
+                    lds_read_tap<PAR * BUF_STRIDE * 8, BW * 8>(tap[pl][s0 + k].base, cv[u & 1][k][0], cv[u & 1][k][1],
+                                                               cv[u & 1][k][2], cv[u & 1][k][3]);
             };
-            auto compute_plane = [&](int pl) {
-                f32x2 sum = refc, sq = refsq;
+            auto accumulate_unit = [&](int u) {
+                const int pl = u / UPP, s0 = (u % UPP) * US;
+                if (u % UPP == 0) { sum = refc; sq = refsq; }
 #pragma unroll
-                for (int s = 0; s < NSRC; ++s) {
-                    const TapD& t = tap[pl][s];
-                    f32x2 wv = cv[pl][s][0] * __builtin_shufflevector(t.wn, t.wn, 0, 0);
-                    wv = __builtin_elementwise_fma(cv[pl][s][1], __builtin_shufflevector(t.wn, t.wn, 1, 1), wv);
-                    wv = __builtin_elementwise_fma(cv[pl][s][2], __builtin_shufflevector(t.ws, t.ws, 0, 0), wv);
-                    wv = __builtin_elementwise_fma(cv[pl][s][3], __builtin_shufflevector(t.ws, t.ws, 1, 1), wv);
+                for (int k = 0; k < US; ++k) {
+                    const TapD& t = tap[pl][s0 + k];
+                    f32x2 wv = cv[u & 1][k][0] * __builtin_shufflevector(t.wn, t.wn, 0, 0);
+                    wv = __builtin_elementwise_fma(cv[u & 1][k][1], __builtin_shufflevector(t.wn, t.wn, 1, 1), wv);
+                    wv = __builtin_elementwise_fma(cv[u & 1][k][2], __builtin_shufflevector(t.ws, t.ws, 0, 0), wv);
+                    wv = __builtin_elementwise_fma(cv[u & 1][k][3], __builtin_shufflevector(t.ws, t.ws, 1, 1), wv);
                     sum = sum + wv;
                     sq = sq + wv * wv;
                 }
-                const f32x2 m = div_by_views2(sum, fV, rV);
-                const f32x2 q = div_by_views2(sq, fV, rV);
-                const f32x2 var = q - m * m;
-                SMVS_T(const unsigned long long ts0 = now();)
-                llvm_raw_buffer_store_f32(var.x, ro.v, (int)ovo[pl], 0, STORE_AUX);
-                llvm_raw_buffer_store_f32(var.y, ro.v, (int)ovo[pl], och1, STORE_AUX);
-                SMVS_T(t_st += now() - ts0;)
-            };
-            read_plane(0);
-#pragma unroll
-            for (int pl = 0; pl < DP; ++pl) {
-                if (pl + 1 < DP) read_plane(pl + 1);
-                // reads per plane = 4*NSRC; everything older than the next plane's reads has returned
-                if constexpr (NSRC == 1) {
-                    f32x2 d0, d1, d2, d3;
-                    d0 = d1 = d2 = d3 = (f32x2)(0.0f);
-                    if (pl + 1 < DP) lds_wait<4>(cv[pl][0][0], cv[pl][0][1], cv[pl][0][2], cv[pl][0][3], d0, d1, d2, d3);
-                    else             lds_wait<0>(cv[pl][0][0], cv[pl][0][1], cv[pl][0][2], cv[pl][0][3], d0, d1, d2, d3);
-                } else {
-#pragma unroll
-                    for (int s = 0; s + 1 < NSRC; s += 2) {
-                        if (pl + 1 < DP) lds_wait<(4 * NSRC <= 15 ? 4 * NSRC : 15)>(cv[pl][s][0], cv[pl][s][1], cv[pl][s][2], cv[pl][s][3],
-                                                       cv[pl][s + 1][0], cv[pl][s + 1][1], cv[pl][s + 1][2], cv[pl][s + 1][3]);
-                        else             lds_wait<0>(cv[pl][s][0], cv[pl][s][1], cv[pl][s][2], cv[pl][s][3],
-                                                     cv[pl][s + 1][0], cv[pl][s + 1][1], cv[pl][s + 1][2], cv[pl][s + 1][3]);
-                    }
-                    if constexpr (NSRC == 3) {
-                        f32x2 d0, d1, d2, d3;
-                        d0 = d1 = d2 = d3 = (f32x2)(0.0f);
-                        if (pl + 1 < DP) lds_wait<12>(cv[pl][2][0], cv[pl][2][1], cv[pl][2][2], cv[pl][2][3], d0, d1, d2, d3);
-                        else             lds_wait<0>(cv[pl][2][0], cv[pl][2][1], cv[pl][2][2], cv[pl][2][3], d0, d1, d2, d3);
-                    }
+                if (u % UPP == UPP - 1) {
+                    const f32x2 m = div_by_views2(sum, fV, rV);
+                    const f32x2 q = div_by_views2(sq, fV, rV);
+                    const f32x2 var = q - m * m;
+                    SMVS_T(const unsigned long long ts0 = now();)
+                    llvm_raw_buffer_store_f32(var.x, ro.v, (int)ovo[pl], 0, STORE_AUX);
+                    llvm_raw_buffer_store_f32(var.y, ro.v, (int)ovo[pl], och1, STORE_AUX);
+                    SMVS_T(t_st += now() - ts0;)
                 }
-                compute_plane(pl);
+            };
+            read_unit(0);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if (u + 1 < NU) read_unit(u + 1);
+                // reads per unit = 4*US; everything older than the next unit's reads has returned
+                f32x2 d0, d1, d2, d3;
+                d0 = d1 = d2 = d3 = (f32x2)(0.0f);
+                if constexpr (US == 1) {
+                    if (u + 1 < NU) lds_wait<4>(cv[u & 1][0][0], cv[u & 1][0][1], cv[u & 1][0][2], cv[u & 1][0][3], d0, d1, d2, d3);
+                    else            lds_wait<0>(cv[u & 1][0][0], cv[u & 1][0][1], cv[u & 1][0][2], cv[u & 1][0][3], d0, d1, d2, d3);
+                } else {
+                    if (u + 1 < NU) lds_wait<8>(cv[u & 1][0][0], cv[u & 1][0][1], cv[u & 1][0][2], cv[u & 1][0][3],
+                                                cv[u & 1][US - 1][0], cv[u & 1][US - 1][1], cv[u & 1][US - 1][2], cv[u & 1][US - 1][3]);
+                    else            lds_wait<0>(cv[u & 1][0][0], cv[u & 1][0][1], cv[u & 1][0][2], cv[u & 1][0][3],
+                                                cv[u & 1][US - 1][0], cv[u & 1][US - 1][1], cv[u & 1][US - 1][2], cv[u & 1][US - 1][3]);
+                }
+                accumulate_unit(u);
             }
         };
         static_assert(NSTEP % 2 == 0, "two steps per loop iteration");
@@ -705,9 +703,11 @@ void costvol_dma_kernel(const CostVolParams p)
     }
 }
 
-// Kernel choice.  The staged kernel serves 2-3 views at C = 16/32 (one channel volume < 4 GiB);
-// everything else (and SMVS_COSTVOL_DIRECT=1 in tuning builds) takes the direct-gather
-// kernel.  Both produce identical bits.
+// Kernel choice.  The staged kernel serves 2-5 views at C = 8/16/32 (one channel volume of the output < 2 GiB);
+// everything else (and SMVS_COSTVOL_DIRECT=1 in tuning builds) takes the direct-gather kernel.  Both produce
+// identical bits.  Planes per wave (DP): a whole sweep is cut into groups of 4 planes (the taps of a group live in
+// registers; with 3-4 sources the LDS tiles allow two workgroups per CU, i.e. 256 VGPRs per lane), the plane-at-a-time
+// launches of the pred loop get DP = 1 so that no float64 work is spent on planes that are not stored.
 enum { K_DIRECT = 0, K_DMA = 2 };
 
 static int kernel_choice()
@@ -715,33 +715,39 @@ static int kernel_choice()
     return tune_int("SMVS_COSTVOL_DIRECT", 0) == 1 ? K_DIRECT : K_DMA;      // A/B switch (tuning builds only)
 }
 
+template <int GEO, int NSRC, int DP>
+static hipError_t launch_staged(CostVolParams p, hipStream_t st)
+{
+    const int nd = p.d_end - p.d_begin;
+    p.xt = (p.W + WV_TX - 1) / WV_TX;
+    p.yt = (p.H + WV_TY * WV_WAVES - 1) / (WV_TY * WV_WAVES);
+    p.dch = DP;
+    p.dct = (nd + DP - 1) / DP;
+    const long long nb = (long long)p.xt * p.yt * p.dct * p.B;
+    if (nb >= (1ll << 31)) return hipErrorInvalidValue;
+    dim3 blk(64 * WV_WAVES), grd((unsigned)nb);
+    switch (p.C) {
+    case 8:  hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 8, DP>), grd, blk, 0, st, p); break;
+    case 16: hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 16, DP>), grd, blk, 0, st, p); break;
+    default: hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 32, DP>), grd, blk, 0, st, p); break;
+    }
+    return hipGetLastError();
+}
+
 template <int GEO, int NSRC>
 static hipError_t launch_ct(CostVolParams p, hipStream_t st)
 {
     const int nd = p.d_end - p.d_begin;
-    if constexpr (NSRC <= 2) {
-        // Measured on MI355X: the staged kernel wins for 2-3 views at C >= 16; at C = 8
-        // the float64 chain dominates and the direct kernel is 8 % faster; with 4+ sources two staging
-        // buffers no longer fit 3 workgroups per CU and the direct kernel is 2x faster.
-        const int kc = kernel_choice();
+    if constexpr (NSRC <= 4) {
         // one channel volume of the output < 2 GiB: the store descriptor spans two of them (num_records is 32-bit)
         // and 2^31 is the offset that marks a dropped store; 2 <= W,H < 65535: packed tap coordinates and the
         // exact-division argument of div_half_int
-        const bool staged_ok = (p.C == 16 || p.C == 32) && p.W >= 2 && p.H >= 2 && p.W < 65535 && p.H < 65535 &&
+        const bool staged_ok = (p.C == 8 || p.C == 16 || p.C == 32) && p.W >= 2 && p.H >= 2 && p.W < 65535 && p.H < 65535 &&
                                (long long)p.D_out * p.H * p.W * 4 < (1ll << 31);
-        if (kc != K_DIRECT && staged_ok) {
-            p.xt = (p.W + WV_TX - 1) / WV_TX;
-            p.yt = (p.H + WV_TY * WV_WAVES - 1) / (WV_TY * WV_WAVES);
-            p.dch = DM_DP;                                    // one staged plane group per wave (measured: 4 -> 0.865, 8 -> 0.873, 16 -> 0.90 ms)
-            p.dct = (nd + DM_DP - 1) / DM_DP;
-            const long long nb = (long long)p.xt * p.yt * p.dct * p.B;
-            if (nb >= (1ll << 31)) return hipErrorInvalidValue;
-            dim3 blk(64 * WV_WAVES), grd((unsigned)nb);
-            switch (p.C) {
-            case 16: hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 16>), grd, blk, 0, st, p); break;
-            default: hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 32>), grd, blk, 0, st, p); break;
-            }
-            return hipGetLastError();
+        if (kernel_choice() != K_DIRECT && staged_ok) {
+            if (nd == 1) return launch_staged<GEO, NSRC, 1>(p, st);
+            if (nd == 2) return launch_staged<GEO, NSRC, 2>(p, st);
+            return launch_staged<GEO, NSRC, 4>(p, st);
         }
     }
     p.xt = (p.W + TILE_X - 1) / TILE_X;
