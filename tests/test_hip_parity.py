@@ -307,27 +307,37 @@ def test_costvol_backward_matches_torch(dev, oracle):
 # ---- BASELINE.json full sizes: properties + oracle spot checks ------------------------------------
 @pytest.mark.parametrize("cfg", [
     dict(V=3, C=32, D=64, H=384, W=768, planes=(0, 31, 63)),      # config 2 (headline metric shape)
-    dict(V=5, C=32, D=8, H=768, W=1536, planes=(5,)),             # config 4: one GPU's 8-plane shard
+    dict(V=5, C=32, D=8, H=768, W=1536, planes=(5,)),             # config 4: one GPU's 8-plane shard, planes 50 m apart (boxes overflow: fallback path)
+    dict(V=5, C=32, D=8, H=768, W=1536, planes=(2,), span=(0.0, 44.4)),   # config 4 shard at its real spacing: 8 of 64 planes (staged 4-source kernel)
+    dict(V=3, C=32, D=48, H=96, W=192, planes=(0, 47)),           # config 3, stage 1: 48 planes on the 1/4-resolution grid
+    dict(V=3, C=16, D=32, H=192, W=384, planes=(7,), span=(150.0, 305.0)),    # config 3, stage 2: 32 planes 5 m apart
+    dict(V=3, C=8, D=8, H=384, W=768, planes=(0, 7), span=(190.0, 207.5)),    # config 3, stage 3: 8 planes 2.5 m apart, C=8
+    dict(V=3, C=32, D=64, H=384, W=768, planes=(0, 40), geo="pinhole"),       # config 5: homography volume at full size
 ])
 def test_full_size_properties(dev, oracle, cfg):
     from satmvs_amd.modules import warping
     V, C, D, H, W = cfg["V"], cfg["C"], cfg["D"], cfg["H"], cfg["W"]
-    feats, rpc, depth = _inputs(1, V, C, D, H, W, seed=11)
+    geo = cfg.get("geo", "rpc")
+    feats, rpc, depth = _inputs(1, V, C, D, H, W, seed=11, geo=geo)
+    if "span" in cfg:                                          # per-pixel jittered planes over the span a real launch sees
+        lo, hi = cfg["span"]
+        rng = np.random.default_rng(12)
+        depth = (np.linspace(lo, hi, D).reshape(1, D, 1, 1) + rng.normal(0, 0.5, (1, D, H, W))).astype(np.float32)
     f = [_t(x, dev) for x in feats]
     r, d = _t(rpc, dev), _t(depth, dev)
-    full = warping.variance_cost_volume(f, r, d, "rpc")
+    full = warping.variance_cost_volume(f, r, d, geo)
     assert full.shape == (1, C, D, H, W)
     assert torch.isfinite(full).all()
     # (1) variance is non-negative up to rounding: |min| << typical value
     assert full.min().item() > -1e-4
     # (2) shard consistency: two half-range launches reproduce the whole volume bit for bit, and
     #     the checksum of checksums matches
-    a = warping.variance_cost_volume(f, r, d, "rpc", d_begin=0, d_end=D // 2)
-    b = warping.variance_cost_volume(f, r, d, "rpc", d_begin=D // 2, d_end=D)
+    a = warping.variance_cost_volume(f, r, d, geo, d_begin=0, d_end=D // 2)
+    b = warping.variance_cost_volume(f, r, d, geo, d_begin=D // 2, d_end=D)
     assert torch.equal(torch.cat([a, b], 2), full)
     assert a.double().sum().item() + b.double().sum().item() == pytest.approx(full.double().sum().item(), rel=1e-12)
     # (3) idempotence: same launch twice, identical bits (no atomics / races in the forward)
-    assert torch.equal(warping.variance_cost_volume(f, r, d, "rpc"), full)
+    assert torch.equal(warping.variance_cost_volume(f, r, d, geo), full)
     # (4) spatially constant feature maps (one constant per channel and view): every in-image
     #     bilinear footprint returns that constant (weights sum to 1), so the volume equals the
     #     across-view variance of the constants wherever all taps are inside the image -- whatever
@@ -335,12 +345,14 @@ def test_full_size_properties(dev, oracle, cfg):
     #     offset by up to half a pixel, SURVEY.md Q1, and we reproduce that.)
     consts = torch.arange(1, V * C + 1, dtype=torch.float32, device=dev).view(V, C) / 7.0
     cf = [consts[v].view(1, C, 1, 1).expand(1, C, H, W).contiguous() for v in range(V)]
-    z = warping.variance_cost_volume(cf, r, d, "rpc", d_begin=D // 2, d_end=D // 2 + 1)
+    #     Evaluated on one plane near the cameras' height offset (small parallax), away from the image border.
+    mid = torch.full((1, 1, H, W), 200.0 if geo == "rpc" else 550.0, dtype=torch.float32, device=dev)
+    z = warping.variance_cost_volume(cf, r, mid, geo)
     want_c = (consts ** 2).mean(0) - consts.mean(0) ** 2
-    m = 48
+    m = min(64 if geo == "rpc" else 96, H // 4)          # the synthetic pinhole rig shifts view 2 by ~80 px at this depth
     err = (z[0, :, 0, m:-m, m:-m] - want_c.view(C, 1, 1)).abs().max().item()
     assert err < 1e-3 * float(want_c.max()), err
     # (5) oracle spot check on whole planes of the full-size volume
     for pl in cfg["planes"]:
-        want = oracle.costvol_variance(feats, rpc, depth, "rpc", d_begin=pl, d_end=pl + 1)[:, :, pl]
+        want = oracle.costvol_variance(feats, rpc, depth, geo, d_begin=pl, d_end=pl + 1)[:, :, pl]
         _close_f32(full[:, :, pl], want)
