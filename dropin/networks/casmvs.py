@@ -1,0 +1,6 @@
+"""Reference module name `networks.casmvs` -> satmvs_amd.networks.casmvs (dropin/README.md)."""
+from satmvs_amd.networks.casmvs import *  # noqa: F401,F403
+from satmvs_amd.networks import casmvs as _impl
+
+globals().update({n: getattr(_impl, n) for n in dir(_impl) if not n.startswith("_") and n != "annotations"})
+__all__ = [n for n in dir(_impl) if not n.startswith("_") and n != "annotations"]

@@ -177,3 +177,30 @@ def test_plane_range_partition():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_dropin_packages_resolve_reference_import_lines(tmp_path):
+    """dropin/ on PYTHONPATH makes the reference's own import lines (train.py:9-11, networks/casred.py:4-6) resolve to
+    the native engine with the reference's names; a stand-in `networks/loss.py` later on the path is still reachable."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake_ref = tmp_path / "ref"
+    (fake_ref / "networks").mkdir(parents=True)
+    (fake_ref / "networks" / "loss.py").write_text("def cas_mvsnet_loss():\n    return 'reference loss'\n")
+    code = (
+        "from networks.casred import CascadeREDNet, Infer_CascadeREDNet\n"
+        "from networks.casmvs import CascadeMVSNet\n"
+        "from networks.ucs import UCSNet\n"
+        "from networks.loss import *\n"
+        "from modules.warping import *\n"
+        "from modules.module import *\n"
+        "from modules.depth_range import *\n"
+        "import satmvs_amd.networks.casred as n, satmvs_amd.modules.warping as w\n"
+        "assert CascadeREDNet is n.CascadeREDNet and rpc_warping is w.rpc_warping and homo_warping is w.homo_warping\n"
+        "assert RPC_Photo2Obj is w.RPC_Photo2Obj and callable(get_depth_range_samples) and callable(depth_regression)\n"
+        "assert cas_mvsnet_loss() == 'reference loss'\n"
+        "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "dropin"), root, str(fake_ref)]))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
