@@ -46,6 +46,23 @@ const char* smvs_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* smvs_last_error(void);
 
+/* ---- height hypotheses generated inside the kernels ----------------------------
+ * Stages 2 and 3 of the cascades derive their hypotheses from the previous stage's height map:
+ * networks/casred.py:134-145 (bilinear resize to the image size, trilinear resize of the samples to the stage
+ * size) + modules/depth_range.py:4-20 (cur -/+ ndepth/2*interval, ndepth samples).  The *_gen entry points below
+ * take this description instead of a (B,D,H,W) tensor and evaluate it per pixel, with ATen's rounding.
+ * `interval` is a double because the reference multiplies python floats before the single cast to float32.
+ * Stage 1 needs no generator: its hypotheses are (B,D) planes (depth_is_4d = 0), exactly. */
+typedef struct smvs_height_gen {
+    const float* prev_height;   /* device, (B, prev_h, prev_w) float32: the previous stage's "depth" output */
+    int prev_h, prev_w;
+    int img_h, img_w;           /* image size; img / stage size must be 1 or 2 */
+    int ndepth;                 /* D of this stage */
+    double interval;            /* depth_inteval_pixel = depth_interals_ratio[stage] * min_interval */
+} smvs_height_gen;
+/* The hypotheses as a tensor (what the reference materialises), out (B,ndepth,H,W): training path and tests. */
+int smvs_height_hypotheses(const smvs_height_gen* gen, float* out, int B, int H, int W, void* stream);
+
 /* ---- fused warp + variance cost volume ----------------------------------------------------
  * Replaces the per-source loop  rpc_warping() + volume_sum/volume_sq_sum + variance
  *   modules/warping.py:310-365 (rpc_warping), networks/casred.py:22-53 (train, whole volume),
@@ -69,6 +86,15 @@ int smvs_homo_costvol_fwd(const float* ref_fea, const float* const* src_fea, int
                           const double* proj, const float* depth, int depth_is_4d, float* out_var,
                           int B, int C, int D, int H, int W,
                           int d_begin, int d_end, int D_out, int d_out_off, void* stream);
+/* The same two launches with the heights generated in the kernel (see smvs_height_gen above). */
+int smvs_rpc_costvol_fwd_gen(const float* ref_fea, const float* const* src_fea, int n_src,
+                             const double* rpc, const smvs_height_gen* gen, float* out_var,
+                             int B, int C, int D, int H, int W,
+                             int d_begin, int d_end, int D_out, int d_out_off, void* stream);
+int smvs_homo_costvol_fwd_gen(const float* ref_fea, const float* const* src_fea, int n_src,
+                              const double* proj, const smvs_height_gen* gen, float* out_var,
+                              int B, int C, int D, int H, int W,
+                              int d_begin, int d_end, int D_out, int d_out_off, void* stream);
 
 /* ---- stand-alone warps (the operator surface itself) ------------------------------------------
  * smvs_rpc_warp_fwd  = rpc_warping(src_fea, src_rpc, ref_rpc, depth_values, coef)
@@ -124,6 +150,12 @@ int smvs_softmax_regress_fwd(const float* reg, const float* depth, int depth_is_
 int smvs_window_regress_fwd(const float* reg, const float* depth, int depth_is_4d,
                             float* out_depth, float* out_conf, float* out_var, float lamb,
                             int B, int D, int H, int W, void* stream);
+/* softmax / window regression with the heights generated in the kernel (smvs_height_gen, gen->ndepth == D) */
+int smvs_softmax_regress_fwd_gen(const float* reg, const smvs_height_gen* gen,
+                                 float* out_depth, float* out_conf, int B, int D, int H, int W, void* stream);
+int smvs_window_regress_fwd_gen(const float* reg, const smvs_height_gen* gen,
+                                float* out_depth, float* out_conf, float* out_var, float lamb,
+                                int B, int D, int H, int W, void* stream);
 /* Pred path, one plane d: prob = exp(double(reg)); max_prob = max(.,prob); depth_img += h*prob;
  * exp_sum += prob (networks/casred.py:218-231).  Accumulators (B,H,W) float64, zeroed by the
  * caller before plane 0.  reg_plane (B,H,W). */
@@ -178,6 +210,17 @@ int smvs_red_volume_planes(int geo_kind, const float* ref_fea, const float* cons
                            float* state1, float* state2, float* state3, float* state4, float* reg_volume,
                            void* workspace, size_t workspace_bytes,
                            int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream);
+/* Both plane pipelines with the heights generated in the kernels (smvs_height_gen, gen->ndepth == D). */
+int smvs_red_pred_planes_gen(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
+                             const double* geo, const smvs_height_gen* gen, const float* packed,
+                             float* state1, float* state2, float* state3, float* state4, double* acc,
+                             void* workspace, size_t workspace_bytes,
+                             int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream);
+int smvs_red_volume_planes_gen(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
+                               const double* geo, const smvs_height_gen* gen, const float* packed,
+                               float* state1, float* state2, float* state3, float* state4, float* reg_volume,
+                               void* workspace, size_t workspace_bytes,
+                               int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream);
 
 /* ---- 3-D convolutional cost regulariser (CostRegNet), inference form ---------------------------------
  * Replaces CostRegNet.forward (modules/module.py:546-577; Conv3d :324, Deconv3d :369) for

@@ -416,6 +416,57 @@ ORC_API void orc_softmax_regress(const float *reg, const float *depth, int depth
         }
 }
 
+/* Height hypotheses of cascade stages 2 and 3 (networks/casred.py:134-145 + modules/depth_range.py:4-20):
+ *   cur = bilinear resize (align_corners=False) of the previous height map (B,hp,wp) to the image size (ih,iw);
+ *   cur_min = cur - c, cur_max = cur + c with c = (float)(ndepth / 2 * interval); step = (cur_max - cur_min) / (ndepth - 1);
+ *   samples[d] = cur_min + d * step at image resolution; trilinear resize (align_corners=False) to (D, ih/scale, iw/scale).
+ * ATen's CPU kernels evaluate every two-term interpolation as fma(w0, v0, w1 * v1) (checked bit for bit against the
+ * reference, tests/test_oracle_golden.py::test_height_hypotheses); the plane axis keeps its size (weights 1 and 0). */
+static float orc_lerp2(float w0, float v0, float w1, float v1) { return fmaf(w0, v0, w1 * v1); }
+
+static void orc_hyp_pixel(const float *prev, int hp, int wp, int ih, int iw, float c, float ndm1, int Y, int X,
+                          float *cmin, float *step)
+{
+    float sh = (float)hp / (float)ih, sw = (float)wp / (float)iw;
+    float sy = fmaxf(sh * ((float)Y + 0.5f) - 0.5f, 0.0f), sx = fmaxf(sw * ((float)X + 0.5f) - 0.5f, 0.0f);
+    int y0 = (int)sy, x0 = (int)sx;
+    int y1 = y0 + 1 < hp ? y0 + 1 : hp - 1, x1 = x0 + 1 < wp ? x0 + 1 : wp - 1;
+    float ly1 = sy - (float)y0, lx1 = sx - (float)x0, ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+    float top = orc_lerp2(lx0, prev[y0 * wp + x0], lx1, prev[y0 * wp + x1]);
+    float bot = orc_lerp2(lx0, prev[y1 * wp + x0], lx1, prev[y1 * wp + x1]);
+    float cur = orc_lerp2(ly0, top, ly1, bot);
+    *cmin = cur - c;
+    *step = ((cur + c) - *cmin) / ndm1;
+}
+
+ORC_API int orc_height_hypotheses(const float *prev, int B, int hp, int wp, int ih, int iw, int ndepth, double interval,
+                                  int H, int W, float *out)
+{
+    if (ih % H || iw % W || ih / H != iw / W) return 1;
+    int scale = ih / H;
+    if (scale != 1 && scale != 2) return 1;
+    float c = (float)(ndepth / 2.0 * interval), ndm1 = (float)(ndepth - 1);
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                float cm[4], st[4];
+                int n = scale == 1 ? 1 : 4;
+                for (int k = 0; k < n; ++k)
+                    orc_hyp_pixel(prev + (size_t)b * hp * wp, hp, wp, ih, iw, c, ndm1,
+                                  scale == 1 ? y : 2 * y + (k >> 1), scale == 1 ? x : 2 * x + (k & 1), &cm[k], &st[k]);
+                for (int d = 0; d < ndepth; ++d) {
+                    float fd = (float)d, v;
+                    if (scale == 1) v = cm[0] + fd * st[0];
+                    else {
+                        float a = cm[0] + fd * st[0], bb = cm[1] + fd * st[1], cc = cm[2] + fd * st[2], dd = cm[3] + fd * st[3];
+                        v = orc_lerp2(0.5f, orc_lerp2(0.5f, a, 0.5f, bb), 0.5f, orc_lerp2(0.5f, cc, 0.5f, dd));
+                    }
+                    out[(((size_t)b * ndepth + d) * H + y) * W + x] = v;
+                }
+            }
+    return 0;
+}
+
 /* CascadeMVSNet / UCSNet regression (networks/casmvs.py:66-74, networks/ucs.py:60-74): softmax over D, expected
  * height, photometric confidence = probability mass of the four hypotheses [idx-1, idx+2] around
  * idx = clamp(trunc(E[index]), 0, D-1) -- F.pad(prob,(0,0,0,0,1,2)) + 4*avg_pool3d((4,1,1)) + gather -- and UCSNet's

@@ -157,6 +157,29 @@ def softmax_regress(reg, depth):
     return od, oc
 
 
+def height_hypotheses(prev, ndepth, interval, img_hw, stage_hw):
+    """(B,D,H,W) hypotheses of a generated cascade stage from the previous height map -- orc_height_hypotheses."""
+    import ctypes
+    prev = _f32(prev)
+    B, hp, wp = prev.shape
+    (ih, iw), (H, W) = img_hw, stage_hw
+    out = np.empty((B, ndepth, H, W), np.float32)
+    f = lib().orc_height_hypotheses
+    f.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    f.restype = ctypes.c_int
+    if f(_p(prev), B, hp, wp, ih, iw, ndepth, float(interval), H, W, _p(out)) != 0:
+        raise ValueError("image / stage size ratio must be 1 or 2")
+    return out
+
+
+def stage1_planes(depth_range, ndepth):
+    """(B,D) planes of stage 1 (modules/depth_range.py:26-33): min + arange * (max - min) / (ndepth - 1), float32."""
+    dr = _f32(depth_range)
+    lo, hi = dr[:, 0], dr[:, -1]
+    step = ((hi - lo).astype(np.float32) / np.float32(ndepth - 1)).astype(np.float32)
+    return (lo[:, None] + (np.arange(ndepth, dtype=np.float32)[None] * step[:, None]).astype(np.float32)).astype(np.float32)
+
+
 def window_regress(reg, depth, lamb=None):
     """casmvs / ucs regression: (depth, window-4 confidence[, lamb * std-dev]) -- orc_window_regress."""
     reg = _f32(reg)

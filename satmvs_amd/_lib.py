@@ -30,6 +30,13 @@ _SIGNATURES = {
     "smvs_rpc_project": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
     "smvs_softmax_regress_fwd": [_vp, _vp, _i, _vp, _vp] + [_i] * 4 + [_vp],
     "smvs_window_regress_fwd": [_vp, _vp, _i, _vp, _vp, _vp, _f] + [_i] * 4 + [_vp],
+    "smvs_height_hypotheses": [_vp, _vp, _i, _i, _i, _vp],
+    "smvs_rpc_costvol_fwd_gen": [_vp, _vp, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp],
+    "smvs_homo_costvol_fwd_gen": [_vp, _vp, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp],
+    "smvs_softmax_regress_fwd_gen": [_vp, _vp, _vp, _vp] + [_i] * 4 + [_vp],
+    "smvs_window_regress_fwd_gen": [_vp, _vp, _vp, _vp, _vp, _f] + [_i] * 4 + [_vp],
+    "smvs_red_pred_planes_gen": [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 7 + [_vp],
+    "smvs_red_volume_planes_gen": [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 7 + [_vp],
     "smvs_stream_regress_step": [_vp, _vp, _i, _vp, _vp, _vp] + [_i] * 5 + [_vp],
     "smvs_stream_regress_final": [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "smvs_red_pack_weights": [_vp, _i, _vp, _vp],

@@ -43,7 +43,8 @@ struct CostVolParams {
     int B, V, C, D, H, W;
     int d_begin, d_end;             // planes built by this launch
     int D_out, d_out_off;           // plane d lands at index d - d_begin + d_out_off of `out`
-    int depth_is_4d;
+    int depth_is_4d;                // HEIGHT_PLANES | HEIGHT_TENSOR | HEIGHT_GENERATED
+    HeightGen hg;                   // HEIGHT_GENERATED: hypotheses computed per pixel from the previous stage's map
     int xt, yt, dct, dch;           // tiles in x, y; plane chunks; planes per chunk
     float rV, r_half_wm1, r_half_hm1;   // RN(1/V), RN(1/((W-1)/2)), RN(1/((H-1)/2)) in float32, divided once on the host
 };
@@ -101,9 +102,11 @@ void costvol_fwd_kernel(const CostVolParams p)
 
     float* outp = p.out + (size_t)b * C * p.D_out * HW + pix;
 
+    HeightPix hpx;
+    if (p.depth_is_4d == HEIGHT_GENERATED) hg_prepare(p.hg, b, y, x, hpx);
     for (int d = d0; d < d1; ++d) {
-        const float hf = p.depth_is_4d ? p.depth[((size_t)b * p.D + d) * HW + pix]
-                                       : p.depth[(size_t)b * p.D + d];
+        const float hf = p.depth_is_4d == HEIGHT_GENERATED ? hg_height(p.hg, hpx, d)
+                         : p.depth_is_4d ? p.depth[((size_t)b * p.D + d) * HW + pix] : p.depth[(size_t)b * p.D + d];
         const double h = (double)hf;
 
         // Launder the (wave-uniform) coefficient pointer once per plane: without this the compiler
@@ -337,10 +340,17 @@ void costvol_dma_kernel(const CostVolParams p)
     SMVS_T(const unsigned long long t_start = now(); unsigned long long t_vm = 0, t_dma = 0, t_st = 0;)
     // heights of the group's planes (tail planes shadow the last one; they are never stored)
     float hf[DP];
+    if (p.depth_is_4d == HEIGHT_GENERATED) {
+        HeightPix hpx;
+        hg_prepare(p.hg, b, min(y, H - 1), min(x, W - 1), hpx);
 #pragma unroll
-    for (int pl = 0; pl < DP; ++pl) {
-        const int d = min(dg + pl, p.d_end - 1);
-        hf[pl] = p.depth_is_4d ? p.depth[((size_t)b * p.D + d) * HW + pix] : p.depth[(size_t)b * p.D + d];
+        for (int pl = 0; pl < DP; ++pl) hf[pl] = hg_height(p.hg, hpx, min(dg + pl, p.d_end - 1));
+    } else {
+#pragma unroll
+        for (int pl = 0; pl < DP; ++pl) {
+            const int d = min(dg + pl, p.d_end - 1);
+            hf[pl] = p.depth_is_4d ? p.depth[((size_t)b * p.D + d) * HW + pix] : p.depth[(size_t)b * p.D + d];
+        }
     }
 
     // ---- A: taps of the group's planes -----------------------------------------------------------
@@ -782,11 +792,11 @@ static hipError_t launch_nsrc(const CostVolParams& p, hipStream_t st)
 }
 
 static int costvol_fwd(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
-                       const double* geo, const float* depth, int depth_is_4d, float* out,
+                       const double* geo, const float* depth, int depth_is_4d, const smvs_height_gen* gen, float* out,
                        int B, int C, int D, int H, int W, int d_begin, int d_end, int D_out, int d_out_off,
                        void* stream)
 {
-    if (!ref_fea || !src_fea || !geo || !depth || !out) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (!ref_fea || !src_fea || !geo || (!depth && !gen) || !out) return fail(SMVS_ERR_ARG, "null pointer argument");
     if (n_src < 1 || n_src > MAX_SRC) return fail(SMVS_ERR_ARG, "n_src must be in [1,7] (2..8 views), got %d", n_src);
     if (B < 1 || C < 1 || D < 1 || H < 1 || W < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
     if (d_begin < 0 || d_end > D || d_begin > d_end) return fail(SMVS_ERR_ARG, "bad plane range [%d,%d) of %d", d_begin, d_end, D);
@@ -802,7 +812,14 @@ static int costvol_fwd(int geo_kind, const float* ref_fea, const float* const* s
     p.geo = geo; p.depth = depth; p.out = out;
     p.B = B; p.V = n_src + 1; p.C = C; p.D = D; p.H = H; p.W = W;
     p.d_begin = d_begin; p.d_end = d_end; p.D_out = D_out; p.d_out_off = d_out_off;
-    p.depth_is_4d = depth_is_4d;
+    p.depth_is_4d = depth_is_4d ? HEIGHT_TENSOR : HEIGHT_PLANES;
+    if (gen) {
+        HeightGenHost hh;
+        if (const char* msg = height_gen_check(gen, D, H, W, hh)) return fail(SMVS_ERR_ARG, "%s", msg);
+        p.depth_is_4d = HEIGHT_GENERATED;
+        p.hg.prev = hh.prev; p.hg.hp = hh.hp; p.hg.wp = hh.wp; p.hg.ih = hh.ih; p.hg.iw = hh.iw; p.hg.scale = hh.scale;
+        p.hg.c = hh.c; p.hg.ndm1 = hh.ndm1;
+    }
     p.rV = 1.0f / (float)(n_src + 1);
     p.r_half_wm1 = 1.0f / (float)((W - 1) * 0.5);
     p.r_half_hm1 = 1.0f / (float)((H - 1) * 0.5);
@@ -831,7 +848,16 @@ SMVS_EXPORT int smvs_rpc_costvol_fwd(const float* ref_fea, const float* const* s
                                      int B, int C, int D, int H, int W,
                                      int d_begin, int d_end, int D_out, int d_out_off, void* stream)
 {
-    return smvs::costvol_fwd(0, ref_fea, src_fea, n_src, rpc, depth, depth_is_4d, out_var,
+    return smvs::costvol_fwd(0, ref_fea, src_fea, n_src, rpc, depth, depth_is_4d, nullptr, out_var,
+                             B, C, D, H, W, d_begin, d_end, D_out, d_out_off, stream);
+}
+
+SMVS_EXPORT int smvs_rpc_costvol_fwd_gen(const float* ref_fea, const float* const* src_fea, int n_src,
+                                         const double* rpc, const smvs_height_gen* gen, float* out_var,
+                                         int B, int C, int D, int H, int W,
+                                         int d_begin, int d_end, int D_out, int d_out_off, void* stream)
+{
+    return smvs::costvol_fwd(0, ref_fea, src_fea, n_src, rpc, nullptr, 0, gen, out_var,
                              B, C, D, H, W, d_begin, d_end, D_out, d_out_off, stream);
 }
 
@@ -840,7 +866,16 @@ SMVS_EXPORT int smvs_homo_costvol_fwd(const float* ref_fea, const float* const* 
                                       int B, int C, int D, int H, int W,
                                       int d_begin, int d_end, int D_out, int d_out_off, void* stream)
 {
-    return smvs::costvol_fwd(1, ref_fea, src_fea, n_src, proj, depth, depth_is_4d, out_var,
+    return smvs::costvol_fwd(1, ref_fea, src_fea, n_src, proj, depth, depth_is_4d, nullptr, out_var,
+                             B, C, D, H, W, d_begin, d_end, D_out, d_out_off, stream);
+}
+
+SMVS_EXPORT int smvs_homo_costvol_fwd_gen(const float* ref_fea, const float* const* src_fea, int n_src,
+                                          const double* proj, const smvs_height_gen* gen, float* out_var,
+                                          int B, int C, int D, int H, int W,
+                                          int d_begin, int d_end, int D_out, int d_out_off, void* stream)
+{
+    return smvs::costvol_fwd(1, ref_fea, src_fea, n_src, proj, nullptr, 0, gen, out_var,
                              B, C, D, H, W, d_begin, d_end, D_out, d_out_off, stream);
 }
 

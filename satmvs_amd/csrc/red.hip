@@ -512,6 +512,10 @@ static void launch_convT(const ConvArgs& a, int B, hipStream_t st)
 // that cross streams form a ring of NBUF planes and one back-pressure wait per plane keeps plane k off the
 // buffers of plane k-NBUF.  SMVS_RED_STREAMS = 0 (caller's stream only) | 2 (levels {4,3} and {2,1}; default:
 // the host enqueue rate, not the GPU, bounds the loop, and this needs the fewest event edges) | 4 (one per level).
+int stream_regress_step(const float* reg_plane, const float* depth, int depth_is_4d, const smvs_height_gen* gen,
+                        double* exp_sum, double* depth_img, double* max_prob,
+                        int B, int D, int H, int W, int d, void* stream);               // regress.hip
+
 constexpr int RING = 2 * NBUF;
 struct RedPipe {
     int mode = 0;
@@ -569,7 +573,7 @@ struct RedRun {
     const float* cost; float* reg_out;
     // pred loop (pred = true): cost-volume plane built here, regression accumulators updated here
     bool pred; int geo_kind; const float* ref_fea; const float* const* src_fea; int n_src; const double* geo;
-    const float* depth; int depth_is_4d; double* acc; int D;
+    const float* depth; int depth_is_4d; const smvs_height_gen* gen; double* acc; int D;
     float* reg_volume;                       // pred with acc == null: regularised planes go to (B,D,H,W) instead
     float* plane[NBUF]; float* reg;
 };
@@ -603,9 +607,13 @@ struct RedIssuer {
         const int enc_in[3] = {C, 16, 32}, enc_out[3] = {16, 32, 64};
         if (r.pred) {
             float* pl = r.plane[buf];
-            const int rc = r.geo_kind == 0
-                ? smvs_rpc_costvol_fwd(r.ref_fea, r.src_fea, r.n_src, r.geo, r.depth, r.depth_is_4d, pl, B, C, r.D, r.H, r.W, d, d + 1, 1, 0, r.main)
-                : smvs_homo_costvol_fwd(r.ref_fea, r.src_fea, r.n_src, r.geo, r.depth, r.depth_is_4d, pl, B, C, r.D, r.H, r.W, d, d + 1, 1, 0, r.main);
+            const int rc = r.gen
+                ? (r.geo_kind == 0
+                   ? smvs_rpc_costvol_fwd_gen(r.ref_fea, r.src_fea, r.n_src, r.geo, r.gen, pl, B, C, r.D, r.H, r.W, d, d + 1, 1, 0, r.main)
+                   : smvs_homo_costvol_fwd_gen(r.ref_fea, r.src_fea, r.n_src, r.geo, r.gen, pl, B, C, r.D, r.H, r.W, d, d + 1, 1, 0, r.main))
+                : (r.geo_kind == 0
+                   ? smvs_rpc_costvol_fwd(r.ref_fea, r.src_fea, r.n_src, r.geo, r.depth, r.depth_is_4d, pl, B, C, r.D, r.H, r.W, d, d + 1, 1, 0, r.main)
+                   : smvs_homo_costvol_fwd(r.ref_fea, r.src_fea, r.n_src, r.geo, r.depth, r.depth_is_4d, pl, B, C, r.D, r.H, r.W, d, d + 1, 1, 0, r.main));
             if (rc) return rc;
         }
         const float* cost = cost_of(k);
@@ -691,8 +699,8 @@ struct RedIssuer {
                     if (r.pred && r.reg_volume) f.out_bstride = (size_t)r.D * r.H * r.W;
                     launch_conv(1, f, B, st);
                     if (r.pred && !r.reg_volume) {
-                        const int rc = smvs_stream_regress_step(reg, r.depth, r.depth_is_4d, r.acc, r.acc + npix, r.acc + 2 * npix,
-                                                                B, r.D, r.H, r.W, d, st);
+                        const int rc = stream_regress_step(reg, r.depth, r.depth_is_4d, r.gen, r.acc, r.acc + npix, r.acc + 2 * npix,
+                                                           B, r.D, r.H, r.W, d, st);
                         if (rc) return rc;
                     }
                     if (multi) (void)hipEventRecord(P.done[slot], st);
@@ -835,7 +843,7 @@ SMVS_EXPORT size_t smvs_red_pred_workspace_bytes(int B, int C, int H, int W)
 }
 
 static int red_planes_entry(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
-                            const double* geo, const float* depth, int depth_is_4d, const float* packed,
+                            const double* geo, const float* depth, int depth_is_4d, const smvs_height_gen* gen, const float* packed,
                             float* state1, float* state2, float* state3, float* state4, double* acc, float* reg_volume,
                             void* workspace, size_t workspace_bytes,
                             int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream)
@@ -847,14 +855,14 @@ static int red_planes_entry(int geo_kind, const float* ref_fea, const float* con
     if (need == 0) return fail(SMVS_ERR_ARG, "plane %dx%d must be a positive multiple of 8 in both dimensions", H, W);
     if (workspace_bytes < need) return fail(SMVS_ERR_ARG, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
     if (d_begin < 0 || d_end > D || d_begin > d_end) return fail(SMVS_ERR_ARG, "bad plane range [%d,%d) of %d", d_begin, d_end, D);
-    if (!packed || !state1 || !state2 || !state3 || !state4 || !ref_fea || !src_fea || !geo || !depth)
+    if (!packed || !state1 || !state2 || !state3 || !state4 || !ref_fea || !src_fea || !geo || (!depth && !gen))
         return fail(SMVS_ERR_ARG, "null pointer argument");
     const size_t red_bytes = smvs_red_workspace_bytes(B, C, H, W);
     RedRun r{};
     r.packed = packed; r.state[0] = state1; r.state[1] = state2; r.state[2] = state3; r.state[3] = state4;
     r.wsf = (float*)workspace; r.B = B; r.C = C; r.H = H; r.W = W; r.main = (hipStream_t)stream;
     r.pred = true; r.geo_kind = geo_kind; r.ref_fea = ref_fea; r.src_fea = src_fea; r.n_src = n_src; r.geo = geo;
-    r.depth = depth; r.depth_is_4d = depth_is_4d; r.acc = acc; r.reg_volume = reg_volume; r.D = D;
+    r.depth = depth; r.depth_is_4d = depth_is_4d; r.gen = gen; r.acc = acc; r.reg_volume = reg_volume; r.D = D;
     r.plane[0] = (float*)((char*)workspace + ((red_bytes + 15) & ~(size_t)15));
     for (int p = 1; p < NBUF; ++p) r.plane[p] = r.plane[p - 1] + (size_t)B * C * H * W;
     r.reg = r.plane[NBUF - 1] + (size_t)B * C * H * W;
@@ -868,7 +876,18 @@ SMVS_EXPORT int smvs_red_pred_planes(int geo_kind, const float* ref_fea, const f
                                      int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream)
 {
     if (!acc) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
-    return red_planes_entry(geo_kind, ref_fea, src_fea, n_src, geo, depth, depth_is_4d, packed, state1, state2, state3, state4,
+    return red_planes_entry(geo_kind, ref_fea, src_fea, n_src, geo, depth, depth_is_4d, nullptr, packed, state1, state2, state3, state4,
+                            acc, nullptr, workspace, workspace_bytes, B, C, D, H, W, d_begin, d_end, stream);
+}
+
+SMVS_EXPORT int smvs_red_pred_planes_gen(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
+                                         const double* geo, const smvs_height_gen* gen, const float* packed,
+                                         float* state1, float* state2, float* state3, float* state4, double* acc,
+                                         void* workspace, size_t workspace_bytes,
+                                         int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream)
+{
+    if (!acc || !gen) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
+    return red_planes_entry(geo_kind, ref_fea, src_fea, n_src, geo, nullptr, 0, gen, packed, state1, state2, state3, state4,
                             acc, nullptr, workspace, workspace_bytes, B, C, D, H, W, d_begin, d_end, stream);
 }
 
@@ -883,7 +902,18 @@ SMVS_EXPORT int smvs_red_volume_planes(int geo_kind, const float* ref_fea, const
                                        int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream)
 {
     if (!reg_volume) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
-    return red_planes_entry(geo_kind, ref_fea, src_fea, n_src, geo, depth, depth_is_4d, packed, state1, state2, state3, state4,
+    return red_planes_entry(geo_kind, ref_fea, src_fea, n_src, geo, depth, depth_is_4d, nullptr, packed, state1, state2, state3, state4,
+                            nullptr, reg_volume, workspace, workspace_bytes, B, C, D, H, W, d_begin, d_end, stream);
+}
+
+SMVS_EXPORT int smvs_red_volume_planes_gen(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
+                                           const double* geo, const smvs_height_gen* gen, const float* packed,
+                                           float* state1, float* state2, float* state3, float* state4, float* reg_volume,
+                                           void* workspace, size_t workspace_bytes,
+                                           int B, int C, int D, int H, int W, int d_begin, int d_end, void* stream)
+{
+    if (!reg_volume || !gen) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
+    return red_planes_entry(geo_kind, ref_fea, src_fea, n_src, geo, nullptr, 0, gen, packed, state1, state2, state3, state4,
                             nullptr, reg_volume, workspace, workspace_bytes, B, C, D, H, W, d_begin, d_end, stream);
 }
 

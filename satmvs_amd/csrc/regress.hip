@@ -17,14 +17,16 @@ namespace smvs {
 // arithmetic as torch's softmax followed by the reference's two reductions; the 2nd/3rd sweep
 // hit L2 (D*4 bytes per pixel, 256 B at D=64).
 __global__ __launch_bounds__(256)
-void softmax_regress_kernel(const float* __restrict__ reg, const float* __restrict__ depth, int depth_is_4d,
+void softmax_regress_kernel(const float* __restrict__ reg, const float* __restrict__ depth, int depth_is_4d, HeightGen hg,
                             float* __restrict__ out_depth, float* __restrict__ out_conf,
-                            int B, int D, int HW)
+                            int B, int D, int HW, int W)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * HW) return;
     const int b = (int)(i / HW);
     const int pix = (int)(i % HW);
+    HeightPix hpx;
+    if (depth_is_4d == HEIGHT_GENERATED) hg_prepare(hg, b, pix / W, pix % W, hpx);
     const float* r = reg + (size_t)b * D * HW + pix;
     float mx = r[0];
     for (int d = 1; d < D; ++d) mx = fmaxf(mx, r[(size_t)d * HW]);
@@ -33,7 +35,8 @@ void softmax_regress_kernel(const float* __restrict__ reg, const float* __restri
     float acc = 0.0f, best = 0.0f;
     for (int d = 0; d < D; ++d) {
         const float pr = __fdiv_rn(expf(r[(size_t)d * HW] - mx), den);
-        const float hv = depth_is_4d ? depth[((size_t)b * D + d) * HW + pix] : depth[(size_t)b * D + d];
+        const float hv = depth_is_4d == HEIGHT_GENERATED ? hg_height(hg, hpx, d)
+                         : depth_is_4d ? depth[((size_t)b * D + d) * HW + pix] : depth[(size_t)b * D + d];
         acc = acc + pr * hv;
         best = (d == 0 || pr > best) ? pr : best;
     }
@@ -49,17 +52,21 @@ void softmax_regress_kernel(const float* __restrict__ reg, const float* __restri
 // One lane per pixel; the D regulariser values of a pixel are re-read per pass (they sit in L2: a stage volume is
 // 3.5 - 9.4 MB).  float32 throughout, same operation order as the torch composite the reference runs.
 __global__ __launch_bounds__(256)
-void window_regress_kernel(const float* __restrict__ reg, const float* __restrict__ depth, int depth_is_4d,
+void window_regress_kernel(const float* __restrict__ reg, const float* __restrict__ depth, int depth_is_4d, HeightGen hg,
                            float* __restrict__ out_depth, float* __restrict__ out_conf, float* __restrict__ out_var,
-                           float lamb, int B, int D, int HW)
+                           float lamb, int B, int D, int HW, int W)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * HW) return;
     const int b = (int)(i / HW);
     const int pix = (int)(i % HW);
     const float* r = reg + (size_t)b * D * HW + pix;
-    const float* hp = depth_is_4d ? depth + (size_t)b * D * HW + pix : depth + (size_t)b * D;
+    const bool gen = depth_is_4d == HEIGHT_GENERATED;
+    HeightPix hpx;
+    if (gen) hg_prepare(hg, b, pix / W, pix % W, hpx);
+    const float* hp = gen ? r : (depth_is_4d ? depth + (size_t)b * D * HW + pix : depth + (size_t)b * D);
     const size_t hs = depth_is_4d ? (size_t)HW : 1;
+    auto height = [&](int d) { return gen ? hg_height(hg, hpx, d) : hp[d * hs]; };
     float mx = r[0];
     for (int d = 1; d < D; ++d) mx = fmaxf(mx, r[(size_t)d * HW]);
     float den = 0.0f;
@@ -67,7 +74,7 @@ void window_regress_kernel(const float* __restrict__ reg, const float* __restric
     float acc = 0.0f, fidx = 0.0f;
     for (int d = 0; d < D; ++d) {
         const float pr = __fdiv_rn(expf(r[(size_t)d * HW] - mx), den);
-        acc = acc + pr * hp[d * hs];
+        acc = acc + pr * height(d);
         fidx = fidx + pr * (float)d;
     }
     int idx = (int)fidx;                                   // .long(): truncation (the value is >= 0)
@@ -84,25 +91,45 @@ void window_regress_kernel(const float* __restrict__ reg, const float* __restric
         float v = 0.0f;
         for (int d = 0; d < D; ++d) {
             const float pr = __fdiv_rn(expf(r[(size_t)d * HW] - mx), den);
-            const float dh = hp[d * hs] - acc;
+            const float dh = height(d) - acc;
             v = v + (dh * dh) * pr;
         }
         out_var[i] = lamb * sqrtf(v);
     }
 }
 
+// ---- the generated hypotheses as a (B,D,H,W) tensor (training path, tests) ------------------------------------
+__global__ __launch_bounds__(256)
+void height_hypotheses_kernel(HeightGen hg, float* __restrict__ out, int B, int D, int HW, int W)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * HW) return;
+    const int b = (int)(i / HW);
+    const int pix = (int)(i % HW);
+    HeightPix hpx;
+    hg_prepare(hg, b, pix / W, pix % W, hpx);
+    for (int d = 0; d < D; ++d) out[((size_t)b * D + d) * HW + pix] = hg_height(hg, hpx, d);
+}
+
 // ---- pred path, one plane: float64 accumulators, no max-subtraction (casred.py:218-231) -----------
 __global__ __launch_bounds__(256)
 void stream_regress_step_kernel(const float* __restrict__ reg_plane, const float* __restrict__ depth,
-                                int depth_is_4d, double* __restrict__ exp_sum, double* __restrict__ depth_img,
-                                double* __restrict__ max_prob, int B, int D, int HW, int d)
+                                int depth_is_4d, HeightGen hg, double* __restrict__ exp_sum, double* __restrict__ depth_img,
+                                double* __restrict__ max_prob, int B, int D, int HW, int W, int d)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * HW) return;
     const int b = (int)(i / HW);
     const int pix = (int)(i % HW);
     const double pr = exp((double)reg_plane[i]);
-    const double hv = depth_is_4d ? (double)depth[((size_t)b * D + d) * HW + pix] : (double)depth[(size_t)b * D + d];
+    double hv;
+    if (depth_is_4d == HEIGHT_GENERATED) {
+        HeightPix hpx;
+        hg_prepare(hg, b, pix / W, pix % W, hpx);
+        hv = (double)hg_height(hg, hpx, d);
+    } else {
+        hv = depth_is_4d ? (double)depth[((size_t)b * D + d) * HW + pix] : (double)depth[(size_t)b * D + d];
+    }
     const double m = max_prob[i];
     max_prob[i] = (m < pr) ? pr : m;
     depth_img[i] = fma(hv, pr, depth_img[i]);
@@ -158,39 +185,117 @@ SMVS_EXPORT const char* smvs_version(void) { return "satmvs-hip 0.1.0 gfx950"; }
 
 SMVS_EXPORT const char* smvs_last_error(void) { return smvs::last_error_buf(); }
 
+}  // extern "C"
+
+namespace smvs {
+
+// heights: exactly one of (depth, gen)
+static int resolve_heights(const float* depth, int depth_is_4d, const smvs_height_gen* gen, int D, int H, int W,
+                           int& mode, HeightGen& hg)
+{
+    hg = HeightGen{};
+    if (gen) {
+        HeightGenHost hh;
+        if (const char* msg = height_gen_check(gen, D, H, W, hh)) return fail(SMVS_ERR_ARG, "%s", msg);
+        hg.prev = hh.prev; hg.hp = hh.hp; hg.wp = hh.wp; hg.ih = hh.ih; hg.iw = hh.iw; hg.scale = hh.scale; hg.c = hh.c; hg.ndm1 = hh.ndm1;
+        mode = HEIGHT_GENERATED;
+        return SMVS_OK;
+    }
+    if (!depth) return fail(SMVS_ERR_ARG, "null pointer argument");
+    mode = depth_is_4d ? HEIGHT_TENSOR : HEIGHT_PLANES;
+    return SMVS_OK;
+}
+
+static int softmax_regress(const float* reg, const float* depth, int depth_is_4d, const smvs_height_gen* gen,
+                           float* out_depth, float* out_conf, int B, int D, int H, int W, void* stream)
+{
+    if (!reg || !out_depth || !out_conf) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (B < 1 || D < 1 || H < 1 || W < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
+    int mode; HeightGen hg;
+    if (int rc = resolve_heights(depth, depth_is_4d, gen, D, H, W, mode, hg)) return rc;
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(softmax_regress_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, reg, depth, mode, hg, out_depth, out_conf, B, D, H * W, W);
+    return check_launch("softmax_regress");
+}
+
+static int window_regress(const float* reg, const float* depth, int depth_is_4d, const smvs_height_gen* gen,
+                          float* out_depth, float* out_conf, float* out_var, float lamb,
+                          int B, int D, int H, int W, void* stream)
+{
+    if (!reg || !out_depth || !out_conf) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (B < 1 || D < 1 || H < 1 || W < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
+    int mode; HeightGen hg;
+    if (int rc = resolve_heights(depth, depth_is_4d, gen, D, H, W, mode, hg)) return rc;
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(window_regress_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, reg, depth, mode, hg, out_depth, out_conf, out_var, lamb, B, D, H * W, W);
+    return check_launch("window_regress");
+}
+
+int stream_regress_step(const float* reg_plane, const float* depth, int depth_is_4d, const smvs_height_gen* gen,
+                        double* exp_sum, double* depth_img, double* max_prob,
+                        int B, int D, int H, int W, int d, void* stream)
+{
+    if (!reg_plane || !exp_sum || !depth_img || !max_prob) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (B < 1 || D < 1 || H < 1 || W < 1 || d < 0 || d >= D) return fail(SMVS_ERR_ARG, "bad dimension or plane index %d of %d", d, D);
+    int mode; HeightGen hg;
+    if (int rc = resolve_heights(depth, depth_is_4d, gen, D, H, W, mode, hg)) return rc;
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(stream_regress_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, reg_plane, depth, mode, hg, exp_sum, depth_img, max_prob, B, D, H * W, W, d);
+    return check_launch("stream_regress_step");
+}
+
+}  // namespace smvs
+
+extern "C" {
+
+SMVS_EXPORT int smvs_height_hypotheses(const smvs_height_gen* gen, float* out, int B, int H, int W, void* stream)
+{
+    if (!gen || !out) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
+    if (B < 1 || H < 1 || W < 1) return smvs::fail(SMVS_ERR_ARG, "non-positive dimension");
+    int mode; smvs::HeightGen hg;
+    if (int rc = smvs::resolve_heights(nullptr, 0, gen, gen->ndepth, H, W, mode, hg)) return rc;
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(smvs::height_hypotheses_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, hg, out, B, gen->ndepth, H * W, W);
+    return smvs::check_launch("height_hypotheses");
+}
+
 SMVS_EXPORT int smvs_softmax_regress_fwd(const float* reg, const float* depth, int depth_is_4d,
                                          float* out_depth, float* out_conf, int B, int D, int H, int W, void* stream)
 {
-    if (!reg || !depth || !out_depth || !out_conf) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
-    if (B < 1 || D < 1 || H < 1 || W < 1) return smvs::fail(SMVS_ERR_ARG, "non-positive dimension");
-    const size_t n = (size_t)B * H * W;
-    hipLaunchKernelGGL(smvs::softmax_regress_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, reg, depth, depth_is_4d, out_depth, out_conf, B, D, H * W);
-    return smvs::check_launch("softmax_regress");
+    return smvs::softmax_regress(reg, depth, depth_is_4d, nullptr, out_depth, out_conf, B, D, H, W, stream);
+}
+
+SMVS_EXPORT int smvs_softmax_regress_fwd_gen(const float* reg, const smvs_height_gen* gen,
+                                             float* out_depth, float* out_conf, int B, int D, int H, int W, void* stream)
+{
+    if (!gen) return smvs::fail(SMVS_ERR_ARG, "null height generator");
+    return smvs::softmax_regress(reg, nullptr, 0, gen, out_depth, out_conf, B, D, H, W, stream);
 }
 
 SMVS_EXPORT int smvs_window_regress_fwd(const float* reg, const float* depth, int depth_is_4d,
                                         float* out_depth, float* out_conf, float* out_var, float lamb,
                                         int B, int D, int H, int W, void* stream)
 {
-    if (!reg || !depth || !out_depth || !out_conf) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
-    if (B < 1 || D < 1 || H < 1 || W < 1) return smvs::fail(SMVS_ERR_ARG, "non-positive dimension");
-    const size_t n = (size_t)B * H * W;
-    hipLaunchKernelGGL(smvs::window_regress_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, reg, depth, depth_is_4d, out_depth, out_conf, out_var, lamb, B, D, H * W);
-    return smvs::check_launch("window_regress");
+    return smvs::window_regress(reg, depth, depth_is_4d, nullptr, out_depth, out_conf, out_var, lamb, B, D, H, W, stream);
+}
+
+SMVS_EXPORT int smvs_window_regress_fwd_gen(const float* reg, const smvs_height_gen* gen,
+                                            float* out_depth, float* out_conf, float* out_var, float lamb,
+                                            int B, int D, int H, int W, void* stream)
+{
+    if (!gen) return smvs::fail(SMVS_ERR_ARG, "null height generator");
+    return smvs::window_regress(reg, nullptr, 0, gen, out_depth, out_conf, out_var, lamb, B, D, H, W, stream);
 }
 
 SMVS_EXPORT int smvs_stream_regress_step(const float* reg_plane, const float* depth, int depth_is_4d,
                                          double* exp_sum, double* depth_img, double* max_prob,
                                          int B, int D, int H, int W, int d, void* stream)
 {
-    if (!reg_plane || !depth || !exp_sum || !depth_img || !max_prob) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
-    if (B < 1 || D < 1 || H < 1 || W < 1 || d < 0 || d >= D) return smvs::fail(SMVS_ERR_ARG, "bad dimension or plane index %d of %d", d, D);
-    const size_t n = (size_t)B * H * W;
-    hipLaunchKernelGGL(smvs::stream_regress_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, reg_plane, depth, depth_is_4d, exp_sum, depth_img, max_prob, B, D, H * W, d);
-    return smvs::check_launch("stream_regress_step");
+    return smvs::stream_regress_step(reg_plane, depth, depth_is_4d, nullptr, exp_sum, depth_img, max_prob, B, D, H, W, d, stream);
 }
 
 SMVS_EXPORT int smvs_stream_regress_final(const double* exp_sum, const double* depth_img, const double* max_prob,

@@ -354,6 +354,67 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
+// ---- height hypotheses generated in the kernel -----------------------------------
+// Stages 2 and 3 of the cascades build their hypotheses from the previous stage's height map
+// (networks/casred.py:134-145 + modules/depth_range.py:4-20):
+//   cur     = F.interpolate(prev, [img_h, img_w], bilinear, align_corners=False)          image resolution
+//   cur_min = cur - c, cur_max = cur + c, c = float(ndepth / 2 * interval);  step = (cur_max - cur_min) / (ndepth - 1)
+//   samples[d] = cur_min + d * step                                                        (B, D, img_h, img_w)
+//   heights = F.interpolate(samples, [D, img_h / scale, img_w / scale], trilinear, align_corners=False)
+// Generating them per pixel in the consuming kernel removes the (B,D,H,W) tensor (4 B/voxel of reads), the
+// image-resolution temporaries and ~8 launches per stage.  The arithmetic below is ATen's, rounding for rounding
+// (checked bit for bit against the reference on the CPU: tests/test_oracle_golden.py::test_height_hypotheses):
+// every two-term interpolation is fma(w0, v0, w1 * v1); in the plane axis the resize is the identity (weight 1 / 0);
+// scale 2 averages a 2x2 block with weights 1/2 (exact products), scale 1 is the identity.
+struct HeightGen {
+    const float* prev;          // (B, hp, wp)
+    int hp, wp, ih, iw, scale;  // previous map size, image size, image size / this stage's size (1 or 2)
+    float c, ndm1;              // float(ndepth / 2 * interval), float(ndepth - 1)
+};
+
+__device__ __forceinline__ float hg_interp2(float w0, float v0, float w1, float v1) { return fmaf(w0, v0, w1 * v1); }
+
+// image-resolution pixel (Y, X) of batch item b: cur_min and step
+__device__ __forceinline__ void hg_pixel(const HeightGen& g, int b, int Y, int X, float& cmin, float& step)
+{
+    const float sh = (float)g.hp / (float)g.ih, sw = (float)g.wp / (float)g.iw;
+    const float sy = fmaxf(sh * ((float)Y + 0.5f) - 0.5f, 0.0f), sx = fmaxf(sw * ((float)X + 0.5f) - 0.5f, 0.0f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, g.hp - 1), x1 = min(x0 + 1, g.wp - 1);
+    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0, ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+    const float* q = g.prev + (size_t)b * g.hp * g.wp;
+    const float top = hg_interp2(lx0, q[y0 * g.wp + x0], lx1, q[y0 * g.wp + x1]);
+    const float bot = hg_interp2(lx0, q[y1 * g.wp + x0], lx1, q[y1 * g.wp + x1]);
+    const float cur = hg_interp2(ly0, top, ly1, bot);
+    cmin = cur - g.c;
+    step = __fdiv_rn((cur + g.c) - cmin, g.ndm1);
+}
+
+// per stage pixel (y, x): the 1 (scale 1) or 4 (scale 2) image-resolution pixels under it
+struct HeightPix { float cmin[4], step[4]; };
+
+__device__ __forceinline__ void hg_prepare(const HeightGen& g, int b, int y, int x, HeightPix& hp)
+{
+    if (g.scale == 1) {
+        hg_pixel(g, b, y, x, hp.cmin[0], hp.step[0]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hg_pixel(g, b, 2 * y + (k >> 1), 2 * x + (k & 1), hp.cmin[k], hp.step[k]);
+    }
+}
+
+__device__ __forceinline__ float hg_height(const HeightGen& g, const HeightPix& hp, int d)
+{
+    const float fd = (float)d;
+    if (g.scale == 1) return hp.cmin[0] + fd * hp.step[0];
+    const float a = hp.cmin[0] + fd * hp.step[0], bb = hp.cmin[1] + fd * hp.step[1];
+    const float c = hp.cmin[2] + fd * hp.step[2], dd = hp.cmin[3] + fd * hp.step[3];
+    return hg_interp2(0.5f, hg_interp2(0.5f, a, 0.5f, bb), 0.5f, hg_interp2(0.5f, c, 0.5f, dd));
+}
+
+// Where a kernel takes its heights from: (B,D) planes, a (B,D,H,W) tensor, or the generator above.
+enum { HEIGHT_PLANES = 0, HEIGHT_TENSOR = 1, HEIGHT_GENERATED = 2 };
+
 // ---- raw buffer access -------------------------------------------------------------------------
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -25,6 +25,22 @@ inline int fail(int code, const char* fmt, ...)
     return code;
 }
 
+// smvs_height_gen (C ABI) -> device-side HeightGen for a stage of size H x W; returns a message on bad arguments
+struct HeightGenHost { const float* prev; int hp, wp, ih, iw, scale; float c, ndm1; };
+inline const char* height_gen_check(const smvs_height_gen* g, int D, int H, int W, HeightGenHost& o)
+{
+    if (!g || !g->prev_height) return "null height generator";
+    if (g->prev_h < 1 || g->prev_w < 1 || g->img_h < 1 || g->img_w < 1 || g->ndepth < 2) return "bad height generator sizes";
+    if (g->ndepth != D) return "height generator ndepth differs from D";
+    if (g->img_h % H || g->img_w % W || g->img_h / H != g->img_w / W) return "image size is not an integer multiple of the stage size";
+    const int scale = g->img_h / H;
+    if (scale != 1 && scale != 2) return "generated heights support image/stage scale 1 or 2 (stage 1 passes (B,D) planes)";
+    o.prev = g->prev_height; o.hp = g->prev_h; o.wp = g->prev_w; o.ih = g->img_h; o.iw = g->img_w; o.scale = scale;
+    o.c = (float)(g->ndepth / 2.0 * (double)g->interval);
+    o.ndm1 = (float)(g->ndepth - 1);
+    return nullptr;
+}
+
 // A/B and tuning switches exist only in tuning builds (tools/ab_build.sh x -DSMVS_TUNING); the shipped library
 // never reads the environment: every switch folds to its default at compile time.
 #ifdef SMVS_TUNING

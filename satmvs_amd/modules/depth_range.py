@@ -1,12 +1,82 @@
 """Height-hypothesis samplers, the step right before the hot path.
 
 Mirror of /root/reference/modules/depth_range.py (get_cur_depth_range_samples :4,
-get_depth_range_samples :23, uncertainty_aware_samples :45).  Stock PyTorch elementwise ops on the
-device; fusing them into the kernel prologue is SURVEY.md section 8(f) item 1.
+get_depth_range_samples :23, uncertainty_aware_samples :45) as PyTorch ops (training, UCS-Net), plus the fused
+form of SURVEY.md section 8(f) item 1: stage-1 hypotheses as exact (B,D) planes and `GeneratedHeights`, the
+description of a later stage's hypotheses that the native kernels evaluate per pixel (no (B,D,H,W) tensor).
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
+import torch.nn.functional as F
+
+
+def stage1_planes(depth_range, ndepth):
+    """(B,D) hypothesis planes of the first stage (depth_range.py:26-33 of the reference).  The reference repeats
+    them to (B,D,img_h,img_w) and resizes trilinearly to the stage grid; every pixel of a plane holds the same value
+    and the resize weights (1/2 + 1/2, 1 + 0) reproduce it exactly, so the planes ARE its depth_values."""
+    lo, hi = depth_range[:, 0], depth_range[:, -1]
+    # a TENSOR divisor: with a python scalar torch's GPU kernels multiply by the rounded reciprocal, which is 1 ulp
+    # off the true quotient the reference gets on the CPU (and the in-kernel generator computes)
+    step = (hi - lo) / torch.full_like(lo, float(ndepth - 1))
+    idx = torch.arange(0, ndepth, device=depth_range.device, dtype=depth_range.dtype).reshape(1, -1)
+    return lo.unsqueeze(1) + idx * step.unsqueeze(1)
+
+
+class _HeightGenStruct(ctypes.Structure):       # smvs_height_gen, include/satmvs.h
+    _fields_ = [("prev_height", ctypes.c_void_p), ("prev_h", ctypes.c_int), ("prev_w", ctypes.c_int),
+                ("img_h", ctypes.c_int), ("img_w", ctypes.c_int), ("ndepth", ctypes.c_int), ("interval", ctypes.c_double)]
+
+
+class GeneratedHeights:
+    """Hypotheses of cascade stage 2 / 3 described instead of materialised (networks/casred.py:134-145 +
+    depth_range.py:4-20): previous height map (B,hp,wp), ndepth, interval, image size, this stage's size.
+
+    Accepted wherever the native paths take `depth_values` (variance_cost_volume, the RED plane pipelines, the
+    regressions); `.materialize()` gives the reference's (B,D,H,W) tensor (one kernel; torch composite on the CPU)."""
+
+    def __init__(self, prev_height, ndepth, interval, img_hw, stage_hw):
+        self.prev = prev_height.detach().to(torch.float32).contiguous()
+        self.ndepth, self.interval = int(ndepth), float(interval)
+        self.img_h, self.img_w = int(img_hw[0]), int(img_hw[1])
+        self.H, self.W = int(stage_hw[0]), int(stage_hw[1])
+
+    @staticmethod
+    def supported(img_hw, stage_hw):
+        (ih, iw), (h, w) = img_hw, stage_hw
+        return ih % h == 0 and iw % w == 0 and ih // h == iw // w and ih // h in (1, 2)
+
+    @property
+    def shape(self):
+        return torch.Size((self.prev.shape[0], self.ndepth, self.H, self.W))
+
+    @property
+    def device(self):
+        return self.prev.device
+
+    def dim(self):
+        return 4
+
+    def c_struct(self):
+        """ctypes smvs_height_gen; keep the returned object (and self) alive until the call has been enqueued."""
+        return _HeightGenStruct(self.prev.data_ptr(), self.prev.shape[1], self.prev.shape[2], self.img_h, self.img_w,
+                                self.ndepth, self.interval)
+
+    def materialize(self):
+        if self.prev.is_cuda:
+            from .. import _lib
+            out = torch.empty(tuple(self.shape), dtype=torch.float32, device=self.prev.device)
+            gs = self.c_struct()
+            with torch.cuda.device(self.prev.device):
+                _lib.call("smvs_height_hypotheses", ctypes.addressof(gs), _lib.ptr(out), out.shape[0], self.H, self.W,
+                          _lib.current_stream(self.prev.device))
+            return out
+        cur = F.interpolate(self.prev.unsqueeze(1), [self.img_h, self.img_w], mode="bilinear", align_corners=False).squeeze(1)
+        samples = get_cur_depth_range_samples(cur, self.ndepth, self.interval, list(cur.shape))
+        return F.interpolate(samples.unsqueeze(1), [self.ndepth, self.H, self.W], mode="trilinear",
+                             align_corners=False).squeeze(1)
 
 
 def get_cur_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, shape):
@@ -43,3 +113,20 @@ def uncertainty_aware_samples(cur_depth, depth_min, depth_max, exp_var, ndepth, 
     high = torch.minimum(cur_depth + exp_var, depth_max.view(b, 1, 1, 1).to(cur_depth.dtype))
     step = (high - low) / (float(ndepth) - 1)
     return torch.cat([low + step * i + eps for i in range(int(ndepth))], 1)
+
+
+def stage_hypotheses(prev_depth, depth_range, ndepth, interval, img_hw, stage_hw, dtype, device, batch):
+    """`depth_values` of one cascade stage, in the cheapest exact form (networks/casred.py:134-145):
+      * first stage (prev_depth None): the (B,D) planes;
+      * later stages without autograd on a GPU: a GeneratedHeights description (evaluated inside the kernels);
+      * otherwise the reference's composite -- bilinear resize, samples, trilinear resize -- as a (B,D,H,W) tensor."""
+    if prev_depth is None:
+        return stage1_planes(depth_range.to(dtype), ndepth)
+    if (not torch.is_grad_enabled() and prev_depth.is_cuda and prev_depth.dtype == torch.float32
+            and GeneratedHeights.supported(img_hw, stage_hw)):
+        return GeneratedHeights(prev_depth, ndepth, interval, img_hw, stage_hw)
+    cur = F.interpolate(prev_depth.unsqueeze(1), list(img_hw), mode="bilinear", align_corners=False).squeeze(1)
+    samples = get_depth_range_samples(cur_depth=cur, ndepth=ndepth, depth_inteval_pixel=interval, dtype=dtype,
+                                      device=device, shape=[batch, img_hw[0], img_hw[1]])
+    return F.interpolate(samples.unsqueeze(1), [ndepth, stage_hw[0], stage_hw[1]], mode="trilinear",
+                         align_corners=False).squeeze(1)

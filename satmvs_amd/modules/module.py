@@ -291,7 +291,14 @@ class _REDCore(nn.Module):
         if c != in_ch:
             raise ValueError("features have %d channels, regulariser expects %d" % (c, in_ch))
         kind, geo = prepare_geometry(features, proj_matrices, geo_model, use_qc)
-        depth, is4d, D = _depth_arg(depth_values, b, h, w)
+        from .depth_range import GeneratedHeights
+        gen = depth_values if isinstance(depth_values, GeneratedHeights) else None
+        if gen is not None:
+            D = gen.ndepth
+            if tuple(gen.shape) != (b, D, h, w):
+                raise ValueError("generated heights %s do not match features" % (tuple(gen.shape),))
+        else:
+            depth, is4d, D = _depth_arg(depth_values, b, h, w)
         lib = _lib.load()
         nbytes = lib.smvs_red_pred_workspace_bytes(b, c, h, w)
         if nbytes == 0:
@@ -301,12 +308,20 @@ class _REDCore(nn.Module):
             if s.dtype != torch.float32 or not s.is_contiguous():
                 raise ValueError("states must be contiguous float32")
         target = acc_state if reg_volume is None else reg_volume
+        name = "smvs_red_pred_planes" if reg_volume is None else "smvs_red_volume_planes"
         with torch.cuda.device(dev):
-            _lib.call("smvs_red_pred_planes" if reg_volume is None else "smvs_red_volume_planes",
-                      kind, _lib.ptr(feats[0]), _lib.ptr_array(feats[1:]), len(feats) - 1,
-                      _lib.ptr(geo), _lib.ptr(depth), is4d, _lib.ptr(packed), *[_lib.ptr(s) for s in states],
-                      _lib.ptr(target), _lib.ptr(ws), nbytes, b, c, D, h, w, d_begin, d_end,
-                      _lib.current_stream(dev))
+            if gen is not None:
+                import ctypes
+                gs = gen.c_struct()
+                _lib.call(name + "_gen", kind, _lib.ptr(feats[0]), _lib.ptr_array(feats[1:]), len(feats) - 1,
+                          _lib.ptr(geo), ctypes.addressof(gs), _lib.ptr(packed), *[_lib.ptr(s) for s in states],
+                          _lib.ptr(target), _lib.ptr(ws), nbytes, b, c, D, h, w, d_begin, d_end,
+                          _lib.current_stream(dev))
+            else:
+                _lib.call(name, kind, _lib.ptr(feats[0]), _lib.ptr_array(feats[1:]), len(feats) - 1,
+                          _lib.ptr(geo), _lib.ptr(depth), is4d, _lib.ptr(packed), *[_lib.ptr(s) for s in states],
+                          _lib.ptr(target), _lib.ptr(ws), nbytes, b, c, D, h, w, d_begin, d_end,
+                          _lib.current_stream(dev))
 
     def native_volume(self, features, proj_matrices, depth_values, geo_model, use_qc):
         """(B,D,H,W) regularised cost of the whole sweep without materialising the variance volume
@@ -614,9 +629,23 @@ def softmax_depth_regression(reg, depth_values):
     (B,H,W).  Equals F.softmax(reg,1) -> depth_regression -> max(1) of networks/casred.py:58-62.
     With autograd enabled on `reg` the torch composite is used instead (it is differentiable).
     """
+    from .depth_range import GeneratedHeights
+    gen = depth_values if isinstance(depth_values, GeneratedHeights) else None
     if torch.is_grad_enabled() and reg.requires_grad:
         p = F.softmax(reg, dim=1)
-        return depth_regression(p, depth_values), p.max(1)[0]
+        return depth_regression(p, gen.materialize() if gen is not None else depth_values), p.max(1)[0]
+    if gen is not None:
+        import ctypes
+        dev = _lib.require_device(reg, gen.prev)
+        r = reg.detach().to(torch.float32).contiguous()
+        B, D, H, W = r.shape
+        depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        conf = torch.empty_like(depth)
+        gs = gen.c_struct()
+        with torch.cuda.device(dev):
+            _lib.call("smvs_softmax_regress_fwd_gen", _lib.ptr(r), ctypes.addressof(gs), _lib.ptr(depth), _lib.ptr(conf),
+                      B, D, H, W, _lib.current_stream(dev))
+        return depth, conf
     dev = _lib.require_device(reg, depth_values)
     r = reg.detach().to(torch.float32).contiguous()
     B, D, H, W = r.shape
@@ -639,10 +668,12 @@ def window_depth_regression(reg, depth_values, lamb=None):
 
     reg (B,D,H,W); depth_values (B,D) or (B,D,H,W).  Returns (depth, confidence) or (depth, confidence, variance).
     With autograd enabled on `reg` the torch composite runs instead (differentiable, same operations)."""
+    from .depth_range import GeneratedHeights
+    gen = depth_values if isinstance(depth_values, GeneratedHeights) else None
     if (torch.is_grad_enabled() and reg.requires_grad) or not reg.is_cuda:
         p = F.softmax(reg, dim=1)
         num_depth = reg.shape[1]
-        dv = depth_values
+        dv = gen.materialize() if gen is not None else depth_values
         depth = depth_regression(p, depth_values=dv)
         with torch.no_grad():
             sum4 = 4 * F.avg_pool3d(F.pad(p.unsqueeze(1), pad=(0, 0, 0, 0, 1, 2)), (4, 1, 1), stride=1, padding=0).squeeze(1)
@@ -653,6 +684,19 @@ def window_depth_regression(reg, depth_values, lamb=None):
         if dv.dim() == 2:
             dv = dv.view(*dv.shape, 1, 1)
         return depth, conf, lamb * torch.sum((dv - depth.unsqueeze(1)) ** 2 * p, dim=1) ** 0.5
+    if gen is not None:
+        import ctypes
+        dev = _lib.require_device(reg, gen.prev)
+        r = reg.detach().to(torch.float32).contiguous()
+        B, D, H, W = r.shape
+        depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        conf = torch.empty_like(depth)
+        var = torch.empty_like(depth) if lamb is not None else None
+        gs = gen.c_struct()
+        with torch.cuda.device(dev):
+            _lib.call("smvs_window_regress_fwd_gen", _lib.ptr(r), ctypes.addressof(gs), _lib.ptr(depth), _lib.ptr(conf),
+                      _lib.ptr(var) if var is not None else None, float(lamb or 0.0), B, D, H, W, _lib.current_stream(dev))
+        return (depth, conf) if lamb is None else (depth, conf, var)
     dev = _lib.require_device(reg, depth_values)
     r = reg.detach().to(torch.float32).contiguous()
     B, D, H, W = r.shape

@@ -258,9 +258,40 @@ def variance_cost_volume(features, proj_matrices, depth_values, geo_model="rpc",
     """
     ref_fea = features[0]
     B, _, H, W = ref_fea.shape
+    from .depth_range import GeneratedHeights
+    if isinstance(depth_values, GeneratedHeights):
+        gen = depth_values
+        if tuple(gen.shape) != (B, gen.ndepth, H, W):
+            raise ValueError("generated heights %s do not match features (B=%d,H=%d,W=%d)" % (tuple(gen.shape), B, H, W))
+        if torch.is_grad_enabled() and any(f.requires_grad for f in features):
+            depth_values = gen.materialize()             # autograd path: the backward kernel takes the tensor
+        else:
+            return _costvol_generated(features, proj_matrices, gen, geo_model, use_qc, d_begin, d_end)
     depth, is4d, D = _depth_arg(depth_values, B, H, W)
     d_end = D if d_end is None else d_end
     if not (0 <= d_begin <= d_end <= D):
         raise ValueError("bad plane range [%d,%d) of %d" % (d_begin, d_end, D))
     kind, geo = prepare_geometry(features, proj_matrices, geo_model, use_qc)
     return _CostVolFn.apply(kind, geo, depth, is4d, d_begin, d_end, ref_fea, *features[1:])
+
+
+def _costvol_generated(features, proj_matrices, gen, geo_model, use_qc, d_begin, d_end):
+    """variance_cost_volume with the hypotheses evaluated inside the kernel (smvs_*_costvol_fwd_gen); no autograd."""
+    import ctypes
+    ref = _f32c(features[0])
+    srcs = [_f32c(s) for s in features[1:]]
+    B, C, H, W = ref.shape
+    D = gen.ndepth
+    d_end = D if d_end is None else d_end
+    if not (0 <= d_begin <= d_end <= D):
+        raise ValueError("bad plane range [%d,%d) of %d" % (d_begin, d_end, D))
+    kind, geo = prepare_geometry(features, proj_matrices, geo_model, use_qc)
+    dev = _lib.require_device(ref, geo, gen.prev, *srcs)
+    nd = d_end - d_begin
+    out = torch.empty((B, C, nd, H, W), dtype=torch.float32, device=dev)
+    gs = gen.c_struct()
+    with torch.cuda.device(dev):
+        _lib.call("smvs_rpc_costvol_fwd_gen" if kind == 0 else "smvs_homo_costvol_fwd_gen", _lib.ptr(ref),
+                  _lib.ptr_array(srcs), len(srcs), _lib.ptr(geo), ctypes.addressof(gs), _lib.ptr(out),
+                  B, C, D, H, W, d_begin, d_end, nd, 0, _lib.current_stream(dev))
+    return out

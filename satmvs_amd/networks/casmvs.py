@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..modules.depth_range import get_depth_range_samples
+from ..modules.depth_range import stage_hypotheses
 from ..modules.module import CostRegNet, FeatureNet, depth_regression, window_depth_regression
 from ..modules.warping import variance_cost_volume
 
@@ -61,16 +61,10 @@ class CascadeMVSNet(nn.Module):
             key = "stage{}".format(stage_idx + 1)
             feats = [f[key] for f in features]
             scale = int(self.stage_infos[key]["scale"])
-            if depth is not None:
-                cur = depth.detach() if self.grad_method == "detach" else depth
-                cur = F.interpolate(cur.unsqueeze(1), [h, w], mode="bilinear", align_corners=Align_Corners_Range).squeeze(1)
-            else:
-                cur = depth_values
-            samples = get_depth_range_samples(cur_depth=cur, ndepth=self.ndepths[stage_idx],
-                                              depth_inteval_pixel=self.depth_interals_ratio[stage_idx] * self.min_interval,
-                                              dtype=imgs.dtype, device=imgs.device, shape=[imgs.shape[0], h, w])
-            dv = F.interpolate(samples.unsqueeze(1), [self.ndepths[stage_idx], h // scale, w // scale], mode="trilinear",
-                               align_corners=Align_Corners_Range).squeeze(1)
+            cur = None if depth is None else (depth.detach() if self.grad_method == "detach" else depth)
+            dv = stage_hypotheses(cur, depth_values, self.ndepths[stage_idx],
+                                  self.depth_interals_ratio[stage_idx] * self.min_interval, (h, w),
+                                  (h // scale, w // scale), imgs.dtype, imgs.device, imgs.shape[0])
             reg = self.cost_regularization if self.share_cr else self.cost_regularization[stage_idx]
             out = self.DepthNet(feats, proj_matrices[key], depth_values=dv, num_depth=self.ndepths[stage_idx],
                                 cost_regularization=reg, geo_model=self.geo_model, use_qc=self.use_qc)

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..modules.depth_range import get_depth_range_samples
+from ..modules.depth_range import GeneratedHeights, stage_hypotheses
 from ..modules.module import (FeatureNet, RED_Regularization, StreamingRegression, slice_RED_Regularization,
                               softmax_depth_regression)
 from ..modules.warping import variance_cost_volume
@@ -42,8 +42,8 @@ def compute_depth_when_train(features, proj_matrices, depth_values, num_depth, c
             and cost_regularization._use_native(features[0])):
         # inference: plane pipeline (variance plane -> RED step) straight into the (B,D,H,W) regularised cost;
         # the (B,C,D,H,W) variance volume is never materialised
-        reg = cost_regularization.native_volume(features, proj_matrices, depth_values.detach().to(torch.float32).contiguous(),
-                                                geo_model, use_qc)
+        dv = depth_values if isinstance(depth_values, GeneratedHeights) else depth_values.detach().to(torch.float32).contiguous()
+        reg = cost_regularization.native_volume(features, proj_matrices, dv, geo_model, use_qc)
     else:
         volume_variance = variance_cost_volume(features, proj_matrices, depth_values, geo_model, use_qc)
         reg = cost_regularization(volume_variance)                 # (B,D,H,W)
@@ -59,12 +59,15 @@ def compute_depth_when_pred(features, proj_matrices, depth_values, num_depth, co
     b, _, h, w = ref.shape
     states = cost_regularization.initial_states(b, h, w, ref.device)
     acc = StreamingRegression(b, h, w, ref.device)
-    dv = depth_values.detach().to(torch.float32).contiguous()
+    gen = isinstance(depth_values, GeneratedHeights)
+    dv = depth_values if gen else depth_values.detach().to(torch.float32).contiguous()
     if hasattr(cost_regularization, "native_pred_planes") and cost_regularization._use_native(ref):
         # the whole plane loop in one native call: variance plane -> RED step -> regression update
         cost_regularization.native_pred_planes(features, proj_matrices, dv, geo_model, use_qc, states, acc.state,
                                                0, num_depth)
     else:
+        if gen:
+            dv = dv.materialize()
         for d in range(num_depth):
             plane = variance_cost_volume(features, proj_matrices, dv, geo_model, use_qc, d_begin=d, d_end=d + 1)
             reg, *states = cost_regularization(plane.squeeze(2), *states)
@@ -105,17 +108,11 @@ class _CascadeRED(nn.Module):
             key = "stage{}".format(stage_idx + 1)
             feats = [f[key] for f in features]
             scale = int(self.stage_infos[key]["scale"])
-            if depth is not None:
-                cur_depth = F.interpolate(depth.unsqueeze(1), [img_h, img_w], mode="bilinear",
-                                          align_corners=False).squeeze(1)
-            else:
-                cur_depth = depth_values
-            samples = get_depth_range_samples(
-                cur_depth=cur_depth, ndepth=self.ndepths[stage_idx],
-                depth_inteval_pixel=self.depth_interals_ratio[stage_idx] * self.min_interval,
-                dtype=imgs.dtype, device=imgs.device, shape=[imgs.shape[0], img_h, img_w])
-            dv = F.interpolate(samples.unsqueeze(1), [self.ndepths[stage_idx], img_h // scale, img_w // scale],
-                               mode="trilinear", align_corners=False).squeeze(1)
+            # hypotheses of this stage (casred.py:134-145): (B,D) planes for stage 1, a per-pixel generator evaluated
+            # inside the kernels for the later stages in inference, the reference's (B,D,H,W) tensor under autograd
+            dv = stage_hypotheses(depth, depth_values, self.ndepths[stage_idx],
+                                  self.depth_interals_ratio[stage_idx] * self.min_interval, (img_h, img_w),
+                                  (img_h // scale, img_w // scale), imgs.dtype, imgs.device, imgs.shape[0])
             out = type(self).compute(feats, proj_matrices[key], depth_values=dv, num_depth=self.ndepths[stage_idx],
                                      cost_regularization=self.cost_regularization[stage_idx],
                                      geo_model=self.geo_model, use_qc=self.use_qc)

@@ -338,7 +338,18 @@ def gen_depth_range():
     s2 = ref_depth_range.get_depth_range_samples(cur, 6, 5.0, "cpu", torch.float32, [B, H, W])
     r1 = torch.nn.functional.interpolate(s1.unsqueeze(1), [8, H // 4, W // 4], mode="trilinear", align_corners=False).squeeze(1)
     r2 = torch.nn.functional.interpolate(s2.unsqueeze(1), [6, H // 2, W // 2], mode="trilinear", align_corners=False).squeeze(1)
-    save("depth_range", dv=dv.numpy(), s1=s1.numpy(), cur=cur.numpy(), s2=s2.numpy(), r1=r1.numpy(), r2=r2.numpy())
+    # the two generated stages end to end, as networks/casred.py:134-145 runs them: previous height map -> bilinear resize to the
+    # image -> samples -> trilinear resize to the stage grid (stage 2: 1/4 -> image -> 1/2; stage 3: 1/2 -> image -> 1/1)
+    prev_a = torch.rand(B, H // 4, W // 4) * 300 + 50
+    cur_a = torch.nn.functional.interpolate(prev_a.unsqueeze(1), [H, W], mode="bilinear", align_corners=False).squeeze(1)
+    s_a = ref_depth_range.get_depth_range_samples(cur_a, 6, 2 * 2.5, "cpu", torch.float32, [B, H, W])
+    r_a = torch.nn.functional.interpolate(s_a.unsqueeze(1), [6, H // 2, W // 2], mode="trilinear", align_corners=False).squeeze(1)
+    prev_b = torch.rand(B, H // 2, W // 2) * 300 + 50
+    cur_b = torch.nn.functional.interpolate(prev_b.unsqueeze(1), [H, W], mode="bilinear", align_corners=False).squeeze(1)
+    s_b = ref_depth_range.get_depth_range_samples(cur_b, 8, 1 * 2.5, "cpu", torch.float32, [B, H, W])
+    r_b = torch.nn.functional.interpolate(s_b.unsqueeze(1), [8, H, W], mode="trilinear", align_corners=False).squeeze(1)
+    save("depth_range", dv=dv.numpy(), s1=s1.numpy(), cur=cur.numpy(), s2=s2.numpy(), r1=r1.numpy(), r2=r2.numpy(),
+         prev_a=prev_a.numpy(), r_a=r_a.numpy(), prev_b=prev_b.numpy(), r_b=r_b.numpy())
 
 
 def gen_cascade():

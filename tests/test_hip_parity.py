@@ -256,6 +256,50 @@ def test_window_regression_golden(dev, golden, oracle):
     np.testing.assert_allclose(vp.cpu().numpy(), ov, rtol=1e-5, atol=1e-4)
 
 
+def test_generated_heights(dev, golden, oracle):
+    """hypotheses evaluated inside the kernels.  (1) smvs_height_hypotheses == the oracle bit for bit and
+    the reference's (B,D,H,W) tensors (tests/golden/depth_range.npz: r2 exact -- sample arithmetic + trilinear resize --,
+    r_a / r_b within 1 ulp -- bilinear resize of the previous map, see tests/test_oracle_golden.py); (2) every consumer
+    fed the generator produces the bits it produces from the materialised tensor: cost volume (staged and direct
+    kernels, plane ranges), softmax and window regressions; (3) stage-1 planes equal the reference's r1."""
+    from satmvs_amd.modules import module as M
+    from satmvs_amd.modules import warping
+    from satmvs_amd.modules.depth_range import GeneratedHeights, stage1_planes
+    g = golden("depth_range")
+    _, H, W = g["cur"].shape
+    cases = [("prev_a", 6, 5.0, (H // 2, W // 2), "r_a", 6.2e-5), ("prev_b", 8, 2.5, (H, W), "r_b", 6.2e-5),
+             ("cur", 6, 5.0, (H // 2, W // 2), "r2", 0.0)]
+    for name, nd, interval, stage, ref_key, tol in cases:
+        gen = GeneratedHeights(_t(g[name], dev), nd, interval, (H, W), stage)
+        got = gen.materialize().cpu().numpy()
+        assert np.array_equal(got, oracle.height_hypotheses(g[name], nd, interval, (H, W), stage)), name
+        assert np.abs(got - g[ref_key]).max() <= tol, name
+    planes = stage1_planes(_t(g["dv"], dev), 8).cpu().numpy()
+    assert np.array_equal(np.broadcast_to(planes[:, :, None, None], g["r1"].shape), g["r1"])
+    # consumers: generator vs materialised tensor, identical bits
+    rng = np.random.default_rng(21)
+    for C, (h, w), up, nd, interval in ((16, (40, 72), 2, 6, 5.0), (8, (40, 72), 1, 8, 2.5), (32, (24, 40), 2, 5, 5.0)):
+        ih, iw = h * up, w * up
+        feats, rpc, _ = _inputs(1, 3, C, nd, h, w, seed=9)
+        prev = (200.0 + rng.normal(0, 6.0, (1, ih // 2, iw // 2))).astype(np.float32)
+        gen = GeneratedHeights(_t(prev, dev), nd, interval, (ih, iw), (h, w))
+        dv = gen.materialize()
+        f = [_t(x, dev) for x in feats]
+        r = _t(rpc, dev)
+        with torch.no_grad():
+            a = warping.variance_cost_volume(f, r, gen, "rpc")
+            b = warping.variance_cost_volume(f, r, dv, "rpc")
+            assert torch.equal(a, b), (C, h, w)
+            a1 = warping.variance_cost_volume(f, r, gen, "rpc", d_begin=2, d_end=3)
+            assert torch.equal(a1, b[:, :, 2:3])
+            reg = -a.mean(1)
+            assert all(torch.equal(x, y) for x, y in zip(M.softmax_depth_regression(reg, gen), M.softmax_depth_regression(reg, dv)))
+            assert all(torch.equal(x, y) for x, y in zip(M.window_depth_regression(reg, gen, lamb=1.5),
+                                                           M.window_depth_regression(reg, dv, lamb=1.5)))
+        want = oracle.costvol_variance(feats, rpc, dv.cpu().numpy(), "rpc")
+        _close_f32(a, want)
+
+
 def test_warp_backward_matches_torch(dev, oracle):
     """grad w.r.t. src_fea == autograd of F.grid_sample on the same (oracle-built) grid."""
     from satmvs_amd.modules import warping

@@ -108,6 +108,22 @@ def test_softmax_regress(oracle, golden):
     np.testing.assert_allclose(conf, r["sm_conf"], rtol=1e-5, atol=1e-6)
 
 
+def test_height_hypotheses(oracle, golden):
+    """Generated hypotheses against the reference's get_depth_range_samples + F.interpolate pipeline.
+    The sample arithmetic and the trilinear resize are reproduced bit for bit (r2: previous map given at image size;
+    r1: stage-1 planes, every pixel of a plane equal).  The bilinear resize of the previous map is reproduced to
+    1 ulp (6.2e-5 m at 256..512 m): ATen's CPU kernel contracts w0*v0 + w1*v1 differently between its vector body and
+    its scalar tail, so its own bits depend on the tensor shape; ours are fma(w0, v0, w1*v1) everywhere."""
+    g = golden("depth_range")
+    _, H, W = g["cur"].shape
+    assert np.array_equal(oracle.height_hypotheses(g["cur"], 6, 5.0, (H, W), (H // 2, W // 2)), g["r2"])
+    planes = oracle.stage1_planes(g["dv"], 8)
+    assert np.array_equal(np.broadcast_to(planes[:, :, None, None], g["r1"].shape), g["r1"])
+    ra = oracle.height_hypotheses(g["prev_a"], 6, 2 * 2.5, (H, W), (H // 2, W // 2))
+    rb = oracle.height_hypotheses(g["prev_b"], 8, 1 * 2.5, (H, W), (H, W))
+    assert np.abs(ra - g["r_a"]).max() <= 6.2e-5 and np.abs(rb - g["r_b"]).max() <= 6.2e-5
+
+
 def test_window_regress(oracle, golden):
     """casmvs / ucs regression (window-4 confidence, ucs std-dev) against the reference's own DepthNet / compute_depth
     outputs (tests/golden/gen_golden.py::gen_regress).  A pixel whose expected index sits within float rounding of an
