@@ -261,6 +261,78 @@ def gen_costvol():
          depth_pin_out=out_p["depth"].numpy(), conf_pin_out=out_p["photometric_confidence"].numpy())
 
 
+def gen_photo():
+    """A PHOTO-CONSISTENT problem with a peaky regulariser: three views of one synthetic textured surface,
+    rendered through their RPCs, pushed through the reference's FeatureNet (seeded), then the reference's
+    compute_depth_when_train (networks/casred.py:10-62) with a stand-in regulariser that returns -lam * mean variance.
+    The softmax is sharply peaked at the plane where the warped features agree, so the regressed height follows the
+    surface and reacts to sub-pixel warp errors (with random features it is a blur of all planes)."""
+    B, D, H, W, V = 1, 16, 64, 128, 3
+    rpc = ref_rpcs(V, H, W, seed=71, batch=B)
+    rng = np.random.default_rng(72)
+    lat0, lon0, ls, os_ = rpc[0, 0, 2], rpc[0, 0, 3], rpc[0, 0, 7], rpc[0, 0, 8]
+
+    def surface(lat, lon):
+        u, v = (lat - lat0) / ls, (lon - lon0) / os_
+        return 200.0 + 22.0 * np.sin(2.1 * u + 0.4) * np.cos(1.7 * v - 0.3) + 9.0 * np.sin(4.3 * v + 1.0)
+
+    waves = [(rng.uniform(20, 220) * rng.choice([-1, 1]), rng.uniform(20, 220), rng.uniform(0, 6.28), rng.uniform(0.3, 1.0)) for _ in range(3 * 28)]
+
+    def texture(ch, lat, lon):
+        u, v = (lat - lat0) / ls, (lon - lon0) / os_
+        return sum(a * np.sin(fu * u + fv * v + ph) for fu, fv, ph, a in waves[28 * ch:28 * ch + 28]) / 4.0
+
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    imgs = np.zeros((B, V, 3, H, W), np.float32)
+    truth = None
+    for v in range(V):
+        h = np.full((H, W), 200.0)
+        for _ in range(12):                                   # ray / surface intersection by fixed-point iteration
+            lat, lon = rpc_synth.photo2obj(rpc[0, v], xx.ravel(), yy.ravel(), h.ravel())
+            h = surface(lat, lon).reshape(H, W)
+        lat, lon = rpc_synth.photo2obj(rpc[0, v], xx.ravel(), yy.ravel(), h.ravel())
+        for ch in range(3):
+            imgs[0, v, ch] = texture(ch, lat, lon).reshape(H, W)
+        if v == 0:
+            truth = h.astype(np.float32)
+    torch.manual_seed(73)
+    fnet = ref_module.FeatureNet(base_channels=8, stride=4, num_stage=3, arch_mode="unet").eval()
+    with torch.no_grad():
+        feats = [fnet(torch.from_numpy(imgs[:, v]))["stage3"] for v in range(V)]       # (B,8,H,W) each
+        dv = height_volume(B, D, H, W, seed=74, lo=160.0, hi=240.0, jitter=1.5)
+        cap = _Capture(lam=float(os.environ.get("PHOTO_LAM", "2e6")))
+        out = ref_casred.compute_depth_when_train(feats, torch.from_numpy(rpc), torch.from_numpy(dv), D, cap, "rpc", False)
+    depth = out["depth"].numpy()
+    vm = cap.seen.mean(1)
+    print("photo: variance mean over channels: min over planes %.4g, mean %.4g" % (float(vm.min(1)[0].mean()), float(vm.mean())))
+    err = np.abs(depth[0] - truth)[8:-8, 8:-8]
+    print("photo: median |height - truth| %.2f m, 90%% %.2f m, mean confidence %.3f" % (
+        np.median(err), np.percentile(err, 90), float(out["photometric_confidence"].mean())))
+    assert np.median(err) < 6.0 and float(out["photometric_confidence"].mean()) > 0.4, "not peaky / not locked on the surface"
+    save("photo", feats=np.stack([f.numpy() for f in feats]), rpc=rpc, depth_values=dv, lam=np.float32(cap.lam),
+         depth=depth, conf=out["photometric_confidence"].numpy(), truth=truth)
+
+
+def gen_grad():
+    """Gradients through the reference's differentiable path: d loss / d features of compute_depth_when_train
+    (networks/casred.py:10-62: rpc_warping's grid_sample backward, the in-place variance accumulation, softmax,
+    depth_regression) with a differentiable stand-in regulariser (-lam * mean variance), loss = sum(w * depth)."""
+    B, C, D, H, W, V = 1, 8, 6, 16, 32, 3
+    torch.manual_seed(81)
+    feats = [torch.randn(B, C, H, W, requires_grad=True) for _ in range(V)]
+    rpc = ref_rpcs(V, H, W, seed=82, batch=B)
+    dv = height_volume(B, D, H, W, seed=83)
+    wmap = torch.randn(B, H, W)
+    lam = 4.0
+    out = ref_casred.compute_depth_when_train(feats, torch.from_numpy(rpc), torch.from_numpy(dv), D,
+                                              lambda vol: -lam * vol.mean(1), "rpc", False)
+    loss = (out["depth"] * wmap).sum()
+    loss.backward()
+    save("grad", feats=np.stack([f.detach().numpy() for f in feats]), rpc=rpc, depth_values=dv, wmap=wmap.numpy(),
+         lam=np.float32(lam), depth=out["depth"].detach().numpy(), loss=np.float64(loss.item()),
+         grads=np.stack([f.grad.numpy() for f in feats]))
+
+
 def gen_pred():
     """compute_depth_when_pred (networks/casred.py:161-238) with seeded slice_RED_Regularization
     weights, and compute_depth_when_train with RED_Regularization on the same weights."""
@@ -495,7 +567,7 @@ def gen_featnet():
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (gen_iccv, gen_project, gen_grid_sample, gen_rpc_warp, gen_qc, gen_homo, gen_costvol, gen_pred,
-               gen_regress, gen_depth_range, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet):
+               gen_regress, gen_depth_range, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad):
         if only and fn.__name__[4:] not in only:
             continue
         fn()

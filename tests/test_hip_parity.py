@@ -300,6 +300,48 @@ def test_generated_heights(dev, golden, oracle):
         _close_f32(a, want)
 
 
+def test_photo_consistent_peaky_problem(dev, golden):
+    """Photo-consistent features + peaky regulariser (gen_golden.py::gen_photo): heights within 1e-3 m of the
+    reference's; and the check means something -- moving one source image by 0.05 px moves the heights by far more."""
+    from satmvs_amd.modules import module as M
+    from satmvs_amd.modules import warping
+    from satmvs_amd.rpc_synth import SAMP_OFF
+    g = golden("photo")
+    feats = [_t(g["feats"][v], dev) for v in range(g["feats"].shape[0])]
+    dv, lam = _t(g["depth_values"], dev), float(g["lam"])
+    with torch.no_grad():
+        var = warping.variance_cost_volume(feats, _t(g["rpc"], dev), dv, "rpc")
+        depth, conf = M.softmax_depth_regression(-lam * var.mean(1), dv)
+        rpc2 = g["rpc"].copy()
+        rpc2[0, 1, SAMP_OFF] += 0.05
+        var2 = warping.variance_cost_volume(feats, _t(rpc2, dev), dv, "rpc")
+        depth2, _ = M.softmax_depth_regression(-lam * var2.mean(1), dv)
+    assert np.abs(depth.cpu().numpy() - g["depth"]).max() <= 1e-3
+    np.testing.assert_allclose(conf.cpu().numpy(), g["conf"], rtol=0, atol=5e-4)
+    assert float((depth2 - depth).abs().max()) > 0.05          # 50x the tolerance: the golden is sensitive to the warp
+
+
+def test_costvol_backward_matches_reference_gradients(dev, golden):
+    """d loss / d features through the native forward + smvs_costvol_bwd against gradients captured from the
+    reference's own differentiable path (gen_golden.py::gen_grad: grid_sample backward, in-place variance
+    accumulation, softmax, depth_regression).  float32 atomics sum in another order: rtol 2e-4 on the gradient scale."""
+    from satmvs_amd.modules.module import depth_regression
+    from satmvs_amd.modules import warping
+    g = golden("grad")
+    feats = [_t(g["feats"][v], dev).requires_grad_(True) for v in range(g["feats"].shape[0])]
+    dv, lam, w = _t(g["depth_values"], dev), float(g["lam"]), _t(g["wmap"], dev)
+    var = warping.variance_cost_volume(feats, _t(g["rpc"], dev), dv, "rpc")
+    p = torch.softmax(-lam * var.mean(1), dim=1)
+    depth = depth_regression(p, depth_values=dv)
+    np.testing.assert_allclose(depth.detach().cpu().numpy(), g["depth"], rtol=0, atol=1e-3)
+    loss = (depth * w).sum()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-3 * max(1.0, abs(float(g["loss"])))
+    loss.backward()
+    scale = np.abs(g["grads"]).max()
+    for v, f in enumerate(feats):
+        np.testing.assert_allclose(f.grad.cpu().numpy(), g["grads"][v], rtol=0, atol=2e-4 * scale)
+
+
 def test_warp_backward_matches_torch(dev, oracle):
     """grad w.r.t. src_fea == autograd of F.grid_sample on the same (oracle-built) grid."""
     from satmvs_amd.modules import warping

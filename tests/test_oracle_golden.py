@@ -108,6 +108,20 @@ def test_softmax_regress(oracle, golden):
     np.testing.assert_allclose(conf, r["sm_conf"], rtol=1e-5, atol=1e-6)
 
 
+def test_photo_consistent_peaky_problem(oracle, golden):
+    """Photo-consistent views + peaky stand-in regulariser (tests/golden/gen_golden.py::gen_photo): the softmax sits on
+    the plane where the warped features agree (mean confidence > 0.4 on 16 planes), so a warp error moves the height.
+    Oracle pipeline (variance volume -> -lam * mean -> softmax regression) vs the reference's outputs."""
+    g = golden("photo")
+    feats = [g["feats"][v] for v in range(g["feats"].shape[0])]
+    var = oracle.costvol_variance(feats, g["rpc"], g["depth_values"], "rpc")
+    reg = (-float(g["lam"]) * var.mean(1, dtype=np.float32)).astype(np.float32)
+    depth, conf = oracle.softmax_regress(reg, g["depth_values"])
+    assert float(g["conf"].mean()) > 0.4
+    assert np.abs(depth - g["depth"]).max() <= 1e-3            # north_star: regressed height within 1e-3 m
+    np.testing.assert_allclose(conf, g["conf"], rtol=0, atol=2e-4)
+
+
 def test_height_hypotheses(oracle, golden):
     """Generated hypotheses against the reference's get_depth_range_samples + F.interpolate pipeline.
     The sample arithmetic and the trilinear resize are reproduced bit for bit (r2: previous map given at image size;
