@@ -145,7 +145,8 @@ def kernel_name(V, C, planes=4):
     direct = V - 1 > 4 or C not in (8, 16, 32)              # dispatch rule of costvol.hip (launch_ct)
     if direct:
         return "costvol_fwd_kernel<rpc,%d,%d>" % (V - 1, C)
-    return "costvol_dma_kernel<rpc,%d,%d,%d>" % (V - 1, C, 1 if planes == 1 else 2 if planes == 2 else 4)
+    dp = 1 if planes == 1 else 2 if planes == 2 else 8 if (planes % 8 == 0 and V - 1 <= 2 and C == 32) else 4
+    return "costvol_dma_kernel<rpc,%d,%d,%d>" % (V - 1, C, dp)
 
 
 def side_workloads(dev, stream):
@@ -168,7 +169,7 @@ def side_workloads(dev, stream):
             step()
         _, ms = time_steps(step, 30)
         bpv = algorithmic_bytes_per_voxel(V, C, D)
-        extra[name] = {"kernel": kernel_name(V, C), "ms": round(ms, 4), "Mvox/s": round(D * H * W / ms / 1e3, 1),
+        extra[name] = {"kernel": kernel_name(V, C, D), "ms": round(ms, 4), "Mvox/s": round(D * H * W / ms / 1e3, 1),
                        "roofline_frac": round(bpv * D * H * W / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         del feats, out
     # cfg5: pinhole (homography) volume, 3-view 768x384x64, C=32
@@ -312,7 +313,7 @@ def main():
                        "planes_total": D, "H": H, "W": W, "depth_values": "per-voxel (B,D,H,W)",
                        "sharding": "height planes of one tile split over the ranks, regression partials all-reduced each step",
                        "prewarm_seconds": args.prewarm_seconds},
-            "roofline": {"bound": "hbm", "kernel": kernel_name(V, C),
+            "roofline": {"bound": "hbm", "kernel": kernel_name(V, C, D_local),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload) if world == 1 else None,
                          "bytes_per_voxel": bpv, "kernel_ms": round(kern_ms, 4)},

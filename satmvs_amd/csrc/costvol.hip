@@ -281,7 +281,7 @@ __device__ __forceinline__ void wait_vmcnt_upto8(int n)
 struct TapD { uint32_t base; f32x2 wn, ws; };       // wn = {nw, ne}, ws = {sw, se}
 
 template <int GEO, int NSRC, int CT, int DP>
-__global__ __launch_bounds__(64 * WV_WAVES, (NSRC <= 2 ? SMVS_WAVES_PER_SIMD : 2))
+__global__ __launch_bounds__(64 * WV_WAVES, (NSRC <= 2 && DP <= 4 ? SMVS_WAVES_PER_SIMD : 2))
 void costvol_dma_kernel(const CostVolParams p)
 {
     constexpr int BW = DM_BW, R = DM_R;
@@ -715,9 +715,9 @@ void costvol_dma_kernel(const CostVolParams p)
 
 // Kernel choice.  The staged kernel serves 2-5 views at C = 8/16/32 (one channel volume of the output < 2 GiB);
 // everything else (and SMVS_COSTVOL_DIRECT=1 in tuning builds) takes the direct-gather kernel.  Both produce
-// identical bits.  Planes per wave (DP): a whole sweep is cut into groups of 4 planes (the taps of a group live in
-// registers; with 3-4 sources the LDS tiles allow two workgroups per CU, i.e. 256 VGPRs per lane), the plane-at-a-time
-// launches of the pred loop get DP = 1 so that no float64 work is spent on planes that are not stored.
+// identical bits.  Planes per wave (DP): a whole sweep is cut into groups of 8 (2-3 views) or 4 planes (the taps of a
+// group live in registers; with 3-4 sources the LDS tiles allow two workgroups per CU, i.e. 256 VGPRs per lane), the
+// plane-at-a-time launches of the pred loop get DP = 1 so that no float64 work is spent on planes that are not stored.
 enum { K_DIRECT = 0, K_DMA = 2 };
 
 static int kernel_choice()
@@ -756,7 +756,12 @@ static hipError_t launch_ct(CostVolParams p, hipStream_t st)
                                (long long)p.D_out * p.H * p.W * 4 < (1ll << 31);
         if (kernel_choice() != K_DIRECT && staged_ok) {
             if (nd == 1) return launch_staged<GEO, NSRC, 1>(p, st);
-            if (nd == 2) return launch_staged<GEO, NSRC, 2>(p, st);
+if (nd == 2) return launch_staged<GEO, NSRC, 2>(p, st);
+            // 8 planes per wave when the sweep divides into eights (48 / 32 / 8 / 64-plane sweeps): half the staging DMA per
+            // voxel and the ref view's plane-invariant part amortised over twice the planes outweigh the drop to two
+            // waves per SIMD (223 VGPRs) -- measured 0.699 vs 0.717 ms at the metric shape; at C = 8 (float64-bound) and for the
+            // homography variant 4 planes per wave stay faster (0.053 vs 0.061 ms, 0.72 vs 0.89 ms)
+            if constexpr (NSRC <= 2 && GEO == 0) { if (nd % 8 == 0 && p.C == 32) return launch_staged<GEO, NSRC, 8>(p, st); }
             return launch_staged<GEO, NSRC, 4>(p, st);
         }
     }
