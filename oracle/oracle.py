@@ -180,6 +180,68 @@ def stage1_planes(depth_range, ndepth):
     return (lo[:, None] + (np.arange(ndepth, dtype=np.float32)[None] * step[:, None]).astype(np.float32)).astype(np.float32)
 
 
+def remap_linear_const(img, x, y, border=-999.0):
+    """cv2.remap(img, x, y, INTER_LINEAR, BORDER_CONSTANT, border) for float32 images, restated from OpenCV's published
+    algorithm (opencv-python 4.5.5.62 is pinned by the reference's environment.yml:156 but absent here: parity unpinned for
+    this step): coordinates go to fixed point with 5 fractional bits (cvRound = round half to even), the bilinear weights
+    come from those fractions, taps outside the image take the border value."""
+    img = _f32(img)
+    H, W = img.shape
+    sx = np.rint(np.asarray(x, np.float32) * np.float32(32)).astype(np.int64)
+    sy = np.rint(np.asarray(y, np.float32) * np.float32(32)).astype(np.int64)
+    ix, iy = sx >> 5, sy >> 5
+    ax, ay = ((sx & 31).astype(np.float32) / np.float32(32)), ((sy & 31).astype(np.float32) / np.float32(32))
+
+    def at(yy, xx):
+        ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+        return np.where(ok, img[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)], np.float32(border)).astype(np.float32)
+    one = np.float32(1)
+    w00, w01, w10, w11 = (one - ax) * (one - ay), ax * (one - ay), (one - ax) * ay, ax * ay
+    return (at(iy, ix) * w00 + at(iy, ix + 1) * w01 + at(iy + 1, ix) * w10 + at(iy + 1, ix + 1) * w11).astype(np.float32)
+
+
+def reproject_with_depth(depth_ref, rpc_ref, depth_src, rpc_src):
+    """tools/rpc_filter.py:11-48 of the reference: -> sampled source heights, reprojected (x, y), source (x, y)."""
+    depth_ref = _f32(depth_ref)
+    H, W = depth_ref.shape
+    xr, yr = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    h = depth_ref.reshape(-1).astype(np.float64)
+    lat, lon = rpc_project(rpc_ref, xr.reshape(-1), yr.reshape(-1), h, 0)
+    xs, ys = rpc_project(rpc_src, lat, lon, h, 1)
+    xs, ys = xs.reshape(H, W), ys.reshape(H, W)
+    sampled = remap_linear_const(depth_src, xs.astype(np.float32), ys.astype(np.float32))
+    sh = sampled.reshape(-1).astype(np.float64)
+    lat, lon = rpc_project(rpc_src, xs.reshape(-1), ys.reshape(-1), sh, 0)
+    xb, yb = rpc_project(rpc_ref, lat, lon, sh, 1)
+    return sampled, xb.reshape(H, W), yb.reshape(H, W), xs, ys
+
+
+def check_geometric_consistency(depth_ref, rpc_ref, depth_src, rpc_src, p_ratio, d_ratio):
+    """tools/rpc_filter.py:51-70."""
+    depth_ref = _f32(depth_ref)
+    H, W = depth_ref.shape
+    xr, yr = np.meshgrid(np.arange(W), np.arange(H))
+    dep, xb, yb, xs, ys = reproject_with_depth(depth_ref, rpc_ref, depth_src, rpc_src)
+    dist = np.sqrt((xb - xr) ** 2 + (yb - yr) ** 2)
+    mask = np.logical_and(dist < p_ratio, np.abs(dep - depth_ref) < d_ratio)
+    dep = dep.copy()
+    dep[~mask] = 0
+    return mask, dep, xs, ys
+
+
+def filter_depth(depths, rpcs, p_ratio, d_ratio, geo_consist_num, prob=None, confidence_ratio=0.0):
+    """tools/rpc_filter.py:73-112."""
+    ref = _f32(depths[0])
+    photo = (np.asarray(prob) > confidence_ratio) if prob is not None else np.ones(ref.shape, bool)
+    geo_sum, ests = 0, []
+    for v in range(1, len(depths)):
+        m, dep, _, _ = check_geometric_consistency(ref, rpcs[0], depths[v], rpcs[v], p_ratio, d_ratio)
+        geo_sum = geo_sum + m.astype(np.int32)
+        ests.append(dep)
+    averaged = (sum(ests) + ref) / (geo_sum + 1)
+    return np.logical_and(photo, geo_sum >= geo_consist_num), averaged
+
+
 def window_regress(reg, depth, lamb=None):
     """casmvs / ucs regression: (depth, window-4 confidence[, lamb * std-dev]) -- orc_window_regress."""
     reg = _f32(reg)

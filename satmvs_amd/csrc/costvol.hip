@@ -187,7 +187,10 @@ void costvol_fwd_kernel(const CostVolParams p)
 
 // ---- geometry shared by the staged (LDS) kernel ----------------------------------------------------
 constexpr int WV_TX = 32, WV_TY = 2;          // ref pixels per wave
-constexpr int WV_WAVES = 4;                   // waves per workgroup, stacked in y: 32 x 8 pixels
+#ifndef SMVS_WG_WAVES
+#define SMVS_WG_WAVES 4
+#endif
+constexpr int WV_WAVES = SMVS_WG_WAVES;       // waves per workgroup, stacked in y: 32 x 8 pixels
 
 __device__ __forceinline__ int wave_min(int v)
 {
