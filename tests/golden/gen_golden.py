@@ -333,6 +333,30 @@ def gen_grad():
          grads=np.stack([f.grad.numpy() for f in feats]))
 
 
+def gen_io():
+    """dataset/data_io.py:17-92 (load_pfm, load_rpc_as_array): the module needs GDAL to import, so the reader functions
+    are exec'd from their source lines with nothing of them stored.  A PFM and an .rpc text written by OUR writers are read
+    by the REFERENCE's readers; the files and what the reference read are the fixture."""
+    import re as _re  # noqa: F401
+    src = open(os.path.join(REF, "dataset", "data_io.py")).read()
+    a, b = src.index("def load_pfm(fname):"), src.index("def save_pfm(file, image, scale=1):")
+    c, d = src.index("def load_rpc_as_array(filepath):"), src.index("def to_tensor(data):")
+    ns = {"np": np, "re": __import__("re"), "os": os, "sys": sys}
+    exec(src[a:b] + src[c:d], ns)
+    from satmvs_amd import data_io
+    rng = np.random.default_rng(91)
+    img = (rng.standard_normal((9, 14)) * 50 + 200).astype(np.float32)
+    rpc = ref_rpcs(1, 32, 64, seed=92)[0, 0]
+    io_dir = os.path.join(HERE, "io")
+    os.makedirs(io_dir, exist_ok=True)
+    data_io.save_pfm(os.path.join(io_dir, "height.pfm"), img)
+    data_io.save_rpc(os.path.join(io_dir, "view.rpc"), rpc)
+    ref_img = ns["load_pfm"](os.path.join(io_dir, "height.pfm"))
+    ref_rpc, hmax, hmin = ns["load_rpc_as_array"](os.path.join(io_dir, "view.rpc"))
+    assert np.array_equal(ref_img, img) and np.array_equal(ref_rpc, rpc)
+    save("io", pfm=np.ascontiguousarray(ref_img), rpc=ref_rpc, h_max=np.float64(hmax), h_min=np.float64(hmin))
+
+
 def gen_pred():
     """compute_depth_when_pred (networks/casred.py:161-238) with seeded slice_RED_Regularization
     weights, and compute_depth_when_train with RED_Regularization on the same weights."""
@@ -567,7 +591,7 @@ def gen_featnet():
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (gen_iccv, gen_project, gen_grid_sample, gen_rpc_warp, gen_qc, gen_homo, gen_costvol, gen_pred,
-               gen_regress, gen_depth_range, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad):
+               gen_regress, gen_depth_range, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad, gen_io):
         if only and fn.__name__[4:] not in only:
             continue
         fn()
