@@ -450,7 +450,7 @@ void costvol_dma_kernel(const CostVolParams p)
                 tap[pl][s].ws.x = n * e;  tap[pl][s].ws.y = n * w;
                 const int ix0 = cvt_i32_sat(xw), iy0 = cvt_i32_sat(yn);
                 const bool ok = ((uint32_t)(ix0 + 1) <= (uint32_t)W) && ((uint32_t)(iy0 + 1) <= (uint32_t)H);
-                txy[pl][s] = ((uint32_t)(iy0 + 1) << 16) | (uint32_t)((ix0 + 1) & 0xffff);
+                txy[pl][s] = (uint32_t)((iy0 + 1) * BW + (ix0 + 1));      // cell index relative to image corner (-1,-1); used only if ok
                 if (ok) okmask |= 1u << (pl * NSRC + s);
                 if (ok && active && pl < np) {
                     lo_x[s] = min(lo_x[s], ix0); hi_x[s] = max(hi_x[s], ix0);
@@ -517,9 +517,8 @@ void costvol_dma_kernel(const CostVolParams p)
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) {
                 const bool ok = (okmask >> (pl * NSRC + s)) & 1u;
-                const int iy0 = (int)(txy[pl][s] >> 16) - 1, ix0 = (int)(txy[pl][s] & 0xffffu) - 1;
-                tap[pl][s].base = tile_lds + 8u * (uint32_t)(ok ? s * SRC_STRIDE + (iy0 - by0[s]) * BW + (ix0 - bx0[s])
-                                                                  : NSRC * SRC_STRIDE);
+                const int box0 = s * SRC_STRIDE - ((by0[s] + 1) * BW + bx0[s] + 1);        // wave-uniform
+                tap[pl][s].base = tile_lds + 8u * (uint32_t)(ok ? (int)txy[pl][s] + box0 : NSRC * SRC_STRIDE);
             }
         uint32_t ovo[DP];                                 // per-plane byte offset of this pixel inside one channel volume
 #pragma unroll
