@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-2 evidence set (run on the GPU box): tools/profile_r02.sh
+#   bench lines (driver flags and default), kernel trace of the default bench command, SQ / TA / traffic PMC passes
+#   (each in its own rocprofv3 run, never combined with tracing), cascade kernel trace, micro-benchmarks.
+set -u
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_r02
+mkdir -p "$OUT"
+python $REPO/bench.py --steps 20 --warmup 5 > "$OUT/bench_driver_flags.json" 2> "$OUT/bench_driver_flags.err"
+python $REPO/bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- python $REPO/bench.py --no-cpu-baseline --no-extra > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --prewarm-seconds 0.05"
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" \
+           "SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INST_LEVEL_VMEM" \
+           "GRBM_GUI_ACTIVE" "TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
+  name=$(echo $set | tr ' ' '+' | cut -c1-40)
+  rocprofv3 --pmc $set -d "$OUT/pmc_$name" -o pmc -- $BENCH > "$OUT/pmc_$name.log" 2>&1 || echo "failed: $set" >> "$OUT/errors.log"
+done
+rocprofv3 --kernel-trace --stats -d "$OUT/trace_cascade" -o trace -- python $REPO/tools/bench_pred.py > "$OUT/cascade.log" 2>&1
+python $REPO/tools/rocpd_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
+for u in valu store dma; do [ -x $REPO/gpurun_ab/ubench_$u ] && timeout 120 $REPO/gpurun_ab/ubench_$u > "$OUT/ubench_$u.txt" 2>&1; done
+find "$OUT" -name "*.db" -delete
+du -sh "$OUT"
