@@ -248,6 +248,9 @@ constexpr int DM_NBUF = 2;
 #ifndef SMVS_ABLATE
 #define SMVS_ABLATE 0                 // profiling builds only (tools/ab_build.sh x -DSMVS_ABLATE=n): 1 stores dropped, 2 no staging DMA, 4 no float64 chain -- results are WRONG
 #endif
+#ifndef SMVS_TAP_PREFETCH
+#define SMVS_TAP_PREFETCH 1           // pipeline units of LDS tap reads in flight ahead of the arithmetic (1 or 2)
+#endif
 #ifndef SMVS_O2P_PLANES
 #define SMVS_O2P_PLANES 4          // planes per evaluation pass of a source view's cubics
 #endif
@@ -598,14 +601,15 @@ void costvol_dma_kernel(const CostVolParams p)
             // from inline asm, in-order return, counted lgkmcnt) while unit u is being accumulated.  Two sources per unit
             // when the source count is even, one otherwise; a plane's sum / sum of squares run across its units.
             constexpr int US = (NSRC % 2 == 0) ? 2 : 1, UPP = NSRC / US, NU = DP * UPP;
-            f32x2 cv[2][US][4];
+            constexpr int PF = DP >= 8 ? SMVS_TAP_PREFETCH : 1;     // units of tap reads in flight ahead of the arithmetic (register budget: DP = 8 runs at 2 waves per SIMD)
+            f32x2 cv[PF + 1][US][4];
             f32x2 sum = refc, sq = refsq;
             auto read_unit = [&](int u) {
                 const int pl = u / UPP, s0 = (u % UPP) * US;
 #pragma unroll
                 for (int k = 0; k < US; ++k)
-                    lds_read_tap<PAR * BUF_STRIDE * 8, BW * 8>(tap[pl][s0 + k].base, cv[u & 1][k][0], cv[u & 1][k][1],
-                                                               cv[u & 1][k][2], cv[u & 1][k][3]);
+                    lds_read_tap<PAR * BUF_STRIDE * 8, BW * 8>(tap[pl][s0 + k].base, cv[u % (PF + 1)][k][0], cv[u % (PF + 1)][k][1],
+                                                               cv[u % (PF + 1)][k][2], cv[u % (PF + 1)][k][3]);
             };
             auto accumulate_unit = [&](int u) {
                 const int pl = u / UPP, s0 = (u % UPP) * US;
@@ -613,10 +617,10 @@ void costvol_dma_kernel(const CostVolParams p)
 #pragma unroll
                 for (int k = 0; k < US; ++k) {
                     const TapD& t = tap[pl][s0 + k];
-                    f32x2 wv = cv[u & 1][k][0] * __builtin_shufflevector(t.wn, t.wn, 0, 0);
-                    wv = __builtin_elementwise_fma(cv[u & 1][k][1], __builtin_shufflevector(t.wn, t.wn, 1, 1), wv);
-                    wv = __builtin_elementwise_fma(cv[u & 1][k][2], __builtin_shufflevector(t.ws, t.ws, 0, 0), wv);
-                    wv = __builtin_elementwise_fma(cv[u & 1][k][3], __builtin_shufflevector(t.ws, t.ws, 1, 1), wv);
+                    f32x2 wv = cv[u % (PF + 1)][k][0] * __builtin_shufflevector(t.wn, t.wn, 0, 0);
+                    wv = __builtin_elementwise_fma(cv[u % (PF + 1)][k][1], __builtin_shufflevector(t.wn, t.wn, 1, 1), wv);
+                    wv = __builtin_elementwise_fma(cv[u % (PF + 1)][k][2], __builtin_shufflevector(t.ws, t.ws, 0, 0), wv);
+                    wv = __builtin_elementwise_fma(cv[u % (PF + 1)][k][3], __builtin_shufflevector(t.ws, t.ws, 1, 1), wv);
                     sum = sum + wv;
                     sq = sq + wv * wv;
                 }
@@ -630,21 +634,27 @@ void costvol_dma_kernel(const CostVolParams p)
                     SMVS_T(t_st += now() - ts0;)
                 }
             };
-            read_unit(0);
+#pragma unroll
+            for (int u = 0; u < PF && u < NU; ++u) read_unit(u);
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
-                if (u + 1 < NU) read_unit(u + 1);
+                if (u + PF < NU) read_unit(u + PF);
+                constexpr int RPU = 4 * US;                               // reads per unit
+                const int ahead = (NU - 1 - u) < PF ? (NU - 1 - u) : PF;  // units issued after unit u
                 // reads per unit = 4*US; everything older than the next unit's reads has returned
                 f32x2 d0, d1, d2, d3;
                 d0 = d1 = d2 = d3 = (f32x2)(0.0f);
                 if constexpr (US == 1) {
-                    if (u + 1 < NU) lds_wait<4>(cv[u & 1][0][0], cv[u & 1][0][1], cv[u & 1][0][2], cv[u & 1][0][3], d0, d1, d2, d3);
-                    else            lds_wait<0>(cv[u & 1][0][0], cv[u & 1][0][1], cv[u & 1][0][2], cv[u & 1][0][3], d0, d1, d2, d3);
+                    if (ahead >= 2)      lds_wait<(2 * RPU < 15 ? 2 * RPU : 15)>(cv[u % (PF + 1)][0][0], cv[u % (PF + 1)][0][1], cv[u % (PF + 1)][0][2], cv[u % (PF + 1)][0][3], d0, d1, d2, d3);
+                    else if (ahead == 1) lds_wait<4>(cv[u % (PF + 1)][0][0], cv[u % (PF + 1)][0][1], cv[u % (PF + 1)][0][2], cv[u % (PF + 1)][0][3], d0, d1, d2, d3);
+                    else            lds_wait<0>(cv[u % (PF + 1)][0][0], cv[u % (PF + 1)][0][1], cv[u % (PF + 1)][0][2], cv[u % (PF + 1)][0][3], d0, d1, d2, d3);
                 } else {
-                    if (u + 1 < NU) lds_wait<8>(cv[u & 1][0][0], cv[u & 1][0][1], cv[u & 1][0][2], cv[u & 1][0][3],
-                                                cv[u & 1][US - 1][0], cv[u & 1][US - 1][1], cv[u & 1][US - 1][2], cv[u & 1][US - 1][3]);
-                    else            lds_wait<0>(cv[u & 1][0][0], cv[u & 1][0][1], cv[u & 1][0][2], cv[u & 1][0][3],
-                                                cv[u & 1][US - 1][0], cv[u & 1][US - 1][1], cv[u & 1][US - 1][2], cv[u & 1][US - 1][3]);
+                    if (ahead >= 2)      lds_wait<15>(cv[u % (PF + 1)][0][0], cv[u % (PF + 1)][0][1], cv[u % (PF + 1)][0][2], cv[u % (PF + 1)][0][3],
+                                                     cv[u % (PF + 1)][US - 1][0], cv[u % (PF + 1)][US - 1][1], cv[u % (PF + 1)][US - 1][2], cv[u % (PF + 1)][US - 1][3]);
+                    else if (ahead == 1) lds_wait<8>(cv[u % (PF + 1)][0][0], cv[u % (PF + 1)][0][1], cv[u % (PF + 1)][0][2], cv[u % (PF + 1)][0][3],
+                                                cv[u % (PF + 1)][US - 1][0], cv[u % (PF + 1)][US - 1][1], cv[u % (PF + 1)][US - 1][2], cv[u % (PF + 1)][US - 1][3]);
+                    else            lds_wait<0>(cv[u % (PF + 1)][0][0], cv[u % (PF + 1)][0][1], cv[u % (PF + 1)][0][2], cv[u % (PF + 1)][0][3],
+                                                cv[u % (PF + 1)][US - 1][0], cv[u % (PF + 1)][US - 1][1], cv[u % (PF + 1)][US - 1][2], cv[u % (PF + 1)][US - 1][3]);
                 }
                 accumulate_unit(u);
             }
