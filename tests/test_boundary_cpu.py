@@ -228,3 +228,53 @@ def test_data_io_matches_reference_readers(golden, tmp_path):
     assert np.array_equal(data_io.load_rpc_as_array(str(tmp_path / "r.rpc"))[0], g["rpc"])
     with pytest.raises(Exception):
         data_io.save_pfm(str(tmp_path / "x.pfm"), col.astype(np.float64))
+
+
+def test_round2_entry_points_validate_arguments(lib):
+    """The entry points added in round 2 (generated heights, window regression, consistency filter) reject bad arguments
+    before any HIP call; the size queries report the kernels' limits as 0 (callers then take the composite)."""
+    from satmvs_amd import _lib
+    from satmvs_amd.modules.depth_range import _HeightGenStruct
+    dummy = C.c_void_p(16)
+    arr = (C.c_void_p * 2)(16, 16)
+
+    def gen(prev=16, hp=8, wp=16, ih=32, iw=64, nd=6, interval=5.0):
+        return _HeightGenStruct(prev, hp, wp, ih, iw, nd, interval)
+    g = gen()
+    with pytest.raises(_lib.SatMVSNativeError, match="ndepth differs"):
+        _lib.call("smvs_rpc_costvol_fwd_gen", dummy, arr, 2, dummy, C.addressof(g), dummy, 1, 8, 7, 16, 32, 0, 7, 7, 0, None)
+    g4 = gen(ih=64, iw=128)                                   # image / stage = 4: only stage 1, which passes planes
+    with pytest.raises(_lib.SatMVSNativeError, match="scale 1 or 2"):
+        _lib.call("smvs_height_hypotheses", C.addressof(g4), dummy, 1, 16, 32, None)
+    gbad = gen(ih=33)
+    with pytest.raises(_lib.SatMVSNativeError, match="integer multiple"):
+        _lib.call("smvs_softmax_regress_fwd_gen", dummy, C.addressof(gbad), dummy, dummy, 1, 6, 16, 32, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="null"):
+        _lib.call("smvs_window_regress_fwd_gen", dummy, None, dummy, dummy, None, 0.0, 1, 6, 16, 32, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="null pointer"):
+        _lib.call("smvs_window_regress_fwd", dummy, None, 1, dummy, dummy, None, 0.0, 1, 6, 16, 32, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="go together"):
+        _lib.call("smvs_rpc_geo_consistency", dummy, dummy, dummy, dummy, 8, 8, 8, 8, 1.0, 2.5, dummy, dummy, dummy, dummy,
+                  dummy, None, None)
+    assert lib.smvs_red_workspace_bytes(1, 32, 4096, 4096) == 0            # (C+8)*H*W*4 >= 2^31: beyond 32-bit offsets
+    assert lib.smvs_costreg_workspace_bytes(1, 8, 64, 8192, 64) == 0        # D*H/4 exceeds one launch grid
+    assert lib.smvs_featnet_workspace_bytes(1, 8192, 8192, 8, 0) == 0       # feature map >= 2 GiB
+
+
+def test_generated_heights_python_composite_matches_reference(golden):
+    """GeneratedHeights.materialize() on the CPU is the reference's own op sequence (bilinear resize, samples, trilinear
+    resize): identical to the reference-generated tensors; stage_hypotheses picks planes / composite as documented."""
+    from satmvs_amd.modules.depth_range import GeneratedHeights, stage1_planes, stage_hypotheses
+    g = golden("depth_range")
+    _, H, W = g["cur"].shape
+    a = GeneratedHeights(torch.from_numpy(g["prev_a"]), 6, 5.0, (H, W), (H // 2, W // 2))
+    assert tuple(a.shape) == (1, 6, H // 2, W // 2) and a.dim() == 4
+    assert np.array_equal(a.materialize().numpy(), g["r_a"])
+    b = GeneratedHeights(torch.from_numpy(g["prev_b"]), 8, 2.5, (H, W), (H, W))
+    assert np.array_equal(b.materialize().numpy(), g["r_b"])
+    assert GeneratedHeights.supported((H, W), (H // 2, W // 2)) and not GeneratedHeights.supported((H, W), (H // 4, W // 4))
+    planes = stage_hypotheses(None, torch.from_numpy(g["dv"]), 8, 10.0, (H, W), (H // 4, W // 4), torch.float32, "cpu", 1)
+    assert planes.shape == (1, 8) and np.array_equal(np.broadcast_to(planes.numpy()[:, :, None, None], g["r1"].shape), g["r1"])
+    assert torch.equal(planes, stage1_planes(torch.from_numpy(g["dv"]), 8))
+    t = stage_hypotheses(torch.from_numpy(g["prev_a"]), None, 6, 5.0, (H, W), (H // 2, W // 2), torch.float32, "cpu", 1)
+    assert isinstance(t, torch.Tensor) and np.array_equal(t.numpy(), g["r_a"])          # CPU: the composite, not a generator
