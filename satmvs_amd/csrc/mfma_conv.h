@@ -242,16 +242,17 @@ inline bool mfma_conv_ok(int CA, int CB, int Cout)
 inline size_t mfma_packed_floats(int cin, int cout, int taps) { return (size_t)(cin / 2) * taps * ((cout + 31) / 32) * 64; }
 
 template <int TAPS>
-inline void mfma_conv_launch(const MfmaConvArgs& a, int B, hipStream_t st)
+inline void mfma_conv_launch(const MfmaConvArgs& a, int B, hipStream_t st, int Bh = 0)   // Bh: batch the variant is chosen for (0 = B)
 {
     const int tiles = ((a.Wo + 31) / 32) * a.Ho * a.Do * B;
+    const int tiles_h = ((a.Wo + 31) / 32) * a.Ho * a.Do * (Bh > 0 ? Bh : B);
     const int nt = a.Cout / 32, ncip = (a.CA + a.CB) / 2;
     // Few tiles (the coarse levels): latency, not throughput, sets the time -- one cout tile per workgroup
     // and as many K-splitting waves as the channel count divides into.  Many tiles: one workgroup carries
     // every cout tile so the X operand is loaded once.
     static const int small = tune_int("SMVS_MFMA_SMALL", 1024);
     static const int maxw = tune_int("SMVS_MFMA_WAVES", 8);
-    if (tiles < small) {
+    if (tiles_h < small) {
         if (ncip % 16 == 0 && maxw >= 16)     hipLaunchKernelGGL((mfma_conv_kernel<TAPS, 1, 16>), dim3(tiles, nt), dim3(1024), 0, st, a);
         else if (ncip % 8 == 0 && maxw >= 8) hipLaunchKernelGGL((mfma_conv_kernel<TAPS, 1, 8>), dim3(tiles, nt), dim3(512), 0, st, a);
         else                    hipLaunchKernelGGL((mfma_conv_kernel<TAPS, 1, 4>), dim3(tiles, nt), dim3(256), 0, st, a);

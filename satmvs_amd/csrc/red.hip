@@ -119,6 +119,11 @@ struct ConvArgs {
     int ngroups;                             // 1, or 2 (gate conv: reset half / update half)
     int Cout, Hi, Wi, Ho, Wo, relu;
     size_t out_bstride;                      // floats between samples of `out`; 0 = Cout*Ho*Wo (dense)
+    // strided view of inA (all 0 = dense (B,CA,Hi,Wi)): the pred loop reads variance planes straight out of a
+    // (B,C,CH,H,W) chunk written by the cost-volume kernel.  Sample s of the launch = (batch s % inA_bmod, plane
+    // s / inA_bmod) when inA_bmod > 0, else (batch s, plane 0); its first channel starts at
+    // inA + batch*inA_bs + plane*inA_ps and channels are inA_cs floats apart.
+    size_t inA_cs, inA_bs, inA_ps; int inA_bmod;
 };
 
 typedef const float __attribute__((address_space(4))) * cw_t;
@@ -159,7 +164,10 @@ void conv3x3_kernel(const ConvArgs a)
             const int iy = oy * STRIDE - 1 + ky, ix = ox * STRIDE - 1 + kx;
             off[ky * 3 + kx] = (active && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) ? (uint32_t)(iy * a.Wi + ix) * 4u : SMVS_OOB;
         }
-    const BufRsrc rA = make_rsrc(a.inA + (size_t)b * a.CA * HWi, (uint32_t)a.CA * (uint32_t)HWi * 4u);
+    const int csA = a.inA_cs ? (int)a.inA_cs : HWi;                 // floats between channels of inA
+    const int bA = a.inA_bmod ? b % a.inA_bmod : b, pA = a.inA_bmod ? b / a.inA_bmod : 0;
+    const BufRsrc rA = make_rsrc(a.inA + (a.inA_cs ? (size_t)bA * a.inA_bs + (size_t)pA * a.inA_ps : (size_t)b * a.CA * HWi),
+                                 ((uint32_t)(a.CA - 1) * (uint32_t)csA + (uint32_t)HWi) * 4u);
     const BufRsrc rB = make_rsrc(a.inB ? a.inB + (size_t)b * a.CB * HWi : a.inA, (uint32_t)(a.inB ? a.CB : 0) * (uint32_t)HWi * 4u);
 
     float acc[COT];
@@ -175,7 +183,7 @@ void conv3x3_kernel(const ConvArgs a)
         i32x4 rx_;                                                                                     \
         rx_.x = fa_ ? rA.v.x : rB.v.x; rx_.y = fa_ ? rA.v.y : rB.v.y;                                  \
         rx_.z = fa_ ? rA.v.z : rB.v.z; rx_.w = rA.v.w;                                                 \
-        const int co_ = (fa_ ? (CC) : (CC) - a.CA) * HWi * 4;                                          \
+        const int co_ = fa_ ? (CC) * csA * 4 : ((CC) - a.CA) * HWi * 4;                                \
         const float sc_ = fa_ ? a.scaleA : 1.0f;                                                       \
         _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_) V[k_] = llvm_raw_buffer_load_f32(rx_, (int)off[k_], co_, 0) * sc_; \
     }
@@ -421,33 +429,52 @@ void gru_combine_kernel(const float* __restrict__ cand, const double* __restrict
 }
 
 // ---- host orchestration ----------------------------------------------------------------------------------------------
-constexpr int NBUF = 4;                      // planes in flight in the pred pipeline (ring of cross-stream buffers)
+// The state-independent front of a plane (cost-volume plane + the three encoder convolutions) is issued for a CHUNK of
+// CH planes per launch; buffers that cross streams exist NSL = 2*CH times (two chunks: the front of chunk j+1 runs
+// under the recurrent levels of chunk j).  CH depends on the geometry only, so that every caller (workspace size,
+// single step, plane loop, any shard of the plane range) sees the same layout and the same kernel variants.
+constexpr int CH_MAX = 8, NSL_MAX = 2 * CH_MAX;
+static int red_chunk(int B, int C, int H, int W)
+{
+    int ch = (size_t)B * H * W <= (size_t)tune_int("SMVS_RED_CHUNK8_BELOW", 131072) ? 8 : 4;   // small planes: the host's enqueue rate binds
+    const int force = tune_int("SMVS_RED_CHUNK", 0);
+    if (force == 1 || force == 2 || force == 4 || force == 8) ch = force;
+    while (ch > 1 && (long long)C * ch * H * W * 4 >= (1ll << 30)) ch >>= 1;                // chunk addressed with 32-bit byte offsets
+    return ch;
+}
+
 struct RedWorkspace {                        // offsets in floats into the caller's workspace
-    // e / up / stats exist NBUF times: they cross streams, so plane k+1.. may be written while plane k is
+    // e / up / stats exist NSL times: they cross streams, so plane k+1.. may be written while plane k is
     // still being read (see red_run_planes).  gates / rh / cand / sum live on one stream each.
-    size_t e[NBUF][3], gates[4], rh[4], cand[4], up[NBUF][3], sum[3], stats[NBUF];   // stats: doubles, offset in floats (8-byte aligned)
+    // e[i] + slot * e_stride[i]: the slots of a chunk are adjacent = one dense batch of CH*B samples.
+    int CH, NSL;
+    size_t e[3], e_stride[3], gates[4], rh[4], cand[4], up[NSL_MAX][3], sum[3], stats[NSL_MAX];   // stats: doubles, offset in floats (8-byte aligned)
     size_t total;
 };
 
 static RedWorkspace red_workspace(int B, int C, int H, int W)
 {
     RedWorkspace w{};
+    w.CH = red_chunk(B, C, H, W);
+    w.NSL = 2 * w.CH;
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };
     const int hs[4] = {H, H / 2, H / 4, H / 8}, ws[4] = {W, W / 2, W / 4, W / 8};
     const int ech[3] = {16, 32, 64};
-    for (int p = 0; p < NBUF; ++p)
-        for (int i = 0; i < 3; ++i) w.e[p][i] = take((size_t)B * ech[i] * hs[i + 1] * ws[i + 1]);
+    for (int i = 0; i < 3; ++i) {
+        w.e_stride[i] = (size_t)B * ech[i] * hs[i + 1] * ws[i + 1];      // multiples of 4 floats: H, W are multiples of 8
+        w.e[i] = take(w.e_stride[i] * w.NSL);
+    }
     for (int i = 0; i < 4; ++i) {
         w.gates[i] = take((size_t)B * 2 * HID[i] * hs[i] * ws[i]);
         w.rh[i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
         w.cand[i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
     }
     for (int i = 0; i < 3; ++i) {            // up[.][i]: output of upconv{i+1} at level i ; sum[i] = up[i] + state{i+1}'
-        for (int p = 0; p < NBUF; ++p) w.up[p][i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
+        for (int p = 0; p < w.NSL; ++p) w.up[p][i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
         w.sum[i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
     }
-    for (int p = 0; p < NBUF; ++p)
+    for (int p = 0; p < w.NSL; ++p)
         w.stats[p] = take((size_t)B * 4 * 3 * NSLOT * 2 * 2);   // 4 GRUs x (reset, update, output) x NSLOT x (sum, sumsq) doubles
     w.total = o;
     return w;
@@ -465,20 +492,23 @@ static int g_split_below()
 }
 
 // `wm` = MFMA-order weights of the same layer (used when the layer qualifies)
-static void launch_conv(int stride, const ConvArgs& a, int B, hipStream_t st, const float* wm = nullptr)
+// Bh = the batch size the kernel VARIANT is chosen for (0 = B): the last chunk of a plane range may be short, and a
+// plane's bits must not depend on how the range was chunked or sharded.
+static void launch_conv(int stride, const ConvArgs& a, int B, hipStream_t st, const float* wm = nullptr, int Bh = 0)
 {
+    if (Bh <= 0) Bh = B;
     if (wm && mfma_conv_ok(a.CA, a.CB, a.Cout) && !g_red_direct_only()) {
         MfmaConvArgs m{};
         m.inA = a.inA; m.CA = a.CA; m.inB = a.inB; m.CB = a.CB; m.scaleA = a.scaleA; m.w = wm; m.bias = a.bias;
         m.out = a.out; m.stats = a.stats; m.ngroups = a.ngroups; m.nslot = NSLOT;
         m.Cout = a.Cout; m.relu = a.relu; m.stride = stride;
         m.Di = m.Do = 1; m.Hi = a.Hi; m.Wi = a.Wi; m.Ho = a.Ho; m.Wo = a.Wo;
-        mfma_conv_launch<9>(m, B, st);
+        mfma_conv_launch<9>(m, B, st, Bh);
         return;
     }
     const int ncog = (a.Cout + COT - 1) / COT;
     const int wx = (a.Wo + 63) / 64;
-    if (wx * ((a.Ho + 3) / 4) * B * ncog < g_split_below()) {          // coarse plane: latency regime
+    if (wx * ((a.Ho + 3) / 4) * Bh * ncog < g_split_below()) {          // coarse plane: latency regime
         dim3 grd(wx, a.Ho, B * ncog), blk(256);
         if (stride == 1) hipLaunchKernelGGL((conv3x3_kernel<1, true>), grd, blk, 0, st, a);
         else             hipLaunchKernelGGL((conv3x3_kernel<2, true>), grd, blk, 0, st, a);
@@ -508,15 +538,15 @@ static void launch_convT(const ConvArgs& a, int B, hipStream_t st)
 //   * only the decoder chain (combine + upconv, coarse to fine) crosses levels.
 // So the GRU levels run on their own HIP streams (gates, gate apply, candidate, combine, upconv to the next
 // finer level), the caller's stream carries cost volume + encoder, and events carry exactly the edges above.
-// In the pred loop plane k+1's cost volume / encoder / coarse levels run under plane k's fine levels: buffers
-// that cross streams form a ring of NBUF planes and one back-pressure wait per plane keeps plane k off the
-// buffers of plane k-NBUF.  SMVS_RED_STREAMS = 0 (caller's stream only) | 2 (levels {4,3} and {2,1}; default:
+// In the pred loop the front (cost volume + encoder) of a whole CHUNK of planes is one launch per kernel (planes =
+// batch dimension) and runs under the levels of the previous chunk: buffers that cross streams form a ring of two
+// chunks, and one back-pressure wait per chunk keeps chunk j off the buffers of chunk j-2.  SMVS_RED_STREAMS = 0 (caller's stream only) | 2 (levels {4,3} and {2,1}; default:
 // the host enqueue rate, not the GPU, bounds the loop, and this needs the fewest event edges) | 4 (one per level).
 int stream_regress_step(const float* reg_plane, const float* depth, int depth_is_4d, const smvs_height_gen* gen,
                         double* exp_sum, double* depth_img, double* max_prob,
                         int B, int D, int H, int W, int d, void* stream);               // regress.hip
 
-constexpr int RING = 2 * NBUF;
+constexpr int RING = 2 * NSL_MAX;
 struct RedPipe {
     int mode = 0;
     hipStream_t lvl[4];
@@ -575,7 +605,7 @@ struct RedRun {
     bool pred; int geo_kind; const float* ref_fea; const float* const* src_fea; int n_src; const double* geo;
     const float* depth; int depth_is_4d; const smvs_height_gen* gen; double* acc; int D;
     float* reg_volume;                       // pred with acc == null: regularised planes go to (B,D,H,W) instead
-    float* plane[NBUF]; float* reg;
+    float* block[2]; float* reg;             // two (B,C,CH,H,W) chunks of variance planes; one regularised plane
 };
 
 // Everything one call needs to enqueue a plane; issue_front() = caller's stream (cost volume, encoder) + the
@@ -595,54 +625,68 @@ struct RedIssuer {
         for (int g = 0; g < 4; ++g) { hs[g] = r.H >> g; wd[g] = r.W >> g; }
     }
     bool head(int g) const { return multi && (g == 3 || lv[g + 1] != lv[g]); }   // first level of its stream
-    double* stats_of(int k) const { return (double*)(r.wsf + ws.stats[k % NBUF]); }
-    const float* cost_of(int k) const { return r.pred ? r.plane[k % NBUF] : r.cost; }
+    int CH() const { return ws.CH; }
+    double* stats_of(int k) const { return (double*)(r.wsf + ws.stats[k % ws.NSL]); }
+    float* e_of(int k, int i) const { return r.wsf + ws.e[i] + (size_t)(k % ws.NSL) * ws.e_stride[i]; }
 
-    // cost-volume plane + encoder on the caller's stream, then GRU levels 3 and 2
-    int issue_front(int k)
+    // the variance plane of plane k as a strided view for the convolutions that read it
+    void cost_view(int k, ConvArgs& a) const
     {
-        const int d = d_begin + k, buf = k % NBUF, slot = k % RING;
-        const int B = r.B, C = r.C;
-        float* wsf = r.wsf;
+        if (!r.pred) { a.inA = r.cost; return; }                                  // single step: the caller's dense plane
+        const size_t HW = (size_t)r.H * r.W;
+        a.inA = r.block[(k / ws.CH) & 1] + (size_t)(k % ws.CH) * HW;
+        a.inA_cs = (size_t)ws.CH * HW; a.inA_bs = (size_t)r.C * ws.CH * HW;
+    }
+
+    // cost-volume planes + encoder of planes [k0, k0+n) on the caller's stream (n <= CH, k0 a multiple of CH)
+    int issue_front(int k0, int n)
+    {
+        const int d = d_begin + k0, slot = k0 % RING;
+        const int B = r.B, C = r.C, ch = ws.CH;
         const int enc_in[3] = {C, 16, 32}, enc_out[3] = {16, 32, 64};
         if (r.pred) {
-            float* pl = r.plane[buf];
+            float* blk = r.block[(k0 / ch) & 1];
             const int rc = r.gen
                 ? (r.geo_kind == 0
-                   ? smvs_rpc_costvol_fwd_gen(r.ref_fea, r.src_fea, r.n_src, r.geo, r.gen, pl, B, C, r.D, r.H, r.W, d, d + 1, 1, 0, r.main)
-                   : smvs_homo_costvol_fwd_gen(r.ref_fea, r.src_fea, r.n_src, r.geo, r.gen, pl, B, C, r.D, r.H, r.W, d, d + 1, 1, 0, r.main))
+                   ? smvs_rpc_costvol_fwd_gen(r.ref_fea, r.src_fea, r.n_src, r.geo, r.gen, blk, B, C, r.D, r.H, r.W, d, d + n, ch, 0, r.main)
+                   : smvs_homo_costvol_fwd_gen(r.ref_fea, r.src_fea, r.n_src, r.geo, r.gen, blk, B, C, r.D, r.H, r.W, d, d + n, ch, 0, r.main))
                 : (r.geo_kind == 0
-                   ? smvs_rpc_costvol_fwd(r.ref_fea, r.src_fea, r.n_src, r.geo, r.depth, r.depth_is_4d, pl, B, C, r.D, r.H, r.W, d, d + 1, 1, 0, r.main)
-                   : smvs_homo_costvol_fwd(r.ref_fea, r.src_fea, r.n_src, r.geo, r.depth, r.depth_is_4d, pl, B, C, r.D, r.H, r.W, d, d + 1, 1, 0, r.main));
+                   ? smvs_rpc_costvol_fwd(r.ref_fea, r.src_fea, r.n_src, r.geo, r.depth, r.depth_is_4d, blk, B, C, r.D, r.H, r.W, d, d + n, ch, 0, r.main)
+                   : smvs_homo_costvol_fwd(r.ref_fea, r.src_fea, r.n_src, r.geo, r.depth, r.depth_is_4d, blk, B, C, r.D, r.H, r.W, d, d + n, ch, 0, r.main));
             if (rc) return rc;
         }
-        const float* cost = cost_of(k);
         // a level's stream waits for the encoder output of the COARSEST level it carries (the finer inputs
         // are older on the caller's stream)
         if (head(0)) (void)hipEventRecord(P.enc[slot][0], r.main);
-        // encoder: e1 = relu(conv1(-cost)), e2 = relu(conv2(e1)), e3 = relu(conv3(e2))
+        // encoder: e1 = relu(conv1(-cost)), e2 = relu(conv2(e1)), e3 = relu(conv3(e2)); samples = (plane, batch)
         for (int i = 0; i < 3; ++i) {
             ConvArgs a{};
-            a.inA = i == 0 ? cost : wsf + ws.e[buf][i - 1]; a.CA = enc_in[i]; a.scaleA = i == 0 ? -1.0f : 1.0f;
-            a.w = r.packed + L.conv_w[i]; a.out = wsf + ws.e[buf][i]; a.Cout = enc_out[i];
+            if (i == 0) { cost_view(k0, a); if (r.pred) { a.inA_ps = (size_t)r.H * r.W; a.inA_bmod = B; } }
+            else a.inA = e_of(k0, i - 1);
+            a.CA = enc_in[i]; a.scaleA = i == 0 ? -1.0f : 1.0f;
+            a.w = r.packed + L.conv_w[i]; a.out = e_of(k0, i); a.Cout = enc_out[i];
             a.Hi = hs[i]; a.Wi = wd[i]; a.Ho = hs[i + 1]; a.Wo = wd[i + 1]; a.relu = 1;
-            launch_conv(2, a, B, r.main, r.packed + L.conv_wm[i]);
+            launch_conv(2, a, n * B, r.main, r.packed + L.conv_wm[i], r.pred ? ch * B : B);
             if (head(i + 1)) (void)hipEventRecord(P.enc[slot][i + 1], r.main);
         }
-        return issue_levels(k, 3, 2);
+        return SMVS_OK;
     }
-    int issue_back(int k) { return issue_levels(k, 1, 0); }
+    int issue_plane(int k)
+    {
+        const int rc = issue_levels(k, 3, 2);
+        return rc ? rc : issue_levels(k, 1, 0);
+    }
 
     // GRU levels g_hi..g_lo (coarse to fine).  Per stream: first the state-only part of all its levels (gates,
     // gate apply, candidate), then the decoder-coupled part (combine with the upsampled coarser level, upconv).
     int issue_levels(int k, int g_hi, int g_lo)
     {
-        const int d = d_begin + k, buf = k % NBUF, slot = k % RING;
+        const int d = d_begin + k, buf = k % ws.NSL, slot = k % RING;
+        const int k0 = k - k % ws.CH;                                   // first plane of the chunk: its front carried the events
         const int B = r.B, C = r.C;
         float* wsf = r.wsf;
         const float* packed = r.packed;
         const int enc_out[3] = {16, 32, 64};
-        const float* cost = cost_of(k);
         double* stats = stats_of(k);
         double* stats_next = d + 1 < d_end ? stats_of(k + 1) : nullptr;
         const size_t npix = (size_t)B * r.H * r.W;
@@ -650,16 +694,17 @@ struct RedIssuer {
             int glo = ghi;
             while (glo > g_lo && lv[glo - 1] == lv[ghi]) --glo;
             hipStream_t st = lv[ghi];
-            if (multi) (void)hipStreamWaitEvent(st, P.enc[slot][ghi], 0);
+            if (multi && k == k0) (void)hipStreamWaitEvent(st, P.enc[k0 % RING][ghi], 0);   // later planes of the chunk follow on the same stream
             for (int g = ghi; g >= glo; --g) {
                 const int hc = HID[g], hw = hs[g] * wd[g];
-                const float* x = g == 0 ? cost : wsf + ws.e[buf][g - 1];
+                const float* x = g == 0 ? nullptr : e_of(k, g - 1);
                 const int cx = g == 0 ? C : enc_out[g - 1];
                 const float sx = g == 0 ? -1.0f : 1.0f;
                 double* sg = stats + (size_t)g * B * 3 * NSLOT * 2;       // [b][reset,update][slot][2], then [b][slot][2] for the output norm
                 double* so = sg + (size_t)B * 2 * NSLOT * 2;
                 ConvArgs a{};
-                a.inA = x; a.CA = cx; a.scaleA = sx; a.inB = r.state[g]; a.CB = hc;
+                if (g == 0) cost_view(k, a); else a.inA = x;
+                a.CA = cx; a.scaleA = sx; a.inB = r.state[g]; a.CB = hc;
                 a.w = packed + L.gate_w[g]; a.bias = packed + L.gate_b[g]; a.out = wsf + ws.gates[g]; a.stats = sg; a.ngroups = 2;
                 a.Cout = 2 * hc; a.Hi = a.Ho = hs[g]; a.Wi = a.Wo = wd[g];
                 launch_conv(1, a, B, st, packed + L.gate_wm[g]);
@@ -668,7 +713,8 @@ struct RedIssuer {
                                    packed + L.rn_w[g], packed + L.rn_b[g], packed + L.un_w[g], packed + L.un_b[g], r.state[g],
                                    wsf + ws.rh[g], B, hc, hw, stats_next ? stats_next + (size_t)g * B * 3 * NSLOT * 2 : nullptr);
                 ConvArgs o{};
-                o.inA = x; o.CA = cx; o.scaleA = sx; o.inB = wsf + ws.rh[g]; o.CB = hc;
+                if (g == 0) cost_view(k, o); else o.inA = x;
+                o.CA = cx; o.scaleA = sx; o.inB = wsf + ws.rh[g]; o.CB = hc;
                 o.w = packed + L.out_w[g]; o.bias = packed + L.out_b[g]; o.out = wsf + ws.cand[g]; o.stats = so; o.ngroups = 1;
                 o.Cout = hc; o.Hi = o.Ho = hs[g]; o.Wi = o.Wo = wd[g];
                 launch_conv(1, o, B, st, packed + L.out_wm[g]);
@@ -726,14 +772,16 @@ static int red_run_planes(const RedRun& r, int d_begin, int d_end)
     // the first plane's statistics are cleared here; afterwards each level clears the next plane's buffer itself
     (void)hipMemsetAsync(r.wsf + is.ws.stats[0], 0, (size_t)r.B * 4 * 3 * NSLOT * 2 * sizeof(double), r.main);
 
-    // Host enqueue is not the limit: a second host thread issuing the fine levels was tried and left the
-    // GPU-complete time unchanged (stage 2) or worse (stage 1) -- the loop is bound by the busiest stream.
+    // The host's enqueue rate binds the small stages (tools/host_bound_probe.py); a second host thread issuing the
+    // fine levels did not help (the runtime serialises), fewer calls per plane do -- hence the chunked front.
     int rc = SMVS_OK;
-    for (int k = 0; k < nplanes && !rc; ++k) {
-        // this ring entry was last used by plane k-NBUF; its finest level finishing implies all of it
-        if (is.multi && k >= NBUF) (void)hipStreamWaitEvent(r.main, P.done[(k - NBUF) % RING], 0);
-        rc = is.issue_front(k);
-        if (!rc) rc = is.issue_back(k);
+    const int ch = is.CH();
+    for (int k0 = 0; k0 < nplanes && !rc; k0 += ch) {
+        const int n = nplanes - k0 < ch ? nplanes - k0 : ch;
+        // this half of the ring was last used by chunk j-2; its last plane's finest level finishing implies all of it
+        if (is.multi && k0 >= 2 * ch) (void)hipStreamWaitEvent(r.main, P.done[(k0 - ch - 1) % RING], 0);
+        rc = is.issue_front(k0, n);
+        for (int k = k0; k < k0 + n && !rc; ++k) rc = is.issue_plane(k);
     }
     if (rc) return rc;
     // join: the caller's stream continues only after the last plane's finest level (which implies the rest)
@@ -839,7 +887,7 @@ SMVS_EXPORT size_t smvs_red_pred_workspace_bytes(int B, int C, int H, int W)
 {
     const size_t r = smvs_red_workspace_bytes(B, C, H, W);
     if (r == 0) return 0;
-    return r + (smvs::NBUF * (size_t)B * C * H * W + (size_t)B * H * W) * sizeof(float) + 64;   // ring of variance planes + reg
+    return r + (2 * (size_t)smvs::red_chunk(B, C, H, W) * B * C * H * W + (size_t)B * H * W) * sizeof(float) + 64;   // two chunks of variance planes + reg
 }
 
 static int red_planes_entry(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
@@ -863,9 +911,10 @@ static int red_planes_entry(int geo_kind, const float* ref_fea, const float* con
     r.wsf = (float*)workspace; r.B = B; r.C = C; r.H = H; r.W = W; r.main = (hipStream_t)stream;
     r.pred = true; r.geo_kind = geo_kind; r.ref_fea = ref_fea; r.src_fea = src_fea; r.n_src = n_src; r.geo = geo;
     r.depth = depth; r.depth_is_4d = depth_is_4d; r.gen = gen; r.acc = acc; r.reg_volume = reg_volume; r.D = D;
-    r.plane[0] = (float*)((char*)workspace + ((red_bytes + 15) & ~(size_t)15));
-    for (int p = 1; p < NBUF; ++p) r.plane[p] = r.plane[p - 1] + (size_t)B * C * H * W;
-    r.reg = r.plane[NBUF - 1] + (size_t)B * C * H * W;
+    const size_t blk = (size_t)red_chunk(B, C, H, W) * B * C * H * W;
+    r.block[0] = (float*)((char*)workspace + ((red_bytes + 15) & ~(size_t)15));
+    r.block[1] = r.block[0] + blk;
+    r.reg = r.block[1] + blk;
     return red_run_planes(r, d_begin, d_end);
 }
 
