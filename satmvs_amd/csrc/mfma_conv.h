@@ -51,18 +51,18 @@ static __global__ void mfma_pack_kernel(const float* __restrict__ src, float* __
 }
 
 // NT = cout tiles per workgroup (blockIdx.y walks the rest), NW = waves splitting K.
+// (bx, by) = the workgroup's grid coordinates; smem: (NW-1)*NT*16*64 floats.
 template <int TAPS, int NT, int NW>
-__global__ __launch_bounds__(NW * 64)
-void mfma_conv_kernel(const MfmaConvArgs a)
+__device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, int by, float* smem)
 {
     constexpr int KD = TAPS == 27 ? 3 : 1;
-    __shared__ float red[NW - 1][NT * 16][64];   // partial accumulators of waves 1..NW-1
-    const int nt_all = (a.Cout + 31) / 32, nt0 = blockIdx.y * NT;
+    float (*red)[NT * 16][64] = (float (*)[NT * 16][64])smem;   // partial accumulators of waves 1..NW-1
+    const int nt_all = (a.Cout + 31) / 32, nt0 = by * NT;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     // tile -> (b, od, oy, x0)
     const int xt = (a.Wo + 31) / 32;
-    int t = blockIdx.x;
+    int t = bx;
     const int x0 = (t % xt) * 32; t /= xt;
     const int oy = t % a.Ho; t /= a.Ho;
     const int od = t % a.Do;
@@ -219,7 +219,7 @@ void mfma_conv_kernel(const MfmaConvArgs a)
             t1 += __shfl_xor(t1, m, 64); t2 += __shfl_xor(t2, m, 64);
         }
         if (lane == 0) {
-            const int slot = blockIdx.x % a.nslot;
+            const int slot = bx % a.nslot;
             double* st = a.stats + (((size_t)b * a.ngroups + 0) * a.nslot + slot) * 2;
             atomicAdd(st, (double)s1);
             atomicAdd(st + 1, (double)s2);
@@ -230,6 +230,14 @@ void mfma_conv_kernel(const MfmaConvArgs a)
             }
         }
     }
+}
+
+template <int TAPS, int NT, int NW>
+__global__ __launch_bounds__(NW * 64)
+void mfma_conv_kernel(const MfmaConvArgs a)
+{
+    __shared__ float smem[(NW - 1) * NT * 16 * 64];
+    mfma_conv_body<TAPS, NT, NW>(a, blockIdx.x, blockIdx.y, smem);
 }
 
 // true if the MFMA kernel serves this layer

@@ -119,6 +119,7 @@ struct ConvArgs {
     int ngroups;                             // 1, or 2 (gate conv: reset half / update half)
     int Cout, Hi, Wi, Ho, Wo, relu;
     size_t out_bstride;                      // floats between samples of `out`; 0 = Cout*Ho*Wo (dense)
+    const float* skip;                       // transposed convolution only: same shape as out, added after the ReLU (decoder skip), or null
     // strided view of inA (all 0 = dense (B,CA,Hi,Wi)): the pred loop reads variance planes straight out of a
     // (B,C,CH,H,W) chunk written by the cost-volume kernel.  Sample s of the launch = (batch s % inA_bmod, plane
     // s / inA_bmod) when inA_bmod > 0, else (batch s, plane 0); its first channel starts at
@@ -142,15 +143,17 @@ __device__ __forceinline__ float wave_sum_f(float v)
 //   LDS.  The coarse planes give a few dozen workgroups on a 256-CU part: there the time is one wave's
 //   serial channel loop (a load round trip per channel), so 4x shorter chains = ~3x shorter kernels.
 // Both: the taps of channel c+1 are in flight while channel c is multiplied.
+// (bx,by,bz) = the workgroup's grid coordinates (blockIdx of the plain launch; decoded from a flat index by the
+// level-batched launch); smem: 3*COT*64 floats (SPLIT) / 8 floats.
+constexpr int CONV_SMEM_FLOATS = 3 * COT * 64;
 template <int STRIDE, bool SPLIT>
-__global__ __launch_bounds__(256)
-void conv3x3_kernel(const ConvArgs a)
+__device__ __forceinline__ void conv3x3_body(const ConvArgs& a, int bx, int by, int bz, float* smem)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ox = blockIdx.x * 64 + lane;
-    const int oy = SPLIT ? (int)blockIdx.y : (int)blockIdx.y * 4 + wave;
+    const int ox = bx * 64 + lane;
+    const int oy = SPLIT ? by : by * 4 + wave;
     const int ncog = (a.Cout + COT - 1) / COT;
-    const int cog = blockIdx.z % ncog, b = blockIdx.z / ncog;
+    const int cog = bz % ncog, b = bz / ncog;
     const bool active = ox < a.Wo && oy < a.Ho;
     const int Cin = a.CA + a.CB;
     const int HWi = a.Hi * a.Wi;
@@ -209,7 +212,7 @@ void conv3x3_kernel(const ConvArgs a)
 #undef SMVS_CONV_FMA
 
     if (SPLIT) {
-        __shared__ float part[3][COT][64];
+        float (*part)[COT][64] = (float (*)[COT][64])smem;
         if (wave > 0) {
 #pragma unroll
             for (int j = 0; j < COT; ++j) part[wave - 1][j][lane] = acc[j];
@@ -236,11 +239,11 @@ void conv3x3_kernel(const ConvArgs a)
         // GroupNorm(1,.) statistics of the raw (pre-activation) output; a cout group of 8 lies inside one
         // norm group because every hidden size is a multiple of 8.  Wave reduce, workgroup reduce through
         // LDS, then ONE float64 atomic pair per workgroup into one of NSLOT partial slots.
-        __shared__ float red[2][4];
+        float (*red)[4] = (float (*)[4])smem;
         s1 = wave_sum_f(s1);
         s2 = wave_sum_f(s2);
         const int grp = (a.ngroups == 2 && cog * COT >= a.Cout / 2) ? 1 : 0;
-        const int slot = (blockIdx.x + blockIdx.y * 7 + cog * 13) % NSLOT;
+        const int slot = (bx + by * 7 + cog * 13) % NSLOT;
         double* st = a.stats + (((size_t)b * a.ngroups + grp) * NSLOT + slot) * 2;
         if (SPLIT) {
             if (lane == 0) { atomicAdd(st, (double)s1); atomicAdd(st + 1, (double)s2); }
@@ -253,6 +256,14 @@ void conv3x3_kernel(const ConvArgs a)
             }
         }
     }
+}
+
+template <int STRIDE, bool SPLIT>
+__global__ __launch_bounds__(256)
+void conv3x3_kernel(const ConvArgs a)
+{
+    __shared__ float smem[SPLIT ? CONV_SMEM_FLOATS : 8];
+    conv3x3_body<STRIDE, SPLIT>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // ConvTranspose2d(k=3, stride=2, pad=1, output_padding=1): lane = one INPUT position (y,x), producing the
@@ -343,11 +354,13 @@ void convT3x3s2_kernel(const ConvArgs a)
     for (int j = 0; j < COT; ++j) {
         const int co = cog * COT + j;
         if (co < a.Cout) {
-            float* o = a.out + ((size_t)b * a.Cout + co) * HWo + (size_t)(2 * y) * a.Wo + 2 * x;
+            const size_t o0 = ((size_t)b * a.Cout + co) * HWo + (size_t)(2 * y) * a.Wo + 2 * x;
+            float* o = a.out + o0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float r = acc[q][j];
                 if (a.relu) r = fmaxf(r, 0.0f);
+                if (a.skip) r = r + a.skip[o0 + (q >> 1) * a.Wo + (q & 1)];
                 o[(q >> 1) * a.Wo + (q & 1)] = r;
             }
         }
@@ -378,54 +391,107 @@ __device__ __forceinline__ void gn_coeffs(const double* st, double n, float eps,
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// gates raw (B,2HC,h,w) -> rh = sigmoid(GN(r)) * h ; u (in place over the update half) = sigmoid(GN(u))
+// ---- level-batched launches ------------------------------------------------------------------------------------------
+// The four ConvGRU levels of a plane do not depend on each other (only the decoder crosses levels), and each of
+// their kernels is a latency chain of a few dozen to a few hundred workgroups.  So one launch carries the same
+// stage of ALL levels: a flat grid whose workgroups look up their job (level) and run the ordinary kernel body.
+// Per plane: gate convolutions, gate apply, candidate convolutions, combine = 4 launches instead of 16, and the
+// levels run side by side without streams or events.
+struct ConvJob {
+    ConvArgs a; MfmaConvArgs m;              // kind 0/1: a (direct, unsplit / channel-split); kind 2: m (MFMA, one cout tile per workgroup)
+    int kind, gx, gy, blk0;                  // grid (gx, gy, rest) flattened; workgroups [blk0, next job's blk0)
+};
+struct ConvJobs { ConvJob j[4]; int n; };
+
+constexpr int JOBS_SMEM_FLOATS = 3 * 16 * 64;            // MFMA split-K partials of 3 waves (12 KiB) >= direct split (6 KiB)
+static_assert(JOBS_SMEM_FLOATS >= CONV_SMEM_FLOATS, "shared scratch of the level-batched convolution");
+
 __global__ __launch_bounds__(256)
-void gru_gate_apply_kernel(float* __restrict__ gates, const double* __restrict__ stats, const float* __restrict__ rn_w,
-                           const float* __restrict__ rn_b, const float* __restrict__ un_w, const float* __restrict__ un_b,
-                           const float* __restrict__ h, float* __restrict__ rh, int B, int HC, int HW,
-                           double* __restrict__ zero_next)
+void conv_jobs_kernel(const ConvJobs J)
+{
+    __shared__ float smem[JOBS_SMEM_FLOATS];
+    int bid = blockIdx.x, l = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < J.n && bid >= J.j[i].blk0) l = i;
+    const ConvJob& jb = J.j[l];
+    bid -= jb.blk0;
+    const int bx = bid % jb.gx, t = bid / jb.gx;
+    if (jb.kind == 2) mfma_conv_body<9, 1, 4>(jb.m, bx, t, smem);
+    else if (jb.kind == 1) conv3x3_body<1, true>(jb.a, bx, t % jb.gy, t / jb.gy, smem);
+    else conv3x3_body<1, false>(jb.a, bx, t % jb.gy, t / jb.gy, smem);
+}
+
+struct GruJob {                              // the element-wise stages of one level
+    float* gates;                            // raw gate convolution (B,2HC,h,w); update half overwritten with u = sigmoid(GN(.))
+    const double *stats_g, *stats_o;         // [b][reset,update][NSLOT][2] ; [b][NSLOT][2]
+    const float *rn_w, *rn_b, *un_w, *un_b, *on_w, *on_b;
+    float* h;                                // hidden state (B,HC,h,w), updated in place by the combine stage
+    float* rh;                               // r*h for the candidate convolution
+    const float* cand;                       // raw candidate convolution
+    float* hsnap;                            // copy of the new state for the decoder (which runs while the next plane updates h)
+    double* zero_next;                       // next plane's statistics of this level, cleared by the apply stage
+    int HC, HW, gx, blk0;                    // gx workgroups per sample; workgroups [blk0, blk0 + gx*B)
+};
+struct GruJobs { GruJob j[4]; int n, B; };
+
+// gates raw -> rh = sigmoid(GN(r)) * h ; u (in place over the update half) = sigmoid(GN(u))
+__global__ __launch_bounds__(256)
+void gru_gate_apply_kernel(const GruJobs J)
 {
     __shared__ float coef[2][2];
-    const int b = blockIdx.y;
-    // the next plane's statistics of this level (other parity buffer) are cleared here: every reader of
-    // that buffer (the previous plane's gate/combine kernels) precedes this kernel on the level's stream,
-    // every writer (the next plane's convolutions) follows it.
-    if (zero_next && blockIdx.x == 0 && b == 0)
-        for (int i = threadIdx.x; i < B * 3 * NSLOT * 2; i += blockDim.x) zero_next[i] = 0.0;
+    int bid = blockIdx.x, l = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < J.n && bid >= J.j[i].blk0) l = i;
+    const GruJob& g = J.j[l];
+    bid -= g.blk0;
+    const int bx = bid % g.gx, b = bid / g.gx;
+    const int HC = g.HC, HW = g.HW;
+    // the next plane's statistics of this level (other ring entry) are cleared here: every reader of that buffer
+    // (an older plane's apply / combine kernels) precedes this kernel on the stream, every writer (the next plane's
+    // convolutions) follows it.
+    if (g.zero_next && bid == 0)
+        for (int i = threadIdx.x; i < J.B * 3 * NSLOT * 2; i += blockDim.x) g.zero_next[i] = 0.0;
     float mr, sr, mu, su;
-    gn_coeffs(stats + ((size_t)b * 2 + 0) * NSLOT * 2, (double)HC * HW, 1e-5f, mr, sr, coef[0]);
-    gn_coeffs(stats + ((size_t)b * 2 + 1) * NSLOT * 2, (double)HC * HW, 1e-5f, mu, su, coef[1]);
-    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // index inside the sample
+    gn_coeffs(g.stats_g + ((size_t)b * 2 + 0) * NSLOT * 2, (double)HC * HW, 1e-5f, mr, sr, coef[0]);
+    gn_coeffs(g.stats_g + ((size_t)b * 2 + 1) * NSLOT * 2, (double)HC * HW, 1e-5f, mu, su, coef[1]);
+    const size_t j = (size_t)bx * blockDim.x + threadIdx.x;      // index inside the sample
     if (j >= (size_t)HC * HW) return;
     const int c = (int)(j / HW), p = (int)(j % HW);
     const size_t i = (size_t)b * HC * HW + j;
-    float* gr = gates + ((size_t)b * 2 * HC + c) * HW + p;
-    float* gu = gates + ((size_t)b * 2 * HC + HC + c) * HW + p;
-    const float r = sigmoidf_(fmaf((*gr - mr) * sr, rn_w[c], rn_b[c]));
-    const float u = sigmoidf_(fmaf((*gu - mu) * su, un_w[c], un_b[c]));
-    rh[i] = r * h[i];
+    float* gr = g.gates + ((size_t)b * 2 * HC + c) * HW + p;
+    float* gu = g.gates + ((size_t)b * 2 * HC + HC + c) * HW + p;
+    const float r = sigmoidf_(fmaf((*gr - mr) * sr, g.rn_w[c], g.rn_b[c]));
+    const float u = sigmoidf_(fmaf((*gu - mu) * su, g.un_w[c], g.un_b[c]));
+    g.rh[i] = r * g.h[i];
     *gu = u;
 }
 
-// h' = u*h + (1-u)*tanh(GN(cand)); state <- h'; optionally sum_out = up + h' (decoder skip)
+// h' = u*h + (1-u)*tanh(GN(cand)); state <- h'; hsnap <- h'
 __global__ __launch_bounds__(256)
-void gru_combine_kernel(const float* __restrict__ cand, const double* __restrict__ stats, const float* __restrict__ on_w,
-                        const float* __restrict__ on_b, const float* __restrict__ gates, float* __restrict__ h,
-                        const float* __restrict__ up, float* __restrict__ sum_out, int B, int HC, int HW)
+void gru_combine_kernel(const GruJobs J)
 {
     __shared__ float coef[2];
-    const int b = blockIdx.y;
+    int bid = blockIdx.x, l = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < J.n && bid >= J.j[i].blk0) l = i;
+    const GruJob& g = J.j[l];
+    bid -= g.blk0;
+    const int bx = bid % g.gx, b = bid / g.gx;
+    const int HC = g.HC, HW = g.HW;
     float m, s;
-    gn_coeffs(stats + (size_t)b * NSLOT * 2, (double)HC * HW, 1e-5f, m, s, coef);
-    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    gn_coeffs(g.stats_o + (size_t)b * NSLOT * 2, (double)HC * HW, 1e-5f, m, s, coef);
+    const size_t j = (size_t)bx * blockDim.x + threadIdx.x;
     if (j >= (size_t)HC * HW) return;
     const int c = (int)(j / HW), p = (int)(j % HW);
     const size_t i = (size_t)b * HC * HW + j;
-    const float y = tanhf(fmaf((cand[i] - m) * s, on_w[c], on_b[c]));
-    const float u = gates[((size_t)b * 2 * HC + HC + c) * HW + p];
-    const float hn = u * h[i] + (1.0f - u) * y;
-    h[i] = hn;
-    if (sum_out) sum_out[i] = up[i] + hn;
+    const float y = tanhf(fmaf((g.cand[i] - m) * s, g.on_w[c], g.on_b[c]));
+    const float u = g.gates[((size_t)b * 2 * HC + HC + c) * HW + p];
+    const float hn = u * g.h[i] + (1.0f - u) * y;
+    g.h[i] = hn;
+    g.hsnap[i] = hn;
 }
 
 // ---- host orchestration ----------------------------------------------------------------------------------------------
@@ -444,11 +510,11 @@ static int red_chunk(int B, int C, int H, int W)
 }
 
 struct RedWorkspace {                        // offsets in floats into the caller's workspace
-    // e / up / stats exist NSL times: they cross streams, so plane k+1.. may be written while plane k is
-    // still being read (see red_run_planes).  gates / rh / cand / sum live on one stream each.
+    // e / hsnap exist NSL times: they cross streams, so plane k+1.. may be written while plane k is still being
+    // read (see red_run_planes).  gates / rh / cand (recurrent stream) and sum (decoder stream) live on one stream.
     // e[i] + slot * e_stride[i]: the slots of a chunk are adjacent = one dense batch of CH*B samples.
     int CH, NSL;
-    size_t e[3], e_stride[3], gates[4], rh[4], cand[4], up[NSL_MAX][3], sum[3], stats[NSL_MAX];   // stats: doubles, offset in floats (8-byte aligned)
+    size_t e[3], e_stride[3], gates[4], rh[4], cand[4], hsnap[NSL_MAX][4], sum[3], stats[2];   // stats: doubles, offset in floats (8-byte aligned)
     size_t total;
 };
 
@@ -469,12 +535,11 @@ static RedWorkspace red_workspace(int B, int C, int H, int W)
         w.gates[i] = take((size_t)B * 2 * HID[i] * hs[i] * ws[i]);
         w.rh[i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
         w.cand[i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
+        for (int p = 0; p < w.NSL; ++p) w.hsnap[p][i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
     }
-    for (int i = 0; i < 3; ++i) {            // up[.][i]: output of upconv{i+1} at level i ; sum[i] = up[i] + state{i+1}'
-        for (int p = 0; p < w.NSL; ++p) w.up[p][i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
+    for (int i = 0; i < 3; ++i)              // sum[i] = relu(upconv{i+1}(.)) + state{i+1}'  (decoder skip fused into the transposed convolution)
         w.sum[i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
-    }
-    for (int p = 0; p < w.NSL; ++p)
+    for (int p = 0; p < 2; ++p)
         w.stats[p] = take((size_t)B * 4 * 3 * NSLOT * 2 * 2);   // 4 GRUs x (reset, update, output) x NSLOT x (sum, sumsq) doubles
     w.total = o;
     return w;
@@ -491,19 +556,24 @@ static int g_split_below()
     return v;                                               // workgroups (unsplit) below which the channel-split kernels run
 }
 
-// `wm` = MFMA-order weights of the same layer (used when the layer qualifies)
+static MfmaConvArgs mfma_args(int stride, const ConvArgs& a, const float* wm)
+{
+    MfmaConvArgs m{};
+    m.inA = a.inA; m.CA = a.CA; m.inB = a.inB; m.CB = a.CB; m.scaleA = a.scaleA; m.w = wm; m.bias = a.bias;
+    m.out = a.out; m.stats = a.stats; m.ngroups = a.ngroups; m.nslot = NSLOT;
+    m.Cout = a.Cout; m.relu = a.relu; m.stride = stride;
+    m.Di = m.Do = 1; m.Hi = a.Hi; m.Wi = a.Wi; m.Ho = a.Ho; m.Wo = a.Wo;
+    return m;
+}
+
+// `wm` = MFMA-order weights of the same layer (used when the layer qualifies; the MFMA kernel reads dense inputs)
 // Bh = the batch size the kernel VARIANT is chosen for (0 = B): the last chunk of a plane range may be short, and a
 // plane's bits must not depend on how the range was chunked or sharded.
 static void launch_conv(int stride, const ConvArgs& a, int B, hipStream_t st, const float* wm = nullptr, int Bh = 0)
 {
     if (Bh <= 0) Bh = B;
-    if (wm && mfma_conv_ok(a.CA, a.CB, a.Cout) && !g_red_direct_only()) {
-        MfmaConvArgs m{};
-        m.inA = a.inA; m.CA = a.CA; m.inB = a.inB; m.CB = a.CB; m.scaleA = a.scaleA; m.w = wm; m.bias = a.bias;
-        m.out = a.out; m.stats = a.stats; m.ngroups = a.ngroups; m.nslot = NSLOT;
-        m.Cout = a.Cout; m.relu = a.relu; m.stride = stride;
-        m.Di = m.Do = 1; m.Hi = a.Hi; m.Wi = a.Wi; m.Ho = a.Ho; m.Wo = a.Wo;
-        mfma_conv_launch<9>(m, B, st, Bh);
+    if (wm && !a.inA_cs && mfma_conv_ok(a.CA, a.CB, a.Cout) && !g_red_direct_only()) {
+        mfma_conv_launch<9>(mfma_args(stride, a, wm), B, st, Bh);
         return;
     }
     const int ncog = (a.Cout + COT - 1) / COT;
@@ -519,6 +589,24 @@ static void launch_conv(int stride, const ConvArgs& a, int B, hipStream_t st, co
     else             hipLaunchKernelGGL((conv3x3_kernel<2, false>), grd, blk, 0, st, a);
 }
 
+// one stride-1 convolution as a job of a level-batched launch; returns its workgroup count
+static int conv_job(ConvJob& j, const ConvArgs& a, int B, const float* wm, int blk0)
+{
+    j.blk0 = blk0;
+    if (wm && !a.inA_cs && mfma_conv_ok(a.CA, a.CB, a.Cout) && !g_red_direct_only()) {
+        j.kind = 2; j.m = mfma_args(1, a, wm);
+        j.gx = ((a.Wo + 31) / 32) * a.Ho * B; j.gy = a.Cout / 32;
+        return j.gx * j.gy;
+    }
+    j.a = a;
+    const int ncog = (a.Cout + COT - 1) / COT;
+    j.gx = (a.Wo + 63) / 64;
+    const bool split = j.gx * ((a.Ho + 3) / 4) * B * ncog < g_split_below();
+    j.kind = split ? 1 : 0;
+    j.gy = split ? a.Ho : (a.Ho + 3) / 4;
+    return j.gx * j.gy * B * ncog;
+}
+
 static void launch_convT(const ConvArgs& a, int B, hipStream_t st)
 {
     const int ncog = (a.Cout + COT - 1) / COT;
@@ -531,40 +619,34 @@ static void launch_convT(const ConvArgs& a, int B, hipStream_t st)
 }
 
 // ---- plane pipeline ------------------------------------------------------------------------------------------
-// The 24 kernels of a plane are small (12..300 workgroups on a 256-CU part) and form a long dependency chain
-// when issued on one stream.  The data flow is wider than that:
-//   * the encoder (and, in the pred loop, the cost-volume plane) does not depend on the recurrent state;
-//   * the four ConvGRU levels only need their encoder level and their own previous state;
-//   * only the decoder chain (combine + upconv, coarse to fine) crosses levels.
-// So the GRU levels run on their own HIP streams (gates, gate apply, candidate, combine, upconv to the next
-// finer level), the caller's stream carries cost volume + encoder, and events carry exactly the edges above.
-// In the pred loop the front (cost volume + encoder) of a whole CHUNK of planes is one launch per kernel (planes =
-// batch dimension) and runs under the levels of the previous chunk: buffers that cross streams form a ring of two
-// chunks, and one back-pressure wait per chunk keeps chunk j off the buffers of chunk j-2.  SMVS_RED_STREAMS = 0 (caller's stream only) | 2 (levels {4,3} and {2,1}; default:
-// the host enqueue rate, not the GPU, bounds the loop, and this needs the fewest event edges) | 4 (one per level).
+// Data flow of a plane:
+//   * the front (cost-volume plane, encoder) does not depend on the recurrent state: caller's stream, issued for a
+//     whole CHUNK of planes per launch (planes = batch dimension);
+//   * the four ConvGRU levels only need their encoder level and their own previous state: four level-batched
+//     launches per plane on the RECURRENT stream (this chain is what bounds the loop);
+//   * the decoder (transposed convolutions with the skip add fused, output convolution, regression update) reads
+//     snapshots of the new states: DECODER stream, running under the next plane's recurrent launches.
+// Events: encoder done (per chunk), states done (per plane), plane done (per plane; the front of chunk j waits for
+// the last plane of chunk j-2, whose ring entries it reuses).  A single plane runs on the caller's stream alone.
 int stream_regress_step(const float* reg_plane, const float* depth, int depth_is_4d, const smvs_height_gen* gen,
                         double* exp_sum, double* depth_img, double* max_prob,
                         int B, int D, int H, int W, int d, void* stream);               // regress.hip
 
 constexpr int RING = 2 * NSL_MAX;
 struct RedPipe {
-    int mode = 0;
-    hipStream_t lvl[4];
-    hipEvent_t enc[RING][4], up[RING][3], done[RING];
+    hipStream_t rec, dec;
+    hipEvent_t enc[RING], state[RING], done[RING];
 };
 
 static RedPipe* red_pipe_create()
 {
     RedPipe* p = new RedPipe();
-    p->mode = tune_int("SMVS_RED_STREAMS", 2);
-    if (p->mode != 0 && p->mode != 2 && p->mode != 4) p->mode = 2;
-    bool ok = true;
-    for (int g = 0; g < 4 && ok; ++g) ok = hipStreamCreateWithFlags(&p->lvl[g], hipStreamNonBlocking) == hipSuccess;
-    for (int r = 0; r < RING && ok; ++r) {
-        for (int g = 0; g < 4 && ok; ++g) ok = hipEventCreateWithFlags(&p->enc[r][g], hipEventDisableTiming) == hipSuccess;
-        for (int g = 0; g < 3 && ok; ++g) ok = hipEventCreateWithFlags(&p->up[r][g], hipEventDisableTiming) == hipSuccess;
-        if (ok) ok = hipEventCreateWithFlags(&p->done[r], hipEventDisableTiming) == hipSuccess;
-    }
+    bool ok = hipStreamCreateWithFlags(&p->rec, hipStreamNonBlocking) == hipSuccess
+           && hipStreamCreateWithFlags(&p->dec, hipStreamNonBlocking) == hipSuccess;
+    for (int r = 0; r < RING && ok; ++r)
+        ok = hipEventCreateWithFlags(&p->enc[r], hipEventDisableTiming) == hipSuccess
+          && hipEventCreateWithFlags(&p->state[r], hipEventDisableTiming) == hipSuccess
+          && hipEventCreateWithFlags(&p->done[r], hipEventDisableTiming) == hipSuccess;
     if (!ok) { delete p; return nullptr; }        // (the few objects created before the failure are abandoned: the device is unusable anyway)
     return p;
 }
@@ -608,26 +690,25 @@ struct RedRun {
     float* block[2]; float* reg;             // two (B,C,CH,H,W) chunks of variance planes; one regularised plane
 };
 
-// Everything one call needs to enqueue a plane; issue_front() = caller's stream (cost volume, encoder) + the
-// coarse GRU levels 4,3; issue_back() = the fine levels 2,1, the output convolution and the regression update.
+// Everything one call needs to enqueue planes: issue_front() = caller's stream (cost volume, encoder of a chunk);
+// issue_recurrent() = the four level-batched launches of a plane; issue_decoder() = its decoder and regression update.
 struct RedIssuer {
-    const RedRun& r; const RedPipe& P; int mode, d_begin, d_end;
+    const RedRun& r; const RedPipe& P; bool multi; int d_begin, d_end;
     RedLayout L; RedWorkspace ws;
-    hipStream_t lv[4]; bool multi;
+    hipStream_t sR, sD;
     int hs[4], wd[4];
 
-    RedIssuer(const RedRun& run, const RedPipe& pipe, int mode_, int d0, int d1)
-        : r(run), P(pipe), mode(mode_), d_begin(d0), d_end(d1), L(red_layout(run.C)), ws(red_workspace(run.B, run.C, run.H, run.W))
+    RedIssuer(const RedRun& run, const RedPipe& pipe, bool multi_, int d0, int d1)
+        : r(run), P(pipe), multi(multi_), d_begin(d0), d_end(d1), L(red_layout(run.C)), ws(red_workspace(run.B, run.C, run.H, run.W))
     {
-        // level -> stream.  mode 4: one stream per level; mode 2: levels {3,2} and {1,0}; mode 0: caller's stream
-        for (int g = 0; g < 4; ++g) lv[g] = mode == 4 ? P.lvl[g] : mode == 2 ? P.lvl[g >> 1] : r.main;
-        multi = mode != 0;
+        sR = multi ? P.rec : r.main;
+        sD = multi ? P.dec : r.main;
         for (int g = 0; g < 4; ++g) { hs[g] = r.H >> g; wd[g] = r.W >> g; }
     }
-    bool head(int g) const { return multi && (g == 3 || lv[g + 1] != lv[g]); }   // first level of its stream
     int CH() const { return ws.CH; }
-    double* stats_of(int k) const { return (double*)(r.wsf + ws.stats[k % ws.NSL]); }
+    double* stats_of(int k) const { return (double*)(r.wsf + ws.stats[k & 1]); }
     float* e_of(int k, int i) const { return r.wsf + ws.e[i] + (size_t)(k % ws.NSL) * ws.e_stride[i]; }
+    float* hsnap_of(int k, int g) const { return r.wsf + ws.hsnap[k % ws.NSL][g]; }
 
     // the variance plane of plane k as a strided view for the convolutions that read it
     void cost_view(int k, ConvArgs& a) const
@@ -641,7 +722,7 @@ struct RedIssuer {
     // cost-volume planes + encoder of planes [k0, k0+n) on the caller's stream (n <= CH, k0 a multiple of CH)
     int issue_front(int k0, int n)
     {
-        const int d = d_begin + k0, slot = k0 % RING;
+        const int d = d_begin + k0;
         const int B = r.B, C = r.C, ch = ws.CH;
         const int enc_in[3] = {C, 16, 32}, enc_out[3] = {16, 32, 64};
         if (r.pred) {
@@ -655,9 +736,6 @@ struct RedIssuer {
                    : smvs_homo_costvol_fwd(r.ref_fea, r.src_fea, r.n_src, r.geo, r.depth, r.depth_is_4d, blk, B, C, r.D, r.H, r.W, d, d + n, ch, 0, r.main));
             if (rc) return rc;
         }
-        // a level's stream waits for the encoder output of the COARSEST level it carries (the finer inputs
-        // are older on the caller's stream)
-        if (head(0)) (void)hipEventRecord(P.enc[slot][0], r.main);
         // encoder: e1 = relu(conv1(-cost)), e2 = relu(conv2(e1)), e3 = relu(conv3(e2)); samples = (plane, batch)
         for (int i = 0; i < 3; ++i) {
             ConvArgs a{};
@@ -667,93 +745,92 @@ struct RedIssuer {
             a.w = r.packed + L.conv_w[i]; a.out = e_of(k0, i); a.Cout = enc_out[i];
             a.Hi = hs[i]; a.Wi = wd[i]; a.Ho = hs[i + 1]; a.Wo = wd[i + 1]; a.relu = 1;
             launch_conv(2, a, n * B, r.main, r.packed + L.conv_wm[i], r.pred ? ch * B : B);
-            if (head(i + 1)) (void)hipEventRecord(P.enc[slot][i + 1], r.main);
         }
+        if (multi) (void)hipEventRecord(P.enc[k0 % RING], r.main);
         return SMVS_OK;
     }
-    int issue_plane(int k)
-    {
-        const int rc = issue_levels(k, 3, 2);
-        return rc ? rc : issue_levels(k, 1, 0);
-    }
 
-    // GRU levels g_hi..g_lo (coarse to fine).  Per stream: first the state-only part of all its levels (gates,
-    // gate apply, candidate), then the decoder-coupled part (combine with the upsampled coarser level, upconv).
-    int issue_levels(int k, int g_hi, int g_lo)
+    // gates, gate apply, candidates, combine of all four levels: one launch each
+    int issue_recurrent(int k)
     {
-        const int d = d_begin + k, buf = k % ws.NSL, slot = k % RING;
-        const int k0 = k - k % ws.CH;                                   // first plane of the chunk: its front carried the events
+        const int d = d_begin + k;
         const int B = r.B, C = r.C;
         float* wsf = r.wsf;
         const float* packed = r.packed;
         const int enc_out[3] = {16, 32, 64};
         double* stats = stats_of(k);
         double* stats_next = d + 1 < d_end ? stats_of(k + 1) : nullptr;
-        const size_t npix = (size_t)B * r.H * r.W;
-        for (int ghi = g_hi; ghi >= g_lo;) {
-            int glo = ghi;
-            while (glo > g_lo && lv[glo - 1] == lv[ghi]) --glo;
-            hipStream_t st = lv[ghi];
-            if (multi && k == k0) (void)hipStreamWaitEvent(st, P.enc[k0 % RING][ghi], 0);   // later planes of the chunk follow on the same stream
-            for (int g = ghi; g >= glo; --g) {
-                const int hc = HID[g], hw = hs[g] * wd[g];
-                const float* x = g == 0 ? nullptr : e_of(k, g - 1);
-                const int cx = g == 0 ? C : enc_out[g - 1];
-                const float sx = g == 0 ? -1.0f : 1.0f;
-                double* sg = stats + (size_t)g * B * 3 * NSLOT * 2;       // [b][reset,update][slot][2], then [b][slot][2] for the output norm
-                double* so = sg + (size_t)B * 2 * NSLOT * 2;
-                ConvArgs a{};
-                if (g == 0) cost_view(k, a); else a.inA = x;
-                a.CA = cx; a.scaleA = sx; a.inB = r.state[g]; a.CB = hc;
-                a.w = packed + L.gate_w[g]; a.bias = packed + L.gate_b[g]; a.out = wsf + ws.gates[g]; a.stats = sg; a.ngroups = 2;
-                a.Cout = 2 * hc; a.Hi = a.Ho = hs[g]; a.Wi = a.Wo = wd[g];
-                launch_conv(1, a, B, st, packed + L.gate_wm[g]);
-                const size_t n = (size_t)hc * hw;                         // per sample; blockIdx.y = sample
-                hipLaunchKernelGGL(gru_gate_apply_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, wsf + ws.gates[g], sg,
-                                   packed + L.rn_w[g], packed + L.rn_b[g], packed + L.un_w[g], packed + L.un_b[g], r.state[g],
-                                   wsf + ws.rh[g], B, hc, hw, stats_next ? stats_next + (size_t)g * B * 3 * NSLOT * 2 : nullptr);
-                ConvArgs o{};
-                if (g == 0) cost_view(k, o); else o.inA = x;
-                o.CA = cx; o.scaleA = sx; o.inB = wsf + ws.rh[g]; o.CB = hc;
-                o.w = packed + L.out_w[g]; o.bias = packed + L.out_b[g]; o.out = wsf + ws.cand[g]; o.stats = so; o.ngroups = 1;
-                o.Cout = hc; o.Hi = o.Ho = hs[g]; o.Wi = o.Wo = wd[g];
-                launch_conv(1, o, B, st, packed + L.out_wm[g]);
-            }
-            for (int g = ghi; g >= glo; --g) {
-                const int hc = HID[g], hw = hs[g] * wd[g];
-                const size_t n = (size_t)hc * hw;
-                double* so = stats + (size_t)g * B * 3 * NSLOT * 2 + (size_t)B * 2 * NSLOT * 2;
-                const bool skip = g < 3;                                  // levels 3,2,1 add the upsampled coarser level
-                if (multi && skip && lv[g + 1] != st) (void)hipStreamWaitEvent(st, P.up[slot][g], 0);
-                hipLaunchKernelGGL(gru_combine_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, wsf + ws.cand[g], so,
-                                   packed + L.on_w[g], packed + L.on_b[g], wsf + ws.gates[g], r.state[g],
-                                   skip ? wsf + ws.up[buf][g] : nullptr, skip ? wsf + ws.sum[g] : nullptr, B, hc, hw);
-                if (g > 0) {
-                    // decoder: up[g-1] = relu(upconv{g}(state4' or sum[g]))
-                    ConvArgs u{};
-                    u.inA = g == 3 ? r.state[3] : wsf + ws.sum[g]; u.CA = hc; u.scaleA = 1.0f;
-                    u.w = packed + L.up_w[g - 1]; u.out = wsf + ws.up[buf][g - 1]; u.Cout = HID[g - 1];
-                    u.Hi = hs[g]; u.Wi = wd[g]; u.Ho = hs[g - 1]; u.Wo = wd[g - 1]; u.relu = 1;
-                    launch_convT(u, B, st);
-                    if (multi && lv[g - 1] != st) (void)hipEventRecord(P.up[slot][g - 1], st);
-                } else {
-                    // reg = upconv2d(up1 + state1') : ConvTranspose2d stride 1 == correlation with flipped taps
-                    float* reg = !r.pred ? r.reg_out : r.reg_volume ? r.reg_volume + (size_t)d * r.H * r.W : r.reg;
-                    ConvArgs f{};
-                    f.inA = wsf + ws.sum[0]; f.CA = 8; f.scaleA = 1.0f; f.w = packed + L.up2d_w; f.bias = packed + L.up2d_b;
-                    f.out = reg; f.Cout = 1; f.Hi = f.Ho = r.H; f.Wi = f.Wo = r.W;
-                    if (r.pred && r.reg_volume) f.out_bstride = (size_t)r.D * r.H * r.W;
-                    launch_conv(1, f, B, st);
-                    if (r.pred && !r.reg_volume) {
-                        const int rc = stream_regress_step(reg, r.depth, r.depth_is_4d, r.gen, r.acc, r.acc + npix, r.acc + 2 * npix,
-                                                           B, r.D, r.H, r.W, d, st);
-                        if (rc) return rc;
-                    }
-                    if (multi) (void)hipEventRecord(P.done[slot], st);
-                }
-            }
-            ghi = glo - 1;
+        if (multi && k % ws.CH == 0) (void)hipStreamWaitEvent(sR, P.enc[k % RING], 0);   // later planes of the chunk follow on the same stream
+        ConvJobs gate{}, cand{};
+        GruJobs gru{};
+        gate.n = cand.n = gru.n = 4; gru.B = B;
+        int nb_gate = 0, nb_cand = 0, nb_gru = 0;
+        for (int q = 0; q < 4; ++q) {
+            const int g = 3 - q;                                          // coarse levels first: longest channel loops
+            const int hc = HID[g], hw = hs[g] * wd[g];
+            const int cx = g == 0 ? C : enc_out[g - 1];
+            const float sx = g == 0 ? -1.0f : 1.0f;
+            double* sg = stats + (size_t)g * B * 3 * NSLOT * 2;           // [b][reset,update][slot][2], then [b][slot][2] for the output norm
+            double* so = sg + (size_t)B * 2 * NSLOT * 2;
+            ConvArgs a{};
+            if (g == 0) cost_view(k, a); else a.inA = e_of(k, g - 1);
+            a.CA = cx; a.scaleA = sx; a.inB = r.state[g]; a.CB = hc;
+            a.w = packed + L.gate_w[g]; a.bias = packed + L.gate_b[g]; a.out = wsf + ws.gates[g]; a.stats = sg; a.ngroups = 2;
+            a.Cout = 2 * hc; a.Hi = a.Ho = hs[g]; a.Wi = a.Wo = wd[g];
+            nb_gate += conv_job(gate.j[q], a, B, packed + L.gate_wm[g], nb_gate);
+            ConvArgs o{};
+            if (g == 0) cost_view(k, o); else o.inA = e_of(k, g - 1);
+            o.CA = cx; o.scaleA = sx; o.inB = wsf + ws.rh[g]; o.CB = hc;
+            o.w = packed + L.out_w[g]; o.bias = packed + L.out_b[g]; o.out = wsf + ws.cand[g]; o.stats = so; o.ngroups = 1;
+            o.Cout = hc; o.Hi = o.Ho = hs[g]; o.Wi = o.Wo = wd[g];
+            nb_cand += conv_job(cand.j[q], o, B, packed + L.out_wm[g], nb_cand);
+            GruJob& u = gru.j[q];
+            u.gates = wsf + ws.gates[g]; u.stats_g = sg; u.stats_o = so;
+            u.rn_w = packed + L.rn_w[g]; u.rn_b = packed + L.rn_b[g]; u.un_w = packed + L.un_w[g]; u.un_b = packed + L.un_b[g];
+            u.on_w = packed + L.on_w[g]; u.on_b = packed + L.on_b[g];
+            u.h = r.state[g]; u.rh = wsf + ws.rh[g]; u.cand = wsf + ws.cand[g]; u.hsnap = hsnap_of(k, g);
+            u.zero_next = stats_next ? stats_next + (size_t)g * B * 3 * NSLOT * 2 : nullptr;
+            u.HC = hc; u.HW = hw; u.gx = (int)(((size_t)hc * hw + 255) / 256); u.blk0 = nb_gru;
+            nb_gru += u.gx * B;
         }
+        hipLaunchKernelGGL(conv_jobs_kernel, dim3(nb_gate), dim3(256), 0, sR, gate);
+        hipLaunchKernelGGL(gru_gate_apply_kernel, dim3(nb_gru), dim3(256), 0, sR, gru);
+        hipLaunchKernelGGL(conv_jobs_kernel, dim3(nb_cand), dim3(256), 0, sR, cand);
+        hipLaunchKernelGGL(gru_combine_kernel, dim3(nb_gru), dim3(256), 0, sR, gru);
+        if (multi) (void)hipEventRecord(P.state[k % RING], sR);
+        return SMVS_OK;
+    }
+
+    // decoder of plane k from the state snapshots, output convolution, regression update
+    int issue_decoder(int k)
+    {
+        const int d = d_begin + k;
+        const int B = r.B;
+        float* wsf = r.wsf;
+        const float* packed = r.packed;
+        const size_t npix = (size_t)B * r.H * r.W;
+        if (multi) (void)hipStreamWaitEvent(sD, P.state[k % RING], 0);
+        for (int g = 3; g >= 1; --g) {
+            // sum[g-1] = relu(upconv{g}(state4' or sum[g])) + state{g}'
+            ConvArgs u{};
+            u.inA = g == 3 ? hsnap_of(k, 3) : wsf + ws.sum[g]; u.CA = HID[g]; u.scaleA = 1.0f;
+            u.w = packed + L.up_w[g - 1]; u.out = wsf + ws.sum[g - 1]; u.skip = hsnap_of(k, g - 1); u.Cout = HID[g - 1];
+            u.Hi = hs[g]; u.Wi = wd[g]; u.Ho = hs[g - 1]; u.Wo = wd[g - 1]; u.relu = 1;
+            launch_convT(u, B, sD);
+        }
+        // reg = upconv2d(up1 + state1') : ConvTranspose2d stride 1 == correlation with flipped taps
+        float* reg = !r.pred ? r.reg_out : r.reg_volume ? r.reg_volume + (size_t)d * r.H * r.W : r.reg;
+        ConvArgs f{};
+        f.inA = wsf + ws.sum[0]; f.CA = 8; f.scaleA = 1.0f; f.w = packed + L.up2d_w; f.bias = packed + L.up2d_b;
+        f.out = reg; f.Cout = 1; f.Hi = f.Ho = r.H; f.Wi = f.Wo = r.W;
+        if (r.pred && r.reg_volume) f.out_bstride = (size_t)r.D * r.H * r.W;
+        launch_conv(1, f, B, sD);
+        if (r.pred && !r.reg_volume) {
+            const int rc = stream_regress_step(reg, r.depth, r.depth_is_4d, r.gen, r.acc, r.acc + npix, r.acc + 2 * npix,
+                                               B, r.D, r.H, r.W, d, sD);
+            if (rc) return rc;
+        }
+        if (multi) (void)hipEventRecord(P.done[k % RING], sD);
         return SMVS_OK;
     }
 };
@@ -766,26 +843,29 @@ static int red_run_planes(const RedRun& r, int d_begin, int d_end)
     const int nplanes = d_end - d_begin;
     if (nplanes <= 0) return SMVS_OK;
     // one plane alone: the cross-stream hops cost more than they buy (measured) -> caller's stream only
-    const int mode = nplanes > 1 ? pp->mode : 0;
-    RedIssuer is(r, *pp, mode, d_begin, d_end);
+    const bool multi = nplanes > 1 && tune_int("SMVS_RED_STREAMS", 2) != 0;
+    RedIssuer is(r, *pp, multi, d_begin, d_end);
     const RedPipe& P = *pp;
     // the first plane's statistics are cleared here; afterwards each level clears the next plane's buffer itself
     (void)hipMemsetAsync(r.wsf + is.ws.stats[0], 0, (size_t)r.B * 4 * 3 * NSLOT * 2 * sizeof(double), r.main);
 
-    // The host's enqueue rate binds the small stages (tools/host_bound_probe.py); a second host thread issuing the
-    // fine levels did not help (the runtime serialises), fewer calls per plane do -- hence the chunked front.
+    // The host's enqueue rate binds the small stages (tools/host_bound_probe.py); a second host thread did not help
+    // (the runtime serialises), fewer calls per plane do: chunked front, level-batched launches.
     int rc = SMVS_OK;
     const int ch = is.CH();
     for (int k0 = 0; k0 < nplanes && !rc; k0 += ch) {
         const int n = nplanes - k0 < ch ? nplanes - k0 : ch;
-        // this half of the ring was last used by chunk j-2; its last plane's finest level finishing implies all of it
-        if (is.multi && k0 >= 2 * ch) (void)hipStreamWaitEvent(r.main, P.done[(k0 - ch - 1) % RING], 0);
+        // this half of the ring was last used by chunk j-2; its last plane leaving the decoder implies all of it
+        if (multi && k0 >= 2 * ch) (void)hipStreamWaitEvent(r.main, P.done[(k0 - ch - 1) % RING], 0);
         rc = is.issue_front(k0, n);
-        for (int k = k0; k < k0 + n && !rc; ++k) rc = is.issue_plane(k);
+        for (int k = k0; k < k0 + n && !rc; ++k) {
+            rc = is.issue_recurrent(k);
+            if (!rc) rc = is.issue_decoder(k);
+        }
     }
     if (rc) return rc;
-    // join: the caller's stream continues only after the last plane's finest level (which implies the rest)
-    if (is.multi) (void)hipStreamWaitEvent(r.main, P.done[(nplanes - 1) % RING], 0);
+    // join: the caller's stream continues only after the last plane's decoder (which implies the rest)
+    if (multi) (void)hipStreamWaitEvent(r.main, P.done[(nplanes - 1) % RING], 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "red planes launch: %s", hipGetErrorString(e));
     return SMVS_OK;
