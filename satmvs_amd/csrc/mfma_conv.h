@@ -20,6 +20,9 @@
 namespace smvs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef SMVS_MFMA_PREFETCH
+#define SMVS_MFMA_PREFETCH 2                 // 9-tap kernels, one cout tile per workgroup: channel pairs in flight per wave
+#endif
 
 struct MfmaConvArgs {
     const float* inA; int CA;                // first CA input channels (must be even)
@@ -128,8 +131,8 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
         _Pragma("unroll") for (int n_ = 0; n_ < NT; ++n_)                                                \
             acc[n_] = __builtin_amdgcn_mfma_f32_32x32x2f32(BT.w[n_][s_], BT.x[s_] * BT.sx, acc[n_], 0, 0, 0);
     static_assert(NB == 1 || NB == 3, "batching assumes 9 or 27 taps");
-    Batch b0, b1;
     if (NB == 3) {
+        Batch b0, b1;
         // per channel pair: batches g = 0,1,2; pipeline: [L0] (M0|L1) (M1|L2) (M2|L0') ...
         SMVS_LOAD_BATCH(0, b0, 0)
         for (int q = 0; q < q_end; q += 3) {
@@ -157,17 +160,21 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
             }
         }
     } else {
-        // 9 taps: one batch per channel pair, two pairs per iteration
-        SMVS_LOAD_BATCH(0, b0, 0)
-        for (int q = 0; q < q_end; q += 2) {
-            if (q + 1 < q_end) SMVS_LOAD_BATCH(0, b1, q + 1)
-            __builtin_amdgcn_sched_barrier(0);
-            SMVS_MMA_BATCH(b0)
-            __builtin_amdgcn_sched_barrier(0);
-            if (q + 2 < q_end) SMVS_LOAD_BATCH(0, b0, q + 2)
-            __builtin_amdgcn_sched_barrier(0);
-            if (q + 1 < q_end) SMVS_MMA_BATCH(b1)
-            __builtin_amdgcn_sched_barrier(0);
+        // 9 taps: one batch per channel pair, NPF-1 pairs in flight while one is multiplied (deeper than 2 measured
+        // no faster on the coarse levels -- the MFMA issue time of the wave's K range is the chain -- and slower on the large ones)
+        constexpr int NPF = NT == 1 ? SMVS_MFMA_PREFETCH : 2;
+        Batch bb[NPF];
+#pragma unroll
+        for (int i = 0; i < NPF - 1; ++i)
+            if (i < q_end) SMVS_LOAD_BATCH(0, bb[i], i)
+        for (int q = 0; q < q_end; q += NPF) {
+#pragma unroll
+            for (int i = 0; i < NPF; ++i) {
+                if (q + i + NPF - 1 < q_end) SMVS_LOAD_BATCH(0, bb[(i + NPF - 1) % NPF], q + i + NPF - 1)
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + i < q_end) SMVS_MMA_BATCH(bb[i])
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 #undef SMVS_LOAD_BATCH

@@ -31,6 +31,19 @@
 namespace smvs {
 
 constexpr int COT = 8;                       // output channels per lane
+// Pipeline depths of the direct kernels.  Measured on the three cascade stages (tools/host_bound_probe.py, ms per
+// stage): depth 2/3 + scalar weights 3.70 / 3.44 / 2.45; depth 4/6 3.58 / 3.63 / 2.57; depth 4/6 + weights through
+// LDS 3.50 / 4.15 / 2.83 -- the deeper variants shave the 192x96 stage and cost more on the larger ones (registers,
+// code size, an LDS copy per workgroup), so the shallow ones ship.
+#ifndef SMVS_CONV_PREFETCH
+#define SMVS_CONV_PREFETCH 2                 // channels of taps in flight per wave in the direct convolutions
+#endif
+#ifndef SMVS_WLDS
+#define SMVS_WLDS 0                          // 1: channel-split direct kernels read their weights from LDS instead of scalar loads
+#endif
+#ifndef SMVS_CONVT_PREFETCH
+#define SMVS_CONVT_PREFETCH 3
+#endif
 constexpr int NSLOT = 64;                    // GroupNorm statistics are accumulated in 64 partial slots per
                                              // (sample, norm group): ~36 same-address float64 atomics per slot
                                              // instead of ~18000 on one address (measured: 237 us -> 25 us for the full-resolution gate convolution)
@@ -142,10 +155,14 @@ __device__ __forceinline__ float wave_sum_f(float v)
 // SPLIT = true : workgroup = 64x1 output pixels, its 4 waves split the input channels and reduce through
 //   LDS.  The coarse planes give a few dozen workgroups on a 256-CU part: there the time is one wave's
 //   serial channel loop (a load round trip per channel), so 4x shorter chains = ~3x shorter kernels.
-// Both: the taps of channel c+1 are in flight while channel c is multiplied.
+// Both: the taps of the next channels are in flight while channel c is multiplied.
+// SPLIT with SMVS_WLDS stages the workgroup's weights ([Cin][9][COT], Cin <= WLDS_MAX_CIN) in LDS first (off: see above).
 // (bx,by,bz) = the workgroup's grid coordinates (blockIdx of the plain launch; decoded from a flat index by the
-// level-batched launch); smem: 3*COT*64 floats (SPLIT) / 8 floats.
-constexpr int CONV_SMEM_FLOATS = 3 * COT * 64;
+// level-batched launch); smem: CONV_SMEM_FLOATS floats (SPLIT) / 8 floats.
+constexpr int WLDS_MAX_CIN = 64;
+constexpr int CONV_PART_FLOATS = 3 * COT * 64;
+constexpr int WLDS_FLOATS = SMVS_WLDS ? WLDS_MAX_CIN * 9 * COT : 0;
+constexpr int CONV_SMEM_FLOATS = CONV_PART_FLOATS + WLDS_FLOATS;
 template <int STRIDE, bool SPLIT>
 __device__ __forceinline__ void conv3x3_body(const ConvArgs& a, int bx, int by, int bz, float* smem)
 {
@@ -177,6 +194,14 @@ __device__ __forceinline__ void conv3x3_body(const ConvArgs& a, int bx, int by, 
 #pragma unroll
     for (int j = 0; j < COT; ++j) acc[j] = 0.0f;
     const cw_t wbase = (cw_t)(uintptr_t)(a.w + (size_t)cog * Cin * 9 * COT);
+    const float* wl = smem + CONV_PART_FLOATS;
+    constexpr bool WL = SPLIT && SMVS_WLDS;
+    if (WL) {
+        const float* wg = a.w + (size_t)cog * Cin * 9 * COT;
+        float* wd = smem + CONV_PART_FLOATS;
+        for (int i = threadIdx.x * 4; i < Cin * 9 * COT; i += 256 * 4) *(float4*)(wd + i) = *(const float4*)(wg + i);
+        __syncthreads();
+    }
 
     const int per = SPLIT ? (Cin + 3) / 4 : Cin;
     const int c0 = SPLIT ? wave * per : 0, c1 = SPLIT ? min(Cin, c0 + per) : Cin;
@@ -191,22 +216,29 @@ __device__ __forceinline__ void conv3x3_body(const ConvArgs& a, int bx, int by, 
         _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_) V[k_] = llvm_raw_buffer_load_f32(rx_, (int)off[k_], co_, 0) * sc_; \
     }
 #define SMVS_CONV_FMA(V, CC)                                                                           \
-    {                                                                                                  \
+    { if (WL) {                                                                                        \
+        const float* wc_ = wl + (CC) * 9 * COT;                                                        \
+        _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_)                                               \
+            _Pragma("unroll") for (int j_ = 0; j_ < COT; ++j_) acc[j_] = fmaf(V[k_], wc_[k_ * COT + j_], acc[j_]); \
+    } else {                                                                                           \
         const cw_t wc_ = wbase + (size_t)(CC) * 9 * COT;                                               \
         _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_)                                               \
             _Pragma("unroll") for (int j_ = 0; j_ < COT; ++j_) acc[j_] = fmaf(V[k_], wc_[k_ * COT + j_], acc[j_]); \
-    }
-    float v0[9], v1[9];
-    if (c0 < c1) SMVS_CONV_LOAD(v0, c0)
-    for (int cc = c0; cc < c1; cc += 2) {
-        if (cc + 1 < c1) SMVS_CONV_LOAD(v1, cc + 1)
-        __builtin_amdgcn_sched_barrier(0);
-        SMVS_CONV_FMA(v0, cc)
-        __builtin_amdgcn_sched_barrier(0);
-        if (cc + 2 < c1) SMVS_CONV_LOAD(v0, cc + 2)
-        __builtin_amdgcn_sched_barrier(0);
-        if (cc + 1 < c1) SMVS_CONV_FMA(v1, cc + 1)
-        __builtin_amdgcn_sched_barrier(0);
+    } }
+    // NPF-1 channels of taps are in flight while one is multiplied.
+    constexpr int NPF = SMVS_CONV_PREFETCH;
+    float v[NPF][9];
+#pragma unroll
+    for (int i = 0; i < NPF - 1; ++i)
+        if (c0 + i < c1) SMVS_CONV_LOAD(v[i], c0 + i)
+    for (int cc = c0; cc < c1; cc += NPF) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            if (cc + i + NPF - 1 < c1) SMVS_CONV_LOAD(v[(i + NPF - 1) % NPF], cc + i + NPF - 1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (cc + i < c1) SMVS_CONV_FMA(v[i], cc + i)
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #undef SMVS_CONV_LOAD
 #undef SMVS_CONV_FMA
@@ -262,7 +294,7 @@ template <int STRIDE, bool SPLIT>
 __global__ __launch_bounds__(256)
 void conv3x3_kernel(const ConvArgs a)
 {
-    __shared__ float smem[SPLIT ? CONV_SMEM_FLOATS : 8];
+    __shared__ __attribute__((aligned(16))) float smem[SPLIT ? CONV_SMEM_FLOATS : 8];
     conv3x3_body<STRIDE, SPLIT>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
@@ -297,13 +329,26 @@ void convT3x3s2_kernel(const ConvArgs a)
 #pragma unroll
         for (int j = 0; j < COT; ++j) acc[q][j] = 0.0f;
     const cw_t wbase = (cw_t)(uintptr_t)(a.w + (size_t)cog * a.CA * 9 * COT);
+    __shared__ __attribute__((aligned(16))) float ct_smem[SPLIT ? 3 * 4 * COT * 64 + WLDS_FLOATS : 4];
+    const float* wl = ct_smem + 3 * 4 * COT * 64;
+    constexpr bool WL = SPLIT && SMVS_WLDS;
+    if (WL) {                                    // weights of this cout group through LDS (see conv3x3_body)
+        const float* wg = a.w + (size_t)cog * a.CA * 9 * COT;
+        float* wd = ct_smem + 3 * 4 * COT * 64;
+        for (int i = threadIdx.x * 4; i < a.CA * 9 * COT; i += 256 * 4) *(float4*)(wd + i) = *(const float4*)(wg + i);
+        __syncthreads();
+    }
     const int per = SPLIT ? (a.CA + 3) / 4 : a.CA;
     const int c0 = SPLIT ? wave * per : 0, c1 = SPLIT ? min(a.CA, c0 + per) : a.CA;
 #define SMVS_CT_LOAD(V, CC) \
     { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) V[k_] = llvm_raw_buffer_load_f32(rA.v, (int)off[k_], (CC) * HWi * 4, 0); }
 #define SMVS_CT_FMA(V, CC)                                                                             \
     {                                                                                                  \
-        const cw_t wc = wbase + (size_t)(CC) * 9 * COT;                                                \
+        if (WL) { const float* wc = wl + (CC) * 9 * COT; SMVS_CT_FMA_BODY(V, wc) }                     \
+        else { const cw_t wc = wbase + (size_t)(CC) * 9 * COT; SMVS_CT_FMA_BODY(V, wc) }               \
+    }
+#define SMVS_CT_FMA_BODY(V, wc)                                                                        \
+    {                                                                                                  \
         _Pragma("unroll") for (int j = 0; j < COT; ++j) {                                              \
             acc[0][j] = fmaf(V[0], wc[4 * COT + j], acc[0][j]);                                        \
             acc[1][j] = fmaf(V[0], wc[5 * COT + j], fmaf(V[1], wc[3 * COT + j], acc[1][j]));           \
@@ -312,28 +357,26 @@ void convT3x3s2_kernel(const ConvArgs a)
                         fmaf(V[2], wc[2 * COT + j], fmaf(V[3], wc[0 * COT + j], acc[3][j]))));         \
         }                                                                                              \
     }
-    // three channels of taps in flight ahead of the multiply (4 loads per channel only)
-    float v0[4], v1[4], v2[4];
-    if (c0 < c1) SMVS_CT_LOAD(v0, c0)
-    if (c0 + 1 < c1) SMVS_CT_LOAD(v1, c0 + 1)
-    for (int cc = c0; cc < c1; cc += 3) {
-        if (cc + 2 < c1) SMVS_CT_LOAD(v2, cc + 2)
-        __builtin_amdgcn_sched_barrier(0);
-        SMVS_CT_FMA(v0, cc)
-        __builtin_amdgcn_sched_barrier(0);
-        if (cc + 3 < c1) SMVS_CT_LOAD(v0, cc + 3)
-        __builtin_amdgcn_sched_barrier(0);
-        if (cc + 1 < c1) SMVS_CT_FMA(v1, cc + 1)
-        __builtin_amdgcn_sched_barrier(0);
-        if (cc + 4 < c1) SMVS_CT_LOAD(v1, cc + 4)
-        __builtin_amdgcn_sched_barrier(0);
-        if (cc + 2 < c1) SMVS_CT_FMA(v2, cc + 2)
-        __builtin_amdgcn_sched_barrier(0);
+    // NPF-1 channels of taps in flight ahead of the multiply (4 loads per channel only)
+    constexpr int NPF = SMVS_CONVT_PREFETCH;
+    float v[NPF][4];
+#pragma unroll
+    for (int i = 0; i < NPF - 1; ++i)
+        if (c0 + i < c1) SMVS_CT_LOAD(v[i], c0 + i)
+    for (int cc = c0; cc < c1; cc += NPF) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            if (cc + i + NPF - 1 < c1) SMVS_CT_LOAD(v[(i + NPF - 1) % NPF], cc + i + NPF - 1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (cc + i < c1) SMVS_CT_FMA(v[i], cc + i)
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #undef SMVS_CT_LOAD
 #undef SMVS_CT_FMA
+#undef SMVS_CT_FMA_BODY
     if (SPLIT) {
-        __shared__ float part[3][4 * COT][64];
+        float (*part)[4 * COT][64] = (float (*)[4 * COT][64])ct_smem;
         if (wave > 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -364,6 +407,63 @@ void convT3x3s2_kernel(const ConvArgs a)
                 o[(q >> 1) * a.Wo + (q & 1)] = r;
             }
         }
+    }
+}
+
+// Output convolution (8 -> 1 channel, ConvTranspose2d stride 1 packed as a correlation) with the streaming
+// regression update of the pred loop (networks/casred.py:218-231, float64 accumulators) in its epilogue: the plane
+// never goes to memory unless the caller wants the regularised volume.  lane = one pixel, 72 taps in flight.
+struct OutConvArgs {
+    const float* in;                         // (B,8,H,W)
+    const float* w;                          // packed [8][9][COT], output channel 0
+    const float* bias;
+    float* reg; size_t reg_bstride;          // regularised plane (floats between samples), or null
+    double *exp_sum, *depth_img, *max_prob;  // (B,H,W) accumulators, or null (no regression update)
+    const float* depth; int hmode; HeightGen hg; int D, d;
+    int B, H, W;
+};
+
+__global__ __launch_bounds__(256)
+void out_conv_regress_kernel(const OutConvArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ox = blockIdx.x * 64 + lane, oy = blockIdx.y * 4 + wave, b = blockIdx.z;
+    const bool active = ox < a.W && oy < a.H;
+    const int HW = a.H * a.W;
+    const BufRsrc rA = make_rsrc(a.in + (size_t)b * 8 * HW, (uint32_t)(8 * HW) * 4u);
+    float v[8][9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int iy = oy - 1 + k / 3, ix = ox - 1 + k % 3;
+        const uint32_t off = (active && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? (uint32_t)(iy * a.W + ix) * 4u : SMVS_OOB;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c][k] = llvm_raw_buffer_load_f32(rA.v, (int)off, c * HW * 4, 0);
+    }
+    const cw_t w = (cw_t)(uintptr_t)a.w;
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc = fmaf(v[c][k], w[(c * 9 + k) * COT], acc);
+    if (!active) return;
+    const float r = acc + a.bias[0];
+    const int pix = oy * a.W + ox;
+    if (a.reg) a.reg[(size_t)b * a.reg_bstride + pix] = r;
+    if (a.exp_sum) {
+        const size_t i = (size_t)b * HW + pix;
+        const double pr = exp((double)r);
+        double hv;
+        if (a.hmode == HEIGHT_GENERATED) {
+            HeightPix hpx;
+            hg_prepare(a.hg, b, oy, ox, hpx);
+            hv = (double)hg_height(a.hg, hpx, a.d);
+        } else {
+            hv = a.hmode == HEIGHT_TENSOR ? (double)a.depth[((size_t)b * a.D + a.d) * HW + pix] : (double)a.depth[(size_t)b * a.D + a.d];
+        }
+        const double m = a.max_prob[i];
+        a.max_prob[i] = (m < pr) ? pr : m;
+        a.depth_img[i] = fma(hv, pr, a.depth_img[i]);
+        a.exp_sum[i] = a.exp_sum[i] + pr;
     }
 }
 
@@ -403,13 +503,12 @@ struct ConvJob {
 };
 struct ConvJobs { ConvJob j[4]; int n; };
 
-constexpr int JOBS_SMEM_FLOATS = 3 * 16 * 64;            // MFMA split-K partials of 3 waves (12 KiB) >= direct split (6 KiB)
-static_assert(JOBS_SMEM_FLOATS >= CONV_SMEM_FLOATS, "shared scratch of the level-batched convolution");
+constexpr int JOBS_SMEM_FLOATS = CONV_SMEM_FLOATS > 3 * 16 * 64 ? CONV_SMEM_FLOATS : 3 * 16 * 64;   // direct split (6 KiB + weights) | MFMA split-K partials of 3 waves (12 KiB)
 
 __global__ __launch_bounds__(256)
 void conv_jobs_kernel(const ConvJobs J)
 {
-    __shared__ float smem[JOBS_SMEM_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[JOBS_SMEM_FLOATS];
     int bid = blockIdx.x, l = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i)
@@ -578,7 +677,7 @@ static void launch_conv(int stride, const ConvArgs& a, int B, hipStream_t st, co
     }
     const int ncog = (a.Cout + COT - 1) / COT;
     const int wx = (a.Wo + 63) / 64;
-    if (wx * ((a.Ho + 3) / 4) * Bh * ncog < g_split_below()) {          // coarse plane: latency regime
+    if (wx * ((a.Ho + 3) / 4) * Bh * ncog < g_split_below() && (!SMVS_WLDS || a.CA + a.CB <= WLDS_MAX_CIN)) {   // coarse plane: latency regime
         dim3 grd(wx, a.Ho, B * ncog), blk(256);
         if (stride == 1) hipLaunchKernelGGL((conv3x3_kernel<1, true>), grd, blk, 0, st, a);
         else             hipLaunchKernelGGL((conv3x3_kernel<2, true>), grd, blk, 0, st, a);
@@ -601,7 +700,7 @@ static int conv_job(ConvJob& j, const ConvArgs& a, int B, const float* wm, int b
     j.a = a;
     const int ncog = (a.Cout + COT - 1) / COT;
     j.gx = (a.Wo + 63) / 64;
-    const bool split = j.gx * ((a.Ho + 3) / 4) * B * ncog < g_split_below();
+    const bool split = j.gx * ((a.Ho + 3) / 4) * B * ncog < g_split_below() && (!SMVS_WLDS || a.CA + a.CB <= WLDS_MAX_CIN);
     j.kind = split ? 1 : 0;
     j.gy = split ? a.Ho : (a.Ho + 3) / 4;
     return j.gx * j.gy * B * ncog;
@@ -628,9 +727,8 @@ static void launch_convT(const ConvArgs& a, int B, hipStream_t st)
 //     snapshots of the new states: DECODER stream, running under the next plane's recurrent launches.
 // Events: encoder done (per chunk), states done (per plane), plane done (per plane; the front of chunk j waits for
 // the last plane of chunk j-2, whose ring entries it reuses).  A single plane runs on the caller's stream alone.
-int stream_regress_step(const float* reg_plane, const float* depth, int depth_is_4d, const smvs_height_gen* gen,
-                        double* exp_sum, double* depth_img, double* max_prob,
-                        int B, int D, int H, int W, int d, void* stream);               // regress.hip
+int resolve_heights(const float* depth, int depth_is_4d, const smvs_height_gen* gen, int D, int H, int W,
+                    int& mode, HeightGen& hg);                                              // regress.hip
 
 constexpr int RING = 2 * NSL_MAX;
 struct RedPipe {
@@ -697,6 +795,7 @@ struct RedIssuer {
     RedLayout L; RedWorkspace ws;
     hipStream_t sR, sD;
     int hs[4], wd[4];
+    int hmode = 0; HeightGen hg{};            // heights of the regression update, resolved once per call
 
     RedIssuer(const RedRun& run, const RedPipe& pipe, bool multi_, int d0, int d1)
         : r(run), P(pipe), multi(multi_), d_begin(d0), d_end(d1), L(red_layout(run.C)), ws(red_workspace(run.B, run.C, run.H, run.W))
@@ -793,9 +892,22 @@ struct RedIssuer {
             u.HC = hc; u.HW = hw; u.gx = (int)(((size_t)hc * hw + 255) / 256); u.blk0 = nb_gru;
             nb_gru += u.gx * B;
         }
+        if (tune_int("SMVS_RED_SPLIT_JOBS", 0)) {                       // tuning builds: one launch per level, to time the jobs
+            for (int pass = 0; pass < 2; ++pass) {
+                const ConvJobs& all = pass ? cand : gate;
+                for (int q = 0; q < 4; ++q) {
+                    ConvJobs one{};
+                    one.n = 1; one.j[0] = all.j[q]; one.j[0].blk0 = 0;
+                    const int nb = (q < 3 ? all.j[q + 1].blk0 : (pass ? nb_cand : nb_gate)) - all.j[q].blk0;
+                    hipLaunchKernelGGL(conv_jobs_kernel, dim3(nb), dim3(256), 0, sR, one);
+                }
+                if (!pass) hipLaunchKernelGGL(gru_gate_apply_kernel, dim3(nb_gru), dim3(256), 0, sR, gru);
+            }
+        } else {
         hipLaunchKernelGGL(conv_jobs_kernel, dim3(nb_gate), dim3(256), 0, sR, gate);
         hipLaunchKernelGGL(gru_gate_apply_kernel, dim3(nb_gru), dim3(256), 0, sR, gru);
         hipLaunchKernelGGL(conv_jobs_kernel, dim3(nb_cand), dim3(256), 0, sR, cand);
+        }
         hipLaunchKernelGGL(gru_combine_kernel, dim3(nb_gru), dim3(256), 0, sR, gru);
         if (multi) (void)hipEventRecord(P.state[k % RING], sR);
         return SMVS_OK;
@@ -818,18 +930,18 @@ struct RedIssuer {
             u.Hi = hs[g]; u.Wi = wd[g]; u.Ho = hs[g - 1]; u.Wo = wd[g - 1]; u.relu = 1;
             launch_convT(u, B, sD);
         }
-        // reg = upconv2d(up1 + state1') : ConvTranspose2d stride 1 == correlation with flipped taps
-        float* reg = !r.pred ? r.reg_out : r.reg_volume ? r.reg_volume + (size_t)d * r.H * r.W : r.reg;
-        ConvArgs f{};
-        f.inA = wsf + ws.sum[0]; f.CA = 8; f.scaleA = 1.0f; f.w = packed + L.up2d_w; f.bias = packed + L.up2d_b;
-        f.out = reg; f.Cout = 1; f.Hi = f.Ho = r.H; f.Wi = f.Wo = r.W;
-        if (r.pred && r.reg_volume) f.out_bstride = (size_t)r.D * r.H * r.W;
-        launch_conv(1, f, B, sD);
-        if (r.pred && !r.reg_volume) {
-            const int rc = stream_regress_step(reg, r.depth, r.depth_is_4d, r.gen, r.acc, r.acc + npix, r.acc + 2 * npix,
-                                               B, r.D, r.H, r.W, d, sD);
-            if (rc) return rc;
+        // reg = upconv2d(up1 + state1') : ConvTranspose2d stride 1 == correlation with flipped taps; the regression
+        // update of the pred loop rides in its epilogue
+        OutConvArgs f{};
+        f.in = wsf + ws.sum[0]; f.w = packed + L.up2d_w; f.bias = packed + L.up2d_b;
+        f.B = B; f.H = r.H; f.W = r.W;
+        if (!r.pred) { f.reg = r.reg_out; f.reg_bstride = (size_t)r.H * r.W; }
+        else if (r.reg_volume) { f.reg = r.reg_volume + (size_t)d * r.H * r.W; f.reg_bstride = (size_t)r.D * r.H * r.W; }
+        else {
+            f.exp_sum = r.acc; f.depth_img = r.acc + npix; f.max_prob = r.acc + 2 * npix;
+            f.depth = r.depth; f.hmode = hmode; f.hg = hg; f.D = r.D; f.d = d;
         }
+        hipLaunchKernelGGL(out_conv_regress_kernel, dim3((r.W + 63) / 64, (r.H + 3) / 4, B), dim3(256), 0, sD, f);
         if (multi) (void)hipEventRecord(P.done[k % RING], sD);
         return SMVS_OK;
     }
@@ -846,6 +958,8 @@ static int red_run_planes(const RedRun& r, int d_begin, int d_end)
     const bool multi = nplanes > 1 && tune_int("SMVS_RED_STREAMS", 2) != 0;
     RedIssuer is(r, *pp, multi, d_begin, d_end);
     const RedPipe& P = *pp;
+    if (r.pred && !r.reg_volume)
+        if (int rc0 = resolve_heights(r.depth, r.depth_is_4d, r.gen, r.D, r.H, r.W, is.hmode, is.hg)) return rc0;
     // the first plane's statistics are cleared here; afterwards each level clears the next plane's buffer itself
     (void)hipMemsetAsync(r.wsf + is.ws.stats[0], 0, (size_t)r.B * 4 * 3 * NSLOT * 2 * sizeof(double), r.main);
 

@@ -190,7 +190,7 @@ SMVS_EXPORT const char* smvs_last_error(void) { return smvs::last_error_buf(); }
 namespace smvs {
 
 // heights: exactly one of (depth, gen)
-static int resolve_heights(const float* depth, int depth_is_4d, const smvs_height_gen* gen, int D, int H, int W,
+int resolve_heights(const float* depth, int depth_is_4d, const smvs_height_gen* gen, int D, int H, int W,
                            int& mode, HeightGen& hg)
 {
     hg = HeightGen{};
