@@ -13,11 +13,13 @@
 // (x,h) / (x,r*h) read from two tensors without materialising the concatenation, bias / ReLU / GroupNorm
 // statistics (float64 atomics into 64 slots) fused in the epilogue; a channel-split variant for the coarse
 // planes.  Layers with >= 32 output channels (gates of levels 2-4, candidates of levels 3-4, encoder
-// conv2/conv3) run on the float32 MFMA implicit-GEMM kernel of mfma_conv.h.  24 launches per plane instead
-// of ~60 in the stock PyTorch composite.
+// conv2/conv3) run on the float32 MFMA implicit-GEMM kernel of mfma_conv.h.  The same stage of the four ConvGRU
+// levels is ONE launch (level-batched: conv_jobs_kernel, gru_gate_apply_kernel, gru_combine_kernel); the decoder fuses
+// the skip add, the output convolution fuses the regression update: 8 launches per plane (+ 4 per chunk of planes for
+// cost volume and encoder) instead of ~60 in the stock PyTorch composite.
 //
 // Entry points: smvs_red_step_fwd (one plane, caller's stream), smvs_red_pred_planes / smvs_red_volume_planes
-// (the whole plane loop incl. the cost-volume plane, as a 3-stream pipeline: see red_run_planes).
+// (the whole plane loop incl. the cost-volume planes, as a 3-stream pipeline: see red_run_planes).
 #include <stdlib.h>
 #include <string.h>
 
@@ -752,7 +754,7 @@ static RedPipe* red_pipe_create()
 // The helper streams / events of the plane pipeline come from a per-device pool guarded by a mutex: a call borrows one
 // set for its duration and returns it, so the number of sets ever created is the peak number of CONCURRENT calls on a
 // device (one per nn.DataParallel replica thread), not the number of threads that ever called -- DataParallel starts
-// fresh threads for every forward, which made a thread_local cache leak 4 streams + 44 events per forward.
+// fresh threads for every forward, which made a thread_local cache leak its streams and events on every forward.
 struct RedPipeLease {
     RedPipe* p = nullptr; int dev = -1;
     static std::mutex& mu() { static std::mutex m; return m; }
@@ -785,7 +787,7 @@ struct RedRun {
     bool pred; int geo_kind; const float* ref_fea; const float* const* src_fea; int n_src; const double* geo;
     const float* depth; int depth_is_4d; const smvs_height_gen* gen; double* acc; int D;
     float* reg_volume;                       // pred with acc == null: regularised planes go to (B,D,H,W) instead
-    float* block[2]; float* reg;             // two (B,C,CH,H,W) chunks of variance planes; one regularised plane
+    float* block[2];                         // two (B,C,CH,H,W) chunks of variance planes
 };
 
 // Everything one call needs to enqueue planes: issue_front() = caller's stream (cost volume, encoder of a chunk);
@@ -1081,7 +1083,7 @@ SMVS_EXPORT size_t smvs_red_pred_workspace_bytes(int B, int C, int H, int W)
 {
     const size_t r = smvs_red_workspace_bytes(B, C, H, W);
     if (r == 0) return 0;
-    return r + (2 * (size_t)smvs::red_chunk(B, C, H, W) * B * C * H * W + (size_t)B * H * W) * sizeof(float) + 64;   // two chunks of variance planes + reg
+    return r + 2 * (size_t)smvs::red_chunk(B, C, H, W) * B * C * H * W * sizeof(float) + 64;   // two chunks of variance planes
 }
 
 static int red_planes_entry(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
@@ -1108,7 +1110,6 @@ static int red_planes_entry(int geo_kind, const float* ref_fea, const float* con
     const size_t blk = (size_t)red_chunk(B, C, H, W) * B * C * H * W;
     r.block[0] = (float*)((char*)workspace + ((red_bytes + 15) & ~(size_t)15));
     r.block[1] = r.block[0] + blk;
-    r.reg = r.block[1] + blk;
     return red_run_planes(r, d_begin, d_end);
 }
 

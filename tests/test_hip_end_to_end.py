@@ -280,15 +280,17 @@ def test_train_path_matches_reference(dev, golden):
     np.testing.assert_allclose(out["photometric_confidence"].cpu().numpy(), g["train_conf"], rtol=1e-4, atol=1e-6)
 
 
-def test_red_volume_pipeline_equals_per_plane_steps(dev):
+@pytest.mark.parametrize("B,D", [(2, 6), (1, 21), (2, 17)])
+def test_red_volume_pipeline_equals_per_plane_steps(dev, B, D):
     """smvs_red_volume_planes (stream-pipelined plane loop, variance volume never materialised, B = 2 to cover
-    the batch stride of the (B,D,H,W) output) against RED_Regularization.forward on the materialised volume
-    (one smvs_red_step_fwd per plane on one stream): same kernels, same per-plane order -> same bits."""
+    the batch stride of the (B,D,H,W) output and the (plane, batch) sample order of the chunked front; 21 / 17 planes =
+    chunks of 8 + a short tail, ring of two chunks reused) against RED_Regularization.forward on the materialised
+    volume (one smvs_red_step_fwd per plane on one stream): same kernels, same per-plane order -> same bits."""
     from satmvs_amd import rpc_synth
     from satmvs_amd.modules.module import RED_Regularization
     from satmvs_amd.modules.warping import variance_cost_volume
     torch.manual_seed(5)
-    B, V, C, H, W, D = 2, 3, 8, 32, 40, 6
+    V, C, H, W = 3, 8, 32, 40
     reg = RED_Regularization(C, 8).to(dev).eval()
     feats = [torch.randn(B, C, H, W, device=dev) for _ in range(V)]
     rpc = np.stack([rpc_synth.make_view_rpcs(V, H, W, seed=11 + b) for b in range(B)])
