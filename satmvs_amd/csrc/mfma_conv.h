@@ -6,11 +6,15 @@
 // same class as the direct kernels).  Rows (M) are 32 output channels, columns (N) 32 consecutive output
 // positions along x -- so every accumulator register of a lane belongs to ONE output position and the store
 // of a register across lanes is a coalesced 128-B row -- and K advances two (channel, tap) pairs per MFMA.
-//   * X operand: one buffer load per lane and MFMA (lane -> position l&31, k-slot l>>5); the per-lane tap
-//     offsets (zero padding = out-of-range offset) are fixed per tile, the channel pair rides in the scalar
-//     offset: no vector ALU work in the K loop.
-//   * W operand: one coalesced load per lane and MFMA from a buffer pre-packed in exactly the order the
-//     lanes consume it ([channel pair][step][cout tile][k-slot][32]).
+//   * 27 taps (3-D): X operand: one buffer load per lane and MFMA (lane -> position l&31, k-slot l>>5); the per-lane
+//     tap offsets (zero padding = out-of-range offset) are fixed per tile, the channel pair rides in the scalar
+//     offset: no vector ALU work in the K loop.  W operand: one coalesced load per lane and MFMA from a buffer
+//     pre-packed in exactly the order the lanes consume it ([channel pair][step][cout tile][k-slot][32]).
+//   * 9 taps (2-D): a CU's texture path, not the matrix pipe, bounded that scheme on the small grids (18 dword loads
+//     per 9 MFMAs and wave: measured ~1700 clocks per batch against 576 of MFMA issue).  So k-slot = CHANNEL of the
+//     pair and step = tap: a lane's nine X values are three rows of three consecutive floats = 3 dwordx3 loads (edge
+//     columns fixed up with selects), its nine weights are contiguous = 3 dwordx4 loads
+//     ([channel pair][cout tile][k-slot][32][12]): 6 loads per batch instead of 18.
 //   * The coarse levels are tiny (a few thousand positions), so a workgroup's 4 waves split K (input
 //     channels) four ways and reduce through LDS: 4x the waves in flight for the same tile.
 // Epilogue (wave 0): bias / BatchNorm scale-shift, ReLU, skip add, GroupNorm statistics.
@@ -20,6 +24,11 @@
 namespace smvs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float mf32x3 __attribute__((ext_vector_type(3)));
+typedef float mf32x4 __attribute__((ext_vector_type(4)));
+__device__ mf32x3 llvm_raw_buffer_load_v3f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v3f32");
+__device__ mf32x4 llvm_raw_buffer_load_v4f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+constexpr int MFMA9_WSLOT = 12;              // 9-tap weights: a lane's 9 taps padded to three float4
 #ifndef SMVS_MFMA_PREFETCH
 #define SMVS_MFMA_PREFETCH 2                 // 9-tap kernels, one cout tile per workgroup: channel pairs in flight per wave
 #endif
@@ -43,6 +52,16 @@ struct MfmaConvArgs {
 static __global__ void mfma_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int cin, int cout, int taps)
 {
     const int nt = (cout + 31) / 32;
+    if (taps == 9) {                             // [cip][nt][h][32][12]: step p = tap p, k-slot h = channel 2*cip + h
+        const int n9 = (cin / 2) * nt * 64 * MFMA9_WSLOT;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n9; i += gridDim.x * blockDim.x) {
+            const int t = i % MFMA9_WSLOT, j = (i / MFMA9_WSLOT) & 31, h = (i / (MFMA9_WSLOT * 32)) & 1;
+            const int tl = (i / (MFMA9_WSLOT * 64)) % nt, cip = i / (MFMA9_WSLOT * 64 * nt);
+            const int co = tl * 32 + j, ci = 2 * cip + h;
+            dst[i] = (t < 9 && co < cout) ? src[((size_t)co * cin + ci) * 9 + t] : 0.0f;
+        }
+        return;
+    }
     const int n = (cin / 2) * taps * nt * 64;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int j = i & 31, h = (i >> 5) & 1, t = (i >> 6) % nt, p = (i / (64 * nt)) % taps, cip = i / (64 * nt * taps);
@@ -53,12 +72,23 @@ static __global__ void mfma_pack_kernel(const float* __restrict__ src, float* __
     }
 }
 
+#ifdef SMVS_TIMING
+// profiling builds only: per-wave phase stamps (shader clocks) of the 9-tap MFMA body, keyed by Cout/32
+// [k][0] waves, [1] entry -> first operands landed, [2] K loop, [3] LDS reduce (wave 0), [4] epilogue (wave 0), [5] whole wave 0
+__device__ unsigned long long smvs_mfma_timing[8][8];
+__device__ __forceinline__ unsigned long long mfma_now() { unsigned long long t = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return t; }
+#define SMVS_MT(...) __VA_ARGS__
+#else
+#define SMVS_MT(...)
+#endif
+
 // NT = cout tiles per workgroup (blockIdx.y walks the rest), NW = waves splitting K.
 // (bx, by) = the workgroup's grid coordinates; smem: (NW-1)*NT*16*64 floats.
 template <int TAPS, int NT, int NW>
 __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, int by, float* smem)
 {
     constexpr int KD = TAPS == 27 ? 3 : 1;
+    SMVS_MT(const unsigned long long mt0 = mfma_now(); unsigned long long mt1 = mt0;)
     float (*red)[NT * 16][64] = (float (*)[NT * 16][64])smem;   // partial accumulators of waves 1..NW-1
     const int nt_all = (a.Cout + 31) / 32, nt0 = by * NT;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -92,7 +122,7 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
     }
     const BufRsrc rA = make_rsrc(a.inA + (size_t)b * a.CA * vol_i, (uint32_t)((size_t)a.CA * vol_i * 4));
     const BufRsrc rB = make_rsrc(a.CB ? a.inB + (size_t)b * a.CB * vol_i : a.inA, (uint32_t)((size_t)a.CB * vol_i * 4));
-    const BufRsrc rW = make_rsrc(a.w, (uint32_t)((size_t)(Cin / 2) * TAPS * nt_all * 64 * 4));
+    const BufRsrc rW = make_rsrc(a.w, (uint32_t)((size_t)(Cin / 2) * (TAPS == 9 ? MFMA9_WSLOT : TAPS) * nt_all * 64 * 4));
 
     f32x16 acc[NT];
 #pragma unroll
@@ -132,10 +162,13 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
             acc[n_] = __builtin_amdgcn_mfma_f32_32x32x2f32(BT.w[n_][s_], BT.x[s_] * BT.sx, acc[n_], 0, 0, 0);
     static_assert(NB == 1 || NB == 3, "batching assumes 9 or 27 taps");
     if (NB == 3) {
+        // per channel pair: batches g = 0,1,2, two register sets used alternately; the loop body covers TWO pairs so that the
+        // sets are back in their roles at the back edge (no register rotation: copying a set waits for its loads).  All
+        // loads are unconditional (see the 9-tap loop); past the end they fetch the last pair again and the MFMAs are skipped.
         Batch b0, b1;
-        // per channel pair: batches g = 0,1,2; pipeline: [L0] (M0|L1) (M1|L2) (M2|L0') ...
+        const int qe = q_end - 3;                                  // first batch of the last pair
         SMVS_LOAD_BATCH(0, b0, 0)
-        for (int q = 0; q < q_end; q += 3) {
+        for (int q = 0; q < q_end; q += 6) {
             SMVS_LOAD_BATCH(1, b1, q + 1)
             __builtin_amdgcn_sched_barrier(0);
             SMVS_MMA_BATCH(b0)
@@ -144,35 +177,89 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
             __builtin_amdgcn_sched_barrier(0);
             SMVS_MMA_BATCH(b1)
             __builtin_amdgcn_sched_barrier(0);
-            if (q + 3 < q_end) SMVS_LOAD_BATCH(0, b1, q + 3)
+            SMVS_LOAD_BATCH(0, b1, min(q + 3, qe))
             __builtin_amdgcn_sched_barrier(0);
             SMVS_MMA_BATCH(b0)
             __builtin_amdgcn_sched_barrier(0);
-            if (q + 3 < q_end) {
-                // rotate: the prefetched batch sits in b1, the loop expects it in b0
-                b0.sx = b1.sx;
-#pragma unroll
-                for (int s_ = 0; s_ < BS; ++s_) {
-                    b0.x[s_] = b1.x[s_];
-#pragma unroll
-                    for (int n_ = 0; n_ < NT; ++n_) b0.w[n_][s_] = b1.w[n_][s_];
-                }
-            }
+            const bool second = q + 3 < q_end;                      // wave-uniform
+            SMVS_LOAD_BATCH(1, b0, min(q + 4, qe + 1))
+            __builtin_amdgcn_sched_barrier(0);
+            if (second) SMVS_MMA_BATCH(b1)
+            __builtin_amdgcn_sched_barrier(0);
+            SMVS_LOAD_BATCH(2, b1, min(q + 5, qe + 2))
+            __builtin_amdgcn_sched_barrier(0);
+            if (second) SMVS_MMA_BATCH(b0)
+            __builtin_amdgcn_sched_barrier(0);
+            SMVS_LOAD_BATCH(0, b0, min(q + 6, qe))
+            __builtin_amdgcn_sched_barrier(0);
+            if (second) SMVS_MMA_BATCH(b1)
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
-        // 9 taps: one batch per channel pair, NPF-1 pairs in flight while one is multiplied (deeper than 2 measured
-        // no faster on the coarse levels -- the MFMA issue time of the wave's K range is the chain -- and slower on the large ones)
+        // 9 taps: one batch per channel pair = 3 row loads (X) + 3*NT weight loads, NPF-1 pairs in flight while one is
+        // multiplied.  Lane (j, h): position x0 + j, channel 2*cip + h of the pair.
         constexpr int NPF = NT == 1 ? SMVS_MFMA_PREFETCH : 2;
-        Batch bb[NPF];
+        const int ix0 = ox * a.stride - 1;                       // column of the west tap
+        const bool padL = ix0 < 0, padR = ix0 + 2 >= a.Wi;       // west / east tap is zero padding
+        uint32_t roff[3];
 #pragma unroll
-        for (int i = 0; i < NPF - 1; ++i)
-            if (i < q_end) SMVS_LOAD_BATCH(0, bb[i], i)
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * a.stride - 1 + ky;
+            const bool in = pos_ok && iy >= 0 && iy < a.Hi;
+            roff[ky] = in ? (uint32_t)(((size_t)h * vol_i + (size_t)iy * a.Wi + (padL ? 0 : ix0)) * 4) : SMVS_OOB;
+        }
+        struct Batch9 { mf32x3 x[3]; mf32x4 w[NT][2]; float w8[NT]; float sx; };   // no dead load components: the compiler would reuse them
+                                                                                    // as scratch and then has to wait for the load in flight
+        Batch9 bb[NPF];
+        auto load9 = [&](Batch9& B, int q) {
+            const int cip = wave * per + q;
+            const bool fromA = 2 * cip < a.CA;                      // wave-uniform: scalar selects
+            const int choff = (int)((size_t)(fromA ? 2 * cip : 2 * cip - a.CA) * vol_i * 4);
+            i32x4 rx;
+            rx.x = fromA ? rA.v.x : rB.v.x; rx.y = fromA ? rA.v.y : rB.v.y;
+            rx.z = fromA ? rA.v.z : rB.v.z; rx.w = rA.v.w;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) B.x[ky] = llvm_raw_buffer_load_v3f32(rx, (int)roff[ky], choff, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int wo = (cip * nt_all + nt0 + n) * (64 * MFMA9_WSLOT * 4);
+                B.w[n][0] = llvm_raw_buffer_load_v4f32(rW.v, lane * (MFMA9_WSLOT * 4), wo, 0);
+                B.w[n][1] = llvm_raw_buffer_load_v4f32(rW.v, lane * (MFMA9_WSLOT * 4) + 16, wo, 0);
+                B.w8[n] = llvm_raw_buffer_load_f32(rW.v, lane * (MFMA9_WSLOT * 4) + 32, wo, 0);
+            }
+            B.sx = fromA ? a.scaleA : 1.0f;                         // applied at MMA time: no wait on the loads here
+        };
+        auto mma9 = [&](const Batch9& B) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                // loaded columns start at max(ix0, 0): shift right by one where the west tap is padding, drop the east one
+                const float l0 = B.x[ky].x, l1 = B.x[ky].y, l2 = B.x[ky].z;
+                float xv[3];
+                xv[0] = padL ? 0.0f : l0;
+                xv[1] = padL ? l0 : l1;
+                xv[2] = padR ? 0.0f : (padL ? l1 : l2);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int p = ky * 3 + kx;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p < 8 ? B.w[n][(p >> 2) & 1][p & 3] : B.w8[n], xv[kx] * B.sx, acc[n], 0, 0, 0);
+                }
+            }
+        };
+        // Every load is UNCONDITIONAL (past the end: the last pair again, unused): a load under a branch makes the number
+        // of outstanding operations unknown at the join, and the compiler then waits with vmcnt(0) before every batch of
+        // MFMAs -- i.e. also for the batch it has just issued, and the prefetch hides nothing (that was the case until
+        // round 2: ~1900 clocks per batch against 576 of MFMA issue).
+#pragma unroll
+        for (int i = 0; i < NPF - 1; ++i) load9(bb[i], min(i, q_end - 1));
+        SMVS_MT(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mt1 = mfma_now();)
         for (int q = 0; q < q_end; q += NPF) {
 #pragma unroll
             for (int i = 0; i < NPF; ++i) {
-                if (q + i + NPF - 1 < q_end) SMVS_LOAD_BATCH(0, bb[(i + NPF - 1) % NPF], q + i + NPF - 1)
+                load9(bb[(i + NPF - 1) % NPF], min(q + i + NPF - 1, q_end - 1));
                 __builtin_amdgcn_sched_barrier(0);
-                if (q + i < q_end) SMVS_MMA_BATCH(bb[i])
+                if (q + i < q_end) mma9(bb[i]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -181,6 +268,7 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
 #undef SMVS_MMA_BATCH
 
     // ---- split-K reduction through LDS: waves 1..3 publish, wave 0 sums and finishes -----------------
+    SMVS_MT(asm volatile("s_nop 7\n s_nop 7" ::: "memory"); const unsigned long long mt2 = mfma_now();)
     if (wave > 0) {
 #pragma unroll
         for (int n = 0; n < NT; ++n)
@@ -196,29 +284,50 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][r] += red[k][n * 16 + r][lane];
 
+    SMVS_MT(const unsigned long long mt3 = mfma_now();)
     // D layout of 32x32 MFMA: register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31
     const size_t vol_o = (size_t)a.Do * a.Ho * a.Wo;
     const size_t pos = ((size_t)od * a.Ho + oy) * a.Wo + ox;
     float s1 = 0.0f, s2 = 0.0f, t1 = 0.0f, t2 = 0.0f;     // stats of norm group 0 / 1
+    // Every load of the epilogue is issued before the first use: on these small grids a wave sees the full memory
+    // latency of each dependent access, and a load -> add -> store chain per register cost 16 round trips (measured:
+    // the epilogue took as long as the K loop).  Cout is a multiple of 32 (mfma_conv_ok), so every row of the tile is
+    // a real channel and the per-channel vectors are read as aligned float4 (rows r..r+3 are consecutive channels).
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+    for (int n = 0; n < NT; ++n) {
+        const int cb = (nt0 + n) * 32 + 4 * h;                      // channel of register 0; register r: cb + (r&3) + 8*(r>>2)
+        float bi[16], sc[16], sh[16], sk[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = (nt0 + n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (co < a.Cout && pos_ok) {
+        for (int g = 0; g < 4; ++g) {
+            const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f), one = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            const float4 tb = a.bias ? *reinterpret_cast<const float4*>(a.bias + cb + 8 * g) : zero;
+            const float4 ts = a.scale ? *reinterpret_cast<const float4*>(a.scale + cb + 8 * g) : one;
+            const float4 th = a.scale ? *reinterpret_cast<const float4*>(a.shift + cb + 8 * g) : zero;
+            bi[4 * g] = tb.x; bi[4 * g + 1] = tb.y; bi[4 * g + 2] = tb.z; bi[4 * g + 3] = tb.w;
+            sc[4 * g] = ts.x; sc[4 * g + 1] = ts.y; sc[4 * g + 2] = ts.z; sc[4 * g + 3] = ts.w;
+            sh[4 * g] = th.x; sh[4 * g + 1] = th.y; sh[4 * g + 2] = th.z; sh[4 * g + 3] = th.w;
+        }
+        const size_t o0 = ((size_t)b * a.Cout + cb) * vol_o + pos;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            sk[r] = (a.skip && pos_ok) ? a.skip[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * vol_o] : 0.0f;
+        if (pos_ok) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb + (r & 3) + 8 * (r >> 2);
                 float v = acc[n][r];
-                if (a.bias) v += a.bias[co];
-                if (a.scale) v = fmaf(v, a.scale[co], a.shift[co]);
+                if (a.bias) v += bi[r];
+                if (a.scale) v = fmaf(v, sc[r], sh[r]);
                 if (a.stats) {
                     if (a.ngroups == 2 && co >= a.Cout / 2) { t1 += v; t2 = fmaf(v, v, t2); }
                     else { s1 += v; s2 = fmaf(v, v, s2); }
                 }
                 if (a.relu) v = fmaxf(v, 0.0f);
-                const size_t o = ((size_t)b * a.Cout + co) * vol_o + pos;
-                if (a.skip) v = a.skip[o] + v;
-                a.out[o] = v;
+                if (a.skip) v = sk[r] + v;
+                a.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * vol_o] = v;
             }
         }
+    }
     if (a.stats) {
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -237,6 +346,13 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
             }
         }
     }
+    SMVS_MT(if (TAPS == 9 && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long mt4 = mfma_now();
+        unsigned long long* T = smvs_mfma_timing[(a.Cout / 32) & 7];
+        atomicAdd(&T[0], 1ull); atomicAdd(&T[1], mt1 - mt0); atomicAdd(&T[2], mt2 - mt1); atomicAdd(&T[3], mt3 - mt2);
+        atomicAdd(&T[4], mt4 - mt3); atomicAdd(&T[5], mt4 - mt0);
+    })
 }
 
 template <int TAPS, int NT, int NW>
@@ -254,7 +370,7 @@ inline bool mfma_conv_ok(int CA, int CB, int Cout)
     return (Cout == 32 || Cout == 64 || Cout == 128) && Cin % 8 == 0 && CA % 2 == 0 && Cin >= 8;
 }
 
-inline size_t mfma_packed_floats(int cin, int cout, int taps) { return (size_t)(cin / 2) * taps * ((cout + 31) / 32) * 64; }
+inline size_t mfma_packed_floats(int cin, int cout, int taps) { return (size_t)(cin / 2) * (taps == 9 ? MFMA9_WSLOT : taps) * ((cout + 31) / 32) * 64; }
 
 template <int TAPS>
 inline void mfma_conv_launch(const MfmaConvArgs& a, int B, hipStream_t st, int Bh = 0)   // Bh: batch the variant is chosen for (0 = B)

@@ -230,13 +230,15 @@ __device__ __forceinline__ void conv3x3_body(const ConvArgs& a, int bx, int by, 
     // NPF-1 channels of taps are in flight while one is multiplied.
     constexpr int NPF = SMVS_CONV_PREFETCH;
     float v[NPF][9];
+    // The loads are UNCONDITIONAL (past the end: the last channel again, unused) -- a load under a branch makes the
+    // compiler wait with vmcnt(0) before every multiply block, and the prefetch hides nothing (mfma_conv.h).
+    const int cl = max(c1 - 1, 0);
 #pragma unroll
-    for (int i = 0; i < NPF - 1; ++i)
-        if (c0 + i < c1) SMVS_CONV_LOAD(v[i], c0 + i)
+    for (int i = 0; i < NPF - 1; ++i) SMVS_CONV_LOAD(v[i], min(c0 + i, cl))
     for (int cc = c0; cc < c1; cc += NPF) {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            if (cc + i + NPF - 1 < c1) SMVS_CONV_LOAD(v[(i + NPF - 1) % NPF], cc + i + NPF - 1)
+            SMVS_CONV_LOAD(v[(i + NPF - 1) % NPF], min(cc + i + NPF - 1, cl))
             __builtin_amdgcn_sched_barrier(0);
             if (cc + i < c1) SMVS_CONV_FMA(v[i], cc + i)
             __builtin_amdgcn_sched_barrier(0);
@@ -362,13 +364,13 @@ void convT3x3s2_kernel(const ConvArgs a)
     // NPF-1 channels of taps in flight ahead of the multiply (4 loads per channel only)
     constexpr int NPF = SMVS_CONVT_PREFETCH;
     float v[NPF][4];
+    const int cl = max(c1 - 1, 0);               // unconditional loads (see conv3x3_body)
 #pragma unroll
-    for (int i = 0; i < NPF - 1; ++i)
-        if (c0 + i < c1) SMVS_CT_LOAD(v[i], c0 + i)
+    for (int i = 0; i < NPF - 1; ++i) SMVS_CT_LOAD(v[i], min(c0 + i, cl))
     for (int cc = c0; cc < c1; cc += NPF) {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            if (cc + i + NPF - 1 < c1) SMVS_CT_LOAD(v[(i + NPF - 1) % NPF], cc + i + NPF - 1)
+            SMVS_CT_LOAD(v[(i + NPF - 1) % NPF], min(cc + i + NPF - 1, cl))
             __builtin_amdgcn_sched_barrier(0);
             if (cc + i < c1) SMVS_CT_FMA(v[i], cc + i)
             __builtin_amdgcn_sched_barrier(0);
@@ -990,6 +992,17 @@ static int red_run_planes(const RedRun& r, int d_begin, int d_end)
 }  // namespace smvs
 
 extern "C" {
+
+#ifdef SMVS_TIMING
+// profiling builds only: copies (and clears) the MFMA body's phase counters, 8 x 8 unsigned long long
+SMVS_EXPORT void smvs_debug_mfma_timing(unsigned long long* out)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(smvs::smvs_mfma_timing), sizeof(unsigned long long) * 64);
+    unsigned long long z[64] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(smvs::smvs_mfma_timing), z, sizeof(z));
+}
+#endif
 
 SMVS_EXPORT size_t smvs_red_packed_floats(int C) { return C > 0 ? smvs::red_layout(C).total : 0; }
 
