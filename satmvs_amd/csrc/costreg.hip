@@ -358,14 +358,17 @@ void convT3d_split_kernel(const Conv3Args a)
                     }                                                                                  \
         }                                                                                              \
     }
+    // prefetch loads are unconditional (past the end: the last channel again): a load under a branch makes the compiler
+    // wait with vmcnt(0) before every multiply block, i.e. also for the loads it has just issued (mfma_conv.h)
     float v0[8], v1[8];
-    if (c0 < c1) SMVS_T3_LOAD(v0, c0)
+    const int cl = max(c1 - 1, 0);
+    SMVS_T3_LOAD(v0, min(c0, cl))
     for (int cc = c0; cc < c1; cc += 2) {
-        if (cc + 1 < c1) SMVS_T3_LOAD(v1, cc + 1)
+        SMVS_T3_LOAD(v1, min(cc + 1, cl))
         __builtin_amdgcn_sched_barrier(0);
         SMVS_T3_FMA(v0, cc)
         __builtin_amdgcn_sched_barrier(0);
-        if (cc + 2 < c1) SMVS_T3_LOAD(v0, cc + 2)
+        SMVS_T3_LOAD(v0, min(cc + 2, cl))
         __builtin_amdgcn_sched_barrier(0);
         if (cc + 1 < c1) SMVS_T3_FMA(v1, cc + 1)
         __builtin_amdgcn_sched_barrier(0);

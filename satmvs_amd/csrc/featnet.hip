@@ -162,13 +162,15 @@ void fn_conv_kernel(const FnConvArgs a)
             _Pragma("unroll") for (int j_ = 0; j_ < FN_COT; ++j_) acc[j_] = fmaf(V[k_], wc_[k_ * FN_COT + j_], acc[j_]); \
     }
     float v0[KK], v1[KK];
+    // prefetch loads are unconditional (past the end: the last channel again): a load under a branch makes the compiler
+    // wait with vmcnt(0) before every multiply block, i.e. also for the loads it has just issued (mfma_conv.h)
     SMVS_FN_LOAD(v0, 0)
     for (int cc = 0; cc < Cin; cc += 2) {
-        if (cc + 1 < Cin) SMVS_FN_LOAD(v1, cc + 1)
+        SMVS_FN_LOAD(v1, min(cc + 1, Cin - 1))
         __builtin_amdgcn_sched_barrier(0);
         SMVS_FN_FMA(v0, cc)
         __builtin_amdgcn_sched_barrier(0);
-        if (cc + 2 < Cin) SMVS_FN_LOAD(v0, cc + 2)
+        SMVS_FN_LOAD(v0, min(cc + 2, Cin - 1))
         __builtin_amdgcn_sched_barrier(0);
         if (cc + 1 < Cin) SMVS_FN_FMA(v1, cc + 1)
         __builtin_amdgcn_sched_barrier(0);
@@ -234,11 +236,11 @@ void fn_convT_kernel(const FnConvArgs a)
     float v0[4], v1[4];
     SMVS_FT_LOAD(v0, 0)
     for (int cc = 0; cc < a.CA; cc += 2) {
-        if (cc + 1 < a.CA) SMVS_FT_LOAD(v1, cc + 1)
+        SMVS_FT_LOAD(v1, min(cc + 1, a.CA - 1))                  // unconditional: see fn_conv_kernel
         __builtin_amdgcn_sched_barrier(0);
         SMVS_FT_FMA(v0, cc)
         __builtin_amdgcn_sched_barrier(0);
-        if (cc + 2 < a.CA) SMVS_FT_LOAD(v0, cc + 2)
+        SMVS_FT_LOAD(v0, min(cc + 2, a.CA - 1))
         __builtin_amdgcn_sched_barrier(0);
         if (cc + 1 < a.CA) SMVS_FT_FMA(v1, cc + 1)
         __builtin_amdgcn_sched_barrier(0);
