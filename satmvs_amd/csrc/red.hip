@@ -397,18 +397,29 @@ void convT3x3s2_kernel(const ConvArgs a)
     }
     if (!active) return;
     const int HWo = a.Ho * a.Wo;
+    // The output quad is two float2 (columns 2x, 2x+1 of rows 2y, 2y+1; 8-byte aligned: Wo is even).  All skip loads are
+    // issued before the first use -- a load -> add -> store chain per value is one memory round trip each on these
+    // small grids.  Channels beyond Cout (cout group padding) read channel 0 and are not stored.
+    float2 sk[2][COT];
+#pragma unroll
+    for (int j = 0; j < COT; ++j) {
+        const int co = cog * COT + j, cs = co < a.Cout ? co : 0;
+        const size_t o0 = ((size_t)b * a.Cout + cs) * HWo + (size_t)(2 * y) * a.Wo + 2 * x;
+#pragma unroll
+        for (int ry = 0; ry < 2; ++ry)
+            sk[ry][j] = a.skip ? *reinterpret_cast<const float2*>(a.skip + o0 + (size_t)ry * a.Wo) : make_float2(0.0f, 0.0f);
+    }
 #pragma unroll
     for (int j = 0; j < COT; ++j) {
         const int co = cog * COT + j;
         if (co < a.Cout) {
             const size_t o0 = ((size_t)b * a.Cout + co) * HWo + (size_t)(2 * y) * a.Wo + 2 * x;
-            float* o = a.out + o0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float r = acc[q][j];
-                if (a.relu) r = fmaxf(r, 0.0f);
-                if (a.skip) r = r + a.skip[o0 + (q >> 1) * a.Wo + (q & 1)];
-                o[(q >> 1) * a.Wo + (q & 1)] = r;
+            for (int ry = 0; ry < 2; ++ry) {
+                float r0 = acc[2 * ry][j], r1 = acc[2 * ry + 1][j];
+                if (a.relu) { r0 = fmaxf(r0, 0.0f); r1 = fmaxf(r1, 0.0f); }
+                if (a.skip) { r0 = r0 + sk[ry][j].x; r1 = r1 + sk[ry][j].y; }
+                *reinterpret_cast<float2*>(a.out + o0 + (size_t)ry * a.Wo) = make_float2(r0, r1);
             }
         }
     }
