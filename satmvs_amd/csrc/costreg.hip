@@ -147,6 +147,14 @@ void conv3d_kernel(const Conv3Args a)
     if (!active) return;
     const size_t vol_o = (size_t)a.Do * a.Ho * a.Wo;
     const size_t pos = ((size_t)od * a.Ho + oy) * a.Wo + ox;
+    // skip values first, all in flight together (a load -> add -> store chain per channel is a memory round trip each;
+    // channels beyond Cout read channel 0 and are not stored)
+    float sk[CR_COT];
+#pragma unroll
+    for (int j = 0; j < CR_COT; ++j) {
+        const int co = cog * CR_COT + j;
+        sk[j] = a.skip ? a.skip[((size_t)b * a.Cout + (co < a.Cout ? co : 0)) * vol_o + pos] : 0.0f;
+    }
 #pragma unroll
     for (int j = 0; j < CR_COT; ++j) {
         const int co = cog * CR_COT + j;
@@ -154,7 +162,7 @@ void conv3d_kernel(const Conv3Args a)
             float r = fmaf(acc[j], a.scale[co], a.shift[co]);
             if (a.relu) r = fmaxf(r, 0.0f);
             const size_t o = ((size_t)b * a.Cout + co) * vol_o + pos;
-            if (a.skip) r = a.skip[o] + r;
+            if (a.skip) r = sk[j] + r;
             a.out[o] = r;
         }
     }
@@ -225,6 +233,12 @@ void conv3d_s1_kernel(const Conv3Args a)
     if (!active) return;
     const size_t vol_o = (size_t)a.Do * a.Ho * a.Wo;
     const size_t pos = ((size_t)od * a.Ho + oy) * a.Wo + ox;
+    float sk[CR_COT];                            // skip values first, all in flight together (see conv3d_kernel)
+#pragma unroll
+    for (int j = 0; j < CR_COT; ++j) {
+        const int co = cog * CR_COT + j;
+        sk[j] = a.skip ? a.skip[((size_t)b * a.Cout + (co < a.Cout ? co : 0)) * vol_o + pos] : 0.0f;
+    }
 #pragma unroll
     for (int j = 0; j < CR_COT; ++j) {
         const int co = cog * CR_COT + j;
@@ -233,7 +247,7 @@ void conv3d_s1_kernel(const Conv3Args a)
             float r = fmaf(av, a.scale[co], a.shift[co]);
             if (a.relu) r = fmaxf(r, 0.0f);
             const size_t o = ((size_t)b * a.Cout + co) * vol_o + pos;
-            if (a.skip) r = a.skip[o] + r;
+            if (a.skip) r = sk[j] + r;
             a.out[o] = r;
         }
     }
@@ -296,14 +310,20 @@ void convT3d_kernel(const Conv3Args a)
         const int co = cog * CR_COT + j;
         if (co < a.Cout) {
             const float sc = a.scale[co], sh = a.shift[co];
+            // the 2x2x2 block as four float2 rows (x pairs; 8-byte aligned: Wo is even); skip rows loaded before the first use
+            size_t o[4];
+            float2 sk[4];
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const size_t o = ((size_t)b * a.Cout + co) * vol_o +
-                                 ((size_t)(2 * d + (p >> 2)) * a.Ho + (2 * y + ((p >> 1) & 1))) * a.Wo + (2 * x + (p & 1));
-                float r = fmaf(acc[p][j], sc, sh);
-                if (a.relu) r = fmaxf(r, 0.0f);
-                if (a.skip) r = a.skip[o] + r;
-                a.out[o] = r;
+            for (int pr = 0; pr < 4; ++pr) {
+                o[pr] = ((size_t)b * a.Cout + co) * vol_o + ((size_t)(2 * d + (pr >> 1)) * a.Ho + (2 * y + (pr & 1))) * a.Wo + 2 * x;
+                sk[pr] = a.skip ? *reinterpret_cast<const float2*>(a.skip + o[pr]) : make_float2(0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                float r0 = fmaf(acc[2 * pr][j], sc, sh), r1 = fmaf(acc[2 * pr + 1][j], sc, sh);
+                if (a.relu) { r0 = fmaxf(r0, 0.0f); r1 = fmaxf(r1, 0.0f); }
+                if (a.skip) { r0 = sk[pr].x + r0; r1 = sk[pr].y + r1; }
+                *reinterpret_cast<float2*>(a.out + o[pr]) = make_float2(r0, r1);
             }
         }
     }
@@ -389,15 +409,25 @@ void convT3d_split_kernel(const Conv3Args a)
         const int co = cog * CR_COT + j;
         if (co < a.Cout) {
             const float sc = a.scale[co], sh = a.shift[co];
+            size_t o[4];                         // four float2 rows, skip rows loaded before the first use (see convT3d_kernel)
+            float2 sk[4];
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const float s = acc[p][j] + part[0][p * CR_COT + j][lane] + part[1][p * CR_COT + j][lane] + part[2][p * CR_COT + j][lane];
-                const size_t o = ((size_t)b * a.Cout + co) * vol_o +
-                                 ((size_t)(2 * d + (p >> 2)) * a.Ho + (2 * y + ((p >> 1) & 1))) * a.Wo + (2 * x + (p & 1));
-                float r = fmaf(s, sc, sh);
-                if (a.relu) r = fmaxf(r, 0.0f);
-                if (a.skip) r = a.skip[o] + r;
-                a.out[o] = r;
+            for (int pr = 0; pr < 4; ++pr) {
+                o[pr] = ((size_t)b * a.Cout + co) * vol_o + ((size_t)(2 * d + (pr >> 1)) * a.Ho + (2 * y + (pr & 1))) * a.Wo + 2 * x;
+                sk[pr] = a.skip ? *reinterpret_cast<const float2*>(a.skip + o[pr]) : make_float2(0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                float r[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int p = 2 * pr + e;
+                    const float s = acc[p][j] + part[0][p * CR_COT + j][lane] + part[1][p * CR_COT + j][lane] + part[2][p * CR_COT + j][lane];
+                    r[e] = fmaf(s, sc, sh);
+                    if (a.relu) r[e] = fmaxf(r[e], 0.0f);
+                }
+                if (a.skip) { r[0] = sk[pr].x + r[0]; r[1] = sk[pr].y + r[1]; }
+                *reinterpret_cast<float2*>(a.out + o[pr]) = make_float2(r[0], r[1]);
             }
         }
     }

@@ -180,13 +180,19 @@ void fn_conv_kernel(const FnConvArgs a)
 
     if (!active) return;
     const int HWo = a.Ho * a.Wo;
+    float upv[FN_COT];                           // lateral-add operands first, all in flight together (channels beyond Cout read channel 0)
+#pragma unroll
+    for (int j = 0; j < FN_COT; ++j) {
+        const int co = cog * FN_COT + j;
+        upv[j] = a.up ? a.up[((size_t)n * a.Cout + (co < a.Cout ? co : 0)) * (HWo / 4) + (size_t)(oy >> 1) * (a.Wo >> 1) + (ox >> 1)] : 0.0f;
+    }
 #pragma unroll
     for (int j = 0; j < FN_COT; ++j) {
         const int co = cog * FN_COT + j;
         if (co < a.Cout) {
             float r = fmaf(acc[j], a.scale[co], a.shift[co]);
             if (a.relu) r = fmaxf(r, 0.0f);
-            if (a.up) r = a.up[((size_t)n * a.Cout + co) * (HWo / 4) + (size_t)(oy >> 1) * (a.Wo >> 1) + (ox >> 1)] + r;
+            if (a.up) r = upv[j] + r;
             a.out[((size_t)n * a.Cout + co) * HWo + (size_t)oy * a.Wo + ox] = r;
         }
     }

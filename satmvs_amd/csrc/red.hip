@@ -475,10 +475,10 @@ void out_conv_regress_kernel(const OutConvArgs a)
         } else {
             hv = a.hmode == HEIGHT_TENSOR ? (double)a.depth[((size_t)b * a.D + a.d) * HW + pix] : (double)a.depth[(size_t)b * a.D + a.d];
         }
-        const double m = a.max_prob[i];
+        const double m = a.max_prob[i], di = a.depth_img[i], es = a.exp_sum[i];   // three loads in flight, then the stores (the pointers may alias as far as the compiler knows)
         a.max_prob[i] = (m < pr) ? pr : m;
-        a.depth_img[i] = fma(hv, pr, a.depth_img[i]);
-        a.exp_sum[i] = a.exp_sum[i] + pr;
+        a.depth_img[i] = fma(hv, pr, di);
+        a.exp_sum[i] = es + pr;
     }
 }
 

@@ -130,10 +130,10 @@ void stream_regress_step_kernel(const float* __restrict__ reg_plane, const float
     } else {
         hv = depth_is_4d ? (double)depth[((size_t)b * D + d) * HW + pix] : (double)depth[(size_t)b * D + d];
     }
-    const double m = max_prob[i];
+    const double m = max_prob[i], di = depth_img[i], es = exp_sum[i];
     max_prob[i] = (m < pr) ? pr : m;
-    depth_img[i] = fma(hv, pr, depth_img[i]);
-    exp_sum[i] = exp_sum[i] + pr;
+    depth_img[i] = fma(hv, pr, di);
+    exp_sum[i] = es + pr;
 }
 
 __global__ __launch_bounds__(256)
