@@ -504,6 +504,28 @@ __device__ __forceinline__ void gn_coeffs(const double* st, double n, float eps,
     rstd = lds2[1];
 }
 
+// two norm groups at once: wave 0 reduces st0, wave 1 reduces st1 (one barrier instead of two dependent ones)
+__device__ __forceinline__ void gn_coeffs2(const double* st0, const double* st1, double n, float eps,
+                                           float& m0, float& r0, float& m1, float& r1, float (*lds2)[2])
+{
+    if (threadIdx.x < 128) {
+        const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        const double* st = w ? st1 : st0;
+        double a = st[l * 2], q = st[l * 2 + 1];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); q += __shfl_xor(q, m, 64); }
+        if (l == 0) {
+            const double mu = a / n;
+            double var = q / n - mu * mu;
+            var = var < 0.0 ? 0.0 : var;
+            lds2[w][0] = (float)mu;
+            lds2[w][1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+    }
+    __syncthreads();
+    m0 = lds2[0][0]; r0 = lds2[0][1]; m1 = lds2[1][0]; r1 = lds2[1][1];
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ---- level-batched launches ------------------------------------------------------------------------------------------
@@ -567,18 +589,23 @@ void gru_gate_apply_kernel(const GruJobs J)
     // convolutions) follows it.
     if (g.zero_next && bid == 0)
         for (int i = threadIdx.x; i < J.B * 3 * NSLOT * 2; i += blockDim.x) g.zero_next[i] = 0.0;
-    float mr, sr, mu, su;
-    gn_coeffs(g.stats_g + ((size_t)b * 2 + 0) * NSLOT * 2, (double)HC * HW, 1e-5f, mr, sr, coef[0]);
-    gn_coeffs(g.stats_g + ((size_t)b * 2 + 1) * NSLOT * 2, (double)HC * HW, 1e-5f, mu, su, coef[1]);
-    const size_t j = (size_t)bx * blockDim.x + threadIdx.x;      // index inside the sample
-    if (j >= (size_t)HC * HW) return;
+    // element operands first (they do not depend on the norm coefficients): their latency runs under the reduction
+    const size_t jr = (size_t)bx * blockDim.x + threadIdx.x;     // index inside the sample
+    const bool valid = jr < (size_t)HC * HW;
+    const size_t j = valid ? jr : 0;
     const int c = (int)(j / HW), p = (int)(j % HW);
     const size_t i = (size_t)b * HC * HW + j;
     float* gr = g.gates + ((size_t)b * 2 * HC + c) * HW + p;
     float* gu = g.gates + ((size_t)b * 2 * HC + HC + c) * HW + p;
-    const float r = sigmoidf_(fmaf((*gr - mr) * sr, g.rn_w[c], g.rn_b[c]));
-    const float u = sigmoidf_(fmaf((*gu - mu) * su, g.un_w[c], g.un_b[c]));
-    g.rh[i] = r * g.h[i];
+    const float vr = *gr, vu = *gu, vh = g.h[i];
+    const float wr = g.rn_w[c], br = g.rn_b[c], wu = g.un_w[c], bu = g.un_b[c];
+    float mr, sr, mu, su;
+    gn_coeffs2(g.stats_g + ((size_t)b * 2 + 0) * NSLOT * 2, g.stats_g + ((size_t)b * 2 + 1) * NSLOT * 2, (double)HC * HW, 1e-5f,
+               mr, sr, mu, su, coef);
+    if (!valid) return;
+    const float r = sigmoidf_(fmaf((vr - mr) * sr, wr, br));
+    const float u = sigmoidf_(fmaf((vu - mu) * su, wu, bu));
+    g.rh[i] = r * vh;
     *gu = u;
 }
 
@@ -595,15 +622,18 @@ void gru_combine_kernel(const GruJobs J)
     bid -= g.blk0;
     const int bx = bid % g.gx, b = bid / g.gx;
     const int HC = g.HC, HW = g.HW;
-    float m, s;
-    gn_coeffs(g.stats_o + (size_t)b * NSLOT * 2, (double)HC * HW, 1e-5f, m, s, coef);
-    const size_t j = (size_t)bx * blockDim.x + threadIdx.x;
-    if (j >= (size_t)HC * HW) return;
+    const size_t jr = (size_t)bx * blockDim.x + threadIdx.x;
+    const bool valid = jr < (size_t)HC * HW;
+    const size_t j = valid ? jr : 0;
     const int c = (int)(j / HW), p = (int)(j % HW);
     const size_t i = (size_t)b * HC * HW + j;
-    const float y = tanhf(fmaf((g.cand[i] - m) * s, g.on_w[c], g.on_b[c]));
-    const float u = g.gates[((size_t)b * 2 * HC + HC + c) * HW + p];
-    const float hn = u * g.h[i] + (1.0f - u) * y;
+    const float vc = g.cand[i], u = g.gates[((size_t)b * 2 * HC + HC + c) * HW + p], vh = g.h[i];   // before the reduction: see the apply kernel
+    const float wo = g.on_w[c], bo = g.on_b[c];
+    float m, s;
+    gn_coeffs(g.stats_o + (size_t)b * NSLOT * 2, (double)HC * HW, 1e-5f, m, s, coef);
+    if (!valid) return;
+    const float y = tanhf(fmaf((vc - m) * s, wo, bo));
+    const float hn = u * vh + (1.0f - u) * y;
     g.h[i] = hn;
     g.hsnap[i] = hn;
 }
