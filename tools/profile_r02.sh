@@ -20,6 +20,15 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
 done
 rocprofv3 --kernel-trace --stats -d "$OUT/trace_cascade" -o trace -- python $REPO/tools/bench_pred.py > "$OUT/cascade.log" 2>&1
 python $REPO/tools/rocpd_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
+python $REPO/tools/make_traffic_json.py "$OUT" > "$OUT/pmc_traffic.json" 2> "$OUT/pmc_traffic.err"
+# RED plane loop: host vs GPU per stage, kernel timeline, MFMA body phases, model forwards
+python $REPO/tools/host_bound_probe.py > "$OUT/host_bound_probe.txt" 2>&1
+rocprofv3 --kernel-trace -d "$OUT/trace_redloop" -o t -- python $REPO/tools/host_bound_probe.py > /dev/null 2>&1
+python $REPO/tools/red_timeline.py "$OUT/trace_redloop" 40 > "$OUT/red_timeline.txt" 2>&1
+[ -f $REPO/gpurun_ab/timing.so ] && SMVS_LIB_PATH=$REPO/gpurun_ab/timing.so python $REPO/tools/mfma_timing.py > "$OUT/mfma_timing.txt" 2>&1
+for t in bench_pred bench_casred_eval bench_casmvs_eval bench_costreg bench_featnet; do python $REPO/tools/$t.py >> "$OUT/models.txt" 2>&1; done
+SMVS_BENCH_BATCH=8 python $REPO/tools/bench_pred.py >> "$OUT/models.txt" 2>&1
+[ -x $REPO/gpurun_ab/ubench_mfma ] && timeout 60 $REPO/gpurun_ab/ubench_mfma > "$OUT/ubench_mfma.txt" 2>&1
 for u in valu store dma; do [ -x $REPO/gpurun_ab/ubench_$u ] && timeout 120 $REPO/gpurun_ab/ubench_$u > "$OUT/ubench_$u.txt" 2>&1; done
 find "$OUT" -name "*.db" -delete
 du -sh "$OUT"
