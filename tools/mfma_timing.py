@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Phase times inside the 9-tap MFMA convolution body during one stage of the RED plane loop (library built with
--DSMVS_TIMING -DSMVS_TUNING):  SMVS_LIB_PATH=gpurun_ab/timing.so python tools/mfma_timing.py"""
+-DSMVS_TIMING: tools/ab_build.sh timing -DSMVS_TIMING):  SMVS_LIB_PATH=gpurun_ab/timing.so python tools/mfma_timing.py"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
