@@ -177,7 +177,11 @@ __device__ __forceinline__ void conv3x3_body(const ConvArgs& a, int bx, int by, 
     const int Cin = a.CA + a.CB;
     const int HWi = a.Hi * a.Wi;
 
-    // the 9 tap offsets of this lane inside one input plane (SMVS_OOB outside the image = zero padding)
+    // Channel-split (latency) variant: the nine taps of a lane are three rows of three consecutive floats = one dwordx3
+    // load per row (a row outside the image = out-of-range offset = zeros).  The loaded columns start at max(ix0, 0);
+    // where the west or east tap is zero padding (image edge lanes only) the values are shifted / dropped with selects --
+    // in the waves that have such lanes.  The throughput variant keeps nine dword taps (measured: row loads cost it 4 %).
+    constexpr bool ROWS = SPLIT;
     uint32_t off[9];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
@@ -186,6 +190,15 @@ __device__ __forceinline__ void conv3x3_body(const ConvArgs& a, int bx, int by, 
             const int iy = oy * STRIDE - 1 + ky, ix = ox * STRIDE - 1 + kx;
             off[ky * 3 + kx] = (active && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) ? (uint32_t)(iy * a.Wi + ix) * 4u : SMVS_OOB;
         }
+    const int ix0 = ox * STRIDE - 1;
+    const bool padL = ix0 < 0, padR = ix0 + 2 >= a.Wi;
+    const bool anypad = __builtin_amdgcn_ballot_w64(active && (padL || padR)) != 0;      // wave-uniform
+    uint32_t roff[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * STRIDE - 1 + ky;
+        roff[ky] = (active && iy >= 0 && iy < a.Hi) ? (uint32_t)(iy * a.Wi + (padL ? 0 : ix0)) * 4u : SMVS_OOB;
+    }
     const int csA = a.inA_cs ? (int)a.inA_cs : HWi;                 // floats between channels of inA
     const int bA = a.inA_bmod ? b % a.inA_bmod : b, pA = a.inA_bmod ? b / a.inA_bmod : 0;
     const BufRsrc rA = make_rsrc(a.inA + (a.inA_cs ? (size_t)bA * a.inA_bs + (size_t)pA * a.inA_ps : (size_t)b * a.CA * HWi),
@@ -214,22 +227,38 @@ __device__ __forceinline__ void conv3x3_body(const ConvArgs& a, int bx, int by, 
         rx_.x = fa_ ? rA.v.x : rB.v.x; rx_.y = fa_ ? rA.v.y : rB.v.y;                                  \
         rx_.z = fa_ ? rA.v.z : rB.v.z; rx_.w = rA.v.w;                                                 \
         const int co_ = fa_ ? (CC) * csA * 4 : ((CC) - a.CA) * HWi * 4;                                \
-        const float sc_ = fa_ ? a.scaleA : 1.0f;                                                       \
-        _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_) V[k_] = llvm_raw_buffer_load_f32(rx_, (int)off[k_], co_, 0) * sc_; \
+        if (ROWS) { _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) V.r[k_] = llvm_raw_buffer_load_v3f32(rx_, (int)roff[k_], co_, 0); } \
+        else { _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_) V.t[k_] = llvm_raw_buffer_load_f32(rx_, (int)off[k_], co_, 0); } \
+    }
+#define SMVS_CONV_TAPS(V, CC)                                                                          \
+    float t_[9];                                                                                       \
+    {                                                                                                  \
+        const float sc_ = (CC) < a.CA ? a.scaleA : 1.0f;                                               \
+        if (ROWS) {                                                                                    \
+            _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) {                                         \
+                float l0_ = V.r[k_].x, l1_ = V.r[k_].y, l2_ = V.r[k_].z;                               \
+                if (anypad) { l2_ = padR ? 0.0f : (padL ? l1_ : l2_); l1_ = padL ? l0_ : l1_; l0_ = padL ? 0.0f : l0_; } \
+                t_[3 * k_] = l0_ * sc_; t_[3 * k_ + 1] = l1_ * sc_; t_[3 * k_ + 2] = l2_ * sc_;         \
+            }                                                                                          \
+        } else {                                                                                       \
+            _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_) t_[k_] = V.t[k_] * sc_;                   \
+        }                                                                                              \
     }
 #define SMVS_CONV_FMA(V, CC)                                                                           \
-    { if (WL) {                                                                                        \
+    { SMVS_CONV_TAPS(V, CC)                                                                            \
+      if (WL) {                                                                                        \
         const float* wc_ = wl + (CC) * 9 * COT;                                                        \
         _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_)                                               \
-            _Pragma("unroll") for (int j_ = 0; j_ < COT; ++j_) acc[j_] = fmaf(V[k_], wc_[k_ * COT + j_], acc[j_]); \
+            _Pragma("unroll") for (int j_ = 0; j_ < COT; ++j_) acc[j_] = fmaf(t_[k_], wc_[k_ * COT + j_], acc[j_]); \
     } else {                                                                                           \
         const cw_t wc_ = wbase + (size_t)(CC) * 9 * COT;                                               \
         _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_)                                               \
-            _Pragma("unroll") for (int j_ = 0; j_ < COT; ++j_) acc[j_] = fmaf(V[k_], wc_[k_ * COT + j_], acc[j_]); \
+            _Pragma("unroll") for (int j_ = 0; j_ < COT; ++j_) acc[j_] = fmaf(t_[k_], wc_[k_ * COT + j_], acc[j_]); \
     } }
     // NPF-1 channels of taps are in flight while one is multiplied.
     constexpr int NPF = SMVS_CONV_PREFETCH;
-    float v[NPF][9];
+    struct Taps { mf32x3 r[ROWS ? 3 : 1]; float t[ROWS ? 1 : 9]; };   // one of the two is used (compile-time)
+    Taps v[NPF];
     // The loads are UNCONDITIONAL (past the end: the last channel again, unused) -- a load under a branch makes the
     // compiler wait with vmcnt(0) before every multiply block, and the prefetch hides nothing (mfma_conv.h).
     const int cl = max(c1 - 1, 0);
@@ -246,6 +275,7 @@ __device__ __forceinline__ void conv3x3_body(const ConvArgs& a, int bx, int by, 
     }
 #undef SMVS_CONV_LOAD
 #undef SMVS_CONV_FMA
+#undef SMVS_CONV_TAPS
 
     if (SPLIT) {
         float (*part)[COT][64] = (float (*)[COT][64])smem;
