@@ -1159,7 +1159,7 @@ SMVS_EXPORT int smvs_red_step_fwd(const float* packed, const float* cost, float*
 
 // The whole plane loop of compute_depth_when_pred (networks/casred.py:191-231) for planes [d_begin,d_end)
 // in ONE call: per plane the fused warp+variance build of that plane, the RED step and the float64
-// streaming-regression update are enqueued back to back from C (about 27 launches per plane, no Python
+// streaming-regression update are enqueued back to back from C (8 launches per plane + 4 per chunk of planes, no Python
 // or allocator work in between).  acc = (3,B,H,W) float64 [exp_sum, depth_img, max_prob], zeroed by the
 // caller before plane 0; states as in smvs_red_step_fwd.  geo_kind 0: rpc (B,V,170); 1: composed
 // homographies (B,n_src,4,4).
