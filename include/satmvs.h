@@ -59,6 +59,12 @@ typedef struct smvs_height_gen {
     int img_h, img_w;           /* image size; img / stage size must be 1 or 2 */
     int ndepth;                 /* D of this stage */
     double interval;            /* depth_inteval_pixel = depth_interals_ratio[stage] * min_interval */
+    /* UCS-Net sampler (modules/depth_range.py:45-86 behind the two bilinear resizes of networks/ucs.py:49-58) when prev_var is
+     * not null: hypotheses span prev_height -+ prev_var (both resized to this stage's grid, so img_h, img_w = the stage size),
+     * clamped to [range_min[b], range_max[b]]; `interval` is ignored.  All three null: the interval sampler above. */
+    const float* prev_var;      /* device, (B, prev_h, prev_w): the previous stage's "variance" output */
+    const float* range_min;     /* device, (B): depth_values[:, 0] */
+    const float* range_max;     /* device, (B): depth_values[:, -1] */
 } smvs_height_gen;
 /* The hypotheses as a tensor (what the reference materialises), out (B,ndepth,H,W): training path and tests. */
 int smvs_height_hypotheses(const smvs_height_gen* gen, float* out, int B, int H, int W, void* stream);

@@ -467,6 +467,45 @@ ORC_API int orc_height_hypotheses(const float *prev, int B, int hp, int wp, int 
     return 0;
 }
 
+/* UCS-Net hypotheses of stages 2 and 3 (networks/ucs.py:49-58 + modules/depth_range.py:45-86, uncertainty_aware_samples):
+ *   cur = bilinear resize (align_corners=False) of the previous stage's height map (B,hp,wp) to this stage's (H,W), ev = the same
+ *   of its standard-deviation map; low = cur - ev, high = cur + ev, each replaced by the batch item's range bound where it
+ *   crosses it (masked assignment: (low - min) < 0, (high - max) > 0); step = (high - low) / (float)(ndepth - 1);
+ *   samples[d] = low + step * d + 1e-12, all float32, at the stage resolution (no further resize). */
+static float orc_bilinear(const float *q, int hp, int wp, int H, int W, int y, int x)
+{
+    float sh = (float)hp / (float)H, sw = (float)wp / (float)W;
+    float sy = fmaxf(sh * ((float)y + 0.5f) - 0.5f, 0.0f), sx = fmaxf(sw * ((float)x + 0.5f) - 0.5f, 0.0f);
+    int y0 = (int)sy, x0 = (int)sx;
+    int y1 = y0 + 1 < hp ? y0 + 1 : hp - 1, x1 = x0 + 1 < wp ? x0 + 1 : wp - 1;
+    float ly1 = sy - (float)y0, lx1 = sx - (float)x0, ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+    float top = orc_lerp2(lx0, q[y0 * wp + x0], lx1, q[y0 * wp + x1]);
+    float bot = orc_lerp2(lx0, q[y1 * wp + x0], lx1, q[y1 * wp + x1]);
+    return orc_lerp2(ly0, top, ly1, bot);
+}
+
+ORC_API int orc_ucs_hypotheses(const float *prev, const float *prev_var, const float *rmin, const float *rmax,
+                               int B, int hp, int wp, int ndepth, int H, int W, float *out)
+{
+    if (ndepth < 2) return 1;
+    float ndm1 = (float)ndepth - 1.0f;
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                float cur = orc_bilinear(prev + (size_t)b * hp * wp, hp, wp, H, W, y, x);
+                float ev = orc_bilinear(prev_var + (size_t)b * hp * wp, hp, wp, H, W, y, x);
+                float low = cur - ev, high = cur + ev;
+                if (low - rmin[b] < 0.0f) low = rmin[b];
+                if (high - rmax[b] > 0.0f) high = rmax[b];
+                float step = (high - low) / ndm1;
+                for (int d = 0; d < ndepth; ++d) {
+                    float v = low + step * (float)d;
+                    out[(((size_t)b * ndepth + d) * H + y) * W + x] = v + 1e-12f;
+                }
+            }
+    return 0;
+}
+
 /* CascadeMVSNet / UCSNet regression (networks/casmvs.py:66-74, networks/ucs.py:60-74): softmax over D, expected
  * height, photometric confidence = probability mass of the four hypotheses [idx-1, idx+2] around
  * idx = clamp(trunc(E[index]), 0, D-1) -- F.pad(prob,(0,0,0,0,1,2)) + 4*avg_pool3d((4,1,1)) + gather -- and UCSNet's

@@ -172,6 +172,21 @@ def height_hypotheses(prev, ndepth, interval, img_hw, stage_hw):
     return out
 
 
+def ucs_hypotheses(prev, prev_var, range_min, range_max, ndepth, stage_hw):
+    """(B,D,H,W) UCS-Net hypotheses of a later stage from the previous height and standard-deviation maps -- orc_ucs_hypotheses."""
+    import ctypes
+    prev, prev_var, rmin, rmax = _f32(prev), _f32(prev_var), _f32(range_min), _f32(range_max)
+    B, hp, wp = prev.shape
+    H, W = stage_hw
+    out = np.empty((B, ndepth, H, W), np.float32)
+    f = lib().orc_ucs_hypotheses
+    f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
+    f.restype = ctypes.c_int
+    if f(_p(prev), _p(prev_var), _p(rmin), _p(rmax), B, hp, wp, ndepth, H, W, _p(out)) != 0:
+        raise ValueError("ndepth must be at least 2")
+    return out
+
+
 def stage1_planes(depth_range, ndepth):
     """(B,D) planes of stage 1 (modules/depth_range.py:26-33): min + arange * (max - min) / (ndepth - 1), float32."""
     dr = _f32(depth_range)

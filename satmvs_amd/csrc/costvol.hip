@@ -835,7 +835,7 @@ static int costvol_fwd(int geo_kind, const float* ref_fea, const float* const* s
         if (const char* msg = height_gen_check(gen, D, H, W, hh)) return fail(SMVS_ERR_ARG, "%s", msg);
         p.depth_is_4d = HEIGHT_GENERATED;
         p.hg.prev = hh.prev; p.hg.hp = hh.hp; p.hg.wp = hh.wp; p.hg.ih = hh.ih; p.hg.iw = hh.iw; p.hg.scale = hh.scale;
-        p.hg.c = hh.c; p.hg.ndm1 = hh.ndm1;
+        p.hg.c = hh.c; p.hg.ndm1 = hh.ndm1; p.hg.var = hh.var; p.hg.rmin = hh.rmin; p.hg.rmax = hh.rmax;
     }
     p.rV = 1.0f / (float)(n_src + 1);
     p.r_half_wm1 = 1.0f / (float)((W - 1) * 0.5);

@@ -197,7 +197,7 @@ int resolve_heights(const float* depth, int depth_is_4d, const smvs_height_gen* 
     if (gen) {
         HeightGenHost hh;
         if (const char* msg = height_gen_check(gen, D, H, W, hh)) return fail(SMVS_ERR_ARG, "%s", msg);
-        hg.prev = hh.prev; hg.hp = hh.hp; hg.wp = hh.wp; hg.ih = hh.ih; hg.iw = hh.iw; hg.scale = hh.scale; hg.c = hh.c; hg.ndm1 = hh.ndm1;
+        hg.prev = hh.prev; hg.hp = hh.hp; hg.wp = hh.wp; hg.ih = hh.ih; hg.iw = hh.iw; hg.scale = hh.scale; hg.c = hh.c; hg.ndm1 = hh.ndm1; hg.var = hh.var; hg.rmin = hh.rmin; hg.rmax = hh.rmax;
         mode = HEIGHT_GENERATED;
         return SMVS_OK;
     }

@@ -390,6 +390,9 @@ struct HeightGen {
     const float* prev;          // (B, hp, wp)
     int hp, wp, ih, iw, scale;  // previous map size, image size, image size / this stage's size (1 or 2)
     float c, ndm1;              // float(ndepth / 2 * interval), float(ndepth - 1)
+    // UCS-Net sampler (depth_range.py:45-86) when var != null: span prev -+ var, clamped to [rmin[b], rmax[b]]; scale == 1
+    const float* var;           // (B, hp, wp) or null
+    const float *rmin, *rmax;   // (B)
 };
 
 __device__ __forceinline__ float hg_interp2(float w0, float v0, float w1, float v1) { return fmaf(w0, v0, w1 * v1); }
@@ -406,6 +409,20 @@ __device__ __forceinline__ void hg_pixel(const HeightGen& g, int b, int Y, int X
     const float top = hg_interp2(lx0, q[y0 * g.wp + x0], lx1, q[y0 * g.wp + x1]);
     const float bot = hg_interp2(lx0, q[y1 * g.wp + x0], lx1, q[y1 * g.wp + x1]);
     const float cur = hg_interp2(ly0, top, ly1, bot);
+    if (g.var) {
+        // the same resize of the standard-deviation map, then the reference's masked clamps ((low - min) < 0, (high - max) > 0)
+        const float* qv = g.var + (size_t)b * g.hp * g.wp;
+        const float tv = hg_interp2(lx0, qv[y0 * g.wp + x0], lx1, qv[y0 * g.wp + x1]);
+        const float bv = hg_interp2(lx0, qv[y1 * g.wp + x0], lx1, qv[y1 * g.wp + x1]);
+        const float ev = hg_interp2(ly0, tv, ly1, bv);
+        float low = cur - ev, high = cur + ev;
+        const float mn = g.rmin[b], mx = g.rmax[b];
+        if (low - mn < 0.0f) low = mn;
+        if (high - mx > 0.0f) high = mx;
+        cmin = low;
+        step = __fdiv_rn(high - low, g.ndm1);
+        return;
+    }
     cmin = cur - g.c;
     step = __fdiv_rn((cur + g.c) - cmin, g.ndm1);
 }
@@ -426,6 +443,7 @@ __device__ __forceinline__ void hg_prepare(const HeightGen& g, int b, int y, int
 __device__ __forceinline__ float hg_height(const HeightGen& g, const HeightPix& hp, int d)
 {
     const float fd = (float)d;
+    if (g.var) return (hp.cmin[0] + hp.step[0] * fd) + 1e-12f;          // low + step * i + eps (depth_range.py:80)
     if (g.scale == 1) return hp.cmin[0] + fd * hp.step[0];
     const float a = hp.cmin[0] + fd * hp.step[0], bb = hp.cmin[1] + fd * hp.step[1];
     const float c = hp.cmin[2] + fd * hp.step[2], dd = hp.cmin[3] + fd * hp.step[3];

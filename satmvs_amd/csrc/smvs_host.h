@@ -26,7 +26,7 @@ inline int fail(int code, const char* fmt, ...)
 }
 
 // smvs_height_gen (C ABI) -> device-side HeightGen for a stage of size H x W; returns a message on bad arguments
-struct HeightGenHost { const float* prev; int hp, wp, ih, iw, scale; float c, ndm1; };
+struct HeightGenHost { const float* prev; int hp, wp, ih, iw, scale; float c, ndm1; const float *var, *rmin, *rmax; };
 inline const char* height_gen_check(const smvs_height_gen* g, int D, int H, int W, HeightGenHost& o)
 {
     if (!g || !g->prev_height) return "null height generator";
@@ -38,6 +38,11 @@ inline const char* height_gen_check(const smvs_height_gen* g, int D, int H, int 
     o.prev = g->prev_height; o.hp = g->prev_h; o.wp = g->prev_w; o.ih = g->img_h; o.iw = g->img_w; o.scale = scale;
     o.c = (float)(g->ndepth / 2.0 * (double)g->interval);
     o.ndm1 = (float)(g->ndepth - 1);
+    o.var = g->prev_var; o.rmin = g->range_min; o.rmax = g->range_max;
+    if (o.var) {
+        if (!o.rmin || !o.rmax) return "UCS height generator needs range_min and range_max";
+        if (scale != 1) return "UCS height generator resizes straight to the stage grid (img size = stage size)";
+    }
     return nullptr;
 }
 

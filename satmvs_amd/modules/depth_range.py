@@ -27,7 +27,8 @@ def stage1_planes(depth_range, ndepth):
 
 class _HeightGenStruct(ctypes.Structure):       # smvs_height_gen, include/satmvs.h
     _fields_ = [("prev_height", ctypes.c_void_p), ("prev_h", ctypes.c_int), ("prev_w", ctypes.c_int),
-                ("img_h", ctypes.c_int), ("img_w", ctypes.c_int), ("ndepth", ctypes.c_int), ("interval", ctypes.c_double)]
+                ("img_h", ctypes.c_int), ("img_w", ctypes.c_int), ("ndepth", ctypes.c_int), ("interval", ctypes.c_double),
+                ("prev_var", ctypes.c_void_p), ("range_min", ctypes.c_void_p), ("range_max", ctypes.c_void_p)]
 
 
 class GeneratedHeights:
@@ -37,11 +38,23 @@ class GeneratedHeights:
     Accepted wherever the native paths take `depth_values` (variance_cost_volume, the RED plane pipelines, the
     regressions); `.materialize()` gives the reference's (B,D,H,W) tensor (one kernel; torch composite on the CPU)."""
 
-    def __init__(self, prev_height, ndepth, interval, img_hw, stage_hw):
+    def __init__(self, prev_height, ndepth, interval, img_hw, stage_hw, prev_var=None, range_min=None, range_max=None):
         self.prev = prev_height.detach().to(torch.float32).contiguous()
         self.ndepth, self.interval = int(ndepth), float(interval)
         self.img_h, self.img_w = int(img_hw[0]), int(img_hw[1])
         self.H, self.W = int(stage_hw[0]), int(stage_hw[1])
+        # UCS-Net sampler (uncertainty_aware_samples behind networks/ucs.py:49-58): previous variance map + the height range
+        self.var = None
+        if prev_var is not None:
+            self.var = prev_var.detach().to(torch.float32).contiguous()
+            self.rmin = range_min.detach().to(torch.float32).contiguous()
+            self.rmax = range_max.detach().to(torch.float32).contiguous()
+            assert (self.img_h, self.img_w) == (self.H, self.W), "the UCS sampler resizes straight to the stage grid"
+
+    @classmethod
+    def ucs(cls, prev_depth, prev_var, range_min, range_max, ndepth, stage_hw):
+        """Hypotheses of UCS-Net stage 2 / 3: prev_depth -+ prev_var resized to the stage grid, clamped to the range."""
+        return cls(prev_depth, ndepth, 0.0, stage_hw, stage_hw, prev_var, range_min, range_max)
 
     @staticmethod
     def supported(img_hw, stage_hw):
@@ -61,8 +74,11 @@ class GeneratedHeights:
 
     def c_struct(self):
         """ctypes smvs_height_gen; keep the returned object (and self) alive until the call has been enqueued."""
+        if self.var is not None:
+            return _HeightGenStruct(self.prev.data_ptr(), self.prev.shape[1], self.prev.shape[2], self.img_h, self.img_w,
+                                    self.ndepth, self.interval, self.var.data_ptr(), self.rmin.data_ptr(), self.rmax.data_ptr())
         return _HeightGenStruct(self.prev.data_ptr(), self.prev.shape[1], self.prev.shape[2], self.img_h, self.img_w,
-                                self.ndepth, self.interval)
+                                self.ndepth, self.interval, None, None, None)
 
     def materialize(self):
         if self.prev.is_cuda:
@@ -73,6 +89,11 @@ class GeneratedHeights:
                 _lib.call("smvs_height_hypotheses", ctypes.addressof(gs), _lib.ptr(out), out.shape[0], self.H, self.W,
                           _lib.current_stream(self.prev.device))
             return out
+        if self.var is not None:
+            cur = F.interpolate(self.prev.unsqueeze(1), [self.H, self.W], mode="bilinear", align_corners=False)
+            ev = F.interpolate(self.var.unsqueeze(1), [self.H, self.W], mode="bilinear", align_corners=False)
+            return uncertainty_aware_samples(cur, self.rmin, self.rmax, ev, self.ndepth, cur.device, cur.dtype,
+                                             [cur.shape[0], self.H, self.W])
         cur = F.interpolate(self.prev.unsqueeze(1), [self.img_h, self.img_w], mode="bilinear", align_corners=False).squeeze(1)
         samples = get_cur_depth_range_samples(cur, self.ndepth, self.interval, list(cur.shape))
         return F.interpolate(samples.unsqueeze(1), [self.ndepth, self.H, self.W], mode="trilinear",

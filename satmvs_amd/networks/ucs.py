@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..modules.depth_range import uncertainty_aware_samples
+from ..modules.depth_range import GeneratedHeights, uncertainty_aware_samples
 from ..modules.module import CostRegNet, FeatureNet, window_depth_regression
 from ..modules.warping import variance_cost_volume
 
@@ -46,18 +46,24 @@ class UCSNet(nn.Module):
             feats = [f[key] for f in features]
             scale = int(self.ds_ratio[key])
             cur_h, cur_w = imgs.shape[3] // scale, imgs.shape[4] // scale
-            if depth is not None:
-                if self.grad_method == "detach":
-                    cur_depth, exp_var = depth.detach(), exp_var.detach()
-                else:
-                    cur_depth = depth
-                cur_depth = F.interpolate(cur_depth.unsqueeze(1), [cur_h, cur_w], mode="bilinear", align_corners=False)
-                exp_var = F.interpolate(exp_var.unsqueeze(1), [cur_h, cur_w], mode="bilinear", align_corners=False)
+            nd = self.stage_configs[stage_idx]
+            if (depth is not None and not torch.is_grad_enabled() and depth.is_cuda and depth.dtype == torch.float32):
+                # inference on the GPU: the two bilinear resizes and the sampler are evaluated inside the kernels
+                # (no (B,D,H,W) hypothesis tensor, no D small launches of the concatenating sampler)
+                samples = GeneratedHeights.ucs(depth, exp_var, depth_min, depth_max, nd, (cur_h, cur_w))
             else:
-                cur_depth = depth_values
-            samples = uncertainty_aware_samples(cur_depth=cur_depth, depth_min=depth_min, depth_max=depth_max,
-                                                exp_var=exp_var, ndepth=self.stage_configs[stage_idx],
-                                                dtype=imgs.dtype, device=imgs.device, shape=[imgs.shape[0], cur_h, cur_w])
+                if depth is not None:
+                    if self.grad_method == "detach":
+                        cur_depth, exp_var = depth.detach(), exp_var.detach()
+                    else:
+                        cur_depth = depth
+                    cur_depth = F.interpolate(cur_depth.unsqueeze(1), [cur_h, cur_w], mode="bilinear", align_corners=False)
+                    exp_var = F.interpolate(exp_var.unsqueeze(1), [cur_h, cur_w], mode="bilinear", align_corners=False)
+                else:
+                    cur_depth = depth_values
+                samples = uncertainty_aware_samples(cur_depth=cur_depth, depth_min=depth_min, depth_max=depth_max,
+                                                    exp_var=exp_var, ndepth=nd,
+                                                    dtype=imgs.dtype, device=imgs.device, shape=[imgs.shape[0], cur_h, cur_w])
             out = compute_depth(feats, proj_matrices[key], depth_samps=samples,
                                 cost_reg=self.cost_regularization[stage_idx], lamb=self.lamb, geo_model=self.geo_model,
                                 is_training=self.training, use_qc=self.use_qc)

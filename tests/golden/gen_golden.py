@@ -448,6 +448,23 @@ def gen_depth_range():
          prev_a=prev_a.numpy(), r_a=r_a.numpy(), prev_b=prev_b.numpy(), r_b=r_b.numpy())
 
 
+def gen_ucs_samples():
+    """UCS-Net stage 2 / 3 hypotheses as networks/ucs.py:49-58 builds them: bilinear resize of the previous depth and
+    variance outputs to the stage grid, then modules/depth_range.py:45-86 (uncertainty_aware_samples).  The range is chosen so
+    that both clamps fire on part of the pixels."""
+    B, H, W = 2, 24, 40
+    torch.manual_seed(23)
+    prev = torch.rand(B, H // 2, W // 2) * 300 + 50
+    var = torch.rand(B, H // 2, W // 2) * 20 + 0.5
+    dmin, dmax = torch.tensor([80.0, 40.0]), torch.tensor([300.0, 360.0])
+    out = {}
+    for name, nd in (("s8", 8), ("s12", 12)):
+        cur = torch.nn.functional.interpolate(prev.unsqueeze(1), [H, W], mode="bilinear", align_corners=False)
+        ev = torch.nn.functional.interpolate(var.unsqueeze(1), [H, W], mode="bilinear", align_corners=False)
+        out[name] = ref_depth_range.uncertainty_aware_samples(cur, dmin, dmax, ev, nd, "cpu", torch.float32, [B, H, W]).numpy()
+    save("ucs_samples", prev=prev.numpy(), var=var.numpy(), dmin=dmin.numpy(), dmax=dmax.numpy(), **out)
+
+
 def gen_cascade():
     """Full forwards at 3-view 64x128 (ndepths 16/8/8): CascadeREDNet, Infer_CascadeREDNet
     (networks/casred.py:114,285), CascadeMVSNet (networks/casmvs.py:79), UCSNet (networks/ucs.py:79).
@@ -591,7 +608,7 @@ def gen_featnet():
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (gen_iccv, gen_project, gen_grid_sample, gen_rpc_warp, gen_qc, gen_homo, gen_costvol, gen_pred,
-               gen_regress, gen_depth_range, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad, gen_io):
+               gen_regress, gen_depth_range, gen_ucs_samples, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad, gen_io):
         if only and fn.__name__[4:] not in only:
             continue
         fn()

@@ -300,6 +300,40 @@ def test_generated_heights(dev, golden, oracle):
         _close_f32(a, want)
 
 
+def test_generated_heights_ucs(dev, golden, oracle):
+    """SURVEY 8f-1, UCS-Net flavour: uncertainty_aware_samples behind its two bilinear resizes evaluated inside the kernels.
+    (1) smvs_height_hypotheses == the oracle bit for bit and the reference's tensors within 1 ulp of the resize
+    (tests/golden/ucs_samples.npz, both range clamps firing); (2) the cost volume and the window regression fed the generator
+    give the bits they give from the materialised tensor."""
+    from satmvs_amd.modules import module as M
+    from satmvs_amd.modules import warping
+    from satmvs_amd.modules.depth_range import GeneratedHeights
+    g = golden("ucs_samples")
+    H, W = g["s8"].shape[2:]
+    for key, nd in (("s8", 8), ("s12", 12)):
+        gen = GeneratedHeights.ucs(_t(g["prev"], dev), _t(g["var"], dev), _t(g["dmin"], dev), _t(g["dmax"], dev), nd, (H, W))
+        got = gen.materialize().cpu().numpy()
+        assert np.array_equal(got, oracle.ucs_hypotheses(g["prev"], g["var"], g["dmin"], g["dmax"], nd, (H, W))), key
+        assert np.abs(got - g[key]).max() <= 6.2e-5, key
+    rng = np.random.default_rng(22)
+    for C, (h, w), nd in ((16, (40, 72), 6), (8, (48, 80), 8)):
+        feats, rpc, _ = _inputs(1, 3, C, nd, h, w, seed=10)
+        prev = (200.0 + rng.normal(0, 6.0, (1, h // 2, w // 2))).astype(np.float32)
+        var = rng.uniform(0.5, 12.0, (1, h // 2, w // 2)).astype(np.float32)
+        lo, hi = np.array([190.0], np.float32), np.array([215.0], np.float32)
+        gen = GeneratedHeights.ucs(_t(prev, dev), _t(var, dev), _t(lo, dev), _t(hi, dev), nd, (h, w))
+        dv = gen.materialize()
+        f = [_t(x, dev) for x in feats]
+        r = _t(rpc, dev)
+        with torch.no_grad():
+            a = warping.variance_cost_volume(f, r, gen, "rpc")
+            b = warping.variance_cost_volume(f, r, dv, "rpc")
+            assert torch.equal(a, b), (C, h, w)
+            reg = -a.mean(1)
+            assert all(torch.equal(x, y) for x, y in zip(M.window_depth_regression(reg, gen, lamb=1.5),
+                                                           M.window_depth_regression(reg, dv, lamb=1.5)))
+
+
 def test_photo_consistent_peaky_problem(dev, golden):
     """Photo-consistent features + peaky regulariser (gen_golden.py::gen_photo): heights within 1e-3 m of the
     reference's; and the check means something -- moving one source image by 0.05 px moves the heights by far more."""

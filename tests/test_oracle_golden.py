@@ -138,6 +138,21 @@ def test_height_hypotheses(oracle, golden):
     assert np.abs(ra - g["r_a"]).max() <= 6.2e-5 and np.abs(rb - g["r_b"]).max() <= 6.2e-5
 
 
+def test_ucs_hypotheses(oracle, golden):
+    """UCS-Net's uncertainty_aware_samples behind its two bilinear resizes (SURVEY 8f-1, gen_golden.py::gen_ucs_samples): the
+    sample arithmetic incl. both range clamps is bit-exact given the resized maps; the resize itself is reproduced to 1 ulp
+    (see test_height_hypotheses), which the clamps and the division pass on: <= 6.2e-5 m on heights of 40..360 m."""
+    g = golden("ucs_samples")
+    H, W = g["s8"].shape[2:]
+    for key, nd in (("s8", 8), ("s12", 12)):
+        got = oracle.ucs_hypotheses(g["prev"], g["var"], g["dmin"], g["dmax"], nd, (H, W))
+        assert got.shape == g[key].shape
+        assert np.abs(got - g[key]).max() <= 6.2e-5, key
+        assert (got == g[key]).mean() > 0.5, key                     # most values are bit-identical
+    lo = g["s8"][:, 0]
+    assert (lo == g["dmin"][:, None, None]).any() and (g["s8"][:, -1] < g["dmax"][:, None, None] + 1).all()   # the clamp fires in the fixture
+
+
 def test_window_regress(oracle, golden):
     """casmvs / ucs regression (window-4 confidence, ucs std-dev) against the reference's own DepthNet / compute_depth
     outputs (tests/golden/gen_golden.py::gen_regress).  A pixel whose expected index sits within float rounding of an
