@@ -726,8 +726,10 @@ static bool g_red_direct_only()
 
 static int g_split_below()
 {
-    static const int v = tune_int("SMVS_CONV_SPLIT_BELOW", 1024);
+    static const int v = tune_int("SMVS_CONV_SPLIT_BELOW", 512);
     return v;                                               // workgroups (unsplit) below which the channel-split kernels run
+                                                            // (1024 -> 512: the 384x192 level-1 gate convolution, 576 workgroups, is
+                                                            //  24 -> ~16 us unsplit; stage 2 of the cascade 3.13 -> 3.01 ms)
 }
 
 static MfmaConvArgs mfma_args(int stride, const ConvArgs& a, const float* wm)
