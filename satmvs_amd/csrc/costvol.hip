@@ -215,11 +215,16 @@ __device__ __forceinline__ int wave_max(int v)
 // works alone -- no workgroup barrier anywhere, waves slide past each other:
 //   A. taps of DM_DP consecutive planes for its 64 pixels (float64 chain): LDS address + 4 weights;
 //   B. bounding box of those taps in each source image (wave min/max);
-//   C. per channel PAIR ("step"): the box rows -- DM_R rows x 64 columns -- go into LDS by LDS-DMA
-//      (buffer_load ... lds: lane -> (column, channel-of-pair), so the DMA itself produces the
-//      pair-interleaved float2 layout; out-of-image lanes/rows deposit zeros = zero padding);
-//   D. every tap corner of the pair is one ds_read_b64 with an immediate offset, feeding packed f32
-//      math (v_pk_fma_f32); the variance pair leaves through two non-temporal buffer stores.
+//   C. per channel PAIR ("step"): the box -- DM_R rows x DM_BW columns x 2 channels, PLANAR: [row][channel][column] --
+//      goes into LDS by 16-byte LDS-DMA chunks (buffer_load_dwordx4 ... lds: lane -> 4 columns of one channel row;
+//      4 instructions per step for two sources instead of ~10 of the round-2 dword map; chunks outside the image
+//      deposit zeros = zero padding);
+//   D. every tap corner of the pair is one ds_read2_b32 (the corner's dword of both channels), feeding packed f32
+//      math in a hand-fixed, hazard-free order (smvs_device.h: pk_bilinear2 / pk_finish2); the variance pair leaves
+//      through two non-temporal buffer stores.
+// The kernel runs AT THE BOARD POWER LIMIT (1400 W, shader clock throttled to ~1.8 GHz: profiles/r03_power.txt), so
+// its time follows the ENERGY of a launch, not the overlap of its phases: fewer cycles at the same work only lower
+// the clock.  What counts is instructions and bytes moved per voxel.
 // Global loads per voxel-channel-source drop from 4 gathers to ~0.6 coalesced DMA lanes; rows shared by
 // the patch's two image rows and by the DM_DP planes are fetched once.  Latency is taken off the
 // wave's critical path three ways:
@@ -234,7 +239,7 @@ __device__ __forceinline__ int wave_max(int v)
 // the oracle.
 // =====================================================================================================
 #ifndef SMVS_BOX_W
-#define SMVS_BOX_W 40
+#define SMVS_BOX_W 44                 // staged box width: 11 chunks of 4 columns (a 40-column box from any 4-aligned origin)
 #endif
 #ifndef SMVS_WAVES_PER_SIMD
 #define SMVS_WAVES_PER_SIMD 3
@@ -246,13 +251,16 @@ constexpr int DM_BW = SMVS_BOX_W;      // staged box width (columns)
 constexpr int DM_R = SMVS_BOX_R;        // staged box rows: 2 pixel rows + south tap + parallax/rotation slack
 constexpr int DM_NBUF = 2;
 #ifndef SMVS_ABLATE
-#define SMVS_ABLATE 0                 // profiling builds only (tools/ab_build.sh x -DSMVS_ABLATE=n): 1 stores dropped, 2 no staging DMA, 4 no float64 chain -- results are WRONG
-#endif
-#ifndef SMVS_TAP_PREFETCH
-#define SMVS_TAP_PREFETCH 1           // pipeline units of LDS tap reads in flight ahead of the arithmetic (1 or 2)
+#define SMVS_ABLATE 0                 // profiling builds only (tools/ab_build.sh x -DSMVS_ABLATE=n): 1 stores dropped, 2 no staging DMA, 4 no float64 chain, 8 no LDS tap reads, 32 no packed arithmetic -- results are WRONG
 #endif
 #ifndef SMVS_O2P_PLANES
 #define SMVS_O2P_PLANES 4          // planes per evaluation pass of a source view's cubics
+#endif
+#ifndef SMVS_WPS_DP8
+#define SMVS_WPS_DP8 2                // waves per SIMD the 8-plane instance is compiled for
+#endif
+#ifndef SMVS_DP8
+#define SMVS_DP8 1                    // 8 planes per wave for rpc C=32 sweeps (A/B switch of profiling builds)
 #endif
 #ifndef SMVS_STORE_AUX
 #define SMVS_STORE_AUX 2              // nt: the variance volume streams out once, keep it from evicting feature rows in L2
@@ -284,20 +292,24 @@ __device__ __forceinline__ void wait_vmcnt_upto8(int n)
 
 // base: LDS byte address of the north-west corner in staging buffer 0.  The weights are kept as two
 // register pairs so that v_pk_* can broadcast either half through op_sel (no v_mov to build {w,w}).
-struct TapD { uint32_t base; f32x2 wn, ws; };       // wn = {nw, ne}, ws = {sw, se}
+struct TapD { uint32_t base[DM_NBUF]; f32x2 wn, ws; };       // base[parity] = LDS address of the NW corner; wn = {nw, ne}, ws = {sw, se}
 
 template <int GEO, int NSRC, int CT, int DP>
-__global__ __launch_bounds__(64 * WV_WAVES, (NSRC <= 2 && DP <= 4 ? SMVS_WAVES_PER_SIMD : 2))
+__global__ __launch_bounds__(64 * WV_WAVES, (NSRC <= 2 && DP <= 4 ? SMVS_WAVES_PER_SIMD : NSRC <= 2 ? SMVS_WPS_DP8 : 2))
 void costvol_dma_kernel(const CostVolParams p)
 {
-    constexpr int BW = DM_BW, R = DM_R;
-    constexpr int NI = (R * BW * 2 + 63) / 64;               // DMA instructions per source box and channel pair
-    constexpr int SRC_STRIDE = NI * 32;                      // float2 cells per source box, padded to whole DMA instructions
-    constexpr int ZPAD = BW + 2;                             // always-zero cells a dropped tap reads (NW..SE span)
-    constexpr int BUF_STRIDE = NSRC * SRC_STRIDE + ZPAD;
+    // Staging layout of one source box and channel pair: [row][channel of the pair][column] dwords, row pitch 2*BW; filled
+    // by 16-byte LDS-DMA chunks (4 columns of one channel row), chunk k of the box at byte 16 k.
+    constexpr int BW = DM_BW, R = DM_R, C4 = BW / 4;
+    constexpr int SLOTS = R * 2 * C4;                        // 16-byte chunks per source box and channel pair
+    constexpr int NI = (SLOTS + 63) / 64;                    // DMA instructions per source box and channel pair
+    constexpr int SRC_DW = NI * 256;                         // dwords per source box, padded to whole DMA instructions
+    constexpr int BUF_DW = NSRC * SRC_DW;
+    constexpr int ZPAD_DW = 3 * BW + 4;                      // always-zero dwords a dropped tap reads (offsets 0 .. 3*BW+1)
+    constexpr int TILE_DW = DM_NBUF * BUF_DW + ZPAD_DW;
     constexpr int NSTEP = CT / 2;
-    static_assert(CT % 2 == 0 && 2 * DP + 2 <= 63 && DP * NSRC <= 32, "steps / vmcnt bookkeeping / tap mask");
-    __shared__ f32x2 tile_all[WV_WAVES][DM_NBUF * BUF_STRIDE];
+    static_assert(BW % 4 == 0 && CT % 2 == 0 && 2 * DP + 2 <= 63 && DP * NSRC <= 32, "chunks / steps / vmcnt bookkeeping / tap mask");
+    __shared__ __attribute__((aligned(16))) uint32_t tile_all[WV_WAVES][(TILE_DW + 3) & ~3];
 #ifdef SMVS_LDS_PAD
     __shared__ float lds_pad[SMVS_LDS_PAD / 4];            // profiling builds only: caps the workgroups per CU
     if (p.B < 0) lds_pad[threadIdx.x] = 0.0f;
@@ -314,7 +326,7 @@ void costvol_dma_kernel(const CostVolParams p)
     const int HW = H * W;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    f32x2* tile = tile_all[wave];
+    uint32_t* tile = tile_all[wave];
     const uint32_t tile_lds = __builtin_amdgcn_readfirstlane(lds_addr(tile));
     const int x = xtile * WV_TX + (lane & (WV_TX - 1));
     const int y = (ytile * WV_WAVES + wave) * WV_TY + (lane >> 5);
@@ -327,10 +339,7 @@ void costvol_dma_kernel(const CostVolParams p)
 
     // zero cells behind each buffer: a tap whose footprint misses the image reads these, so it
     // contributes 0 * weight exactly like four masked gathers (0, or NaN for a NaN coordinate)
-    for (int i = lane; i < ZPAD; i += 64) {
-        tile[NSRC * SRC_STRIDE + i] = (f32x2)(0.0f);
-        tile[BUF_STRIDE + NSRC * SRC_STRIDE + i] = (f32x2)(0.0f);
-    }
+    for (int i = lane; i < ZPAD_DW; i += 64) tile[DM_NBUF * BUF_DW + i] = 0u;
 
     const float fV = (float)p.V;
     const float rV = p.rV;
@@ -453,7 +462,7 @@ void costvol_dma_kernel(const CostVolParams p)
                 tap[pl][s].ws.x = n * e;  tap[pl][s].ws.y = n * w;
                 const int ix0 = cvt_i32_sat(xw), iy0 = cvt_i32_sat(yn);
                 const bool ok = ((uint32_t)(ix0 + 1) <= (uint32_t)W) && ((uint32_t)(iy0 + 1) <= (uint32_t)H);
-                txy[pl][s] = (uint32_t)((iy0 + 1) * BW + (ix0 + 1));      // cell index relative to image corner (-1,-1); used only if ok
+                txy[pl][s] = (uint32_t)((iy0 + 1) * (2 * BW) + (ix0 + 1)); // dword index relative to image corner (-1,-1); used only if ok
                 if (ok) okmask |= 1u << (pl * NSRC + s);
                 if (ok && active && pl < np) {
                     lo_x[s] = min(lo_x[s], ix0); hi_x[s] = max(hi_x[s], ix0);
@@ -466,6 +475,10 @@ void costvol_dma_kernel(const CostVolParams p)
 
     SMVS_T(const unsigned long long t_geo = now();)
     // ---- B: the wave's bounding box per source -------------------------------------------------------
+    // The box origin is moved left onto a chunk grid that the image edge it may touch falls on (column 0, or column W
+    // when the last column a tap reads lies within a chunk of the right edge and W is not a multiple of 4): a 16-byte
+    // chunk is then inside the image row or outside it as a whole, and outside chunks deposit zeros = zero padding.
+    // For W % 4 == 0 every chunk is 16-byte aligned in memory as well.
     int bx0[NSRC], by0[NSRC], bw[NSRC], bh[NSRC];
     bool fits = true;
 #pragma unroll
@@ -473,10 +486,12 @@ void costvol_dma_kernel(const CostVolParams p)
         int a0 = lo_x[s], a1 = hi_x[s], b0 = lo_y[s], b1 = hi_y[s];
         wave_minmax4(a0, a1, b0, b1);
         const bool empty = a1 < a0;
-        bx0[s] = empty ? 0 : a0; by0[s] = empty ? 0 : b0;
-        bw[s] = empty ? 0 : a1 - a0 + 2;
+        const int al = (a1 + 4 >= W) ? (W & 3) : 0;
+        const int ax = a0 - ((a0 - al) & 3);
+        bx0[s] = empty ? 0 : ax; by0[s] = empty ? 0 : b0;
+        bw[s] = empty ? 0 : a1 + 2 - ax;                   // columns from the aligned origin
         bh[s] = empty ? 0 : b1 - b0 + 2;
-        fits = fits && (bw[s] <= BW) && (bh[s] <= R);
+        fits = fits && (bw[s] <= BW) && (bh[s] <= R) && !(bx0[s] < 0 && (bx0[s] & 3) != 0);
     }
 
     BufRsrc rs[NSRC];
@@ -487,32 +502,21 @@ void costvol_dma_kernel(const CostVolParams p)
     const size_t ostride = (size_t)p.D_out * HW;             // floats between channels of the output
 
     if (fits) {
-        // DMA lane map.  A source box is R rows x BW columns x 2 channels = R*BW*2 dwords laid out row-major in LDS with the
-        // channel pair innermost; DMA instruction j of a source deposits dwords [64 j, 64 j + 64) of that block, so lane l of
-        // instruction j carries box cell (row, col, ch) of dword 64 j + l -- rows are packed back to back and no instruction
-        // is spent on the empty tail of a row (a vector-memory instruction costs the texture path ~8 clocks whatever
-        // its active lanes: tools/ubench_dma.hip).  Cells outside the box or the image get an out-of-range offset = 0.
+        // DMA lane map.  Chunk k of a source box = 4 columns of (row, channel) with k = (row * 2 + channel) * C4 + column / 4;
+        // lane l of DMA instruction j carries chunk 64 j + l to LDS byte 16 (64 j + l) of the box.  Chunks outside the box
+        // rows, the image, or right of the last column any tap reads get an out-of-range offset = zeros.
         uint32_t vo[NSRC][NI];
-        {
-            int rlo[NSRC], rn[NSRC], clo[NSRC], cn[NSRC], boxbase[NSRC];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int slot = 64 * j + lane;
+            const int row = slot / (2 * C4), rem = slot - row * (2 * C4);
+            const int ch = rem >= C4 ? 1 : 0, col = (rem - ch * C4) * 4;
+            const int rel = (row * W + col) * 4 + ch * HW * 4;
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) {
-                rlo[s] = max(0, -by0[s]); rn[s] = min(bh[s], H - by0[s]) - rlo[s];     // valid box rows [rlo, rlo + rn)
-                clo[s] = max(0, -bx0[s]); cn[s] = min(bw[s], W - bx0[s]) - clo[s];     // valid box columns
-                rn[s] = max(rn[s], 0); cn[s] = max(cn[s], 0);
-                boxbase[s] = (by0[s] * W + bx0[s]) * 4;
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int slot = 64 * j + lane;
-                const int row = slot / (2 * BW), rem = slot - row * (2 * BW);
-                const int col = rem >> 1;
-                const int rel = (row * W + col) * 4 + (rem & 1) * HW * 4;
-#pragma unroll
-                for (int s = 0; s < NSRC; ++s) {
-                    const bool valid = ((uint32_t)(row - rlo[s]) < (uint32_t)rn[s]) && ((uint32_t)(col - clo[s]) < (uint32_t)cn[s]);
-                    vo[s][j] = valid ? (uint32_t)(rel + boxbase[s]) : SMVS_OOB;
-                }
+                const int gx = bx0[s] + col, gy = by0[s] + row;
+                const bool valid = (row < bh[s]) && (col < bw[s]) && ((uint32_t)gy < (uint32_t)H) && (gx >= 0) && (gx + 4 <= W);
+                vo[s][j] = valid ? (uint32_t)(rel + (by0[s] * W + bx0[s]) * 4) : SMVS_OOB;
             }
         }
 #pragma unroll
@@ -520,8 +524,11 @@ void costvol_dma_kernel(const CostVolParams p)
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) {
                 const bool ok = (okmask >> (pl * NSRC + s)) & 1u;
-                const int box0 = s * SRC_STRIDE - ((by0[s] + 1) * BW + bx0[s] + 1);        // wave-uniform
-                tap[pl][s].base = tile_lds + 8u * (uint32_t)(ok ? (int)txy[pl][s] + box0 : NSRC * SRC_STRIDE);
+                const int box0 = s * SRC_DW - ((by0[s] + 1) * (2 * BW) + bx0[s] + 1);      // wave-uniform
+                const uint32_t a = tile_lds + 4u * (uint32_t)((int)txy[pl][s] + box0);
+                const uint32_t z = tile_lds + 4u * (uint32_t)(DM_NBUF * BUF_DW);
+                tap[pl][s].base[0] = ok ? a : z;
+                tap[pl][s].base[1] = ok ? a + 4u * (uint32_t)BUF_DW : z;
             }
         uint32_t ovo[DP];                                 // per-plane byte offset of this pixel inside one channel volume
 #pragma unroll
@@ -532,7 +539,7 @@ void costvol_dma_kernel(const CostVolParams p)
         // (s, j) are unrolled loop indices but not constant expressions: dispatch to the immediate-offset variant
         auto dma_at = [&](int s, int j, uint32_t buf, uint32_t voff, int so) {
 #define SMVS_DMA_CASE(S, J) \
-    case (S) * 8 + (J): dma_dword_to_lds_at<((S) * SRC_STRIDE * 8 + (J) * 256)>(rs[(S) < NSRC ? (S) : 0], buf, voff, so); break;
+    case (S) * 8 + (J): dma_x4_to_lds_at<((S) * SRC_DW * 4 + (J) * 1024)>(rs[(S) < NSRC ? (S) : 0], buf, voff, so); break;
             static_assert(NI <= 8 && NSRC <= 4, "instruction dispatch");
             switch (s * 8 + j) {
                 SMVS_DMA_CASE(0, 0) SMVS_DMA_CASE(0, 1) SMVS_DMA_CASE(0, 2) SMVS_DMA_CASE(0, 3) SMVS_DMA_CASE(0, 4) SMVS_DMA_CASE(0, 5) SMVS_DMA_CASE(0, 6) SMVS_DMA_CASE(0, 7)
@@ -545,10 +552,10 @@ void costvol_dma_kernel(const CostVolParams p)
         };
         int ni[NSRC];                                      // instructions that carry rows of the box (wave-uniform)
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) ni[s] = (bh[s] * 2 * BW + 63) >> 6;
+        for (int s = 0; s < NSRC; ++s) ni[s] = (bh[s] * 2 * C4 + 63) >> 6;
         auto issue_dma = [&](int st) {
             if (SMVS_ABLATE & 2) return;
-            const uint32_t buf = tile_lds + (uint32_t)((st & 1) * BUF_STRIDE * 8);
+            const uint32_t buf = tile_lds + (uint32_t)((st & 1) * BUF_DW * 4);
             const int choff = 2 * st * HW * 4;
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) {
@@ -597,67 +604,72 @@ void costvol_dma_kernel(const CostVolParams p)
             // through the scalar offset
             const BufRsrc ro = make_rsrc(p.out + ((size_t)b * CT + 2 * st) * ostride, (uint32_t)(2 * ostride * 4));
             const int och1 = (int)(ostride * 4);
-            // Software pipeline over UNITS = (plane, group of US sources): the taps of unit u+1 are in flight (ds_read_b64
+            // Software pipeline over UNITS = (plane, group of US sources): the taps of unit u+1 are in flight (ds_read2_b32
             // from inline asm, in-order return, counted lgkmcnt) while unit u is being accumulated.  Two sources per unit
-            // when the source count is even, one otherwise; a plane's sum / sum of squares run across its units.
+            // when the source count is even, one otherwise; a plane's sum / sum of squares run across its units.  The packed
+            // arithmetic is the hand-ordered blocks of smvs_device.h (pk_bilinear / pk_accumulate / pk_finish / pk_variance:
+            // no instruction reads a packed result in the slot right behind its producer); a plane's last instruction
+            // (var = meansq - mean^2) and its two stores are issued behind the bilinear block of the NEXT unit.
             constexpr int US = (NSRC % 2 == 0) ? 2 : 1, UPP = NSRC / US, NU = DP * UPP;
-            constexpr int PF = DP >= 8 ? SMVS_TAP_PREFETCH : 1;     // units of tap reads in flight ahead of the arithmetic (register budget: DP = 8 runs at 2 waves per SIMD)
-            f32x2 cv[PF + 1][US][4];
-            f32x2 sum = refc, sq = refsq;
+            f32x2 cv[2][US][4];
+            f32x2 accS[2], accT[2];                         // partial sums of a plane between its units (3+ sources)
+            f32x2 S, T;                                     // mean^2 and meansq of the plane whose stores are pending
+            const f32x2 rvv = {rV, fV};
             auto read_unit = [&](int u) {
                 const int pl = u / UPP, s0 = (u % UPP) * US;
+                if (SMVS_ABLATE & 8) {
+#pragma unroll
+                    for (int k = 0; k < US; ++k) cv[u & 1][k][0] = cv[u & 1][k][1] = cv[u & 1][k][2] = cv[u & 1][k][3] = tap[pl][s0 + k].wn;
+                    return;
+                }
 #pragma unroll
                 for (int k = 0; k < US; ++k)
-                    lds_read_tap<PAR * BUF_STRIDE * 8, BW * 8>(tap[pl][s0 + k].base, cv[u % (PF + 1)][k][0], cv[u % (PF + 1)][k][1],
-                                                               cv[u % (PF + 1)][k][2], cv[u % (PF + 1)][k][3]);
+                    lds_read_tap_planar<BW>(tap[pl][s0 + k].base[PAR], cv[u & 1][k][0], cv[u & 1][k][1], cv[u & 1][k][2], cv[u & 1][k][3]);
             };
-            auto accumulate_unit = [&](int u) {
-                const int pl = u / UPP, s0 = (u % UPP) * US;
-                if (u % UPP == 0) { sum = refc; sq = refsq; }
-#pragma unroll
-                for (int k = 0; k < US; ++k) {
-                    const TapD& t = tap[pl][s0 + k];
-                    f32x2 wv = cv[u % (PF + 1)][k][0] * __builtin_shufflevector(t.wn, t.wn, 0, 0);
-                    wv = __builtin_elementwise_fma(cv[u % (PF + 1)][k][1], __builtin_shufflevector(t.wn, t.wn, 1, 1), wv);
-                    wv = __builtin_elementwise_fma(cv[u % (PF + 1)][k][2], __builtin_shufflevector(t.ws, t.ws, 0, 0), wv);
-                    wv = __builtin_elementwise_fma(cv[u % (PF + 1)][k][3], __builtin_shufflevector(t.ws, t.ws, 1, 1), wv);
-                    sum = sum + wv;
-                    sq = sq + wv * wv;
-                }
-                if (u % UPP == UPP - 1) {
-                    const f32x2 m = div_by_views2(sum, fV, rV);
-                    const f32x2 q = div_by_views2(sq, fV, rV);
-                    const f32x2 var = q - m * m;
-                    SMVS_T(const unsigned long long ts0 = now();)
-                    llvm_raw_buffer_store_f32(var.x, ro.v, (int)ovo[pl], 0, STORE_AUX);
-                    llvm_raw_buffer_store_f32(var.y, ro.v, (int)ovo[pl], och1, STORE_AUX);
-                    SMVS_T(t_st += now() - ts0;)
-                }
+            auto store_plane = [&](int pl, f32x2 var) {
+                SMVS_T(const unsigned long long ts0 = now();)
+                llvm_raw_buffer_store_f32(var.x, ro.v, (int)ovo[pl], 0, STORE_AUX);
+                llvm_raw_buffer_store_f32(var.y, ro.v, (int)ovo[pl], och1, STORE_AUX);
+                SMVS_T(t_st += now() - ts0;)
             };
-#pragma unroll
-            for (int u = 0; u < PF && u < NU; ++u) read_unit(u);
+            read_unit(0);
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
-                if (u + PF < NU) read_unit(u + PF);
-                constexpr int RPU = 4 * US;                               // reads per unit
-                const int ahead = (NU - 1 - u) < PF ? (NU - 1 - u) : PF;  // units issued after unit u
+                if (u + 1 < NU) read_unit(u + 1);
                 // reads per unit = 4*US; everything older than the next unit's reads has returned
-                f32x2 d0, d1, d2, d3;
-                d0 = d1 = d2 = d3 = (f32x2)(0.0f);
-                if constexpr (US == 1) {
-                    if (ahead >= 2)      lds_wait<(2 * RPU < 15 ? 2 * RPU : 15)>(cv[u % (PF + 1)][0][0], cv[u % (PF + 1)][0][1], cv[u % (PF + 1)][0][2], cv[u % (PF + 1)][0][3], d0, d1, d2, d3);
-                    else if (ahead == 1) lds_wait<4>(cv[u % (PF + 1)][0][0], cv[u % (PF + 1)][0][1], cv[u % (PF + 1)][0][2], cv[u % (PF + 1)][0][3], d0, d1, d2, d3);
-                    else            lds_wait<0>(cv[u % (PF + 1)][0][0], cv[u % (PF + 1)][0][1], cv[u % (PF + 1)][0][2], cv[u % (PF + 1)][0][3], d0, d1, d2, d3);
+                f32x2 (&c)[US][4] = cv[u & 1];
+                if (SMVS_ABLATE & 8) {
+                } else if constexpr (US == 1) {
+                    f32x2 d0, d1, d2, d3;
+                    d0 = d1 = d2 = d3 = (f32x2)(0.0f);
+                    if (u + 1 < NU) lds_wait<4>(c[0][0], c[0][1], c[0][2], c[0][3], d0, d1, d2, d3);
+                    else            lds_wait<0>(c[0][0], c[0][1], c[0][2], c[0][3], d0, d1, d2, d3);
                 } else {
-                    if (ahead >= 2)      lds_wait<15>(cv[u % (PF + 1)][0][0], cv[u % (PF + 1)][0][1], cv[u % (PF + 1)][0][2], cv[u % (PF + 1)][0][3],
-                                                     cv[u % (PF + 1)][US - 1][0], cv[u % (PF + 1)][US - 1][1], cv[u % (PF + 1)][US - 1][2], cv[u % (PF + 1)][US - 1][3]);
-                    else if (ahead == 1) lds_wait<8>(cv[u % (PF + 1)][0][0], cv[u % (PF + 1)][0][1], cv[u % (PF + 1)][0][2], cv[u % (PF + 1)][0][3],
-                                                cv[u % (PF + 1)][US - 1][0], cv[u % (PF + 1)][US - 1][1], cv[u % (PF + 1)][US - 1][2], cv[u % (PF + 1)][US - 1][3]);
-                    else            lds_wait<0>(cv[u % (PF + 1)][0][0], cv[u % (PF + 1)][0][1], cv[u % (PF + 1)][0][2], cv[u % (PF + 1)][0][3],
-                                                cv[u % (PF + 1)][US - 1][0], cv[u % (PF + 1)][US - 1][1], cv[u % (PF + 1)][US - 1][2], cv[u % (PF + 1)][US - 1][3]);
+                    if (u + 1 < NU) lds_wait<8>(c[0][0], c[0][1], c[0][2], c[0][3], c[1][0], c[1][1], c[1][2], c[1][3]);
+                    else            lds_wait<0>(c[0][0], c[0][1], c[0][2], c[0][3], c[1][0], c[1][1], c[1][2], c[1][3]);
                 }
-                accumulate_unit(u);
+                const int pl = u / UPP, k = u % UPP, s0 = k * US;
+                f32x2 a, b;
+                if (SMVS_ABLATE & 32) {
+                    if (u > 0 && k == 0) store_plane(pl - 1, c[0][0]);
+                    continue;
+                }
+                if constexpr (US == 2) pk_bilinear2(a, b, c[0][0], c[0][1], c[0][2], c[0][3], tap[pl][s0].wn, tap[pl][s0].ws,
+                                                    c[1][0], c[1][1], c[1][2], c[1][3], tap[pl][s0 + 1].wn, tap[pl][s0 + 1].ws);
+                else                   pk_bilinear1(a, c[0][0], c[0][1], c[0][2], c[0][3], tap[pl][s0].wn, tap[pl][s0].ws);
+                if (u > 0 && k == 0) store_plane(pl - 1, pk_variance<0>(T, S));      // the previous plane leaves under this unit
+                const f32x2& sin = (k == 0) ? refc : accS[(k - 1) & 1];
+                const f32x2& tin = (k == 0) ? refsq : accT[(k - 1) & 1];
+                if (k == UPP - 1) {
+                    if constexpr (US == 2) pk_finish2(S, T, sin, tin, a, b, rvv);
+                    else                   pk_finish1(S, T, sin, tin, a, rvv);
+                } else {
+                    if constexpr (US == 2) pk_accumulate2(accS[k & 1], accT[k & 1], sin, tin, a, b);
+                    else                   pk_accumulate1(accS[k & 1], accT[k & 1], sin, tin, a);
+                }
             }
+            if (SMVS_ABLATE & 32) store_plane(DP - 1, cv[0][0][1]);
+            else store_plane(DP - 1, pk_variance<1>(T, S));
         };
         static_assert(NSTEP % 2 == 0, "two steps per loop iteration");
         for (int st = 0; st < NSTEP; st += 2) {
@@ -748,12 +760,18 @@ static hipError_t launch_staged(CostVolParams p, hipStream_t st)
     const long long nb = (long long)p.xt * p.yt * p.dct * p.B;
     if (nb >= (1ll << 31)) return hipErrorInvalidValue;
     dim3 blk(64 * WV_WAVES), grd((unsigned)nb);
+#ifdef SMVS_ONLY_BENCH
+    // profiling builds: only the instances the headline bench launches (seconds instead of a minute to compile)
+    if constexpr (GEO == 0 && NSRC == 2 && DP >= 4) { if (p.C == 32) hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 32, DP>), grd, blk, 0, st, p); }
+    return hipGetLastError();
+#else
     switch (p.C) {
     case 8:  hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 8, DP>), grd, blk, 0, st, p); break;
     case 16: hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 16, DP>), grd, blk, 0, st, p); break;
     default: hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 32, DP>), grd, blk, 0, st, p); break;
     }
     return hipGetLastError();
+#endif
 }
 
 template <int GEO, int NSRC>
@@ -768,12 +786,14 @@ static hipError_t launch_ct(CostVolParams p, hipStream_t st)
                                (long long)p.D_out * p.H * p.W * 4 < (1ll << 31);
         if (kernel_choice() != K_DIRECT && staged_ok) {
             if (nd == 1) return launch_staged<GEO, NSRC, 1>(p, st);
-if (nd == 2) return launch_staged<GEO, NSRC, 2>(p, st);
+            if (nd == 2) return launch_staged<GEO, NSRC, 2>(p, st);
             // 8 planes per wave when the sweep divides into eights (48 / 32 / 8 / 64-plane sweeps): half the staging DMA per
             // voxel and the ref view's plane-invariant part amortised over twice the planes outweigh the drop to two
             // waves per SIMD (223 VGPRs) -- measured 0.699 vs 0.717 ms at the metric shape; at C = 8 (float64-bound) and for the
             // homography variant 4 planes per wave stay faster (0.053 vs 0.061 ms, 0.72 vs 0.89 ms)
+#if SMVS_DP8
             if constexpr (NSRC <= 2 && GEO == 0) { if (nd % 8 == 0 && p.C == 32) return launch_staged<GEO, NSRC, 8>(p, st); }
+#endif
             return launch_staged<GEO, NSRC, 4>(p, st);
         }
     }
@@ -784,12 +804,14 @@ if (nd == 2) return launch_staged<GEO, NSRC, 2>(p, st);
     const long long nblocks = (long long)p.xt * p.yt * p.dct * p.B;
     if (nblocks >= (1ll << 31)) return hipErrorInvalidValue;
     dim3 blk(TILE_X, TILE_Y);
+#ifndef SMVS_ONLY_BENCH
     switch (p.C) {
     case 8:  hipLaunchKernelGGL((costvol_fwd_kernel<GEO, NSRC, 8>), dim3(nblocks), blk, 0, st, p); break;
     case 16: hipLaunchKernelGGL((costvol_fwd_kernel<GEO, NSRC, 16>), dim3(nblocks), blk, 0, st, p); break;
     case 32: hipLaunchKernelGGL((costvol_fwd_kernel<GEO, NSRC, 32>), dim3(nblocks), blk, 0, st, p); break;
     default: hipLaunchKernelGGL((costvol_fwd_kernel<GEO, NSRC, 0>), dim3(nblocks), blk, 0, st, p); break;
     }
+#endif
     return hipGetLastError();
 }
 

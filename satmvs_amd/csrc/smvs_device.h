@@ -509,7 +509,36 @@ __device__ __forceinline__ void dma_dword_to_lds_at(const BufRsrc& rs, uint32_t 
                  :: "s"(lds_base), "v"(voffset), "s"(rs.v), "s"(soffset), "n"(OFF) : "memory", "m0", "scc");
 }
 
+// 16 bytes per lane: lane l deposits the four dwords at buffer offset voffset + soffset into LDS at
+// m0 + 16 * l (gfx950's b128 LDS-DMA), i.e. one instruction lays down 1 KiB of LDS from 64 independent 16-byte
+// chunks.  The range check covers the whole chunk: a lane whose offset is out of range deposits four zeros
+// (tests/test_hip_parity.py::test_costvol_edge_boxes pins both on the hardware).  Costs the texture path 6.9 ns
+// per CU against 6.9 ns for ONE dword instruction of the channel-interleaved map (tools/ubench_dma.hip).
+template <int OFF>
+__device__ __forceinline__ void dma_x4_to_lds_at(const BufRsrc& rs, uint32_t lds_base, uint32_t voffset, int soffset)
+{
+    asm volatile("s_add_u32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_base), "v"(voffset), "s"(rs.v), "s"(soffset), "n"(OFF) : "memory", "m0", "scc");
+}
+
 #pragma clang diagnostic pop
+
+// The four corners of one tap for a channel pair out of the PLANAR staging layout [row][channel of the pair][column]
+// (row pitch 2*BW dwords): one ds_read2_b32 per corner fetches the corner's dword of both channels into a register
+// pair, ready for v_pk_*_f32.  The two 8-bit dword offsets are all the immediate there is, so buffer parity and source
+// live in the address register.
+template <int BW>
+__device__ __forceinline__ void lds_read_tap_planar(uint32_t addr, f32x2& nw, f32x2& ne, f32x2& sw, f32x2& se)
+{
+    static_assert(3 * BW + 1 <= 255, "ds_read2_b32 offsets are 8-bit dword counts");
+    asm volatile("ds_read2_b32 %0, %4 offset0:%5 offset1:%6\n\t"
+                 "ds_read2_b32 %1, %4 offset0:%7 offset1:%8\n\t"
+                 "ds_read2_b32 %2, %4 offset0:%9 offset1:%10\n\t"
+                 "ds_read2_b32 %3, %4 offset0:%11 offset1:%12"
+                 : "=&v"(nw), "=&v"(ne), "=&v"(sw), "=&v"(se)
+                 : "v"(addr), "n"(0), "n"(BW), "n"(1), "n"(BW + 1), "n"(2 * BW), "n"(3 * BW), "n"(2 * BW + 1), "n"(3 * BW + 1)
+                 : "memory");
+}
 
 // The four corners of one tap for a channel pair, as four ds_read_b64 (256 B/clk) rather than the
 // two ds_read2_b64 (128 B/clk) hipcc merges them into.  Issued from inline asm, so completion is
@@ -617,6 +646,116 @@ __device__ __forceinline__ f32x2 tap_fetch2(const BufRsrc& rs, const Tap& t, int
     r = __builtin_elementwise_fma(c, (f32x2)(t.sw), r);
     r = __builtin_elementwise_fma(d, (f32x2)(t.se), r);
     return r;
+}
+
+// ---- hand-ordered packed arithmetic of the staged cost-volume kernel -----------------------------------------
+// gfx950 needs one wait state between a v_pk_*_f32 and a VALU instruction that reads its result; hipcc's
+// scheduler does not model that and its hazard pass then fills the gaps with s_nop (66 per channel pair in the
+// round-2 kernel = one issue slot in five).  The blocks below fix an order in which every result is consumed at
+// least two instructions after it was produced: the taps of TWO sources run interleaved, and the sum and
+// sum-of-squares strands of the variance alternate.  The four bilinear weights of a tap stay in two register
+// pairs {nw, ne}, {sw, se}; op_sel broadcasts the half a multiply needs (no {w, w} copies: -64 VGPRs at 8 planes).
+// Arithmetic and rounding sequence are exactly tap_fetch2 / div_by_views2 below (ATen's sampler, true division
+// by the view count), so the bits do not change.
+
+// a = bilinear(ca[0..3]; wa), b = bilinear(cb[0..3]; wb):  r = c0*nw; r = fma(c1, ne, r); r = fma(c2, sw, r); r = fma(c3, se, r)
+__device__ __forceinline__ void pk_bilinear2(f32x2& a, f32x2& b,
+                                             const f32x2& a0, const f32x2& a1, const f32x2& a2, const f32x2& a3, const f32x2& wan, const f32x2& was,
+                                             const f32x2& b0, const f32x2& b1, const f32x2& b2, const f32x2& b3, const f32x2& wbn, const f32x2& wbs)
+{
+    asm volatile("v_pk_mul_f32 %0, %2, %6 op_sel_hi:[1,0]\n\t"
+                 "v_pk_mul_f32 %1, %8, %12 op_sel_hi:[1,0]\n\t"
+                 "v_pk_fma_f32 %0, %3, %6, %0 op_sel:[0,1,0]\n\t"
+                 "v_pk_fma_f32 %1, %9, %12, %1 op_sel:[0,1,0]\n\t"
+                 "v_pk_fma_f32 %0, %4, %7, %0 op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 %1, %10, %13, %1 op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 %0, %5, %7, %0 op_sel:[0,1,0]\n\t"
+                 "v_pk_fma_f32 %1, %11, %13, %1 op_sel:[0,1,0]"
+                 : "=&v"(a), "=&v"(b)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(wan), "v"(was), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(wbn), "v"(wbs));
+}
+
+// One source only (odd source counts): the chain is serial, every step waits one state
+__device__ __forceinline__ void pk_bilinear1(f32x2& a, const f32x2& a0, const f32x2& a1, const f32x2& a2, const f32x2& a3,
+                                             const f32x2& wan, const f32x2& was)
+{
+    asm volatile("v_pk_mul_f32 %0, %1, %5 op_sel_hi:[1,0]\n\ts_nop 0\n\t"
+                 "v_pk_fma_f32 %0, %2, %5, %0 op_sel:[0,1,0]\n\ts_nop 0\n\t"
+                 "v_pk_fma_f32 %0, %3, %6, %0 op_sel_hi:[1,0,1]\n\ts_nop 0\n\t"
+                 "v_pk_fma_f32 %0, %4, %6, %0 op_sel:[0,1,0]\n\ts_nop 0"
+                 : "=&v"(a) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(wan), "v"(was));
+}
+
+// sum += a (+ b), sq += a*a (+ b*b) for a plane whose sources are not finished yet.  Consumes a and b.
+__device__ __forceinline__ void pk_accumulate2(f32x2& s, f32x2& t, const f32x2& sin, const f32x2& tin, f32x2& a, f32x2& b)
+{
+    asm volatile("v_pk_add_f32 %0, %4, %2\n\t"          // s = sin + a
+                 "v_pk_mul_f32 %2, %2, %2\n\t"          // a = a*a
+                 "v_pk_add_f32 %0, %0, %3\n\t"          // s += b
+                 "v_pk_mul_f32 %3, %3, %3\n\t"          // b = b*b
+                 "v_pk_add_f32 %1, %5, %2\n\t"          // t = tin + a*a
+                 "s_nop 0\n\t"
+                 "v_pk_add_f32 %1, %1, %3\n\t"          // t += b*b
+                 "s_nop 0"
+                 : "=&v"(s), "=&v"(t), "+v"(a), "+v"(b) : "v"(sin), "v"(tin));
+}
+
+__device__ __forceinline__ void pk_accumulate1(f32x2& s, f32x2& t, const f32x2& sin, const f32x2& tin, f32x2& a)
+{
+    asm volatile("v_pk_add_f32 %0, %3, %2\n\t"
+                 "v_pk_mul_f32 %2, %2, %2\n\t"
+                 "s_nop 0\n\t"
+                 "v_pk_add_f32 %1, %4, %2\n\t"
+                 "s_nop 0"
+                 : "=&v"(s), "=&v"(t), "+v"(a) : "v"(sin), "v"(tin));
+}
+
+// Last sources of a plane: accumulate a (+ b), then mean = sum / V, meansq = sq / V (div_by_views2: q0 = x*rv,
+// r = fma(-q0, V, x), q = fma(r, rv, q0)) and mean*mean.  Leaves s = mean*mean and t = sq / V; the caller finishes with
+// pk_variance(): var = t - s, TWO or more instructions later (the block ends on the write of t).  rvv = {1/V, V}.
+__device__ __forceinline__ void pk_finish2(f32x2& s, f32x2& t, const f32x2& sin, const f32x2& tin, f32x2& a, f32x2& b, const f32x2& rvv)
+{
+    f32x2 m0, q0;
+    asm volatile("v_pk_add_f32 %0, %6, %4\n\t"                                   //  1 s = sin + a
+                 "v_pk_mul_f32 %4, %4, %4\n\t"                                   //  2 a = a*a
+                 "v_pk_add_f32 %0, %0, %5\n\t"                                   //  3 s += b
+                 "v_pk_mul_f32 %5, %5, %5\n\t"                                   //  4 b = b*b
+                 "v_pk_add_f32 %1, %7, %4\n\t"                                   //  5 t = tin + a*a
+                 "v_pk_mul_f32 %2, %0, %8 op_sel_hi:[1,0]\n\t"                   //  6 m0 = s * rv
+                 "v_pk_add_f32 %1, %1, %5\n\t"                                   //  7 t += b*b
+                 "v_pk_fma_f32 %4, %2, %8, %0 op_sel:[0,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   //  8 a = fma(-m0, V, s)
+                 "v_pk_mul_f32 %3, %1, %8 op_sel_hi:[1,0]\n\t"                   //  9 q0 = t * rv
+                 "v_pk_fma_f32 %0, %4, %8, %2 op_sel_hi:[1,0,1]\n\t"             // 10 s = fma(a, rv, m0)      mean
+                 "v_pk_fma_f32 %5, %3, %8, %1 op_sel:[0,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   // 11 b = fma(-q0, V, t)
+                 "v_pk_mul_f32 %0, %0, %0\n\t"                                   // 12 s = mean*mean
+                 "v_pk_fma_f32 %1, %5, %8, %3 op_sel_hi:[1,0,1]"                 // 13 t = fma(b, rv, q0)      meansq
+                 : "=&v"(s), "=&v"(t), "=&v"(m0), "=&v"(q0), "+v"(a), "+v"(b) : "v"(sin), "v"(tin), "v"(rvv));
+}
+
+__device__ __forceinline__ void pk_finish1(f32x2& s, f32x2& t, const f32x2& sin, const f32x2& tin, f32x2& a, const f32x2& rvv)
+{
+    f32x2 m0, q0, r;
+    asm volatile("v_pk_add_f32 %0, %6, %5\n\t"                                   //  1 s = sin + a
+                 "v_pk_mul_f32 %5, %5, %5\n\t"                                   //  2 a = a*a
+                 "v_pk_mul_f32 %2, %0, %8 op_sel_hi:[1,0]\n\t"                   //  3 m0 = s * rv
+                 "v_pk_add_f32 %1, %7, %5\n\t"                                   //  4 t = tin + a*a
+                 "v_pk_fma_f32 %4, %2, %8, %0 op_sel:[0,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   //  5 r = fma(-m0, V, s)
+                 "v_pk_mul_f32 %3, %1, %8 op_sel_hi:[1,0]\n\t"                   //  6 q0 = t * rv
+                 "v_pk_fma_f32 %0, %4, %8, %2 op_sel_hi:[1,0,1]\n\t"             //  7 s = fma(r, rv, m0)
+                 "v_pk_fma_f32 %5, %3, %8, %1 op_sel:[0,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   //  8 a = fma(-q0, V, t)
+                 "v_pk_mul_f32 %0, %0, %0\n\t"                                   //  9 s = mean*mean
+                 "v_pk_fma_f32 %1, %5, %8, %3 op_sel_hi:[1,0,1]"                 // 10 t = fma(a, rv, q0)
+                 : "=&v"(s), "=&v"(t), "=&v"(m0), "=&v"(q0), "=&v"(r), "+v"(a) : "v"(sin), "v"(tin), "v"(rvv));
+}
+
+// var = meansq - mean*mean.  NOP = 1 when it directly follows pk_finish (nothing in between to cover the wait state).
+template <int NOP>
+__device__ __forceinline__ f32x2 pk_variance(const f32x2& t, const f32x2& s)
+{
+    f32x2 v;
+    if (NOP) asm volatile("s_nop 0\n\tv_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(v) : "v"(t), "v"(s));
+    else     asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(v) : "v"(t), "v"(s));
+    return v;
 }
 
 __device__ __forceinline__ f32x2 div_by_views2(f32x2 x, float v, float rv)
