@@ -148,8 +148,10 @@ int smvs_rpc_project(const double* rpc170, const double* a, const double* b, con
  * reference pixel + height -> ground -> source image (float64); the source height map sampled there like
  * cv2.remap(INTER_LINEAR, BORDER_CONSTANT, -999) on float32 coordinates; back to the ground with the sampled
  * height and into the reference image; mask = (|reprojected - pixel| < p_ratio) & (|sampled - height| < d_ratio).
- * depth_ref (H,W), depth_src (Hs,Ws) float32; rpc_* 170 float64; mask (H,W) uint8; depth_reproj (H,W) float32 (0 outside
- * the mask); x_src, y_src (H,W) float64 source-image coordinates; x_back, y_back (H,W) float64 or both NULL. */
+ * depth_ref (H,W), depth_src (Hs,Ws) float32; rpc_* 170 float64; mask (H,W) uint8; depth_reproj (H,W) float32: 0 outside
+ * the mask when x_back/y_back are NULL (check_geometric_consistency), the raw sampled height everywhere when they are
+ * given (reproject_with_depth); x_src, y_src (H,W) float64 source-image coordinates; x_back, y_back (H,W) float64 or
+ * both NULL. */
 int smvs_rpc_geo_consistency(const float* depth_ref, const double* rpc_ref, const float* depth_src,
                              const double* rpc_src, int H, int W, int Hs, int Ws, double p_ratio, double d_ratio,
                              unsigned char* mask, float* depth_reproj, double* x_src, double* y_src,

@@ -6,7 +6,8 @@
 //   2. the source height map sampled there: cv2.remap(depth_src, float32 coordinates, INTER_LINEAR, BORDER_CONSTANT -999);
 //   3. that source pixel + sampled height -> ground through the source view's inverse RPC -> back into the reference image;
 //   4. mask = |reprojected - pixel| < p_ratio  and  |sampled height - reference height| < d_ratio; heights outside the mask -> 0.
-// cv2.remap is a third-party step (opencv-python 4.5.5.62, environment.yml:156; cv2 is absent from this image, so this
+// Pinned by tests/golden/filter.npz = the reference's own rpc_filter.py + rpc_tensor.py run as they are -- except
+// cv2.remap, a third-party step (opencv-python 4.5.5.62, environment.yml:156; cv2 is absent from this image, so this
 // step is restated from OpenCV's published algorithm and NOT pinned by a reference run): coordinates are rounded to 1/32
 // pixel (cvRound(x * 32): round half to even), the four bilinear weights come from the 5-bit fractions, taps outside the
 // image take the border value.
@@ -51,7 +52,9 @@ void geo_consistency_kernel(const float* __restrict__ depth_ref, const double* _
     const float ddiff = fabsf(sampled - depth_ref[i]);
     const bool ok = (dist < p_ratio) && ((double)ddiff < d_ratio);
     mask[i] = ok ? 1 : 0;
-    depth_reproj[i] = ok ? sampled : 0.0f;
+    // check_geometric_consistency zeroes the heights outside the mask (rpc_filter.py:66); reproject_with_depth (the caller
+    // that asks for the back-projected coordinates) returns the raw remap value, NaN / border value included (:30-47)
+    depth_reproj[i] = (ok || x_back) ? sampled : 0.0f;
     x_src[i] = xs; y_src[i] = ys;
     if (x_back) { x_back[i] = xb; y_back[i] = yb; }
 }

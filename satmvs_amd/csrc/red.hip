@@ -1054,7 +1054,12 @@ static int red_run_planes(const RedRun& r, int d_begin, int d_end)
             if (!rc) rc = is.issue_decoder(k);
         }
     }
-    if (rc) return rc;
+    if (rc) {
+        // a launch failed mid-loop: drain the helper streams before the lease goes back to the pool and the caller
+        // (who will raise) frees or reuses the workspace, states and accumulators earlier planes still touch
+        if (multi) { (void)hipStreamSynchronize(P.rec); (void)hipStreamSynchronize(P.dec); }
+        return rc;
+    }
     // join: the caller's stream continues only after the last plane's decoder (which implies the rest)
     if (multi) (void)hipStreamWaitEvent(r.main, P.done[(nplanes - 1) % RING], 0);
     hipError_t e = hipGetLastError();

@@ -23,7 +23,7 @@ def load_pfm(fname):
         scale = float(f.readline().decode("latin-1").rstrip())
         data = np.frombuffer(f.read(), "<f4" if scale < 0 else ">f4")
     shape = (height, width, 3) if header == "PF" else (height, width)
-    return np.flip(data.reshape(shape), 0)
+    return np.flip(data.reshape(shape), 0).copy()          # writable and contiguous, like the reference's np.fromfile + flipud
 
 
 def save_pfm(file, image, scale=1):

@@ -18,6 +18,7 @@ torch.manual_seed yields the same initial parameters.
 from __future__ import annotations
 
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -41,7 +42,9 @@ def _tensors_by_path(module, names):
 
 
 _PACK_CACHE = {}        # key -> (packed tensor, weak references to the source storages); module-level so that it survives
-_PACK_CACHE_MAX = 16    # DataParallel's per-forward replicas (the device-0 replica shares the parent's storages)
+_PACK_CACHE_PER_DEVICE = 16   # DataParallel's per-forward replicas (the device-0 replica shares the parent's storages);
+                              # entries are counted per device, so 8 replicas do not evict each other every forward
+_PACK_CACHE_LOCK = threading.Lock()   # nn.DataParallel runs its replicas on one Python thread per device
 
 
 def _packed(kind, device, tensors, build):
@@ -51,17 +54,22 @@ def _packed(kind, device, tensors, build):
     packed from are still alive (weak references), because the caching allocator hands a freed parameter's address
     to the next model's parameters."""
     from torch.multiprocessing.reductions import StorageWeakRef
-    key = (kind, str(device)) + tuple((t.data_ptr(), t._version) for t in tensors)
-    hit = _PACK_CACHE.get(key)
-    if hit is not None and any(r.expired() for r in hit[1]):
-        hit = None
+    dkey = str(device)
+    key = (kind, dkey) + tuple((t.data_ptr(), t._version) for t in tensors)
+    with _PACK_CACHE_LOCK:
+        hit = _PACK_CACHE.get(key)
+        if hit is not None and any(r.expired() for r in hit[1]):
+            hit = None
     if hit is None:
-        for k in [k for k, v in _PACK_CACHE.items() if any(r.expired() for r in v[1])]:
-            del _PACK_CACHE[k]
-        if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
-            _PACK_CACHE.pop(next(iter(_PACK_CACHE)))
-        hit = (build(), [StorageWeakRef(t.untyped_storage()) for t in tensors])
-        _PACK_CACHE[key] = hit
+        packed = build()                                   # device work outside the lock: replicas pack concurrently
+        refs = [StorageWeakRef(t.untyped_storage()) for t in tensors]
+        with _PACK_CACHE_LOCK:
+            for k in [k for k, v in _PACK_CACHE.items() if any(r.expired() for r in v[1])]:
+                del _PACK_CACHE[k]
+            mine = [k for k in _PACK_CACHE if k[1] == dkey]
+            if len(mine) >= _PACK_CACHE_PER_DEVICE:
+                del _PACK_CACHE[mine[0]]                   # oldest entry of this device (dicts keep insertion order)
+            hit = _PACK_CACHE.setdefault(key, (packed, refs))
     return hit[0]
 
 

@@ -52,7 +52,8 @@ def _pair(depth_ref, rpc_ref, depth_src, rpc_src, p_ratio, d_ratio, want_back):
 
 def reproject_with_depth(depth_ref, rpc_ref, depth_src, rpc_src):
     """rpc_filter.py:11-48 -> (sampled_depth_src, x_reprojected, y_reprojected, x_src, y_src)."""
-    _, dep, xs, ys, xb, yb = _pair(depth_ref, rpc_ref, depth_src, rpc_src, np.inf, np.inf, True)   # no masking
+    # asking for the back-projection makes the kernel return the raw remap value everywhere (no masking, NaN included)
+    _, dep, xs, ys, xb, yb = _pair(depth_ref, rpc_ref, depth_src, rpc_src, np.inf, np.inf, True)
     return dep.cpu().numpy(), xb.cpu().numpy(), yb.cpu().numpy(), xs.cpu().numpy(), ys.cpu().numpy()
 
 

@@ -605,10 +605,73 @@ def gen_featnet():
              s3=y["stage3"].numpy(), **arrays)
 
 
+def filter_scene(H=64, W=96, V=3, seed=3):
+    """V consistent height maps of one smooth surface (one per view, through OUR synthesiser: inputs only), an 8 m
+    blunder patch in the last view and a confidence map with a low-confidence corner."""
+    rpc = rpc_synth.make_view_rpcs(V, H, W, seed=seed)
+    lat0, lon0, ls, os_ = rpc[0][2], rpc[0][3], rpc[0][7], rpc[0][8]
+
+    def surface(lat, lon):
+        u, v = (lat - lat0) / ls, (lon - lon0) / os_
+        return 200.0 + 30.0 * np.sin(2.3 * u + 0.2) * np.cos(1.9 * v - 0.4)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    depths = []
+    for v in range(V):
+        h = np.full((H, W), 200.0)
+        for _ in range(12):
+            lat, lon = rpc_synth.photo2obj(rpc[v], xx.ravel(), yy.ravel(), h.ravel())
+            h = surface(lat, lon).reshape(H, W)
+        depths.append(h.astype(np.float32))
+    depths = np.stack(depths)
+    depths[V - 1, 10:20, 30:50] += 8.0
+    prob = np.random.default_rng(seed).uniform(0.2, 1.0, (H, W)).astype(np.float32)
+    prob[:8, :12] = 0.05
+    return depths, rpc, prob
+
+
+def gen_filter():
+    """tools/rpc_filter.py:11-112 run AS IS: reproject_with_depth, check_geometric_consistency, filter_depth, on top of the
+    reference's own cupy projector tools/rpc_tensor.py:109-165.  Two modules the image lacks are stood in for at import
+    time, nothing of the reference is edited or stored: `cupy` by numpy (the eight array functions rpc_tensor.py calls),
+    and `cv2` by a module whose remap() is the oracle's restatement of OpenCV's fixed-point bilinear remap -- so every
+    step of the filter is pinned by this fixture EXCEPT cv2.remap itself."""
+    import types
+    from oracle import oracle as orc
+    cupy = types.ModuleType("cupy")
+    for name in ("array", "asarray", "einsum", "ones_like", "stack", "tensordot"):
+        setattr(cupy, name, getattr(np, name))
+    cupy.asnumpy = np.asarray
+    cupy.float = float
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_LINEAR, cv2.BORDER_CONSTANT = 1, 0
+
+    def remap(src, map1, map2, interpolation=None, borderMode=None, borderValue=0):
+        assert interpolation == cv2.INTER_LINEAR and borderMode == cv2.BORDER_CONSTANT
+        assert map1.dtype == np.float32 and map2.dtype == np.float32
+        return orc.remap_linear_const(src, map1, map2, border=float(borderValue))
+    cv2.remap = remap
+    sys.modules["cupy"], sys.modules["cv2"] = cupy, cv2
+    np.float, np.bool = float, bool                        # numpy < 1.24 aliases the reference still uses (rpc_filter.py:21,84)
+    from tools import rpc_filter as ref_filter
+    depths, rpc, prob = filter_scene()
+    out = {"depths": depths, "rpc": rpc, "prob": prob, "p_ratio": np.float64(1.0), "d_ratio": np.float64(2.5),
+           "geo_consist_num": np.int64(2), "confidence_ratio": np.float64(0.3)}
+    for v in (1, 2):
+        dep, xb, yb, xs, ys = ref_filter.reproject_with_depth(depths[0].copy(), rpc[0], depths[v].copy(), rpc[v])
+        m, dm, xs2, ys2 = ref_filter.check_geometric_consistency(depths[0].copy(), rpc[0], depths[v].copy(), rpc[v], 1.0, 2.5)
+        assert np.array_equal(xs, xs2) and np.array_equal(ys, ys2)
+        out.update({"v%d.sampled" % v: dep, "v%d.x_back" % v: xb, "v%d.y_back" % v: yb, "v%d.x_src" % v: xs, "v%d.y_src" % v: ys,
+                    "v%d.mask" % v: m, "v%d.depth_masked" % v: dm})
+    final, avg = ref_filter.filter_depth(depths.copy(), rpc, 1.0, 2.5, 2, prob=prob, confidence_ratio=0.3)
+    final0, avg0 = ref_filter.filter_depth(depths.copy(), rpc, 1.0, 2.5, 1)
+    out.update({"final_mask": final, "averaged": avg, "final_mask_noprob": final0, "averaged_noprob": avg0})
+    save("filter", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (gen_iccv, gen_project, gen_grid_sample, gen_rpc_warp, gen_qc, gen_homo, gen_costvol, gen_pred,
-               gen_regress, gen_depth_range, gen_ucs_samples, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad, gen_io):
+               gen_regress, gen_depth_range, gen_ucs_samples, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad, gen_io, gen_filter):
         if only and fn.__name__[4:] not in only:
             continue
         fn()

@@ -1,47 +1,60 @@
 """Geometric-consistency filter (/root/reference/tools/rpc_filter.py:11-112).
 
-Pin status: the projector halves are pinned by tests/golden/rpc_project.npz; cv2.remap is NOT (cv2 and cupy are absent
-from the build image, so tools/rpc_filter.py cannot be imported): the oracle restates OpenCV's published fixed-point
-bilinear remap (oracle/oracle.py::remap_linear_const) and these tests check (CPU) that the oracle behaves like the
-reference's docstring promises on a consistent scene, and (GPU) that the kernel equals the oracle."""
+Pin status: tests/golden/filter.npz holds the outputs of the reference's OWN rpc_filter.py (reproject_with_depth,
+check_geometric_consistency, filter_depth) on top of its own cupy projector rpc_tensor.py, run unmodified by
+tests/golden/gen_golden.py::gen_filter with two import-time stand-ins for modules the image lacks: cupy -> numpy, and
+cv2.remap -> the oracle's restatement of OpenCV's published fixed-point bilinear remap.  So the projector halves, the
+control flow, the thresholds, the masking and the averaging are pinned by a reference run; cv2.remap itself is the one
+step that is not (opencv-python 4.5.5.62 is absent here).  CPU: oracle vs that fixture.  GPU: kernel vs that fixture.
+
+Tolerances: float64 coordinates 1e-8 px (the reference contracts quaternary-cubic tensors, the oracle and the kernel sum
+20 products / run Horner chains); the remap rounds coordinates to 1/32 px, so a coordinate within 1e-8 px of a rounding
+boundary may pick the neighbouring fraction: <= 1e-3 of the pixels may differ there, the rest agree to 1e-4 m."""
 import numpy as np
 import pytest
 import torch
 
 
-def _scene(H=96, W=160, V=3, seed=0):
-    """V consistent height maps of one smooth surface, one per view, through our RPC synthesiser (inputs only)."""
-    from satmvs_amd import rpc_synth
-    rpc = rpc_synth.make_view_rpcs(V, H, W, seed=seed)
-    lat0, lon0, ls, os_ = rpc[0][2], rpc[0][3], rpc[0][7], rpc[0][8]
-
-    def surface(lat, lon):
-        u, v = (lat - lat0) / ls, (lon - lon0) / os_
-        return 200.0 + 30.0 * np.sin(2.3 * u + 0.2) * np.cos(1.9 * v - 0.4)
-    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
-    depths = []
-    for v in range(V):
-        h = np.full((H, W), 200.0)
-        for _ in range(12):
-            lat, lon = rpc_synth.photo2obj(rpc[v], xx.ravel(), yy.ravel(), h.ravel())
-            h = surface(lat, lon).reshape(H, W)
-        depths.append(h.astype(np.float32))
-    return np.stack(depths), rpc
+def _check_pair(g, v, dep, xb, yb, xs, ys, m, dm):
+    np.testing.assert_allclose(xs, g["v%d.x_src" % v], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(ys, g["v%d.y_src" % v], rtol=0, atol=1e-8)
+    want = g["v%d.sampled" % v]
+    assert dep.dtype == want.dtype and dep.shape == want.shape
+    close = np.abs(dep - want) <= 1e-4
+    assert close.mean() >= 0.999
+    ok = close & (want > -900)
+    np.testing.assert_allclose(xb[ok], g["v%d.x_back" % v][ok], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(yb[ok], g["v%d.y_back" % v][ok], rtol=0, atol=1e-6)
+    wm = g["v%d.mask" % v]
+    assert m.dtype == wm.dtype and (m != wm).mean() <= 1e-3
+    same = m == wm
+    np.testing.assert_allclose(dm[same], g["v%d.depth_masked" % v][same], rtol=0, atol=1e-4)
+    assert (dm[~m] == 0).all()
 
 
-def test_oracle_filter_on_a_consistent_scene(oracle):
-    depths, rpc = _scene()
-    mask, dep, xs, ys = oracle.check_geometric_consistency(depths[0], rpc[0], depths[1], rpc[1], 1.0, 2.5)
-    inner = mask[8:-8, 16:-16]
-    assert inner.mean() > 0.99                                   # consistent maps reproject onto themselves
-    assert np.abs(dep[mask] - depths[0][mask]).max() < 0.5
-    bad = depths.copy()
-    bad[1] += 10.0                                               # a 10 m blunder in the source map fails the 2.5 m test
-    m2, d2, _, _ = oracle.check_geometric_consistency(bad[0], rpc[0], bad[1], rpc[1], 1.0, 2.5)
-    assert m2.mean() < 0.01 and (d2[~m2] == 0).all()
-    final, avg = oracle.filter_depth(depths, rpc, 1.0, 2.5, 2)
-    assert final[8:-8, 16:-16].mean() > 0.99 and np.abs(avg - depths[0])[final].max() < 0.5
-    # remap: integer coordinates return the pixel, the border value appears outside
+def _check_filter(g, fd):
+    depths, rpc, prob = g["depths"], g["rpc"], g["prob"]
+    p, d, n, c = float(g["p_ratio"]), float(g["d_ratio"]), int(g["geo_consist_num"]), float(g["confidence_ratio"])
+    for key_m, key_a, kw, nn in (("final_mask", "averaged", dict(prob=prob, confidence_ratio=c), n),
+                                 ("final_mask_noprob", "averaged_noprob", {}, 1)):
+        f, a = fd(depths, rpc, p, d, nn, **kw)
+        assert f.dtype == g[key_m].dtype and a.dtype == g[key_a].dtype
+        assert (f != g[key_m]).mean() <= 1e-3
+        np.testing.assert_allclose(a[f & g[key_m]], g[key_a][f & g[key_m]], rtol=0, atol=1e-3)
+    f, _ = fd(depths, rpc, p, d, n, prob=prob, confidence_ratio=c)
+    assert not f[10:20, 30:50].any() and not f[:8, :12].any() and f[30:50, 55:90].mean() > 0.5   # blunder and low confidence rejected
+
+
+def test_oracle_filter_vs_reference(oracle, golden):
+    g = golden("filter")
+    depths, rpc = g["depths"], g["rpc"]
+    for v in (1, 2):
+        dep, xb, yb, xs, ys = oracle.reproject_with_depth(depths[0], rpc[0], depths[v], rpc[v])
+        m, dm, xs2, ys2 = oracle.check_geometric_consistency(depths[0], rpc[0], depths[v], rpc[v], float(g["p_ratio"]), float(g["d_ratio"]))
+        assert np.array_equal(xs, xs2) and np.array_equal(ys, ys2)
+        _check_pair(g, v, dep, xb, yb, xs, ys, m, dm)
+    _check_filter(g, oracle.filter_depth)
+    # remap: integer coordinates return the pixel, the border value appears outside, halves interpolate
     img = np.arange(12, dtype=np.float32).reshape(3, 4)
     assert oracle.remap_linear_const(img, np.array([[1.0]]), np.array([[2.0]]))[0, 0] == img[2, 1]
     assert oracle.remap_linear_const(img, np.array([[-5.0]]), np.array([[0.0]]))[0, 0] == -999.0
@@ -49,32 +62,35 @@ def test_oracle_filter_on_a_consistent_scene(oracle):
 
 
 @pytest.mark.gpu
-def test_filter_kernel_matches_oracle(oracle):
+def test_filter_kernel_matches_reference(oracle, golden):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     from satmvs_amd import rpc_filter
-    depths, rpc = _scene(seed=3)
-    depths[2, 10:20, 30:50] += 8.0                               # an inconsistent patch in one source view
+    g = golden("filter")
+    depths, rpc = g["depths"], g["rpc"]
     for v in (1, 2):
-        dep_o, xb_o, yb_o, xs_o, ys_o = oracle.reproject_with_depth(depths[0], rpc[0], depths[v], rpc[v])
         dep, xb, yb, xs, ys = rpc_filter.reproject_with_depth(depths[0], rpc[0], depths[v], rpc[v])
-        np.testing.assert_allclose(xs, xs_o, rtol=0, atol=1e-8)
-        np.testing.assert_allclose(ys, ys_o, rtol=0, atol=1e-8)
-        # the remap rounds coordinates to 1/32 px: a coordinate within 1e-8 px of a rounding boundary may pick the
-        # neighbouring fraction -- allow 1e-3 of the pixels to differ there
-        close = np.abs(dep - dep_o) <= 1e-4
-        assert close.mean() >= 0.999
-        ok = close & (dep_o > -900)
-        np.testing.assert_allclose(xb[ok], xb_o[ok], rtol=0, atol=1e-6)
-        np.testing.assert_allclose(yb[ok], yb_o[ok], rtol=0, atol=1e-6)
-        m_o, d_o, _, _ = oracle.check_geometric_consistency(depths[0], rpc[0], depths[v], rpc[v], 1.0, 2.5)
-        m, d, _, _ = rpc_filter.check_geometric_consistency(depths[0], rpc[0], depths[v], rpc[v], 1.0, 2.5)
-        assert (m != m_o).mean() <= 1e-3
-        same = m == m_o
-        np.testing.assert_allclose(d[same], d_o[same], rtol=0, atol=1e-4)
-    f_o, a_o = oracle.filter_depth(depths, rpc, 1.0, 2.5, 2)
-    f, a = rpc_filter.filter_depth(depths, rpc, 1.0, 2.5, 2)
-    assert (f != f_o).mean() <= 1e-3 and a.dtype == a_o.dtype
-    same = f == f_o
-    np.testing.assert_allclose(a[same], a_o[same], rtol=0, atol=1e-3)
-    assert not f[10:20, 30:50].any() and f[30:60, 60:120].all()   # the blunder is rejected, the rest accepted
+        m, dm, xs2, ys2 = rpc_filter.check_geometric_consistency(depths[0], rpc[0], depths[v], rpc[v], float(g["p_ratio"]), float(g["d_ratio"]))
+        assert np.array_equal(xs, xs2) and np.array_equal(ys, ys2)
+        _check_pair(g, v, dep, xb, yb, xs, ys, m, dm)
+        # kernel == oracle on the same inputs, coordinate for coordinate
+        od, oxb, oyb, oxs, oys = oracle.reproject_with_depth(depths[0], rpc[0], depths[v], rpc[v])
+        np.testing.assert_allclose(xs, oxs, rtol=0, atol=1e-8)
+        assert (np.abs(dep - od) <= 1e-4).mean() >= 0.999
+    _check_filter(g, rpc_filter.filter_depth)
+
+
+@pytest.mark.gpu
+def test_reproject_returns_raw_samples_for_non_finite_heights(golden):
+    """rpc_filter.py:30-47 hands back cv2.remap's value untouched: NaN source heights / the -999 border must come through
+    reproject_with_depth, only check_geometric_consistency zeroes what fails the mask."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from satmvs_amd import rpc_filter
+    g = golden("filter")
+    depths, rpc = g["depths"].copy(), g["rpc"]
+    depths[1, 20:30, 40:60] = np.nan
+    dep, xb, yb, xs, ys = rpc_filter.reproject_with_depth(depths[0], rpc[0], depths[1], rpc[1])
+    assert np.isnan(dep).any() and (dep == -999.0).any() == (g["v1.sampled"] == -999.0).any()
+    m, dm, _, _ = rpc_filter.check_geometric_consistency(depths[0], rpc[0], depths[1], rpc[1], 1.0, 2.5)
+    assert not np.isnan(dm).any() and not m[np.isnan(dep)].any()

@@ -44,10 +44,18 @@ def _worker(rank, world, port, out_dir, recurrent):
         single = compute_depth_when_pred(feats, rpc, dv, dv.shape[1], reg, "rpc", False)
         shrd = shard.sharded_compute_depth_when_pred(feats, rpc, dv, dv.shape[1], reg, "rpc", False,
                                                      recurrent_handoff=recurrent)
+        # a later cascade stage: hypotheses arrive as a GeneratedHeights description (no (B,D,H,W) tensor), 6 planes
+        # 2.5 m apart around the height map the first call produced (the sharded path must take it)
+        from satmvs_amd.modules.depth_range import GeneratedHeights
+        h, w = feats[0].shape[2:]
+        gen = GeneratedHeights(single["depth"], 6, 2.5, (h, w), (h, w))
+        gsingle = compute_depth_when_pred(feats, rpc, gen, 6, reg, "rpc", False)
+        gshrd = shard.sharded_compute_depth_when_pred(feats, rpc, gen, 6, reg, "rpc", False, recurrent_handoff=recurrent)
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank),
              single_depth=single["depth"].cpu().numpy(), single_conf=single["photometric_confidence"].cpu().numpy(),
              depth=shrd["depth"].cpu().numpy(), conf=shrd["photometric_confidence"].cpu().numpy(),
+             gen_single=gsingle["depth"].cpu().numpy(), gen_depth=gshrd["depth"].cpu().numpy(),
              planes=np.array(shard.plane_range(dv.shape[1], rank, world)))
     dist.barrier()
     dist.destroy_process_group()
@@ -63,6 +71,8 @@ def test_sharded_red_pred_two_ranks_bit_identical(tmp_path):
         assert np.array_equal(r[k]["depth"], r[k]["single_depth"]), "rank %d depth differs from the single-GPU run" % k
         assert np.array_equal(r[k]["conf"], r[k]["single_conf"])
     assert np.array_equal(r[0]["depth"], r[1]["depth"]) and np.array_equal(r[0]["conf"], r[1]["conf"])
+    for k in range(2):                                      # generated (stage 2/3 style) hypotheses through the sharded path
+        assert np.array_equal(r[k]["gen_depth"], r[k]["gen_single"]), "rank %d: generated-heights stage differs" % k
     g = np.load(os.path.join(ROOT, "tests", "golden", "red_pred.npz"))
     assert np.abs(r[0]["depth"] - g["pred_depth"]).max() <= 1e-3          # and it is the reference's height map
 
@@ -74,5 +84,6 @@ def test_sharded_without_handoff_differs_only_by_the_recurrence(tmp_path):
         pytest.skip("needs an MI355X")
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), False), nprocs=2, join=True)
     r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(2)]
-    assert np.isfinite(r[0]["depth"]).all()
+    assert np.isfinite(r[0]["depth"]).all() and np.isfinite(r[0]["gen_depth"]).all()
     assert np.array_equal(r[0]["depth"], r[1]["depth"]) and np.array_equal(r[0]["conf"], r[1]["conf"])
+    assert np.array_equal(r[0]["gen_depth"], r[1]["gen_depth"])
