@@ -27,6 +27,8 @@ The JSON line also carries
                recorded on the launch stream, against the 8 TB/s HBM3E peak.
   cpu_baseline the CPU oracle (oracle/oracle.c, OpenMP, all host cores) timed on a bounded sample
                of the same workload -- a reported baseline only.
+  cpu_baseline_torch  the reference's torch device=cpu operator sequence (oracle/torch_composite.py) on a
+               bounded sample of planes of the same tile -- what north_star calls "the reference's CPU path".
 """
 import argparse
 import json
@@ -91,6 +93,29 @@ def cpu_baseline(V, C, D, H, W, budget_s=12.0):
             "kind": "port",
             "sample": "%d passes over the same %dx%dx%d tile (V=%d,C=%d) in %.1f s, oracle/oracle.c with OpenMP" % (
                 passes, W, H, D, V, C, dt)}
+
+
+def cpu_baseline_torch(V, C, D, H, W, budget_s=8.0):
+    """The reference's CPU (torch, device=cpu) path: its operator sequence as a stock-PyTorch composite
+    (oracle/torch_composite.py, bit-identical to the reference on the golden fixture), plane at a time like the pred
+    loop, on a bounded sample of planes of the same tile with all host cores."""
+    from oracle import torch_composite as tc
+    from satmvs_amd import rpc_synth
+    torch.set_num_threads(os.cpu_count() or 1)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    feats = [torch.randn((1, C, H, W), generator=g, dtype=torch.float32) for _ in range(V)]
+    rpc = torch.from_numpy(rpc_synth.make_view_rpcs(V, H, W, seed=0)[None])
+    depth = torch.linspace(0.0, 400.0, D, dtype=torch.float32).view(1, D, 1, 1).expand(1, D, H, W).contiguous()
+    tc.variance_planes(feats, rpc, depth, 0, 1)                                   # warm-up (thread pool, allocator)
+    planes, dt = 0, 0.0
+    t0 = time.perf_counter()
+    while dt < budget_s and planes < D:
+        tc.variance_planes(feats, rpc, depth, planes, planes + 1)
+        planes += 1
+        dt = time.perf_counter() - t0
+    return {"value": round(planes * H * W / dt / 1e6, 3), "unit": "Mvox/s", "cores": torch.get_num_threads(), "kind": "torch",
+            "sample": "%d of the %d planes of the same %dx%d tile (V=%d,C=%d), plane at a time, in %.1f s; "
+                      "oracle/torch_composite.py = the reference's torch operator sequence on device=cpu" % (planes, D, W, H, V, C, dt)}
 
 
 def kernel_source_hash():
@@ -172,6 +197,27 @@ def side_workloads(dev, stream):
         extra[name] = {"kernel": kernel_name(V, C, D), "ms": round(ms, 4), "Mvox/s": round(D * H * W / ms / 1e3, 1),
                        "roofline_frac": round(bpv * D * H * W / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         del feats, out
+    # cfg2 with per-pixel jittered hypotheses (SURVEY 8d's second height variant: what cascade stages 2-3 hand over --
+    # plane + N(0, 2 m) per pixel, wider tap boxes than plane-constant heights)
+    V, C, D, H, W = WORKLOADS["cfg2_rpc_3view_768x384x64_c32"]
+    feats, rpc, depth = make_inputs(V, C, D, D, 0, H, W, dev)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    depth = (depth.cpu() + 2.0 * torch.randn((1, D, H, W), generator=g)).contiguous().to(dev)
+    out = torch.empty((1, C, D, H, W), dtype=torch.float32, device=dev)
+    srcs = _lib.ptr_array(feats[1:])
+
+    def stepj():
+        _lib.call("smvs_rpc_costvol_fwd", _lib.ptr(feats[0]), srcs, V - 1, _lib.ptr(rpc), _lib.ptr(depth), 1,
+                  _lib.ptr(out), 1, C, D, H, W, 0, D, D, 0, stream)
+    for _ in range(10):
+        stepj()
+    _, ms = time_steps(stepj, 30)
+    bpv = algorithmic_bytes_per_voxel(V, C, D)
+    extra["cfg2_jittered_heights_768x384x64_c32"] = {
+        "kernel": kernel_name(V, C, D), "ms": round(ms, 4), "Mvox/s": round(D * H * W / ms / 1e3, 1),
+        "roofline_frac": round(bpv * D * H * W / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "note": "same tile, heights = plane + N(0, 2 m) per pixel"}
+    del feats, out, depth
     # cfg5: pinhole (homography) volume, 3-view 768x384x64, C=32
     V, C, D, H, W = 3, 32, 64, 384, 768
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -332,7 +378,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         _, ex_ms = time_steps(lambda: shard.allreduce_regression_state(state), 20, barrier)
-        exchange = {"op": "all_reduce(sum,sum,max) of (3,1,%d,%d) f64 regression partials, inside the timed step" % (H, W),
+        exchange = {"op": "one all_gather of the (3,1,%d,%d) f64 regression partials + rank-ordered local (sum,sum,max), inside the timed step" % (H, W),
                     "bytes": int(state.numel() * 8), "ms": round(ex_ms, 4)}
 
     cfg4 = None
@@ -371,6 +417,7 @@ def main():
                 line["extra"].update(side_workloads(dev, stream))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(V, C, D, H, W)
+            line["cpu_baseline_torch"] = cpu_baseline_torch(V, C, D, H, W)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -116,6 +116,58 @@ def sharded_compute_depth_when_pred(features, proj_matrices, depth_values, num_d
     return {"depth": depth, "photometric_confidence": confidence}
 
 
+def sharded_pred_stream(tiles, num_depth, cost_regularization, geo_model="rpc", use_qc=False, group=None):
+    """A STREAM of tiles through the plane-sharded RED pred path, pipelined over the ranks.
+
+    The recurrence over planes serialises the shards of ONE tile (rank g can only start when rank g-1 hands over the
+    hidden states and accumulators), so sharding a single tile buys memory, not latency.  Over a stream of tiles the
+    ranks form a pipeline instead: while rank g+1 continues tile t, rank g already runs its planes of tile t+1 --
+    rank g works on tile t-g at any moment, every GPU is busy once the pipe is full, and each tile's result is still the
+    single-GPU one bit for bit (same kernels, same plane order, float64 sums continued, never re-associated).
+    Hand-offs are non-blocking sends of fresh per-tile buffers; the finished accumulators stay on the last rank until
+    the end of the stream and are broadcast once.
+
+    tiles: iterable of (features, proj_matrices, depth_values) -- replicated on every rank, like
+    sharded_compute_depth_when_pred.  Returns one {"depth", "photometric_confidence"} dict per tile on every rank."""
+    from .modules.depth_range import GeneratedHeights
+    from .modules.module import StreamingRegression
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = plane_range(num_depth, rank, world)
+    native = None
+    finished, pending = [], []
+    for features, proj_matrices, depth_values in tiles:
+        ref = features[0]
+        b, _, h, w = ref.shape
+        if native is None:
+            native = hasattr(cost_regularization, "native_pred_planes") and cost_regularization._use_native(ref)
+            if not native:
+                raise RuntimeError("sharded_pred_stream drives the native RED plane pipeline (GPU tensors, no autograd)")
+        states = cost_regularization.initial_states(b, h, w, ref.device)          # fresh buffers: the previous tile's may still be in flight
+        acc = StreamingRegression(b, h, w, ref.device)
+        if rank > 0:
+            for s in states + [acc.state]:
+                _recv(s, _global_rank(group, rank - 1), group)
+        gen = isinstance(depth_values, GeneratedHeights)
+        dv = depth_values if gen else depth_values.detach().to(torch.float32).contiguous()
+        cost_regularization.native_pred_planes(features, proj_matrices, dv, geo_model, use_qc, states, acc.state, lo, hi)
+        if rank < world - 1:
+            for s in states + [acc.state]:
+                pending.append(_isend(s, _global_rank(group, rank + 1), group))
+        finished.append(acc)
+    for req, _keep in pending:
+        req.wait()
+    if world > 1:
+        for a in finished:                                                      # the last rank holds every finished sum
+            _broadcast(a.state, _global_rank(group, world - 1), group)
+    out = []
+    for a in finished:
+        depth, confidence = a.result()
+        out.append({"depth": depth, "photometric_confidence": confidence})
+    return out
+
+
 def _host_staged(t, group):
     """gloo moves only host memory point to point; RCCL ("nccl") takes device tensors as they are."""
     return t.is_cuda and dist.get_backend(group) == "gloo"
@@ -123,6 +175,21 @@ def _host_staged(t, group):
 
 def _send(t, dst, group):
     dist.send(t.cpu() if _host_staged(t, group) else t, dst=dst, group=group)
+
+
+def _isend(t, dst, group):
+    """Non-blocking send; returns (request, buffer kept alive until the request completes)."""
+    buf = t.cpu() if _host_staged(t, group) else t.contiguous()    # .cpu() waits for the producing kernels; RCCL orders itself behind the stream
+    return dist.isend(buf, dst=dst, group=group), buf
+
+
+def _broadcast(t, src, group):
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
 
 
 def _recv(t, src, group):

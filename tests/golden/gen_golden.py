@@ -605,6 +605,53 @@ def gen_featnet():
              s3=y["stage3"].numpy(), **arrays)
 
 
+def gen_train():
+    """One training step of the reference, train.py:267-302 without the optimiser: CascadeREDNet in train() mode
+    (BatchNorm on batch statistics, whole-volume RED regulariser, differentiable warp: networks/casred.py:22-62, :114-158)
+    -> cas_mvsnet_loss (networks/loss.py:5-25, dlossw 0.5/1/2 as in train.py's default) -> loss.backward().
+    Stored: the loss, the per-stage heights, d loss / d parameter in full for FeatureNet and for conv_gru1 of every
+    stage's regulariser, and a (sum, sum of squares) checksum of EVERY parameter gradient.  Inputs, seed and weights are
+    those of gen_cascade (the net is rebuilt from seed 17; the fixture carries the parameter checksums)."""
+    from networks.loss import cas_mvsnet_loss
+    B, V, H, W = 1, 3, 64, 128
+    nd = [16, 8, 8]
+    torch.manual_seed(16)
+    imgs = torch.randn(B, V, 3, H, W)
+    rpc_full = ref_rpcs(V, H, W, seed=51, batch=B)
+    proj = {"stage1": torch.from_numpy(rpc_synth.rescale_rpc(rpc_full, 4)),
+            "stage2": torch.from_numpy(rpc_synth.rescale_rpc(rpc_full, 2)),
+            "stage3": torch.from_numpy(rpc_full)}
+    dv = torch.tensor([[20.0, 380.0]])
+    gt, mask = {}, {}
+    for i, s in enumerate((4, 2, 1)):
+        h, w = H // s, W // s
+        yy, xx = torch.meshgrid(torch.linspace(0, 1, h), torch.linspace(0, 1, w), indexing="ij")
+        gt["stage%d" % (i + 1)] = (200.0 + 40.0 * torch.sin(3.0 * xx + 0.3) * torch.cos(2.0 * yy - 0.2)).unsqueeze(0)
+        m = torch.ones(1, h, w)
+        m[:, : h // 8, : w // 6] = 0.0
+        mask["stage%d" % (i + 1)] = m
+    torch.manual_seed(17)
+    net = ref_casred.CascadeREDNet("rpc", min_interval=2.5, ndepths=nd).train()
+    out = net(imgs, proj, dv)
+    loss, depth_loss = cas_mvsnet_loss(out, gt, mask, dlossw=[0.5, 1.0, 2.0])
+    loss.backward()
+    arrays = {"loss": loss.detach().numpy(), "depth_loss": depth_loss.detach().numpy(), "seed": np.int64(17), "ndepths": np.array(nd),
+              "dlossw": np.array([0.5, 1.0, 2.0])}
+    for s in ("stage1", "stage2", "stage3"):
+        arrays["gt." + s], arrays["mask." + s] = gt[s].numpy(), mask[s].numpy()
+        arrays["depth." + s] = out[s]["depth"].detach().numpy()
+    names, sums = [], []
+    for k, p_ in net.named_parameters():
+        assert p_.grad is not None, k
+        g_ = p_.grad
+        names.append(k)
+        sums.append([float(g_.double().sum()), float((g_.double() ** 2).sum())])
+        if k.startswith("feature.") or ".conv_gru1." in k:
+            arrays["grad." + k] = g_.numpy()
+    arrays["grad_names"], arrays["grad_sums"] = np.array(names), np.array(sums)
+    save("train_step", **arrays)
+
+
 def filter_scene(H=64, W=96, V=3, seed=3):
     """V consistent height maps of one smooth surface (one per view, through OUR synthesiser: inputs only), an 8 m
     blunder patch in the last view and a confidence map with a low-confidence corner."""
@@ -671,7 +718,7 @@ def gen_filter():
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (gen_iccv, gen_project, gen_grid_sample, gen_rpc_warp, gen_qc, gen_homo, gen_costvol, gen_pred,
-               gen_regress, gen_depth_range, gen_ucs_samples, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad, gen_io, gen_filter):
+               gen_regress, gen_depth_range, gen_ucs_samples, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad, gen_io, gen_filter, gen_train):
         if only and fn.__name__[4:] not in only:
             continue
         fn()

@@ -333,6 +333,53 @@ def test_training_step_runs_and_gradients_flow(dev, golden):
     assert np.isfinite(gnorm) and gnorm > 0
 
 
+def test_training_step_matches_reference(dev, golden):
+    """One training step against the reference's own (train.py:267-302 without the optimiser; fixture
+    tests/golden/train_step.npz = CascadeREDNet.train() -> cas_mvsnet_loss -> backward, run on the CPU by
+    gen_golden.py::gen_train): same seed => same weights, native cost-volume forward AND backward under the PyTorch
+    composites of FeatureNet / RED.  Loss within 1e-5 relative; every stored gradient (all of FeatureNet, conv_gru1 of
+    each stage's regulariser) within 2e-4 of its largest entry; the (sum, sum of squares) checksums of ALL 183
+    parameter gradients within 1e-3 relative -- float32 convolutions in another order, atomics in the scatter."""
+    import torch.nn.functional as F
+    from satmvs_amd.networks import casred
+    g, gc = golden("train_step"), golden("cascade")
+    nd = [int(v) for v in g["ndepths"]]
+    torch.manual_seed(int(g["seed"]))
+    net = casred.CascadeREDNet("rpc", min_interval=2.5, ndepths=nd)
+    sd = {k: v for k, v in net.state_dict().items() if "num_batches_tracked" not in k}
+    sums = np.array([[float(v.double().sum()), float((v.double() ** 2).sum())] for v in sd.values()])
+    np.testing.assert_allclose(sums, gc["red.param_sums"], rtol=1e-12, atol=1e-12)
+    net = net.to(dev).train()
+    imgs, proj, dv = _inputs(gc, dev)
+    out = net(imgs, proj, dv)
+    # cas_mvsnet_loss, networks/loss.py:5-25: smooth-L1 over the masked pixels of every stage, weighted
+    loss = torch.zeros((), device=dev)
+    for i, s in enumerate(("stage1", "stage2", "stage3")):
+        m = torch.from_numpy(g["mask." + s]).to(dev) > 0.5
+        loss = loss + float(g["dlossw"][i]) * F.smooth_l1_loss(out[s]["depth"][m], torch.from_numpy(g["gt." + s]).to(dev)[m],
+                                                               reduction="mean")
+        assert np.abs(out[s]["depth"].detach().cpu().numpy() - g["depth." + s]).max() <= H_TOL, s
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=1e-5)
+    grads = {k: p.grad for k, p in net.named_parameters()}
+    assert list(grads) == [str(n) for n in g["grad_names"]]
+    worst = 0.0
+    for k in g.files:
+        if not k.startswith("grad."):
+            continue
+        want, got = g[k], grads[k[5:]].detach().cpu().numpy()
+        scale = float(np.abs(want).max())
+        err = float(np.abs(got - want).max()) / max(scale, 1e-12)
+        worst = max(worst, err)
+        assert err <= 2e-4, "%s: %.3g of its largest entry" % (k, err)
+    # every parameter: gradient norm within 1e-3 (the bias of the last layer has a mathematically ZERO gradient -- softmax
+    # over planes is shift-invariant -- so pure round-off there is measured against the largest norm instead)
+    nmax = float(np.sqrt(g["grad_sums"][:, 1].max()))
+    for (name, (s1, s2)) in zip(g["grad_names"], g["grad_sums"]):
+        n = float(grads[str(name)].double().norm())
+        assert abs(n - np.sqrt(s2)) <= 1e-3 * np.sqrt(s2) + 1e-6 * nmax, name
+
+
 def test_native_modules_match_composites_at_ragged_shapes(dev):
     """FeatureNet / CostRegNet / RED native kernels vs the PyTorch composites of the same modules at sizes that are
     ragged against every tile (64-wide lanes, 32-wide MFMA tiles, 4-row workgroups), with batch > 1: tile-edge

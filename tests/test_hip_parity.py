@@ -104,8 +104,8 @@ def test_rpc_warping_golden(dev, golden, oracle, kind):
     g = golden("rpc_warp")
     out = warping.rpc_warping(_t(g["src_fea"], dev), _t(g["rpc"][:, 1], dev), _t(g["rpc"][:, 0], dev),
                               _t(g["depth" + kind], dev), None)
-    _close_f32(out, g["warped" + kind], frac=1e-3)
-    _close_f32(out, oracle.rpc_warping(g["src_fea"], g["rpc"][:, 1], g["rpc"][:, 0], g["depth" + kind]), frac=1e-3)
+    _close_f32(out, g["warped" + kind])
+    _close_f32(out, oracle.rpc_warping(g["src_fea"], g["rpc"][:, 1], g["rpc"][:, 0], g["depth" + kind]))
 
 
 def test_rpc_warping_enisum_golden(dev, golden):
@@ -122,7 +122,7 @@ def test_rpc_warping_enisum_golden(dev, golden):
         return d
 
     out = warping.rpc_warping_enisum(_t(g["src_fea"], dev), qc(g["rpc"][:, 1]), qc(g["rpc"][:, 0]), _t(g["depth4"], dev))
-    _close_f32(out, g["warped"], frac=1e-3)
+    _close_f32(out, g["warped"])
 
 
 @pytest.mark.parametrize("kind", ["4", "2"])
@@ -131,7 +131,7 @@ def test_homo_warping_golden(dev, golden, kind):
     g = golden("homo_warp")
     out = warping.homo_warping(_t(g["src_fea"], dev), _t(g["proj"][:, 1], dev), _t(g["proj"][:, 0], dev),
                                _t(g["depth" + kind], dev))
-    _close_f32(out, g["warped" + kind], frac=1e-3)
+    _close_f32(out, g["warped" + kind])
     comp = warping._compose_homography(_t(g["proj"][:, 1], dev), _t(g["proj"][:, 0], dev))
     np.testing.assert_allclose(comp.cpu().numpy(), g["composed"], rtol=1e-11, atol=1e-9)
 
@@ -141,9 +141,9 @@ def test_costvol_golden(dev, golden):
     g = golden("costvol")
     feats = [_t(f, dev) for f in g["feats"]]
     var = warping.variance_cost_volume(feats, _t(g["rpc"], dev), _t(g["depth"], dev), "rpc")
-    _close_f32(var, g["variance_rpc"], frac=1e-3)
+    _close_f32(var, g["variance_rpc"])
     varp = warping.variance_cost_volume(feats, _t(g["proj"], dev), _t(g["depth_pin"], dev), "pinhole")
-    _close_f32(varp, g["variance_pin"], frac=1e-3)
+    _close_f32(varp, g["variance_pin"])
 
 
 @pytest.mark.parametrize("cfg", [

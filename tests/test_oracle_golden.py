@@ -82,6 +82,19 @@ def test_costvol_variance_rpc(oracle, golden):
     _close_f32(var, g["variance_rpc"])
 
 
+def test_torch_composite_matches_reference(golden):
+    """oracle/torch_composite.py (the reference's operator sequence on device=cpu, timed by bench.py as the torch CPU
+    baseline) reproduces the reference's variance volume bit for bit -- same torch operators on the same dtypes."""
+    import torch
+    from oracle import torch_composite as tc
+    g = golden("costvol")
+    feats = [torch.from_numpy(f) for f in g["feats"]]
+    var = tc.variance_planes(feats, torch.from_numpy(g["rpc"]), torch.from_numpy(g["depth"]))
+    assert np.array_equal(var.numpy(), g["variance_rpc"])
+    part = tc.variance_planes(feats, torch.from_numpy(g["rpc"]), torch.from_numpy(g["depth"]), 2, 5)
+    assert np.array_equal(part.numpy(), g["variance_rpc"][:, :, 2:5])
+
+
 def test_costvol_variance_pinhole(oracle, golden):
     g = golden("costvol")
     var = oracle.costvol_variance(list(g["feats"]), g["proj"], g["depth_pin"], "pinhole")

@@ -87,3 +87,75 @@ def test_sharded_without_handoff_differs_only_by_the_recurrence(tmp_path):
     assert np.isfinite(r[0]["depth"]).all() and np.isfinite(r[0]["gen_depth"]).all()
     assert np.array_equal(r[0]["depth"], r[1]["depth"]) and np.array_equal(r[0]["conf"], r[1]["conf"])
     assert np.array_equal(r[0]["gen_depth"], r[1]["gen_depth"])
+
+
+def _stream_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    from satmvs_amd import shard
+    from satmvs_amd.modules.module import slice_RED_Regularization
+    from satmvs_amd.networks.casred import compute_depth_when_pred
+    g = np.load(os.path.join(ROOT, "tests", "golden", "red_pred.npz"))
+    reg = slice_RED_Regularization(8, 8).eval()
+    reg.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")})
+    reg = reg.to(dev)
+    rpc, dv = torch.from_numpy(g["rpc"]).to(dev), torch.from_numpy(g["depth"]).to(dev)
+    tiles = []
+    for t in range(4):                                      # four different tiles: features scaled / rolled, hypotheses shifted
+        feats = [torch.roll(torch.from_numpy(f).to(dev) * (1.0 + 0.25 * t), shifts=3 * t, dims=3) for f in g["feats"]]
+        tiles.append((feats, rpc, (dv + 1.5 * t).contiguous()))
+    D = dv.shape[1]
+    with torch.no_grad():
+        singles = [compute_depth_when_pred(f, r, d, D, reg, "rpc", False) for f, r, d in tiles]
+        outs = shard.sharded_pred_stream(tiles, D, reg, "rpc", False)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "stream%d.npz" % rank),
+             **{"single%d" % t: s["depth"].cpu().numpy() for t, s in enumerate(singles)},
+             **{"depth%d" % t: o["depth"].cpu().numpy() for t, o in enumerate(outs)},
+             **{"conf%d" % t: o["photometric_confidence"].cpu().numpy() for t, o in enumerate(outs)},
+             **{"sconf%d" % t: s["photometric_confidence"].cpu().numpy() for t, s in enumerate(singles)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_pipelined_stream_two_ranks_bit_identical(tmp_path):
+    """shard.sharded_pred_stream: 4 tiles through 2 ranks (rank 1 continues tile t while rank 0 already runs tile t+1);
+    every tile's height map and confidence equal the single-process ones bit for bit on both ranks."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    mp.spawn(_stream_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "stream%d.npz" % k)) for k in range(2)]
+    for k in range(2):
+        for t in range(4):
+            assert np.array_equal(r[k]["depth%d" % t], r[k]["single%d" % t]), "rank %d tile %d" % (k, t)
+            assert np.array_equal(r[k]["conf%d" % t], r[k]["sconf%d" % t]), "rank %d tile %d" % (k, t)
+    assert not np.array_equal(r[0]["depth0"], r[0]["depth1"])                   # the tiles really differ
+
+
+def test_bench_two_rank_rehearsal_on_one_device(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), both ranks on cuda:0
+    with the gloo rendezvous: the strong-scaling step (plane shard + slab exchange inside the timed region, cfg2 and
+    cfg4) runs end to end and prints its JSON line.  Not a measurement -- the N>1 numbers come from the driver's 8-GPU
+    node -- but the code path the SCALE run takes is executed on every GPU test run."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    env = dict(os.environ, SMVS_BENCH_ONE_DEVICE="1", SMVS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--prewarm-seconds", "0.05"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["planes_per_gpu"] == 32 and line["scaling"] == "strong"
+    assert line["exchange"]["bytes"] == 3 * 384 * 768 * 8 and line["exchange"]["ms"] > 0
+    assert line["extra"]["cfg4_strong_scaling"]["planes_per_gpu"] == 32
+    assert line["value"] > 0 and "cpu_baseline" not in line

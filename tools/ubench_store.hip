@@ -95,7 +95,7 @@ int main()
     run<1, 64, 1, 1, 2, 0>("64x1 wave, 4 waves in x, dword, nt", out);
     run<2, 32, 2, 0, 2, 0>("64x2 wave (2 px/lane), 4 waves in y, dwordx2, nt", out);
     run<2, 64, 1, 0, 2, 0>("128x1 wave (2 px/lane), 4 waves in y, dwordx2, nt", out);
-    run<2, 64, 1, 1, 2, 0>("128x1 wave (2 px/lane), 4 waves in x, dwordx2, nt", out);
+    // (128x1 waves side by side in x would need W % 512 == 0; at W = 768 that variant skips a third of the volume)
     run<4, 32, 2, 0, 2, 0>("128x2 wave (4 px/lane), 4 waves in y, dwordx4, nt", out);
     run<4, 64, 1, 0, 2, 0>("256x1 wave (4 px/lane), 4 waves in y, dwordx4, nt", out);
     run<4, 16, 4, 0, 2, 0>("64x4 wave (4 px/lane), 4 waves in y, dwordx4, nt", out);
