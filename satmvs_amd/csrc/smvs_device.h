@@ -578,6 +578,7 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p)
 struct Tap {
     uint32_t o_nw, o_ne, o_sw, o_se;   // byte offsets inside one H*W plane, or SMVS_OOB (tap dropped)
     float nw, ne, sw, se;
+    int x0, y0;                        // north-west cell, -1 .. W-1 / -1 .. H-1 (0 where that axis is out of reach)
 };
 
 // Normalised grid coordinate -> tap.  fx = W/2, fy = H/2 (exact in float32).
@@ -597,6 +598,7 @@ __device__ __forceinline__ Tap tap_from_grid(float gx, float gy, int H, int W)
     const int x0 = (xin0 || xin1) ? (int)xw : 0;
     const int y0 = (yin0 || yin1) ? (int)yn : 0;
     const int base = (y0 * W + x0) * 4;
+    t.x0 = x0; t.y0 = y0;
     t.o_nw = (xin0 && yin0) ? (uint32_t)base : SMVS_OOB;
     t.o_ne = (xin1 && yin0) ? (uint32_t)(base + 4) : SMVS_OOB;
     t.o_sw = (xin0 && yin1) ? (uint32_t)(base + 4 * W) : SMVS_OOB;
