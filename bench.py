@@ -101,7 +101,9 @@ def cpu_baseline_torch(V, C, D, H, W, budget_s=8.0):
     loop, on a bounded sample of planes of the same tile with all host cores."""
     from oracle import torch_composite as tc
     from satmvs_amd import rpc_synth
-    torch.set_num_threads(os.cpu_count() or 1)
+    # intra-op threads: the reference's small element-wise ops stop scaling early (GPU-box host, s per plane: 8-32 threads
+    # 0.30, 64 threads 0.52, 128 threads 1.0, 256 threads 34) -- time it where it is fastest
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     g = torch.Generator(device="cpu").manual_seed(0)
     feats = [torch.randn((1, C, H, W), generator=g, dtype=torch.float32) for _ in range(V)]
     rpc = torch.from_numpy(rpc_synth.make_view_rpcs(V, H, W, seed=0)[None])
