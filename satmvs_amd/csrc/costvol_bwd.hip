@@ -12,10 +12,12 @@
 // reductions BEFORE the atomics, none of which changes what is summed (only the order, like any atomic scatter):
 //   * a lane owns its pixel for a chunk of DCH planes: the reference gradient is summed over the chunk in a
 //     register -- one atomic per DCH planes;
-//   * neighbouring lanes of a wave (one image row) hit neighbouring cells: where lane i+1's north-west cell IS lane
-//     i's north-east cell (same source row, next column; decided once per tap, not per channel), lane i hands its two
-//     east contributions to lane i+1 over the DPP network (wave_shr:1) and lane i+1 folds them into its west ones:
-//     2 atomics per tap instead of 4 inside a run of such lanes;
+//   * neighbouring lanes of a wave (a PX x 64/PX patch of ref pixels) hit neighbouring cells: where the lane to the
+//     east has its north-west cell ON this lane's north-east cell (decided once per tap, not per channel), this lane
+//     hands its two east contributions over the DPP network (wave_shr:1) and the neighbour folds them into its west
+//     ones: 2 atomics per tap instead of 4 inside a run of such lanes.  (With PX < 64 a lane likewise hands its two
+//     south contributions to the lane one patch row below, ds_bpermute: one atomic per interior tap -- measured, no
+//     gain over the single-row patch, which ships);
 //   * consecutive planes of a lane whose taps fall into the SAME cell (small parallax per plane: cascade stages 2-3,
 //     coarse stage 1) are summed in registers and flushed when the cell changes.
 // Taps that touch the image border (some corner outside) keep the plain per-corner path; bits of the loss are
@@ -41,6 +43,11 @@ struct CostVolBwdParams {
     int xt, yt, dct, dch;
 };
 
+#ifndef SMVS_BWD_PX
+#define SMVS_BWD_PX 64                 // patch width of a wave: 64 = one image row (east hand-over only).  32 (32 x 2) and 16 (16 x 4) add the
+                                       // south hand-over: measured 9.35 / 11.2 ms against 9.33 ms at the metric shape (fewer atomics, but
+                                       // shorter row segments per gather and store), so the single row ships
+#endif
 constexpr uint32_t TAP_DROPPED = 0x80000000u;      // = SMVS_OOB: a load through it returns 0
 constexpr uint32_t TAP_PARTIAL = 0xC0000000u;      // | (y0+1) << 15 | (x0+1): some corner lies outside the image
 
@@ -52,25 +59,32 @@ __device__ __forceinline__ float dpp_from_prev_lane(float v)
 __device__ __forceinline__ uint32_t dpp_from_prev_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)TAP_DROPPED, (int)v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ uint32_t dpp_from_next_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
 
-template <int GEO, int NSRC, int DCH>
-__global__ __launch_bounds__(TILE_X * TILE_Y)
+__device__ __forceinline__ float lane_from(float v, int src_lane) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v))); }
+__device__ __forceinline__ uint32_t lane_from(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
+
+// PX = patch width of a wave (64: one image row; 32: 32 x 2; 16: 16 x 4); a workgroup of 4 waves covers 64 x 4 pixels
+template <int GEO, int NSRC, int DCH, int PX>
+__global__ __launch_bounds__(TILE_X * TILE_Y, 3)
 void costvol_bwd_kernel(const CostVolBwdParams p)
 {
     static_assert(DCH * NSRC <= 32, "tap flag masks");
+    constexpr int PY = 64 / PX;
     uint32_t L = xcd_remap(blockIdx.x, gridDim.x);
     const int xtile = L % p.xt; L /= p.xt;
     const int dchunk = L % p.dct; L /= p.dct;
     const int ytile = L % p.yt;
     const int b = L / p.yt;
-    const int lane = threadIdx.x;                           // a wave = 64 consecutive pixels of one image row
-    const int x = xtile * TILE_X + lane;
-    const int y = ytile * TILE_Y + threadIdx.y;
-    if (y >= p.H) return;                                   // wave-uniform
-    const bool active = x < p.W;
+    const int lane = threadIdx.x;                           // blockDim = (64, 4): threadIdx.y = wave
+    const int wv_ = threadIdx.y;
+    const int lx = lane % PX, ly = lane / PX;                // position inside the wave's PX x PY patch
+    const int x = xtile * TILE_X + (wv_ % (TILE_X / PX)) * PX + lx;
+    const int y = ytile * TILE_Y + (wv_ / (TILE_X / PX)) * PY + ly;
+    if (ytile * TILE_Y + (wv_ / (TILE_X / PX)) * PY >= p.H) return;      // whole wave below the image (wave-uniform)
+    const bool active = x < p.W && y < p.H;
 
     const int H = p.H, W = p.W, C = p.C, D = p.D;
     const int HW = H * W;
-    const int pix = y * W + min(x, W - 1);
+    const int pix = min(y, H - 1) * W + min(x, W - 1);
     const int d0 = dchunk * DCH, d1 = min(d0 + DCH, D);
     const float half_wm1 = (float)((W - 1) * 0.5), half_hm1 = (float)((H - 1) * 0.5);
     const float fV = (float)p.V, rV = __fdiv_rn(1.0f, fV), two_over_v = 2.0f / fV;
@@ -82,8 +96,9 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
     // ---- A: taps of the chunk's planes (float64 chain), once for all channels ------------------------------------
     uint32_t tb[DCH][NSRC];                                 // full tap: byte offset of its north-west cell | partial | dropped
     float tw[DCH][NSRC][4];                                 // nw, ne, sw, se
-    uint32_t take = 0, give = 0;                            // bit d*NSRC+s: fold the previous lane's east pair in / hand mine on
-    uint32_t any_partial = 0, any_take = 0;                 // wave-uniform: some lane of the wave has such a tap
+    uint32_t take = 0, give = 0;                            // bit d*NSRC+s: fold the west lane's east pair in / hand mine to the east lane
+    uint32_t take_n = 0, give_s = 0, north_east = 0;        // same towards south; north_east: the lane above still owned its east pair
+    uint32_t any_partial = 0, any_take = 0, any_take_n = 0; // wave-uniform: some lane of the wave has such a tap
     {
         const cgeo_t geo_b = as_cgeo((GEO == 0) ? p.geo + (size_t)b * p.V * RPC_LEN : p.geo + (size_t)b * (p.V - 1) * 16);
         RpcInv ref_n, src_n[NSRC];
@@ -92,7 +107,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) src_n[s] = rpc_inv_ground(geo_b + (size_t)(s + 1) * RPC_LEN);
         }
-        const double fx = (double)min(x, W - 1), fy = (double)y;
+        const double fx = (double)min(x, W - 1), fy = (double)min(y, H - 1);
 #pragma unroll
         for (int k = 0; k < DCH; ++k) {
             const int d = min(d0 + k, D - 1);
@@ -128,10 +143,21 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
                 const uint32_t bit = 1u << (k * NSRC + s);
                 const bool full = (e & TAP_DROPPED) == 0;
                 const uint32_t pe = dpp_from_prev_lane(e);
-                const bool tk = full && lane > 0 && (pe & TAP_DROPPED) == 0 && pe + 4u == e;
+                const bool tk = full && lx > 0 && (pe & TAP_DROPPED) == 0 && pe + 4u == e;
                 const uint32_t nt = dpp_from_next_lane(tk ? 1u : 0u);
+                const bool gv = lx < PX - 1 && nt;
                 if (tk) take |= bit;
-                if (lane < 63 && nt) give |= bit;
+                if (gv) give |= bit;
+                if (PY > 1) {
+                    const uint32_t ue = lane_from(e, lane - PX);                      // lanes of the first patch row read garbage: masked by ly > 0
+                    const bool tn = full && ly > 0 && (ue & TAP_DROPPED) == 0 && ue + 4u * (uint32_t)W == e;
+                    const uint32_t st = lane_from(tn ? 1u : 0u, lane + PX);
+                    const uint32_t uk = lane_from(gv ? 0u : 1u, lane - PX);
+                    if (tn) take_n |= bit;
+                    if (ly < PY - 1 && st) give_s |= bit;
+                    if (tn && uk) north_east |= bit;
+                    if (__builtin_amdgcn_ballot_w64(tn) != 0) any_take_n |= bit;
+                }
                 if (__builtin_amdgcn_ballot_w64((e & TAP_PARTIAL) == TAP_PARTIAL) != 0) any_partial |= bit;
                 if (__builtin_amdgcn_ballot_w64(tk) != 0) any_take |= bit;
                 __builtin_amdgcn_sched_barrier(0);          // one view at a time: its 80 coefficients leave the SGPRs before the next view's arrive
@@ -140,6 +166,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
     }
     any_partial = __builtin_amdgcn_readfirstlane(any_partial);
     any_take = __builtin_amdgcn_readfirstlane(any_take);
+    any_take_n = __builtin_amdgcn_readfirstlane(any_take_n);
 
     // ---- B: channels ---------------------------------------------------------------------------------------------
     const float* refp = p.ref + (size_t)b * C * HW + pix;
@@ -162,21 +189,22 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
         for (int k = 0; k < DCH; ++k)
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) asm volatile("" : "+v"(tb[k][s]));
-        asm volatile("" : "+v"(take), "+v"(give));
+        asm volatile("" : "+v"(take), "+v"(give), "+v"(take_n), "+v"(give_s), "+v"(north_east));
         const float r = refp[(size_t)c * HW];
         const int choff = c * HW * 4;
         float gref = 0.0f;
         uint32_t rkey[NSRC];                                // run of planes whose tap sits in the same cell: key + 4 sums
         float racc[NSRC][4];
-        bool reast[NSRC];                                   // the run's east pair was not handed to the next lane on every plane
+        bool live1[NSRC], live2[NSRC], live3[NSRC];         // the run still owns its north-east / south-west / south-east cell on some plane
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) { rkey[s] = TAP_DROPPED; racc[s][0] = racc[s][1] = racc[s][2] = racc[s][3] = 0.0f; reast[s] = false; }
+        for (int s = 0; s < NSRC; ++s) { rkey[s] = TAP_DROPPED; racc[s][0] = racc[s][1] = racc[s][2] = racc[s][3] = 0.0f; live1[s] = live2[s] = live3[s] = false; }
         auto flush = [&](int s) {
             if ((rkey[s] & TAP_DROPPED) == 0) {
                 float* q = p.grad_src[s] + ((size_t)b * C + c) * HW + (rkey[s] >> 2);
                 unsafeAtomicAdd(q, racc[s][0]);
-                unsafeAtomicAdd(q + W, racc[s][2]);
-                if (reast[s]) { unsafeAtomicAdd(q + 1, racc[s][1]); unsafeAtomicAdd(q + W + 1, racc[s][3]); }
+                if (live1[s]) unsafeAtomicAdd(q + 1, racc[s][1]);
+                if (live2[s]) unsafeAtomicAdd(q + W, racc[s][2]);
+                if (live3[s]) unsafeAtomicAdd(q + W + 1, racc[s][3]);
             }
         };
 #pragma unroll
@@ -213,18 +241,27 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
                 const uint32_t e = tb[k][s], bit = 1u << (k * NSRC + s);
                 const float gw = g * (wv[s] - m);
                 float c0 = gw * tw[k][s][0], c1 = gw * tw[k][s][1], c2 = gw * tw[k][s][2], c3 = gw * tw[k][s][3];
+                // contributions funnel EAST, then SOUTH (cells: east lane's NW/SW = my NE/SE; south lane's NW/NE = my SW/SE)
+                const bool ge = (give & bit) != 0, gs = PY > 1 && (give_s & bit) != 0;
                 if (any_take & bit) {                       // wave-uniform: somewhere in the wave an east pair moves one lane on
                     const float p1 = dpp_from_prev_lane(c1), p3 = dpp_from_prev_lane(c3);
                     if (take & bit) { c0 += p1; c2 += p3; }
                 }
-                const bool keep_east = (give & bit) == 0;
+                if (ge) { c1 = 0.0f; c3 = 0.0f; }
+                if (PY > 1 && (any_take_n & bit)) {         // wave-uniform: somewhere a south pair moves one patch row down
+                    const float n2 = lane_from(c2, lane - PX), n3 = lane_from(c3, lane - PX);
+                    if (take_n & bit) { c0 += n2; c1 += n3; }
+                }
+                if (gs) { c2 = 0.0f; c3 = 0.0f; }
                 if ((e & TAP_DROPPED) == 0) {               // full tap: extend the run or start a new one
                     if (e != rkey[s]) {
                         flush(s);
-                        rkey[s] = e; racc[s][0] = racc[s][1] = racc[s][2] = racc[s][3] = 0.0f; reast[s] = false;
+                        rkey[s] = e; racc[s][0] = racc[s][1] = racc[s][2] = racc[s][3] = 0.0f; live1[s] = live2[s] = live3[s] = false;
                     }
-                    racc[s][0] += c0; racc[s][2] += c2;
-                    if (keep_east) { racc[s][1] += c1; racc[s][3] += c3; reast[s] = true; }
+                    racc[s][0] += c0; racc[s][1] += c1; racc[s][2] += c2; racc[s][3] += c3;
+                    live1[s] = live1[s] || !ge || (north_east & bit) != 0;
+                    live2[s] = live2[s] || !gs;
+                    live3[s] = live3[s] || (!ge && !gs);
                 } else if ((e & TAP_PARTIAL) == TAP_PARTIAL) {
                     float* plane = p.grad_src[s] + ((size_t)b * C + c) * HW;
                     const float cc[4] = {c0, c1, c2, c3};
@@ -251,7 +288,7 @@ static hipError_t launch_bwd_n(CostVolBwdParams p, hipStream_t st)
     p.dct = (p.D + DCH - 1) / DCH;
     const long long nb = (long long)p.xt * p.yt * p.dct * p.B;
     if (nb >= (1ll << 31)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((costvol_bwd_kernel<GEO, NSRC, DCH>), dim3((unsigned)nb), dim3(TILE_X, TILE_Y), 0, st, p);
+    hipLaunchKernelGGL((costvol_bwd_kernel<GEO, NSRC, DCH, SMVS_BWD_PX>), dim3((unsigned)nb), dim3(TILE_X, TILE_Y), 0, st, p);
     return hipGetLastError();
 }
 
