@@ -169,10 +169,10 @@ def time_steps(step, steps, barrier=lambda: None):
 
 
 def kernel_name(V, C, planes=4):
-    direct = V - 1 > 4 or C not in (8, 16, 32)              # dispatch rule of costvol.hip (launch_ct)
+    direct = C not in (8, 16, 32)                           # dispatch rule of costvol.hip (launch_ct)
     if direct:
         return "costvol_fwd_kernel<rpc,%d,%d>" % (V - 1, C)
-    dp = 1 if planes == 1 else 2 if planes == 2 else 8 if (planes % 8 == 0 and V - 1 <= 2 and C == 32) else 4
+    dp = 1 if planes == 1 else 2 if (planes == 2 or V - 1 > 4) else 8 if (planes % 8 == 0 and V - 1 <= 2 and C == 32) else 4
     return "costvol_dma_kernel<rpc,%d,%d,%d>" % (V - 1, C, dp)
 
 

@@ -540,12 +540,15 @@ void costvol_dma_kernel(const CostVolParams p)
         auto dma_at = [&](int s, int j, uint32_t buf, uint32_t voff, int so) {
 #define SMVS_DMA_CASE(S, J) \
     case (S) * 8 + (J): dma_x4_to_lds_at<((S) * SRC_DW * 4 + (J) * 1024)>(rs[(S) < NSRC ? (S) : 0], buf, voff, so); break;
-            static_assert(NI <= 8 && NSRC <= 4, "instruction dispatch");
+            static_assert(NI <= 8 && NSRC <= 7, "instruction dispatch");
             switch (s * 8 + j) {
                 SMVS_DMA_CASE(0, 0) SMVS_DMA_CASE(0, 1) SMVS_DMA_CASE(0, 2) SMVS_DMA_CASE(0, 3) SMVS_DMA_CASE(0, 4) SMVS_DMA_CASE(0, 5) SMVS_DMA_CASE(0, 6) SMVS_DMA_CASE(0, 7)
                 SMVS_DMA_CASE(1, 0) SMVS_DMA_CASE(1, 1) SMVS_DMA_CASE(1, 2) SMVS_DMA_CASE(1, 3) SMVS_DMA_CASE(1, 4) SMVS_DMA_CASE(1, 5) SMVS_DMA_CASE(1, 6) SMVS_DMA_CASE(1, 7)
                 SMVS_DMA_CASE(2, 0) SMVS_DMA_CASE(2, 1) SMVS_DMA_CASE(2, 2) SMVS_DMA_CASE(2, 3) SMVS_DMA_CASE(2, 4) SMVS_DMA_CASE(2, 5) SMVS_DMA_CASE(2, 6) SMVS_DMA_CASE(2, 7)
                 SMVS_DMA_CASE(3, 0) SMVS_DMA_CASE(3, 1) SMVS_DMA_CASE(3, 2) SMVS_DMA_CASE(3, 3) SMVS_DMA_CASE(3, 4) SMVS_DMA_CASE(3, 5) SMVS_DMA_CASE(3, 6) SMVS_DMA_CASE(3, 7)
+                SMVS_DMA_CASE(4, 0) SMVS_DMA_CASE(4, 1) SMVS_DMA_CASE(4, 2) SMVS_DMA_CASE(4, 3) SMVS_DMA_CASE(4, 4) SMVS_DMA_CASE(4, 5) SMVS_DMA_CASE(4, 6) SMVS_DMA_CASE(4, 7)
+                SMVS_DMA_CASE(5, 0) SMVS_DMA_CASE(5, 1) SMVS_DMA_CASE(5, 2) SMVS_DMA_CASE(5, 3) SMVS_DMA_CASE(5, 4) SMVS_DMA_CASE(5, 5) SMVS_DMA_CASE(5, 6) SMVS_DMA_CASE(5, 7)
+                SMVS_DMA_CASE(6, 0) SMVS_DMA_CASE(6, 1) SMVS_DMA_CASE(6, 2) SMVS_DMA_CASE(6, 3) SMVS_DMA_CASE(6, 4) SMVS_DMA_CASE(6, 5) SMVS_DMA_CASE(6, 6) SMVS_DMA_CASE(6, 7)
                 default: break;
             }
 #undef SMVS_DMA_CASE
@@ -737,7 +740,7 @@ void costvol_dma_kernel(const CostVolParams p)
     }
 }
 
-// Kernel choice.  The staged kernel serves 2-5 views at C = 8/16/32 (one channel volume of the output < 2 GiB);
+// Kernel choice.  The staged kernel serves 2-8 views at C = 8/16/32 (one channel volume of the output < 2 GiB);
 // everything else (and SMVS_COSTVOL_DIRECT=1 in tuning builds) takes the direct-gather kernel.  Both produce
 // identical bits.  Planes per wave (DP): a whole sweep is cut into groups of 8 (2-3 views) or 4 planes (the taps of a
 // group live in registers; with 3-4 sources the LDS tiles allow two workgroups per CU, i.e. 256 VGPRs per lane), the
@@ -778,7 +781,7 @@ template <int GEO, int NSRC>
 static hipError_t launch_ct(CostVolParams p, hipStream_t st)
 {
     const int nd = p.d_end - p.d_begin;
-    if constexpr (NSRC <= 4) {
+    {
         // one channel volume of the output < 2 GiB: the store descriptor spans two of them (num_records is 32-bit)
         // and 2^31 is the offset that marks a dropped store; 2 <= W,H < 65535: packed tap coordinates and the
         // exact-division argument of div_half_int
@@ -786,7 +789,8 @@ static hipError_t launch_ct(CostVolParams p, hipStream_t st)
                                (long long)p.D_out * p.H * p.W * 4 < (1ll << 31);
         if (kernel_choice() != K_DIRECT && staged_ok) {
             if (nd == 1) return launch_staged<GEO, NSRC, 1>(p, st);
-            if (nd == 2) return launch_staged<GEO, NSRC, 2>(p, st);
+            // 6-8 views: 4 planes x 5-7 sources of tap state need more than 256 registers (one wave per SIMD) -> 2 planes per wave
+            if (nd == 2 || NSRC > 4) return launch_staged<GEO, NSRC, 2>(p, st);
             // 8 planes per wave when the sweep divides into eights (48 / 32 / 8 / 64-plane sweeps): half the staging DMA per
             // voxel and the ref view's plane-invariant part amortised over twice the planes outweigh the drop to two
             // waves per SIMD (223 VGPRs) -- measured 0.699 vs 0.717 ms at the metric shape; at C = 8 (float64-bound) and for the
@@ -794,7 +798,7 @@ static hipError_t launch_ct(CostVolParams p, hipStream_t st)
 #if SMVS_DP8
             if constexpr (NSRC <= 2 && GEO == 0) { if (nd % 8 == 0 && p.C == 32) return launch_staged<GEO, NSRC, 8>(p, st); }
 #endif
-            return launch_staged<GEO, NSRC, 4>(p, st);
+            if constexpr (NSRC <= 4) return launch_staged<GEO, NSRC, 4>(p, st);
         }
     }
     p.xt = (p.W + TILE_X - 1) / TILE_X;

@@ -155,6 +155,9 @@ def test_costvol_golden(dev, golden):
     dict(B=2, V=3, C=16, D=11, H=37, W=70, jitter=True),       # staged kernel: ragged tile, batch 2, odd plane count
     dict(B=1, V=2, C=32, D=6, H=20, W=40, jitter=False),       # staged kernel: one source, (B,D) heights
     dict(B=1, V=3, C=16, D=3, H=5, W=9, jitter=True),          # staged kernel: smaller than one wave patch
+    dict(B=1, V=6, C=16, D=5, H=40, W=72, jitter=True),        # staged kernel, 5 sources (2 planes per wave, odd plane count)
+    dict(B=2, V=7, C=32, D=4, H=24, W=66, jitter=False),       # staged kernel, 6 sources, batch 2, (B,D) heights, ragged width
+    dict(B=1, V=8, C=8, D=1, H=16, W=96, jitter=True),         # staged kernel, 7 sources, single plane
 ])
 def test_costvol_vs_oracle(dev, oracle, cfg):
     from satmvs_amd.modules import warping
