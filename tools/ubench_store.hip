@@ -79,12 +79,42 @@ static void run(const char* name, float* out)
     printf("%-58s %8.3f ms  %7.0f GB/s\n", name, ms, (double)C * D * H * W * 4 / ms / 1e6);
 }
 
-int main()
+// sustained mode: ubench_store <variant 0..4> <seconds> -- loops one variant so that power can be sampled beside it (tools/power_probe.sh)
+template <int PPL, int TXL, int TY, int WGX, int AUX, int ORDER>
+static void sustain(const char* name, float* out, double seconds)
+{
+    constexpr int TX = TXL * PPL;
+    constexpr int WX = WGX ? 4 : 1, WY = WGX ? 1 : 4;
+    const int nb = (W / (TX * WX)) * (H / (TY * WY)) * (D / DP);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    const int n = (int)(seconds / 0.42e-3);
+    hipEventRecord(a);
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL((store_kernel<PPL, TXL, TY, WGX, AUX, ORDER>), dim3(nb), dim3(256), 0, 0, out, 1.0f);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    printf("%-58s %8.3f ms per launch over %d launches\n", name, ms / n, n);
+}
+
+int main(int argc, char** argv)
 {
     setvbuf(stdout, NULL, _IONBF, 0);
     float* out;
     hipMalloc(&out, (size_t)C * D * H * W * 4);
     hipMemset(out, 0, (size_t)C * D * H * W * 4);
+    if (argc > 2) {
+        const double sec = atof(argv[2]);
+        switch (atoi(argv[1])) {
+        case 0: sustain<1, 32, 2, 0, 2, 0>("32x2 wave, 4 waves in y, dword, nt (kernel)", out, sec); break;
+        case 1: sustain<1, 64, 1, 1, 2, 0>("64x1 wave, 4 waves in x, dword, nt", out, sec); break;
+        case 2: sustain<4, 16, 4, 0, 2, 0>("64x4 wave (4 px/lane), 4 waves in y, dwordx4, nt", out, sec); break;
+        case 3: sustain<4, 64, 1, 0, 2, 0>("256x1 wave (4 px/lane), 4 waves in y, dwordx4, nt", out, sec); break;
+        default: sustain<1, 32, 2, 0, 0, 0>("32x2 wave, 4 waves in y, dword, default policy", out, sec); break;
+        }
+        return 0;
+    }
     //   PPL TXL TY WGX AUX ORDER
     run<1, 32, 2, 0, 2, 0>("32x2 wave, 4 waves in y, dword, nt   (current kernel)", out);
     run<1, 32, 2, 0, 0, 0>("32x2 wave, 4 waves in y, dword, default policy", out);
