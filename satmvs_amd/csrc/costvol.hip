@@ -259,6 +259,9 @@ constexpr int DM_NBUF = 2;
 #ifndef SMVS_WPS_DP8
 #define SMVS_WPS_DP8 2                // waves per SIMD the 8-plane instance is compiled for
 #endif
+#ifndef SMVS_DP8_MINC
+#define SMVS_DP8_MINC 32              // fewest channels for which a sweep that divides into eights takes 8 planes per wave
+#endif
 #ifndef SMVS_DP8_HOMO
 #define SMVS_DP8_HOMO 1               // 8 planes per wave for the homography variant too (round 3: 0.557 vs 0.583 ms at 768x384x64, C=32)
 #endif
@@ -799,7 +802,7 @@ static hipError_t launch_ct(CostVolParams p, hipStream_t st)
             // waves per SIMD (219 VGPRs) -- measured 0.699 vs 0.717 ms at the metric shape; at C = 8 (float64-bound) 4 planes per
             // wave stay faster (0.053 vs 0.061 ms)
 #if SMVS_DP8
-            if constexpr (NSRC <= 2 && (GEO == 0 || SMVS_DP8_HOMO)) { if (nd % 8 == 0 && p.C == 32) return launch_staged<GEO, NSRC, 8>(p, st); }
+            if constexpr (NSRC <= 2 && (GEO == 0 || SMVS_DP8_HOMO)) { if (nd % 8 == 0 && p.C >= SMVS_DP8_MINC) return launch_staged<GEO, NSRC, 8>(p, st); }
 #endif
             if constexpr (NSRC <= 4) return launch_staged<GEO, NSRC, 4>(p, st);
         }

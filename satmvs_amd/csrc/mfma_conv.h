@@ -45,6 +45,7 @@ struct MfmaConvArgs {
     int Cout, relu, stride;
     int Di, Hi, Wi, Do, Ho, Wo;              // 2-D: Di = Do = 1
     float scaleA;                            // multiplies the A-tensor inputs (-1 feeds -cost)
+    int ntiles;                              // tiles of 32 positions in the launch (KS < NW variants: decode / bound of the flat unit index)
 };
 
 // W pack kernel: src (Cout, Cin, TAPS) [conv] -> dst [cip][p][nt][h][32]
@@ -82,26 +83,38 @@ __device__ __forceinline__ unsigned long long mfma_now() { unsigned long long t 
 #define SMVS_MT(...)
 #endif
 
-// NT = cout tiles per workgroup (blockIdx.y walks the rest), NW = waves splitting K.
-// (bx, by) = the workgroup's grid coordinates; smem: (NW-1)*NT*16*64 floats.
-template <int TAPS, int NT, int NW>
+// NT = cout tiles per workgroup (blockIdx.y walks the rest), NW = waves per workgroup, KS = waves that split the K range of
+// one (tile, cout tile) unit and reduce through LDS.
+// KS = NW (default; latency regime: a few hundred tiles on 256 CUs): one unit per workgroup, (bx, by) = (tile, cout tile block).
+// KS < NW (throughput regime, round 3): NW/KS units per workgroup, unit = bx * NW/KS + wave / KS of a flat
+//   (cout tile block, tile) index.  With K split four ways a 32-channel layer of the full-resolution stage is 36 MFMAs per
+//   wave -- all prologue -- and three of four waves idle through the epilogue (MFMA pipe 20 % busy,
+//   profiles/r03_mfma_utilisation.txt); KS = 1 / 2 gives 144-288 MFMAs per wave at 4-5 resident waves per SIMD.
+// smem: (NW - NW/KS)*NT*16*64 floats.
+template <int TAPS, int NT, int NW, int KS = NW>
 __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, int by, float* smem)
 {
+    static_assert(NW % KS == 0, "waves per unit");
+    constexpr int TW = NW / KS;                            // units per workgroup
     constexpr int KD = TAPS == 27 ? 3 : 1;
     SMVS_MT(const unsigned long long mt0 = mfma_now(); unsigned long long mt1 = mt0;)
     float (*red)[NT * 16][64] = (float (*)[NT * 16][64])smem;   // partial accumulators of waves 1..NW-1
-    const int nt_all = (a.Cout + 31) / 32, nt0 = by * NT;
+    const int nt_all = (a.Cout + 31) / 32;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kw = KS == NW ? wave : wave % KS, tw = KS == NW ? 0 : wave / KS;   // K share, unit inside the workgroup
+    const int unit = bx * TW + tw;
+    const bool unit_ok = KS == NW || unit < a.ntiles * (nt_all / NT);          // the last workgroup may hold fewer units
+    const int nt0 = (KS == NW ? by : unit / a.ntiles) * NT;
     const int j = lane & 31, h = lane >> 5;
     // tile -> (b, od, oy, x0)
     const int xt = (a.Wo + 31) / 32;
-    int t = bx;
+    int t = KS == NW ? bx : unit % a.ntiles;
     const int x0 = (t % xt) * 32; t /= xt;
     const int oy = t % a.Ho; t /= a.Ho;
     const int od = t % a.Do;
     const int b = t / a.Do;
     const int ox = x0 + j;
-    const bool pos_ok = ox < a.Wo;
+    const bool pos_ok = unit_ok && ox < a.Wo;
     const int HWi = a.Hi * a.Wi;
     const size_t vol_i = (size_t)a.Di * HWi;
     const int Cin = a.CA + a.CB;
@@ -136,13 +149,13 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
     // no occupancy to hide latency with -- the prefetch is what keeps the matrix pipe fed.
     constexpr int BS = (TAPS == 27) ? 9 : 9;               // steps per batch (TAPS is a multiple of 9)
     constexpr int NB = TAPS / BS;                          // batches per channel pair
-    const int ncip = Cin / 2, per = ncip / NW;
+    const int ncip = Cin / 2, per = ncip / KS;
     const int q_end = per * NB;
     struct Batch { float x[BS]; float w[NT][BS]; float sx; };
     // explicit variants so that every off[] / register index is a compile-time constant
 #define SMVS_LOAD_BATCH(G, BT, Q)                                                                        \
     {                                                                                                    \
-        const int cip_ = wave * per + (Q) / NB;                                                          \
+        const int cip_ = kw * per + (Q) / NB;                                                            \
         const bool fromA_ = 2 * cip_ < a.CA;                      /* wave-uniform: scalar selects */    \
         const int choff_ = (int)((size_t)(fromA_ ? 2 * cip_ : 2 * cip_ - a.CA) * vol_i * 4);            \
         i32x4 rx_;                                                                                       \
@@ -212,7 +225,7 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
                                                                                     // as scratch and then has to wait for the load in flight
         Batch9 bb[NPF];
         auto load9 = [&](Batch9& B, int q) {
-            const int cip = wave * per + q;
+            const int cip = kw * per + q;
             const bool fromA = 2 * cip < a.CA;                      // wave-uniform: scalar selects
             const int choff = (int)((size_t)(fromA ? 2 * cip : 2 * cip - a.CA) * vol_i * 4);
             i32x4 rx;
@@ -269,20 +282,23 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
 
     // ---- split-K reduction through LDS: waves 1..3 publish, wave 0 sums and finishes -----------------
     SMVS_MT(asm volatile("s_nop 7\n s_nop 7" ::: "memory"); const unsigned long long mt2 = mfma_now();)
-    if (wave > 0) {
+    if (KS > 1) {
+        if (kw > 0) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[wave - 1][n * 16 + r][lane] = acc[n][r];
-    }
-    __syncthreads();
-    if (wave > 0) return;
+                for (int r = 0; r < 16; ++r) red[tw * (KS - 1) + kw - 1][n * 16 + r][lane] = acc[n][r];
+        }
+        __syncthreads();
+        if (kw > 0) return;
 #pragma unroll 1
-    for (int k = 0; k < NW - 1; ++k)         // one partial at a time: 16*NT loads in flight, not 16*NT*(NW-1)
+        for (int k = 0; k < KS - 1; ++k)     // one partial at a time: 16*NT loads in flight, not 16*NT*(KS-1)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][r] += red[k][n * 16 + r][lane];
+                for (int r = 0; r < 16; ++r) acc[n][r] += red[tw * (KS - 1) + k][n * 16 + r][lane];
+    }
+    if (!unit_ok) return;                    // (after the barrier) nothing to finish: the per-channel vectors below are indexed by the unit
 
     SMVS_MT(const unsigned long long mt3 = mfma_now();)
     // D layout of 32x32 MFMA: register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31
@@ -335,7 +351,7 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
             t1 += __shfl_xor(t1, m, 64); t2 += __shfl_xor(t2, m, 64);
         }
         if (lane == 0) {
-            const int slot = bx % a.nslot;
+            const int slot = (KS == NW ? bx : unit) % a.nslot;
             double* st = a.stats + (((size_t)b * a.ngroups + 0) * a.nslot + slot) * 2;
             atomicAdd(st, (double)s1);
             atomicAdd(st + 1, (double)s2);
@@ -355,12 +371,12 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
     })
 }
 
-template <int TAPS, int NT, int NW>
+template <int TAPS, int NT, int NW, int KS = NW>
 __global__ __launch_bounds__(NW * 64)
 void mfma_conv_kernel(const MfmaConvArgs a)
 {
-    __shared__ float smem[(NW - 1) * NT * 16 * 64];
-    mfma_conv_body<TAPS, NT, NW>(a, blockIdx.x, blockIdx.y, smem);
+    __shared__ float smem[KS > 1 ? (NW - NW / KS) * NT * 16 * 64 : 1];
+    mfma_conv_body<TAPS, NT, NW, KS>(a, blockIdx.x, blockIdx.y, smem);
 }
 
 // true if the MFMA kernel serves this layer

@@ -583,7 +583,9 @@ void conv_jobs_kernel(const ConvJobs J)
     const ConvJob& jb = J.j[l];
     bid -= jb.blk0;
     const int bx = bid % jb.gx, t = bid / jb.gx;
-    if (jb.kind == 2) mfma_conv_body<9, 1, 4>(jb.m, bx, t, smem);
+    if (jb.kind == 4) mfma_conv_body<9, 1, 4, 1>(jb.m, bid, 0, smem);        // MFMA, throughput regime: a (tile, cout tile) unit per wave
+    else if (jb.kind == 3) mfma_conv_body<9, 1, 4, 2>(jb.m, bid, 0, smem);   // two units per workgroup, K split in two
+    else if (jb.kind == 2) mfma_conv_body<9, 1, 4>(jb.m, bx, t, smem);
     else if (jb.kind == 1) conv3x3_body<1, true>(jb.a, bx, t % jb.gy, t / jb.gy, smem);
     else conv3x3_body<1, false>(jb.a, bx, t % jb.gy, t / jb.gy, smem);
 }
@@ -724,6 +726,15 @@ static bool g_red_direct_only()
     return tune_int("SMVS_CONV_DIRECT", 0) == 1;            // A/B switch (tuning builds): direct kernels only
 }
 
+#ifndef SMVS_MFMA_UNIT_WAVES
+#define SMVS_MFMA_UNIT_WAVES 1               // level-batched RED launches: unit-per-wave MFMA jobs in the throughput regime (0: round 2, A/B)
+#endif
+static int g_mfma_units(int which)
+{
+    static const int v1 = tune_int("SMVS_MFMA_UNITS_KS1", 1024), v2 = tune_int("SMVS_MFMA_UNITS_KS2", 512);
+    return which == 0 ? v1 : v2;                            // (tile, cout tile) units of a layer from which its MFMA job runs one / two waves per unit
+}
+
 static int g_split_below()
 {
     static const int v = tune_int("SMVS_CONV_SPLIT_BELOW", 512);
@@ -772,6 +783,13 @@ static int conv_job(ConvJob& j, const ConvArgs& a, int B, const float* wm, int b
     if (wm && !a.inA_cs && mfma_conv_ok(a.CA, a.CB, a.Cout) && !g_red_direct_only()) {
         j.kind = 2; j.m = mfma_args(1, a, wm);
         j.gx = ((a.Wo + 31) / 32) * a.Ho * B; j.gy = a.Cout / 32;
+        j.m.ntiles = j.gx;
+        // Many (tile, cout tile) units -- the levels of the full-resolution stage: a unit per wave (or per two waves) instead of
+        // per workgroup, so that a wave's K loop is long enough to stream (mfma_conv.h).  Chosen from the geometry of ONE
+        // sample: a plane's bits do not depend on batch, chunking or sharding.
+        const int units1 = ((a.Wo + 31) / 32) * a.Ho * j.gy;
+        if (SMVS_MFMA_UNIT_WAVES && units1 >= g_mfma_units(0)) { j.kind = 4; j.gx = (j.gx * j.gy + 3) / 4; return j.gx; }
+        if (SMVS_MFMA_UNIT_WAVES && units1 >= g_mfma_units(1)) { j.kind = 3; j.gx = (j.gx * j.gy + 1) / 2; return j.gx; }
         return j.gx * j.gy;
     }
     j.a = a;
