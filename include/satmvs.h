@@ -45,6 +45,14 @@ enum { SMVS_OK = 0, SMVS_ERR_ARG = 1, SMVS_ERR_LAUNCH = 2, SMVS_ERR_UNSUPPORTED 
 const char* smvs_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* smvs_last_error(void);
+/* The plane pipelines (smvs_red_pred_planes / smvs_red_volume_planes) normally fan out over two library-owned
+ * non-blocking helper streams joined to the caller's stream by events.  smvs_red_set_streams(0) keeps every launch
+ * of later calls on the caller's stream (slower, but legal inside hipStreamBeginCapture / hipGraph capture);
+ * any other value restores the default.  Process-wide, thread-safe; returns the previous setting (0 or 2). */
+int smvs_red_set_streams(int n);
+/* Releases what the library keeps between calls (the pooled helper streams and events of the plane pipelines).
+ * Call with no library work in flight, e.g. before unloading; later calls re-create what they need.  Returns SMVS_OK. */
+int smvs_shutdown(void);
 
 /* ---- height hypotheses generated inside the kernels ----------------------------
  * Stages 2 and 3 of the cascades derive their hypotheses from the previous stage's height map:

@@ -53,7 +53,7 @@ _SIZE_FUNCS = {"smvs_red_packed_floats": [_i], "smvs_red_workspace_bytes": [_i] 
                "smvs_red_pred_workspace_bytes": [_i] * 4, "smvs_costreg_packed_floats": [_i],
                "smvs_costreg_workspace_bytes": [_i] * 5, "smvs_featnet_packed_floats": [_i] * 2,
                "smvs_featnet_workspace_bytes": [_i] * 5}
-EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SIZE_FUNCS) + ["smvs_version", "smvs_last_error"])
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SIZE_FUNCS) + ["smvs_version", "smvs_last_error", "smvs_red_set_streams", "smvs_shutdown"])
 
 _lib = None
 
@@ -82,6 +82,10 @@ def load():
         fn.restype = C.c_size_t
     lib.smvs_version.restype = C.c_char_p
     lib.smvs_last_error.restype = C.c_char_p
+    lib.smvs_red_set_streams.argtypes = [_i]
+    lib.smvs_red_set_streams.restype = C.c_int
+    lib.smvs_shutdown.argtypes = []
+    lib.smvs_shutdown.restype = C.c_int
     _lib = lib
     return lib
 

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -870,7 +871,21 @@ struct RedPipeLease {
     }
     RedPipeLease(const RedPipeLease&) = delete;
     RedPipeLease& operator=(const RedPipeLease&) = delete;
+    static void release_all()                   // smvs_shutdown(): destroy every pooled set (none may be on lease)
+    {
+        std::lock_guard<std::mutex> g(mu());
+        for (int d = 0; d < 64; ++d) {
+            for (RedPipe* q : pool(d)) {
+                (void)hipStreamDestroy(q->rec); (void)hipStreamDestroy(q->dec);
+                for (int r = 0; r < RING; ++r) { (void)hipEventDestroy(q->enc[r]); (void)hipEventDestroy(q->state[r]); (void)hipEventDestroy(q->done[r]); }
+                delete q;
+            }
+            pool(d).clear();
+        }
+    }
 };
+
+static std::atomic<int> g_red_streams{2};     // smvs_red_set_streams(): 0 = caller's stream only (capture-safe)
 
 struct RedRun {
     const float* packed; float* state[4]; float* wsf; int B, C, H, W; hipStream_t main;
@@ -1050,7 +1065,7 @@ static int red_run_planes(const RedRun& r, int d_begin, int d_end)
     const int nplanes = d_end - d_begin;
     if (nplanes <= 0) return SMVS_OK;
     // one plane alone: the cross-stream hops cost more than they buy (measured) -> caller's stream only
-    const bool multi = nplanes > 1 && tune_int("SMVS_RED_STREAMS", 2) != 0;
+    const bool multi = nplanes > 1 && tune_int("SMVS_RED_STREAMS", 2) != 0 && g_red_streams.load(std::memory_order_relaxed) != 0;
     RedIssuer is(r, *pp, multi, d_begin, d_end);
     const RedPipe& P = *pp;
     if (r.pred && !r.reg_volume)
@@ -1099,6 +1114,10 @@ SMVS_EXPORT void smvs_debug_mfma_timing(unsigned long long* out)
     (void)hipMemcpyToSymbol(HIP_SYMBOL(smvs::smvs_mfma_timing), z, sizeof(z));
 }
 #endif
+
+SMVS_EXPORT int smvs_red_set_streams(int n) { return smvs::g_red_streams.exchange(n == 0 ? 0 : 2); }
+
+SMVS_EXPORT int smvs_shutdown(void) { smvs::RedPipeLease::release_all(); return SMVS_OK; }
 
 SMVS_EXPORT size_t smvs_red_packed_floats(int C) { return C > 0 ? smvs::red_layout(C).total : 0; }
 

@@ -304,6 +304,38 @@ def test_red_volume_pipeline_equals_per_plane_steps(dev, B, D):
     assert torch.equal(a, b)
 
 
+def test_single_stream_mode_graph_capture_and_shutdown(dev, golden):
+    """smvs_red_set_streams(0): the plane pipeline stays on the caller's stream -- same bits as the default three-stream
+    pipeline, and legal under stream capture (the whole pred loop of a stage recorded into one hipGraph and replayed).
+    smvs_shutdown() releases the pooled helper streams / events; the next call re-creates them."""
+    from satmvs_amd import _lib
+    from satmvs_amd.modules.module import slice_RED_Regularization
+    from satmvs_amd.networks.casred import compute_depth_when_pred
+    g = golden("red_pred")
+    reg, feats, rpc, dv = _red_pred_setup(g, dev, slice_RED_Regularization)
+    lib = _lib.load()
+    with torch.no_grad():
+        want = compute_depth_when_pred(feats, rpc, dv, dv.shape[1], reg, "rpc", False)
+        assert lib.smvs_red_set_streams(0) == 2
+        try:
+            got = compute_depth_when_pred(feats, rpc, dv, dv.shape[1], reg, "rpc", False)
+            assert torch.equal(got["depth"], want["depth"]) and torch.equal(got["photometric_confidence"], want["photometric_confidence"])
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    cap = compute_depth_when_pred(feats, rpc, dv, dv.shape[1], reg, "rpc", False)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(cap["depth"], want["depth"])
+        finally:
+            assert lib.smvs_red_set_streams(2) == 0
+        assert lib.smvs_shutdown() == 0
+        again = compute_depth_when_pred(feats, rpc, dv, dv.shape[1], reg, "rpc", False)
+    assert torch.equal(again["depth"], want["depth"])
+
+
 def test_sharded_pred_equals_unsharded_on_one_gpu(dev, golden):
     """satmvs_amd.shard with no process group (world 1) is the plain pred path, bit for bit."""
     from satmvs_amd import shard
