@@ -167,6 +167,26 @@ def test_costvol_vs_oracle(dev, oracle, cfg):
     _close_f32(got, want)
 
 
+def test_costvol_unaligned_feature_pointers(dev, oracle):
+    """Feature maps that are contiguous VIEWS at odd element offsets of a larger allocation (base pointers 4-byte but not
+    16-byte aligned) and a width that is not a multiple of 4: the 16-byte LDS-DMA chunks of the staged kernel are then
+    unaligned in memory everywhere.  Same bits as the oracle."""
+    from satmvs_amd.modules import warping
+    B, V, C, D, H, W = 1, 3, 16, 8, 40, 90
+    feats, rpc, depth = _inputs(B, V, C, D, H, W, seed=9, jitter=True)
+    views = []
+    for k, f in enumerate(feats):
+        big = torch.zeros(f.size + 7, dtype=torch.float32, device=dev)
+        off = 1 + 2 * k                                            # 4, 12, 20 bytes past a 256-byte aligned allocation
+        big[off:off + f.size] = _t(f, dev).reshape(-1)
+        v = big[off:off + f.size].view(B, C, H, W)
+        assert v.is_contiguous() and v.data_ptr() % 16 != 0
+        views.append(v)
+    want = oracle.costvol_variance(feats, rpc, depth, "rpc")
+    got = warping.variance_cost_volume(views, _t(rpc, dev), _t(depth, dev), "rpc")
+    _close_f32(got, want)
+
+
 def test_costvol_pinhole_vs_oracle(dev, oracle):
     from satmvs_amd.modules import warping
     feats, proj, depth = _inputs(1, 3, 16, 12, 48, 96, seed=4, geo="pinhole")

@@ -140,7 +140,10 @@ def test_height_hypotheses(oracle, golden):
     The sample arithmetic and the trilinear resize are reproduced bit for bit (r2: previous map given at image size;
     r1: stage-1 planes, every pixel of a plane equal).  The bilinear resize of the previous map is reproduced to
     1 ulp (6.2e-5 m at 256..512 m): ATen's CPU kernel contracts w0*v0 + w1*v1 differently between its vector body and
-    its scalar tail, so its own bits depend on the tensor shape; ours are fma(w0, v0, w1*v1) everywhere."""
+    its scalar tail, so its own bits depend on the tensor shape; ours are fma(w0, v0, w1*v1) everywhere -- the form a
+    contracting compiler gives the scalar expression `w0*v0 + w1*v1`.  Measured against torch 2.10 on a 40x77 output: that
+    form, fma(w1, v1, w0*v0) and the uncontracted sum reproduce 63 % / 65 % / 60 % of ATen's elements bit for bit, i.e.
+    no single contraction is "ATen's"; all three stay within 1 ulp of it, which is the bound asserted below."""
     g = golden("depth_range")
     _, H, W = g["cur"].shape
     assert np.array_equal(oracle.height_hypotheses(g["cur"], 6, 5.0, (H, W), (H // 2, W // 2)), g["r2"])
