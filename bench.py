@@ -380,7 +380,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         _, ex_ms = time_steps(lambda: shard.allreduce_regression_state(state), 20, barrier)
-        exchange = {"op": "one all_gather of the (3,1,%d,%d) f64 regression partials + rank-ordered local (sum,sum,max), inside the timed step" % (H, W),
+        exchange = {"op": "reduce-scatter (all_to_all of pixel chunks + rank-ordered local sum,sum,max) + all_gather of the (3,1,%d,%d) f64 regression partials, inside the timed step" % (H, W),
                     "bytes": int(state.numel() * 8), "ms": round(ex_ms, 4)}
 
     cfg4 = None

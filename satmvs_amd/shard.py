@@ -33,27 +33,37 @@ def plane_range(num_planes, rank, world):
 def allreduce_regression_state(state, group=None):
     """In-place reduction of the (3,B,H,W) float64 accumulators over the ranks: rows 0,1 summed, row 2 maxed.
 
-    ONE collective: the slabs are all-gathered (7 MB per rank at 768x384, 28 MB at 1536x768; on xGMI every rank sends
-    its slab straight to its 7 peers) and folded locally in rank order, so every rank computes the same bits and the
-    (sum, sum, max) pair of reductions costs one exchange instead of two ring all-reduces."""
+    A hand-rolled reduce-scatter + all-gather that carries all three rows at once: every rank sends pixel chunk r of its
+    slab to rank r (all_to_all: on xGMI seven direct point-to-point transfers in parallel, 7/8 of 7 MB out per rank at
+    768x384), folds the chunks it received in rank order (sum, sum, max -- the same association on every run, so the
+    result is deterministic and identical on all ranks), and the reduced chunks are all-gathered.  Two exchange phases of
+    optimal volume instead of the four of two ring all-reduces (round 2), no 8x-volume gather (an all-gather of whole
+    slabs moves 49 MB into every rank)."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return state
     if state.shape[0] != 3:
         raise ValueError("state must be (3,B,H,W): [exp_sum, depth_img, max_prob]")
     world = dist.get_world_size(group)
-    src = state.detach().contiguous()
-    staged = _host_staged(src, group)
+    staged = _host_staged(state, group)
+    flat = state.detach().reshape(3, -1)
     if staged:
-        src = src.cpu()
-    slabs = torch.empty((world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
-    dist.all_gather(list(slabs.unbind(0)), src, group=group)
-    if staged:
-        slabs = slabs.to(state.device)
-    total = slabs[0].clone()
-    for r in range(1, world):                              # rank order: identical association on every rank
-        total[:2] += slabs[r, :2]
-        torch.maximum(total[2], slabs[r, 2], out=total[2])
-    state.copy_(total)
+        flat = flat.cpu()
+    n = flat.shape[1]
+    chunk = (n + world - 1) // world
+    send = torch.zeros((world, 3, chunk), dtype=flat.dtype, device=flat.device)        # [destination rank][row][pixel of its chunk]
+    padded = torch.zeros((3, world * chunk), dtype=flat.dtype, device=flat.device)
+    padded[:, :n] = flat
+    send.copy_(padded.view(3, world, chunk).permute(1, 0, 2))
+    recv = torch.empty_like(send)                                                       # [source rank][row][pixel of MY chunk]
+    dist.all_to_all_single(recv, send, group=group)
+    mine = recv[0].clone()
+    for r in range(1, world):                              # rank order: identical association on every rank and run
+        mine[:2] += recv[r, :2]
+        torch.maximum(mine[2], recv[r, 2], out=mine[2])
+    gathered = torch.empty((world, 3, chunk), dtype=flat.dtype, device=flat.device)
+    dist.all_gather_into_tensor(gathered.view(-1), mine.reshape(-1), group=group)
+    out = gathered.permute(1, 0, 2).reshape(3, world * chunk)[:, :n]
+    state.copy_(out.reshape(state.shape).to(state.device))
     return state
 
 
