@@ -50,18 +50,18 @@ def allreduce_regression_state(state, group=None):
         flat = flat.cpu()
     n = flat.shape[1]
     chunk = (n + world - 1) // world
-    send = torch.zeros((world, 3, chunk), dtype=flat.dtype, device=flat.device)        # [destination rank][row][pixel of its chunk]
-    padded = torch.zeros((3, world * chunk), dtype=flat.dtype, device=flat.device)
-    padded[:, :n] = flat
-    send.copy_(padded.view(3, world, chunk).permute(1, 0, 2))
+    if n != world * chunk:                                 # ragged pixel count: pad the tail chunk (zeros are neutral for the sums; the
+        padded = torch.zeros((3, world * chunk), dtype=flat.dtype, device=flat.device)   # padded max entries are cut off again)
+        padded[:, :n] = flat
+        flat = padded
+    send = flat.view(3, world, chunk).permute(1, 0, 2).contiguous()                     # [destination rank][row][pixel of its chunk]
     recv = torch.empty_like(send)                                                       # [source rank][row][pixel of MY chunk]
     dist.all_to_all_single(recv, send, group=group)
-    mine = recv[0].clone()
-    for r in range(1, world):                              # rank order: identical association on every rank and run
-        mine[:2] += recv[r, :2]
-        torch.maximum(mine[2], recv[r, 2], out=mine[2])
+    mine = torch.empty((3, chunk), dtype=flat.dtype, device=flat.device)
+    torch.sum(recv[:, :2], dim=0, out=mine[:2])            # one kernel each; the same reduction order on every rank and run
+    torch.amax(recv[:, 2], dim=0, out=mine[2])
     gathered = torch.empty((world, 3, chunk), dtype=flat.dtype, device=flat.device)
-    dist.all_gather_into_tensor(gathered.view(-1), mine.reshape(-1), group=group)
+    dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)
     out = gathered.permute(1, 0, 2).reshape(3, world * chunk)[:, :n]
     state.copy_(out.reshape(state.shape).to(state.device))
     return state
