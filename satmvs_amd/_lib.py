@@ -82,10 +82,11 @@ def load():
         fn.restype = C.c_size_t
     lib.smvs_version.restype = C.c_char_p
     lib.smvs_last_error.restype = C.c_char_p
-    lib.smvs_red_set_streams.argtypes = [_i]
-    lib.smvs_red_set_streams.restype = C.c_int
-    lib.smvs_shutdown.argtypes = []
-    lib.smvs_shutdown.restype = C.c_int
+    if hasattr(lib, "smvs_red_set_streams"):               # (older A/B builds loaded through SMVS_LIB_PATH predate these two)
+        lib.smvs_red_set_streams.argtypes = [_i]
+        lib.smvs_red_set_streams.restype = C.c_int
+        lib.smvs_shutdown.argtypes = []
+        lib.smvs_shutdown.restype = C.c_int
     _lib = lib
     return lib
 
