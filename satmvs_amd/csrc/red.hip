@@ -592,7 +592,7 @@ void conv_jobs_kernel(const ConvJobs J)
 }
 
 struct GruJob {                              // the element-wise stages of one level
-    float* gates;                            // raw gate convolution (B,2HC,h,w); update half overwritten with u = sigmoid(GN(.))
+    const float* gates;                      // raw gate convolution (B,2HC,h,w): reset half read by the apply stage, update half by the combine stage
     const double *stats_g, *stats_o;         // [b][reset,update][NSLOT][2] ; [b][NSLOT][2]
     const float *rn_w, *rn_b, *un_w, *un_b, *on_w, *on_b;
     float* h;                                // hidden state (B,HC,h,w), updated in place by the combine stage
@@ -604,11 +604,12 @@ struct GruJob {                              // the element-wise stages of one l
 };
 struct GruJobs { GruJob j[4]; int n, B; };
 
-// gates raw -> rh = sigmoid(GN(r)) * h ; u (in place over the update half) = sigmoid(GN(u))
+// gates raw -> rh = sigmoid(GN(r)) * h.  (The update gate is normalised by the combine stage straight from the raw
+// convolution output: writing u here and reading it back there was 2 of this pass's 5 memory streams -- round 3.)
 __global__ __launch_bounds__(256)
 void gru_gate_apply_kernel(const GruJobs J)
 {
-    __shared__ float coef[2][2];
+    __shared__ float coef[2];
     int bid = blockIdx.x, l = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i)
@@ -628,25 +629,20 @@ void gru_gate_apply_kernel(const GruJobs J)
     const size_t j = valid ? jr : 0;
     const int c = (int)(j / HW), p = (int)(j % HW);
     const size_t i = (size_t)b * HC * HW + j;
-    float* gr = g.gates + ((size_t)b * 2 * HC + c) * HW + p;
-    float* gu = g.gates + ((size_t)b * 2 * HC + HC + c) * HW + p;
-    const float vr = *gr, vu = *gu, vh = g.h[i];
-    const float wr = g.rn_w[c], br = g.rn_b[c], wu = g.un_w[c], bu = g.un_b[c];
-    float mr, sr, mu, su;
-    gn_coeffs2(g.stats_g + ((size_t)b * 2 + 0) * NSLOT * 2, g.stats_g + ((size_t)b * 2 + 1) * NSLOT * 2, (double)HC * HW, 1e-5f,
-               mr, sr, mu, su, coef);
+    const float vr = g.gates[((size_t)b * 2 * HC + c) * HW + p], vh = g.h[i];
+    const float wr = g.rn_w[c], br = g.rn_b[c];
+    float mr, sr;
+    gn_coeffs(g.stats_g + ((size_t)b * 2 + 0) * NSLOT * 2, (double)HC * HW, 1e-5f, mr, sr, coef);
     if (!valid) return;
     const float r = sigmoidf_(fmaf((vr - mr) * sr, wr, br));
-    const float u = sigmoidf_(fmaf((vu - mu) * su, wu, bu));
     g.rh[i] = r * vh;
-    *gu = u;
 }
 
-// h' = u*h + (1-u)*tanh(GN(cand)); state <- h'; hsnap <- h'
+// u = sigmoid(GN(update gate)); h' = u*h + (1-u)*tanh(GN(cand)); state <- h'; hsnap <- h'
 __global__ __launch_bounds__(256)
 void gru_combine_kernel(const GruJobs J)
 {
-    __shared__ float coef[2];
+    __shared__ float coef[2][2];
     int bid = blockIdx.x, l = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i)
@@ -660,11 +656,12 @@ void gru_combine_kernel(const GruJobs J)
     const size_t j = valid ? jr : 0;
     const int c = (int)(j / HW), p = (int)(j % HW);
     const size_t i = (size_t)b * HC * HW + j;
-    const float vc = g.cand[i], u = g.gates[((size_t)b * 2 * HC + HC + c) * HW + p], vh = g.h[i];   // before the reduction: see the apply kernel
-    const float wo = g.on_w[c], bo = g.on_b[c];
-    float m, s;
-    gn_coeffs(g.stats_o + (size_t)b * NSLOT * 2, (double)HC * HW, 1e-5f, m, s, coef);
+    const float vc = g.cand[i], vu = g.gates[((size_t)b * 2 * HC + HC + c) * HW + p], vh = g.h[i];   // before the reduction: see the apply kernel
+    const float wu = g.un_w[c], bu = g.un_b[c], wo = g.on_w[c], bo = g.on_b[c];
+    float mu, su, m, s;
+    gn_coeffs2(g.stats_g + ((size_t)b * 2 + 1) * NSLOT * 2, g.stats_o + (size_t)b * NSLOT * 2, (double)HC * HW, 1e-5f, mu, su, m, s, coef);
     if (!valid) return;
+    const float u = sigmoidf_(fmaf((vu - mu) * su, wu, bu));
     const float y = tanhf(fmaf((vc - m) * s, wo, bo));
     const float hn = u * vh + (1.0f - u) * y;
     g.h[i] = hn;
