@@ -8,20 +8,29 @@
 // are scattered with hardware float32 atomics, like torch's grid_sampler backward.
 //
 // The scatter is bound by the L2's float atomics (~1 lane-atomic per clock per channel: 270 G/s); round 2 issued 9
-// per voxel-channel (1 for the reference gradient + 4 per source tap) = 20 ms at the 3-view 768x384x64 shape.  Three
-// reductions BEFORE the atomics, none of which changes what is summed (only the order, like any atomic scatter):
+// per voxel-channel (1 for the reference gradient + 4 per source tap) = 20 ms at the 3-view 768x384x64 shape.
+// Reductions BEFORE the L2 atomics, none of which changes what is summed (only the order, like any atomic scatter):
 //   * a lane owns its pixel for a chunk of DCH planes: the reference gradient is summed over the chunk in a
 //     register -- one atomic per DCH planes;
-//   * neighbouring lanes of a wave (a PX x 64/PX patch of ref pixels) hit neighbouring cells: where the lane to the
-//     east has its north-west cell ON this lane's north-east cell (decided once per tap, not per channel), this lane
-//     hands its two east contributions over the DPP network (wave_shr:1) and the neighbour folds them into its west
-//     ones: 2 atomics per tap instead of 4 inside a run of such lanes.  (With PX < 64 a lane likewise hands its two
-//     south contributions to the lane one patch row below, ds_bpermute: one atomic per interior tap -- measured, no
-//     gain over the single-row patch, which ships);
-//   * consecutive planes of a lane whose taps fall into the SAME cell (small parallax per plane: cascade stages 2-3,
-//     coarse stage 1) are summed in registers and flushed when the cell changes.
+//   * BOXED waves.  The taps of a wave's 32 x 2 pixels x DCH planes fall into a small box of each source view (the
+//     observation the forward's staging rests on).  When every view's box fits 64 x 8 cells the wave
+//       - stages the box of the NEXT channel of every view into LDS with b128 LDS-DMA while it works on this one
+//         (two buffers; no register, no wait on the way), and reads its taps from there (2 ds_read2_b32 per tap)
+//         instead of 4 gathers from memory;
+//       - keeps a PRIVATE gradient box per view in LDS, adds its 4 contributions per tap there and flushes the box
+//         once per channel: one L2 atomic per TOUCHED cell (~35 x 5) instead of 4 per tap (512 taps).  The flush
+//         reads and clears a cell in one ds_wrxchg; cells that stayed 0 send nothing; it is issued at the top of the
+//         NEXT channel so that the atomics drain under that channel's arithmetic.
+//     The gradient box is float64 because of the hardware, not the arithmetic: on gfx950 ds_add_f32 retires one
+//     lane every 3 clocks (192 clocks per wave instruction) while ds_add_f64 and the integer atomics take 6-8 clocks
+//     per instruction (tools/ubench_ldsatomic.hip, profiles/r03_ubench_ldsatomic.txt).  The box therefore sums in
+//     double -- more exact than any float32 order -- and is rounded to float32 once, when it is flushed;
+//   * waves where some view's box does not fit (large parallax per plane, strong rotation) keep the register scheme
+//     of the first half of round 3: where the lane to the east has its north-west cell ON this lane's north-east
+//     cell this lane hands its two east contributions over the DPP network (wave_shr:1), and consecutive planes of
+//     a lane whose taps fall into the SAME cell are summed in registers and flushed when the cell changes.
 // Taps that touch the image border (some corner outside) keep the plain per-corner path; bits of the loss are
-// unaffected, gradients differ from round 2 by float32 summation order only (tests: reference-captured gradients,
+// unaffected, gradients differ from round 2 by summation order only (tests: reference-captured gradients,
 // tests/golden/grad.npz and train_step.npz, and autograd of the torch composite).
 #include "smvs_device.h"
 #include "smvs_host.h"
@@ -29,7 +38,9 @@
 namespace smvs {
 
 constexpr int MAX_SRC = 7;
-constexpr int TILE_X = 64, TILE_Y = 4;
+constexpr int PX = 32, PY = 2;                     // patch of a wave: 32 x 2 pixels
+constexpr int BWD_WAVES = 2;                       // waves of a workgroup, side by side: 64 x 2 pixels (no workgroup barrier anywhere)
+constexpr int TILE_X = PX * BWD_WAVES, TILE_Y = PY;
 
 struct CostVolBwdParams {
     const float* grad_var;          // (B,C,D,H,W)
@@ -43,13 +54,24 @@ struct CostVolBwdParams {
     int xt, yt, dct, dch;
 };
 
-#ifndef SMVS_BWD_PX
-#define SMVS_BWD_PX 64                 // patch width of a wave: 64 = one image row (east hand-over only).  32 (32 x 2) and 16 (16 x 4) add the
-                                       // south hand-over: measured 9.35 / 11.2 ms against 9.33 ms at the metric shape (fewer atomics, but
-                                       // shorter row segments per gather and store), so the single row ships
+#ifndef SMVS_BWD_OCC
+#define SMVS_BWD_OCC 2                 // waves per SIMD the kernel is compiled for
 #endif
+#ifndef SMVS_BWD_ABLATE
+#define SMVS_BWD_ABLATE 0              // timing experiments only (wrong results): 1 no flush atomics, 2 no box adds, 4 no reference atomic
+#endif
+#ifndef SMVS_BWD_LDS
+#define SMVS_BWD_LDS 1                 // 0: never take the boxed path (A/B)
+#endif
+// one word per tap: 00 | y0 << 15 | x0 while the geometry runs, then the byte offset the tap's path wants
 constexpr uint32_t TAP_DROPPED = 0x80000000u;      // = SMVS_OOB: a load through it returns 0
 constexpr uint32_t TAP_PARTIAL = 0xC0000000u;      // | (y0+1) << 15 | (x0+1): some corner lies outside the image
+
+// boxes of one source view, per wave: BOX_H rows of 64 cells -- features float32 (two buffers), gradient float64
+constexpr int BOX_W = 64, BOX_H = 8, BOX_CELLS = BOX_H * BOX_W;
+constexpr int FBOX_BYTES = BOX_CELLS * 4, GBOX_BYTES = BOX_CELLS * 8;
+constexpr int BOX_MAX_SRC = 4;                     // per wave 8 KB per view: 32 KB per workgroup at 2 source views
+static_assert(BOX_W == 64 && BOX_H == 8, "DMA slot map and flush are written for 64 x 8");
 
 __device__ __forceinline__ float dpp_from_prev_lane(float v)
 {
@@ -59,31 +81,75 @@ __device__ __forceinline__ float dpp_from_prev_lane(float v)
 __device__ __forceinline__ uint32_t dpp_from_prev_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)TAP_DROPPED, (int)v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ uint32_t dpp_from_next_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
 
-__device__ __forceinline__ float lane_from(float v, int src_lane) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v))); }
-__device__ __forceinline__ uint32_t lane_from(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
+// north pair (nw, ne) and south pair (sw, se) of a tap out of a staged feature box (row pitch 64 dwords)
+__device__ __forceinline__ void fbox_read(uint32_t addr, f32x2& north, f32x2& south)
+{
+    asm volatile("ds_read2_b32 %0, %2 offset1:1\n\t"
+                 "ds_read2_b32 %1, %2 offset0:64 offset1:65"
+                 : "=&v"(north), "=&v"(south) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void fbox_wait(f32x2& north, f32x2& south)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(north), "+v"(south) :: "memory");
+}
+// the four corners of a full tap into the gradient box (LDS byte address of the north-west cell); no return value, in order per wave
+__device__ __forceinline__ void gbox_add4(uint32_t addr, float c0, float c1, float c2, float c3)
+{
+    const double d0 = (double)c0, d1 = (double)c1, d2 = (double)c2, d3 = (double)c3;
+    asm volatile("ds_add_f64 %0, %1\n\t"
+                 "ds_add_f64 %0, %2 offset:8\n\t"
+                 "ds_add_f64 %0, %3 offset:%5\n\t"
+                 "ds_add_f64 %0, %4 offset:%6"
+                 :: "v"(addr), "v"(d0), "v"(d1), "v"(d2), "v"(d3), "n"(BOX_W * 8), "n"(BOX_W * 8 + 8) : "memory");
+}
+// read and clear the lane's cell of each of the 8 box rows
+__device__ __forceinline__ void gbox_take8(uint32_t addr, float (&v)[BOX_H])
+{
+    const double zero = 0.0;
+    double d[BOX_H];
+    asm volatile("ds_wrxchg_rtn_b64 %0, %8, %9\n\t"
+                 "ds_wrxchg_rtn_b64 %1, %8, %9 offset:%10\n\t"
+                 "ds_wrxchg_rtn_b64 %2, %8, %9 offset:%11\n\t"
+                 "ds_wrxchg_rtn_b64 %3, %8, %9 offset:%12\n\t"
+                 "ds_wrxchg_rtn_b64 %4, %8, %9 offset:%13\n\t"
+                 "ds_wrxchg_rtn_b64 %5, %8, %9 offset:%14\n\t"
+                 "ds_wrxchg_rtn_b64 %6, %8, %9 offset:%15\n\t"
+                 "ds_wrxchg_rtn_b64 %7, %8, %9 offset:%16\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+                 : "v"(addr), "v"(zero), "n"(BOX_W * 8), "n"(BOX_W * 16), "n"(BOX_W * 24), "n"(BOX_W * 32),
+                   "n"(BOX_W * 40), "n"(BOX_W * 48), "n"(BOX_W * 56)
+                 : "memory");
+#pragma unroll
+    for (int i = 0; i < BOX_H; ++i) v[i] = (float)d[i];
+}
 
-// PX = patch width of a wave (64: one image row; 32: 32 x 2; 16: 16 x 4); a workgroup of 4 waves covers 64 x 4 pixels
-template <int GEO, int NSRC, int DCH, int PX>
-__global__ __launch_bounds__(TILE_X * TILE_Y, 3)
+template <int GEO, int NSRC, int DCH>
+__global__ __launch_bounds__(64 * BWD_WAVES, SMVS_BWD_OCC)
 void costvol_bwd_kernel(const CostVolBwdParams p)
 {
     static_assert(DCH * NSRC <= 32, "tap flag masks");
-    constexpr int PY = 64 / PX;
+    constexpr bool BOX = SMVS_BWD_LDS && NSRC <= BOX_MAX_SRC;
+    constexpr int WAVE_LDS = NSRC * (2 * FBOX_BYTES + GBOX_BYTES);          // [2 buffers][view] feature boxes, then [view] gradient boxes
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[BOX ? BWD_WAVES * WAVE_LDS : 16];
     uint32_t L = xcd_remap(blockIdx.x, gridDim.x);
     const int xtile = L % p.xt; L /= p.xt;
     const int dchunk = L % p.dct; L /= p.dct;
     const int ytile = L % p.yt;
     const int b = L / p.yt;
-    const int lane = threadIdx.x;                           // blockDim = (64, 4): threadIdx.y = wave
+    const int lane = threadIdx.x;                           // blockDim = (64, BWD_WAVES): threadIdx.y = wave
     const int wv_ = threadIdx.y;
-    const int lx = lane % PX, ly = lane / PX;                // position inside the wave's PX x PY patch
-    const int x = xtile * TILE_X + (wv_ % (TILE_X / PX)) * PX + lx;
-    const int y = ytile * TILE_Y + (wv_ / (TILE_X / PX)) * PY + ly;
-    if (ytile * TILE_Y + (wv_ / (TILE_X / PX)) * PY >= p.H) return;      // whole wave below the image (wave-uniform)
-    const bool active = x < p.W && y < p.H;
-
+    // The wave's pixels: a 32 x 2 patch (the two waves side by side) where the boxed path exists; kernels without it (more
+    // than 4 source views) take a 64 x 1 patch (the two waves one above the other): longer runs of east hand-overs and
+    // whole-row gathers (measured at the 3-view 768x384x64 shape with every wave on the register scheme: 9.3 ms against
+    // 11.9 ms on 32 x 2 -- which is what a wave pays whose boxes do not fit)
+    constexpr int pw = BOX ? PX : 64;
+    const int lx = lane % pw;
+    const int x = xtile * TILE_X + (BOX ? wv_ * PX : 0) + lx;
+    const int y = ytile * TILE_Y + (BOX ? lane / PX : wv_);
     const int H = p.H, W = p.W, C = p.C, D = p.D;
     const int HW = H * W;
+    const bool active = x < W && y < H;
     const int pix = min(y, H - 1) * W + min(x, W - 1);
     const int d0 = dchunk * DCH, d1 = min(d0 + DCH, D);
     const float half_wm1 = (float)((W - 1) * 0.5), half_hm1 = (float)((H - 1) * 0.5);
@@ -93,12 +159,21 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
 #pragma unroll
     for (int s = 0; s < NSRC; ++s) rs[s] = make_rsrc(p.src[s] + (size_t)b * C * HW, (uint32_t)C * (uint32_t)HW * 4u);
 
+    // the wave's gradient boxes start out clear; every flush leaves them clear again
+    const uint32_t wave_lds = BOX ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr(lds_all) + (uint32_t)(wv_ * WAVE_LDS))) : 0u;
+    const uint32_t gbox_lds = wave_lds + (uint32_t)(NSRC * 2 * FBOX_BYTES);
+    if (BOX) {
+        double* mine = (double*)(lds_all + wv_ * WAVE_LDS + NSRC * 2 * FBOX_BYTES);
+        for (int i = lane; i < NSRC * BOX_CELLS; i += 64) mine[i] = 0.0;
+    }
+
     // ---- A: taps of the chunk's planes (float64 chain), once for all channels ------------------------------------
-    uint32_t tb[DCH][NSRC];                                 // full tap: byte offset of its north-west cell | partial | dropped
-    float tw[DCH][NSRC][4];                                 // nw, ne, sw, se
+    uint32_t tt[DCH][NSRC];                                 // see TAP_*: full taps end up as a byte offset (boxed: inside the box; else: inside the plane)
+    float tf[DCH][NSRC][2];                                 // x and y fraction of the tap: the four weights are rebuilt per channel (2 registers instead of 4)
     uint32_t take = 0, give = 0;                            // bit d*NSRC+s: fold the west lane's east pair in / hand mine to the east lane
-    uint32_t take_n = 0, give_s = 0, north_east = 0;        // same towards south; north_east: the lane above still owned its east pair
-    uint32_t any_partial = 0, any_take = 0, any_take_n = 0; // wave-uniform: some lane of the wave has such a tap
+    uint32_t any_partial = 0, any_take = 0, any_hole = 0;   // wave-uniform: some lane of the wave has such a tap (hole: not a full tap)
+    bool boxed = BOX;                                       // wave-uniform: every view's box fits
+    int box_g0[NSRC];                                       // wave-uniform: element offset of the box's first cell inside an H x W plane
     {
         const cgeo_t geo_b = as_cgeo((GEO == 0) ? p.geo + (size_t)b * p.V * RPC_LEN : p.geo + (size_t)b * (p.V - 1) * 16);
         RpcInv ref_n, src_n[NSRC];
@@ -107,66 +182,115 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) src_n[s] = rpc_inv_ground(geo_b + (size_t)(s + 1) * RPC_LEN);
         }
+        int lo_x[NSRC], hi_x[NSRC], lo_y[NSRC], hi_y[NSRC];  // extent of the lane's full taps, per view
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) { lo_x[s] = lo_y[s] = 0x7fffffff; hi_x[s] = hi_y[s] = -0x7fffffff; }
         const double fx = (double)min(x, W - 1), fy = (double)min(y, H - 1);
+        // the forward's chain (costvol.hip): image -> ground with the plane-invariant part of the four cubics formed once per
+        // pixel, ground -> image for PQ planes per pass so that a view's coefficients are fetched once for all of them
+        constexpr int PQ = DCH < 4 ? DCH : 4;
+        static_assert(DCH % PQ == 0, "planes per pass");
+        float hf[DCH];
+        double lat[DCH], lon[DCH];
 #pragma unroll
         for (int k = 0; k < DCH; ++k) {
             const int d = min(d0 + k, D - 1);
-            const float hf = p.depth_is_4d ? p.depth[((size_t)b * D + d) * HW + pix] : p.depth[(size_t)b * D + d];
-            const double h = (double)hf;
+            hf[k] = p.depth_is_4d ? p.depth[((size_t)b * D + d) * HW + pix] : p.depth[(size_t)b * D + d];
+        }
+        if (GEO == 0) {
+            P2OPix px;
+            p2o_pixel(geo_b, ref_n, fx, fy, px);
+#pragma unroll
+            for (int k = 0; k < DCH; ++k) {
+                p2o_plane(launder(geo_b), ref_n, px, (double)hf[k], lat[k], lon[k]);
+                pin(lat[k]); pin(lon[k]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int pq = 0; pq < DCH; pq += PQ) {
             const cgeo_t geo_d = launder(geo_b);
-            double lat = 0.0, lon = 0.0;
-            if (GEO == 0) { rpc_photo2obj(geo_d, ref_n, fx, fy, h, lat, lon); pin(lat); pin(lon); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) {
-                Tap t;
+                Tap tq[PQ];
                 if (GEO == 0) {
-                    double samp, line;
-                    rpc_obj2photo(launder(geo_d) + (size_t)(s + 1) * RPC_LEN, src_n[s], lat, lon, h, samp, line);
-                    t = tap_from_pixel((float)samp, (float)line, H, W, half_wm1, half_hm1);
+                    double samp[PQ], line[PQ], hh[PQ];
+#pragma unroll
+                    for (int u = 0; u < PQ; ++u) hh[u] = (double)hf[pq + u];
+                    o2p_xn<PQ>(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat + pq, lon + pq, hh, samp, line);
+#pragma unroll
+                    for (int u = 0; u < PQ; ++u) tq[u] = tap_from_pixel((float)samp[u], (float)line[u], H, W, half_wm1, half_hm1);
                 } else {
                     const cgeo_t P = geo_d + s * 16;
-                    const double rx = fma(P[1], fy, P[0] * fx) + P[2];
-                    const double ry = fma(P[5], fy, P[4] * fx) + P[6];
-                    const double rz = fma(P[9], fy, P[8] * fx) + P[10];
-                    const double X = fma(rx, h, P[3]), Y = fma(ry, h, P[7]), Z = fma(rz, h, P[11]);
-                    t = tap_from_grid((float)((X / Z) / ((W - 1) * 0.5) - 1.0), (float)((Y / Z) / ((H - 1) * 0.5) - 1.0), H, W);
+#pragma unroll
+                    for (int u = 0; u < PQ; ++u) {
+                        const double h = (double)hf[pq + u];
+                        const double rx = fma(P[1], fy, P[0] * fx) + P[2];
+                        const double ry = fma(P[5], fy, P[4] * fx) + P[6];
+                        const double rz = fma(P[9], fy, P[8] * fx) + P[10];
+                        const double X = fma(rx, h, P[3]), Y = fma(ry, h, P[7]), Z = fma(rz, h, P[11]);
+                        tq[u] = tap_from_grid((float)((X / Z) / ((W - 1) * 0.5) - 1.0), (float)((Y / Z) / ((H - 1) * 0.5) - 1.0), H, W);
+                    }
                 }
-                tw[k][s][0] = t.nw; tw[k][s][1] = t.ne; tw[k][s][2] = t.sw; tw[k][s][3] = t.se;
-                const bool in = active && d0 + k < d1;
-                const bool v0 = t.o_nw != SMVS_OOB, v1 = t.o_ne != SMVS_OOB, v2 = t.o_sw != SMVS_OOB, v3 = t.o_se != SMVS_OOB;
-                uint32_t e = TAP_DROPPED;
-                if (in && v0 && v1 && v2 && v3) e = t.o_nw;
-                else if (in && (v0 || v1 || v2 || v3)) {
-                    e = TAP_PARTIAL | ((uint32_t)(t.y0 + 1) << 15) | (uint32_t)(t.x0 + 1);   // -1 <= y0 <= H-1, -1 <= x0 <= W-1
+#pragma unroll
+                for (int u = 0; u < PQ; ++u) {
+                    const int k = pq + u;
+                    const Tap& t = tq[u];
+                    tf[k][s][0] = t.fw; tf[k][s][1] = t.fn;
+                    const bool in = active && d0 + k < d1;
+                    const bool v0 = t.o_nw != SMVS_OOB, v1 = t.o_ne != SMVS_OOB, v2 = t.o_sw != SMVS_OOB, v3 = t.o_se != SMVS_OOB;
+                    uint32_t e = TAP_DROPPED;
+                    if (in && v0 && v1 && v2 && v3) e = ((uint32_t)t.y0 << 15) | (uint32_t)t.x0;            // 0 <= y0 <= H-2, 0 <= x0 <= W-2
+                    else if (in && (v0 || v1 || v2 || v3)) {
+                        e = TAP_PARTIAL | ((uint32_t)(t.y0 + 1) << 15) | (uint32_t)(t.x0 + 1);   // -1 <= y0 <= H-1, -1 <= x0 <= W-1
+                    }
+                    tt[k][s] = e;
+                    const uint32_t bit = 1u << (k * NSRC + s);
+                    const bool full = (e & TAP_DROPPED) == 0;
+                    if (full) {
+                        lo_x[s] = min(lo_x[s], t.x0); hi_x[s] = max(hi_x[s], t.x0);
+                        lo_y[s] = min(lo_y[s], t.y0); hi_y[s] = max(hi_y[s], t.y0);
+                    }
+                    const uint32_t pe = dpp_from_prev_lane(e);
+                    const bool tk = full && lx > 0 && (pe & TAP_DROPPED) == 0 && pe + 1u == e;     // same row, one cell to the west
+                    const uint32_t nt = dpp_from_next_lane(tk ? 1u : 0u);
+                    const bool gv = lx < pw - 1 && nt;
+                    if (tk) take |= bit;
+                    if (gv) give |= bit;
+                    if (__builtin_amdgcn_ballot_w64((e & TAP_PARTIAL) == TAP_PARTIAL) != 0) any_partial |= bit;
+                    if (__builtin_amdgcn_ballot_w64(!full) != 0) any_hole |= bit;
+                    if (__builtin_amdgcn_ballot_w64(tk) != 0) any_take |= bit;
                 }
-                tb[k][s] = e;
-                const uint32_t bit = 1u << (k * NSRC + s);
-                const bool full = (e & TAP_DROPPED) == 0;
-                const uint32_t pe = dpp_from_prev_lane(e);
-                const bool tk = full && lx > 0 && (pe & TAP_DROPPED) == 0 && pe + 4u == e;
-                const uint32_t nt = dpp_from_next_lane(tk ? 1u : 0u);
-                const bool gv = lx < PX - 1 && nt;
-                if (tk) take |= bit;
-                if (gv) give |= bit;
-                if (PY > 1) {
-                    const uint32_t ue = lane_from(e, lane - PX);                      // lanes of the first patch row read garbage: masked by ly > 0
-                    const bool tn = full && ly > 0 && (ue & TAP_DROPPED) == 0 && ue + 4u * (uint32_t)W == e;
-                    const uint32_t st = lane_from(tn ? 1u : 0u, lane + PX);
-                    const uint32_t uk = lane_from(gv ? 0u : 1u, lane - PX);
-                    if (tn) take_n |= bit;
-                    if (ly < PY - 1 && st) give_s |= bit;
-                    if (tn && uk) north_east |= bit;
-                    if (__builtin_amdgcn_ballot_w64(tn) != 0) any_take_n |= bit;
-                }
-                if (__builtin_amdgcn_ballot_w64((e & TAP_PARTIAL) == TAP_PARTIAL) != 0) any_partial |= bit;
-                if (__builtin_amdgcn_ballot_w64(tk) != 0) any_take |= bit;
                 __builtin_amdgcn_sched_barrier(0);          // one view at a time: its 80 coefficients leave the SGPRs before the next view's arrive
+            }
+        }
+        // does every view's box fit?  (extent of the north-west cells + 1 in both directions; a view without a full tap needs none)
+        int org_x[NSRC], org_y[NSRC];
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) {
+            int ax = lo_x[s], bx = hi_x[s], ay = lo_y[s], by = hi_y[s];
+            if (BOX) wave_minmax4(ax, bx, ay, by);
+            const bool none = bx < ax;
+            if (none) { ax = 0; ay = 0; }
+            else if (bx - ax + 2 > BOX_W || by - ay + 2 > BOX_H) boxed = false;
+            org_x[s] = ax; org_y[s] = ay;
+        }
+        // full taps: packed cell -> byte offset inside the box (boxed) or inside the H x W plane
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) {
+            box_g0[s] = boxed ? org_y[s] * W + org_x[s] : 0;
+            const int pitch = boxed ? BOX_W : W;
+            const int org = boxed ? org_y[s] * BOX_W + org_x[s] : 0;
+#pragma unroll
+            for (int k = 0; k < DCH; ++k) {
+                const uint32_t e = tt[k][s];
+                if ((e & TAP_DROPPED) == 0) tt[k][s] = (uint32_t)(((int)(e >> 15) * pitch + (int)(e & 0x7fffu) - org) * 4);
             }
         }
     }
     any_partial = __builtin_amdgcn_readfirstlane(any_partial);
     any_take = __builtin_amdgcn_readfirstlane(any_take);
-    any_take_n = __builtin_amdgcn_readfirstlane(any_take_n);
+    any_hole = __builtin_amdgcn_readfirstlane(any_hole);
 
     // ---- B: channels ---------------------------------------------------------------------------------------------
     const float* refp = p.ref + (size_t)b * C * HW + pix;
@@ -180,7 +304,140 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
         const int y0 = (int)((e >> 15) & 0x7fffu) - 1 + (k >> 1), x0 = (int)(e & 0x7fffu) - 1 + (k & 1);
         return ((uint32_t)y0 < (uint32_t)H && (uint32_t)x0 < (uint32_t)W) ? (uint32_t)(y0 * W + x0) * 4u : SMVS_OOB;
     };
+    // the four weights, as tap_from_grid forms them
+    auto weights = [&](int k, int s, float (&w4)[4]) {
+        asm volatile("" : "+v"(tf[k][s][0]), "+v"(tf[k][s][1]));      // opaque per use: else all 4 * DCH * NSRC products are hoisted out of the channel loop
+        const float w = tf[k][s][0], n = tf[k][s][1], ee = 1.0f - w, ss = 1.0f - n;
+        w4[0] = ss * ee; w4[1] = ss * w; w4[2] = n * ee; w4[3] = n * w;
+    };
+    // a border tap's contributions: per corner, straight to memory
+    auto scatter_partial = [&](uint32_t e, int s, int c, float c0, float c1, float c2, float c3) {
+        float* plane = p.grad_src[s] + ((size_t)b * C + c) * HW;
+        const float cc[4] = {c0, c1, c2, c3};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t o = corner_off(e, q);
+            if (o != SMVS_OOB) unsafeAtomicAdd(plane + (o >> 2), cc[q]);
+        }
+    };
 
+    // the next channel's reference value and gradient planes are requested a whole iteration ahead in both loops: they are
+    // bound by memory latency (SQ_WAIT_ANY 71 % of the wave cycles without it), not by any unit
+    float r_next = refp[0], g_next[DCH];
+#pragma unroll
+    for (int k = 0; k < DCH; ++k) g_next[k] = gp[(size_t)min(k, d1 - d0 - 1) * HW];
+
+    if (SMVS_BWD_ABLATE & 16) { if (tt[0][0] == 0x12345u) p.grad_ref[lane] = tf[0][0][0] + (float)take + (float)give + (float)box_g0[0]; return; }
+    if (BOX && boxed) {
+        // ================================ boxed waves ==========================================================
+        // DMA slot map of a feature box: lane l of instruction j lays down cells (row 4j + l/16, columns 4(l%16) .. +3); cells
+        // beyond the image or the tensor hold other rows' data or zeros -- no full tap reads them
+        uint32_t dvo[NSRC];
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) dvo[s] = (uint32_t)((box_g0[s] + (lane >> 4) * W + (lane & 15) * 4) * 4);
+        auto stage = [&](int cn, int par) {
+            const int so = cn * HW * 4;
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s) {
+                const uint32_t fb = wave_lds + (uint32_t)((par * NSRC + s) * FBOX_BYTES);
+                dma_x4_to_lds_at<0>(rs[s], fb, dvo[s], so);
+                dma_x4_to_lds_at<FBOX_BYTES / 2>(rs[s], fb, dvo[s], so + 4 * W4);
+            }
+        };
+        auto flush_boxes = [&](int c) {                     // one atomic per touched cell: row i of the box, column = lane
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s) {
+                float v[BOX_H];
+                gbox_take8(gbox_lds + (uint32_t)(s * GBOX_BYTES) + (uint32_t)lane * 8u, v);
+                float* q = p.grad_src[s] + ((size_t)b * C + c) * HW + box_g0[s] + lane;
+#pragma unroll
+                for (int i = 0; i < BOX_H; ++i)
+                    if (v[i] != 0.0f && !((SMVS_BWD_ABLATE & 1) && v[i] != 1234.5f)) unsafeAtomicAdd(q + i * W, v[i]);
+            }
+        };
+        stage(0, 0);
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int k = 0; k < DCH; ++k)
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s) asm volatile("" : "+v"(tt[k][s]));       // see the other loop
+            // everything requested one iteration ago has had this channel's arithmetic to arrive: this channel's boxes, r and g
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float r = r_next;
+            float gq[DCH];
+#pragma unroll
+            for (int k = 0; k < DCH; ++k) gq[k] = g_next[k];
+            {
+                const int cn = min(c + 1, C - 1);
+                stage(cn, (c + 1) & 1);
+                r_next = refp[(size_t)cn * HW];
+#pragma unroll
+                for (int k = 0; k < DCH; ++k) g_next[k] = gp[((size_t)cn * D + min(k, d1 - d0 - 1)) * HW];
+            }
+            if (c > 0) flush_boxes(c - 1);                  // the previous channel's sums leave while this one is worked on
+            const int choff = c * HW * 4;
+            const uint32_t fpar = wave_lds + (uint32_t)((c & 1) * NSRC * FBOX_BYTES);
+            float gref = 0.0f;
+#pragma unroll
+            for (int k = 0; k < DCH; ++k) {
+                const float g = (active && d0 + k < d1) ? gq[k] * two_over_v : 0.0f;
+                float wv[NSRC], tw[NSRC][4];
+                f32x2 north[NSRC], south[NSRC];
+                float sum = r;
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s) {
+                    asm volatile("" : "+v"(tt[k][s]));      // opaque per plane: addresses and masks derived from it are formed here, not a channel ahead
+                    const uint32_t e = tt[k][s];
+                    // holes (dropped / border taps) read cell 0 of the box and are overridden below
+                    fbox_read(fpar + (uint32_t)(s * FBOX_BYTES) + ((e & TAP_DROPPED) ? 0u : e), north[s], south[s]);
+                }
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s) {
+                    const uint32_t e = tt[k][s], bit = 1u << (k * NSRC + s);
+                    fbox_wait(north[s], south[s]);
+                    float a0 = north[s].x, a1 = north[s].y, a2 = south[s].x, a3 = south[s].y;
+                    if (any_hole & bit) {                   // wave-uniform: some lane's tap is dropped or touches the border
+                        if (e & TAP_DROPPED) { a0 = 0.0f; a1 = 0.0f; a2 = 0.0f; a3 = 0.0f; }
+                        if (any_partial & bit) {
+                            if ((e & TAP_PARTIAL) == TAP_PARTIAL) {
+                                a0 = llvm_raw_buffer_load_f32(rs[s].v, (int)corner_off(e, 0), choff, 0);
+                                a1 = llvm_raw_buffer_load_f32(rs[s].v, (int)corner_off(e, 1), choff, 0);
+                                a2 = llvm_raw_buffer_load_f32(rs[s].v, (int)corner_off(e, 2), choff, 0);
+                                a3 = llvm_raw_buffer_load_f32(rs[s].v, (int)corner_off(e, 3), choff, 0);
+                            }
+                        }
+                    }
+                    weights(k, s, tw[s]);
+                    float t = a0 * tw[s][0];
+                    t = fmaf(a1, tw[s][1], t);
+                    t = fmaf(a2, tw[s][2], t);
+                    t = fmaf(a3, tw[s][3], t);
+                    wv[s] = t;
+                    sum = sum + t;
+                }
+                const float m = div_by_views(sum, fV, rV);
+                gref = fmaf(g, r - m, gref);
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s) {
+                    const uint32_t e = tt[k][s], bit = 1u << (k * NSRC + s);
+                    const float gw = g * (wv[s] - m);
+                    const float c0 = gw * tw[s][0], c1 = gw * tw[s][1], c2 = gw * tw[s][2], c3 = gw * tw[s][3];
+                    const uint32_t ga = gbox_lds + (uint32_t)(s * GBOX_BYTES) + 2u * e;
+                    if (any_hole & bit) {
+                        if ((e & TAP_DROPPED) == 0) { if (!(SMVS_BWD_ABLATE & 2)) gbox_add4(ga, c0, c1, c2, c3); }
+                        else if ((e & TAP_PARTIAL) == TAP_PARTIAL) scatter_partial(e, s, c, c0, c1, c2, c3);
+                    } else if (!(SMVS_BWD_ABLATE & 2)) {
+                        gbox_add4(ga, c0, c1, c2, c3);
+                    }
+                }
+            }
+            if (active && !((SMVS_BWD_ABLATE & 4) && gref != 1234.5f)) unsafeAtomicAdd(grefp + (size_t)c * HW, gref);
+        }
+        flush_boxes(C - 1);
+        return;
+    }
+
+    // ================================ register scheme ==========================================================
     for (int c = 0; c < C; ++c) {
         // Re-materialise the per-tap words every channel: otherwise every lane mask derived from them (full / partial /
         // take / give, ~100 of them) is hoisted out of the loop as an SGPR pair and spilled (measured: 640 SGPR spills,
@@ -188,33 +445,41 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
 #pragma unroll
         for (int k = 0; k < DCH; ++k)
 #pragma unroll
-            for (int s = 0; s < NSRC; ++s) asm volatile("" : "+v"(tb[k][s]));
-        asm volatile("" : "+v"(take), "+v"(give), "+v"(take_n), "+v"(give_s), "+v"(north_east));
-        const float r = refp[(size_t)c * HW];
+            for (int s = 0; s < NSRC; ++s) asm volatile("" : "+v"(tt[k][s]));
+        asm volatile("" : "+v"(take), "+v"(give));
+        const float r = r_next;
+        float gq[DCH];
+#pragma unroll
+        for (int k = 0; k < DCH; ++k) gq[k] = g_next[k];
+        {
+            const int cn = min(c + 1, C - 1);
+            r_next = refp[(size_t)cn * HW];
+#pragma unroll
+            for (int k = 0; k < DCH; ++k) g_next[k] = gp[((size_t)cn * D + min(k, d1 - d0 - 1)) * HW];
+        }
         const int choff = c * HW * 4;
         float gref = 0.0f;
         uint32_t rkey[NSRC];                                // run of planes whose tap sits in the same cell: key + 4 sums
         float racc[NSRC][4];
-        bool live1[NSRC], live2[NSRC], live3[NSRC];         // the run still owns its north-east / south-west / south-east cell on some plane
+        bool live1[NSRC];                                   // the run still owns its east pair on some plane
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) { rkey[s] = TAP_DROPPED; racc[s][0] = racc[s][1] = racc[s][2] = racc[s][3] = 0.0f; live1[s] = live2[s] = live3[s] = false; }
+        for (int s = 0; s < NSRC; ++s) { rkey[s] = TAP_DROPPED; racc[s][0] = racc[s][1] = racc[s][2] = racc[s][3] = 0.0f; live1[s] = false; }
         auto flush = [&](int s) {
             if ((rkey[s] & TAP_DROPPED) == 0) {
                 float* q = p.grad_src[s] + ((size_t)b * C + c) * HW + (rkey[s] >> 2);
                 unsafeAtomicAdd(q, racc[s][0]);
-                if (live1[s]) unsafeAtomicAdd(q + 1, racc[s][1]);
-                if (live2[s]) unsafeAtomicAdd(q + W, racc[s][2]);
-                if (live3[s]) unsafeAtomicAdd(q + W + 1, racc[s][3]);
+                unsafeAtomicAdd(q + W, racc[s][2]);
+                if (live1[s]) { unsafeAtomicAdd(q + 1, racc[s][1]); unsafeAtomicAdd(q + W + 1, racc[s][3]); }
             }
         };
 #pragma unroll
         for (int k = 0; k < DCH; ++k) {
-            const float g = (active && d0 + k < d1) ? gp[((size_t)c * D + k) * HW] * two_over_v : 0.0f;
-            float wv[NSRC];
+            const float g = (active && d0 + k < d1) ? gq[k] * two_over_v : 0.0f;
+            float wv[NSRC], tw[NSRC][4];
             float sum = r;
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) {
-                const uint32_t e = tb[k][s], bit = 1u << (k * NSRC + s);
+                const uint32_t e = tt[k][s], bit = 1u << (k * NSRC + s);
                 float a0, a1, a2, a3;
                 if (any_partial & bit) {                    // wave-uniform: this tap touches the border somewhere in the wave
                     a0 = llvm_raw_buffer_load_f32(rs[s].v, (int)corner_off(e, 0), choff, 0);
@@ -227,10 +492,11 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
                     a2 = llvm_raw_buffer_load_f32(rs[s].v, (int)e, choff + W4, 0);
                     a3 = llvm_raw_buffer_load_f32(rs[s].v, (int)e + 4, choff + W4, 0);
                 }
-                float t = a0 * tw[k][s][0];
-                t = fmaf(a1, tw[k][s][1], t);
-                t = fmaf(a2, tw[k][s][2], t);
-                t = fmaf(a3, tw[k][s][3], t);
+                weights(k, s, tw[s]);
+                float t = a0 * tw[s][0];
+                t = fmaf(a1, tw[s][1], t);
+                t = fmaf(a2, tw[s][2], t);
+                t = fmaf(a3, tw[s][3], t);
                 wv[s] = t;
                 sum = sum + t;
             }
@@ -238,44 +504,31 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
             gref = fmaf(g, r - m, gref);
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) {
-                const uint32_t e = tb[k][s], bit = 1u << (k * NSRC + s);
+                const uint32_t e = tt[k][s], bit = 1u << (k * NSRC + s);
                 const float gw = g * (wv[s] - m);
-                float c0 = gw * tw[k][s][0], c1 = gw * tw[k][s][1], c2 = gw * tw[k][s][2], c3 = gw * tw[k][s][3];
-                // contributions funnel EAST, then SOUTH (cells: east lane's NW/SW = my NE/SE; south lane's NW/NE = my SW/SE)
-                const bool ge = (give & bit) != 0, gs = PY > 1 && (give_s & bit) != 0;
+                float c0 = gw * tw[s][0], c1 = gw * tw[s][1], c2 = gw * tw[s][2], c3 = gw * tw[s][3];
+                // contributions funnel EAST (cells: east lane's NW/SW = my NE/SE)
+                const bool ge = (give & bit) != 0;
                 if (any_take & bit) {                       // wave-uniform: somewhere in the wave an east pair moves one lane on
                     const float p1 = dpp_from_prev_lane(c1), p3 = dpp_from_prev_lane(c3);
                     if (take & bit) { c0 += p1; c2 += p3; }
                 }
                 if (ge) { c1 = 0.0f; c3 = 0.0f; }
-                if (PY > 1 && (any_take_n & bit)) {         // wave-uniform: somewhere a south pair moves one patch row down
-                    const float n2 = lane_from(c2, lane - PX), n3 = lane_from(c3, lane - PX);
-                    if (take_n & bit) { c0 += n2; c1 += n3; }
-                }
-                if (gs) { c2 = 0.0f; c3 = 0.0f; }
                 if ((e & TAP_DROPPED) == 0) {               // full tap: extend the run or start a new one
                     if (e != rkey[s]) {
                         flush(s);
-                        rkey[s] = e; racc[s][0] = racc[s][1] = racc[s][2] = racc[s][3] = 0.0f; live1[s] = live2[s] = live3[s] = false;
+                        rkey[s] = e; racc[s][0] = racc[s][1] = racc[s][2] = racc[s][3] = 0.0f; live1[s] = false;
                     }
                     racc[s][0] += c0; racc[s][1] += c1; racc[s][2] += c2; racc[s][3] += c3;
-                    live1[s] = live1[s] || !ge || (north_east & bit) != 0;
-                    live2[s] = live2[s] || !gs;
-                    live3[s] = live3[s] || (!ge && !gs);
+                    live1[s] = live1[s] || !ge;
                 } else if ((e & TAP_PARTIAL) == TAP_PARTIAL) {
-                    float* plane = p.grad_src[s] + ((size_t)b * C + c) * HW;
-                    const float cc[4] = {c0, c1, c2, c3};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const uint32_t o = corner_off(e, q);
-                        if (o != SMVS_OOB) unsafeAtomicAdd(plane + (o >> 2), cc[q]);
-                    }
+                    scatter_partial(e, s, c, c0, c1, c2, c3);
                 }
             }
         }
 #pragma unroll
         for (int s = 0; s < NSRC; ++s) flush(s);
-        if (active) unsafeAtomicAdd(grefp + (size_t)c * HW, gref);
+        if (active && !((SMVS_BWD_ABLATE & 4) && gref != 1234.5f)) unsafeAtomicAdd(grefp + (size_t)c * HW, gref);
     }
 }
 
@@ -288,7 +541,7 @@ static hipError_t launch_bwd_n(CostVolBwdParams p, hipStream_t st)
     p.dct = (p.D + DCH - 1) / DCH;
     const long long nb = (long long)p.xt * p.yt * p.dct * p.B;
     if (nb >= (1ll << 31)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((costvol_bwd_kernel<GEO, NSRC, DCH, SMVS_BWD_PX>), dim3((unsigned)nb), dim3(TILE_X, TILE_Y), 0, st, p);
+    hipLaunchKernelGGL((costvol_bwd_kernel<GEO, NSRC, DCH>), dim3((unsigned)nb), dim3(64, BWD_WAVES), 0, st, p);
     return hipGetLastError();
 }
 

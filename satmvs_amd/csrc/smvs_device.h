@@ -579,6 +579,7 @@ struct Tap {
     uint32_t o_nw, o_ne, o_sw, o_se;   // byte offsets inside one H*W plane, or SMVS_OOB (tap dropped)
     float nw, ne, sw, se;
     int x0, y0;                        // north-west cell, -1 .. W-1 / -1 .. H-1 (0 where that axis is out of reach)
+    float fw, fn;                      // fractions the weights are products of: nw = (1-fn)(1-fw), ne = (1-fn) fw, sw = fn (1-fw), se = fn fw
 };
 
 // Normalised grid coordinate -> tap.  fx = W/2, fy = H/2 (exact in float32).
@@ -590,6 +591,7 @@ __device__ __forceinline__ Tap tap_from_grid(float gx, float gy, int H, int W)
     const float xw = floorf(x), yn = floorf(y);
     const float w = x - xw, e = 1.0f - w, n = y - yn, s = 1.0f - n;
     t.nw = s * e; t.ne = s * w; t.sw = n * e; t.se = n * w;
+    t.fw = w; t.fn = n;
     // bounds in float: NaN / huge coordinates compare false everywhere -> all four taps dropped
     const bool xin0 = (xw >= 0.0f) && (xw <= (float)(W - 1));
     const bool xin1 = (xw >= -1.0f) && (xw <= (float)(W - 2));

@@ -447,6 +447,54 @@ def test_costvol_backward_matches_torch(dev, oracle):
         torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, V=3, C=8, D=12, H=40, W=70),                                  # ragged tiles, D not a multiple of the 8-plane chunk, boxed waves
+    dict(B=1, V=2, C=4, D=8, H=64, W=96),                                   # one source view
+    dict(B=1, V=3, C=6, D=5, H=33, W=130, jitter=False),                    # per-plane heights (B,D), odd sizes
+    dict(B=1, V=5, C=4, D=6, H=48, W=80),                                   # four source views: 4-plane chunks, 64 KB of boxes per workgroup
+    dict(B=1, V=6, C=4, D=5, H=24, W=72),                                   # five source views: no boxed path, 64 x 1 patches
+    dict(B=1, V=8, C=2, D=3, H=16, W=40),                                   # seven source views
+    dict(B=1, V=3, C=4, D=8, H=48, W=96, span=(0.0, 30000.0)),              # tens of cells of parallax per plane: boxes overflow, register scheme
+    dict(B=1, V=3, C=4, D=6, H=40, W=72, geo="pinhole"),                    # homography volume
+    dict(B=2, V=4, C=4, D=9, H=36, W=66, geo="pinhole", jitter=False),
+])
+def test_costvol_backward_matrix(dev, cfg):
+    """smvs_costvol_bwd over view counts, geometries, ragged sizes and both scatter schemes (wave-private LDS boxes /
+    register runs) against autograd through the per-view warp operators (their own backward kernel, itself checked against
+    torch's grid_sample backward above) and torch arithmetic for the variance.  Summation order differs: rtol 1e-4 on the
+    gradient scale."""
+    from satmvs_amd.modules import warping
+    B, V, C, D, H, W = (cfg[k] for k in "BVCDHW")
+    geo = cfg.get("geo", "rpc")
+    feats, gp, depth = _inputs(B, V, C, D, H, W, seed=31 + V, jitter=cfg.get("jitter", True), geo=geo)
+    if "span" in cfg:
+        lo, hi = cfg["span"]
+        depth = np.broadcast_to(np.linspace(lo, hi, D, dtype=np.float32).reshape(1, D, 1, 1), (B, D, H, W)).copy()
+    gpt, dt = _t(gp, dev), _t(depth, dev)
+    fs = [_t(f, dev).requires_grad_(True) for f in feats]
+    var = warping.variance_cost_volume(fs, gpt, dt, geo)
+    gout = torch.randn_like(var)
+    var.backward(gout)
+    fs2 = [_t(f, dev).requires_grad_(True) for f in feats]
+    s = fs2[0].unsqueeze(2).repeat(1, 1, D, 1, 1)
+    q = s ** 2
+    for v in range(1, V):
+        if geo == "rpc":
+            w = warping.rpc_warping(fs2[v], gpt[:, v], gpt[:, 0], dt, None)
+        else:
+            w = warping.homo_warping(fs2[v], gpt[:, v], gpt[:, 0], dt)
+        s = s + w
+        q = q + w ** 2
+    var2 = q / V - (s / V) ** 2
+    torch.testing.assert_close(var, var2, rtol=1e-5, atol=1e-5)
+    var2.backward(gout)
+    for v, (a, b) in enumerate(zip(fs, fs2)):
+        scale = float(b.grad.abs().max())
+        assert scale > 0
+        err = float((a.grad - b.grad).abs().max())
+        assert err <= 1e-4 * scale, "view %d: max error %.3g on a gradient scale of %.3g" % (v, err, scale)
+
+
 # ---- BASELINE.json full sizes: properties + oracle spot checks ------------------------------------
 @pytest.mark.parametrize("cfg", [
     dict(V=3, C=32, D=64, H=384, W=768, planes=(0, 31, 63)),      # config 2 (headline metric shape)
