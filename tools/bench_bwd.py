@@ -7,13 +7,18 @@ from satmvs_amd import rpc_synth
 from satmvs_amd.modules.warping import variance_cost_volume
 
 dev = torch.device("cuda:0")
-for name, (C, H, W, D, s) in {"cfg2 C32 768x384x64": (32, 384, 768, 64, 1), "stage1 C32 192x96x48": (32, 96, 192, 48, 4),
-                              "stage3 C8 768x384x8": (8, 384, 768, 8, 1)}.items():
+# heights: the headline span for cfg2; the cascade's own spacings for the stage shapes (stage 1: the whole range on 48 planes,
+# stage 2: 32 planes 5 m apart, stage 3: 8 planes 2.5 m apart) and, last, a spacing whose boxes overflow (register scheme)
+for name, (C, H, W, D, s, lo, hi) in {"cfg2 C32 768x384x64": (32, 384, 768, 64, 1, 0.0, 400.0),
+                                      "stage1 C32 192x96x48": (32, 96, 192, 48, 4, 0.0, 400.0),
+                                      "stage2 C16 384x192x32": (16, 192, 384, 32, 2, 150.0, 305.0),
+                                      "stage3 C8 768x384x8": (8, 384, 768, 8, 1, 190.0, 207.5),
+                                      "overflow C8 768x384x8, 57 m planes": (8, 384, 768, 8, 1, 0.0, 400.0)}.items():
     V = 3
     torch.manual_seed(0)
     feats = [torch.randn(1, C, H, W, device=dev, requires_grad=True) for _ in range(V)]
     proj = torch.from_numpy(rpc_synth.rescale_rpc(rpc_synth.make_view_rpcs(V, 384, 768, seed=0)[None], s)).to(dev)
-    dv = torch.linspace(0, 400, D, device=dev).view(1, D, 1, 1).expand(1, D, H, W).contiguous()
+    dv = torch.linspace(lo, hi, D, device=dev).view(1, D, 1, 1).expand(1, D, H, W).contiguous()
     vol = variance_cost_volume(feats, proj, dv, "rpc", False)
     g = torch.randn_like(vol)
     for _ in range(2):
@@ -29,4 +34,4 @@ for name, (C, H, W, D, s) in {"cfg2 C32 768x384x64": (32, 384, 768, 64, 1), "sta
         vol = variance_cost_volume(feats, proj, dv, "rpc", False)
         vol.backward(g)
     torch.cuda.synchronize(); tfb = (time.perf_counter() - t0) / n * 1e3
-    print("%-22s forward %.3f ms   forward+backward %.3f ms   (backward %.3f ms)" % (name, tf, tfb, tfb - tf))
+    print("%-36s forward %.3f ms   forward+backward %.3f ms   (backward %.3f ms)" % (name, tf, tfb, tfb - tf))
