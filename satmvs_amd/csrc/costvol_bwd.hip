@@ -92,6 +92,13 @@ __device__ __forceinline__ void fbox_wait(f32x2& north, f32x2& south)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(north), "+v"(south) :: "memory");
 }
+// counted form: LDS operations of a wave complete in order, so "at most N still in flight" releases everything issued before
+// the last N (the straight-line loop body below issues no scalar memory load in between -- those share the counter)
+template <int N>
+__device__ __forceinline__ void fbox_wait_n(f32x2& north, f32x2& south)
+{
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(north), "+v"(south) : "n"(N < 15 ? N : 15) : "memory");
+}
 // the four corners of a full tap into the gradient box (LDS byte address of the north-west cell); no return value, in order per wave
 __device__ __forceinline__ void gbox_add4(uint32_t addr, float c0, float c1, float c2, float c3)
 {
@@ -378,10 +385,53 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
             const int choff = c * HW * 4;
             const uint32_t fpar = wave_lds + (uint32_t)((c & 1) * NSRC * FBOX_BYTES);
             float gref = 0.0f;
+            if (any_hole == 0) {
+                // Interior of the image (every tap of the chunk is a full tap, every lane and plane is live): straight-line code,
+                // the next plane's taps are requested before this plane's are waited for
+                f32x2 nq[2][NSRC], sq[2][NSRC];
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s) fbox_read(fpar + (uint32_t)(s * FBOX_BYTES) + tt[0][s], nq[0][s], sq[0][s]);
+#pragma unroll
+                for (int k = 0; k < DCH; ++k) {
+                    if (k + 1 < DCH) {
+#pragma unroll
+                        for (int s = 0; s < NSRC; ++s) fbox_read(fpar + (uint32_t)(s * FBOX_BYTES) + tt[k + 1][s], nq[(k + 1) & 1][s], sq[(k + 1) & 1][s]);
+                    }
+                    const float g = gq[k] * two_over_v;
+                    float wv[NSRC];
+                    f32x2 wn[NSRC], ws[NSRC];
+                    float sum = r;
+#pragma unroll
+                    for (int s = 0; s < NSRC; ++s) {
+                        // in flight behind this plane's reads: the previous plane's 4 adds per view, the next plane's 2 reads per view
+                        if (k == 0) fbox_wait_n<2 * NSRC>(nq[0][s], sq[0][s]);
+                        else if (k + 1 < DCH) fbox_wait_n<6 * NSRC>(nq[k & 1][s], sq[k & 1][s]);
+                        else fbox_wait_n<4 * NSRC>(nq[k & 1][s], sq[k & 1][s]);
+                        asm volatile("" : "+v"(tf[k][s][0]), "+v"(tf[k][s][1]));
+                        const float w = tf[k][s][0], n = tf[k][s][1];
+                        const f32x2 ew = {1.0f - w, w};
+                        wn[s] = ew * (1.0f - n);
+                        ws[s] = ew * n;
+                        const f32x2 acc = __builtin_elementwise_fma(sq[k & 1][s], ws[s], nq[k & 1][s] * wn[s]);
+                        const float t = acc.x + acc.y;
+                        wv[s] = t;
+                        sum = sum + t;
+                    }
+                    const float m = div_by_views(sum, fV, rV);
+                    gref = fmaf(g, r - m, gref);
+#pragma unroll
+                    for (int s = 0; s < NSRC; ++s) {
+                        const float gw = g * (wv[s] - m);
+                        const f32x2 cn = wn[s] * gw, cs = ws[s] * gw;
+                        if (!(SMVS_BWD_ABLATE & 2)) gbox_add4(gbox_lds + (uint32_t)(s * GBOX_BYTES) + 2u * tt[k][s], cn.x, cn.y, cs.x, cs.y);
+                    }
+                }
+            } else
 #pragma unroll
             for (int k = 0; k < DCH; ++k) {
                 const float g = (active && d0 + k < d1) ? gq[k] * two_over_v : 0.0f;
-                float wv[NSRC], tw[NSRC][4];
+                float wv[NSRC];
+                f32x2 wn[NSRC], ws[NSRC];                   // (nw, ne), (sw, se)
                 f32x2 north[NSRC], south[NSRC];
                 float sum = r;
 #pragma unroll
@@ -407,11 +457,16 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
                             }
                         }
                     }
-                    weights(k, s, tw[s]);
-                    float t = a0 * tw[s][0];
-                    t = fmaf(a1, tw[s][1], t);
-                    t = fmaf(a2, tw[s][2], t);
-                    t = fmaf(a3, tw[s][3], t);
+                    // the same four products tap_from_grid forms, two per v_pk_mul_f32; the warped value sums north and south
+                    // in one v_pk_fma_f32 and the two halves last (another order than the forward's: within its rounding)
+                    asm volatile("" : "+v"(tf[k][s][0]), "+v"(tf[k][s][1]));      // opaque per use: else every weight is hoisted out of the channel loop
+                    const float w = tf[k][s][0], n = tf[k][s][1];
+                    const f32x2 ew = {1.0f - w, w};
+                    wn[s] = ew * (1.0f - n);
+                    ws[s] = ew * n;
+                    const f32x2 an = {a0, a1}, as = {a2, a3};
+                    const f32x2 acc = __builtin_elementwise_fma(as, ws[s], an * wn[s]);
+                    const float t = acc.x + acc.y;
                     wv[s] = t;
                     sum = sum + t;
                 }
@@ -421,7 +476,8 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
                 for (int s = 0; s < NSRC; ++s) {
                     const uint32_t e = tt[k][s], bit = 1u << (k * NSRC + s);
                     const float gw = g * (wv[s] - m);
-                    const float c0 = gw * tw[s][0], c1 = gw * tw[s][1], c2 = gw * tw[s][2], c3 = gw * tw[s][3];
+                    const f32x2 cn = wn[s] * gw, cs = ws[s] * gw;
+                    const float c0 = cn.x, c1 = cn.y, c2 = cs.x, c3 = cs.y;
                     const uint32_t ga = gbox_lds + (uint32_t)(s * GBOX_BYTES) + 2u * e;
                     if (any_hole & bit) {
                         if ((e & TAP_DROPPED) == 0) { if (!(SMVS_BWD_ABLATE & 2)) gbox_add4(ga, c0, c1, c2, c3); }
