@@ -495,6 +495,59 @@ def test_costvol_backward_matrix(dev, cfg):
         assert err <= 1e-4 * scale, "view %d: max error %.3g on a gradient scale of %.3g" % (v, err, scale)
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(V=3, C=32, D=64, H=384, W=768),                                     # config 2 (headline metric shape)
+    dict(V=3, C=16, D=32, H=192, W=384, span=(150.0, 305.0)),                # config 3, stage 2
+    dict(V=5, C=32, D=8, H=768, W=1536, span=(0.0, 44.4)),                   # config 4: one rank's 8-plane shard, four source views
+    dict(V=3, C=32, D=64, H=384, W=768, geo="pinhole"),                      # config 5
+])
+def test_costvol_backward_full_size_adjoint(dev, cfg):
+    """smvs_costvol_bwd at BASELINE.json's full sizes through a size-independent identity.  The variance volume is a
+    QUADRATIC function of the feature maps, so its central difference is exact: var(f + d) - var(f - d) = 2 J(f) d for any
+    direction d, and therefore  < g, (var(f+d) - var(f-d)) / 2 >  =  < (J^T g)_v, d_v >  for a direction d that moves view v
+    only -- the left side needs only the forward kernel (pinned bit for bit by the oracle at these sizes,
+    test_full_size_properties), the right side is the backward kernel.  Per view, two directions: the gradient itself
+    (right side = |grad_v|^2 up to scale: no cancellation, 1e-4 relative -- any error in the gradient's magnitude shows) and
+    a random one (tolerance relative to the root-sum-square of the terms -- errors orthogonal to the gradient show)."""
+    from satmvs_amd.modules import warping
+    V, C, D, H, W = cfg["V"], cfg["C"], cfg["D"], cfg["H"], cfg["W"]
+    geo = cfg.get("geo", "rpc")
+    feats, gp, depth = _inputs(1, V, C, D, H, W, seed=17, geo=geo)
+    if "span" in cfg:
+        lo, hi = cfg["span"]
+        rng = np.random.default_rng(18)
+        depth = (np.linspace(lo, hi, D).reshape(1, D, 1, 1) + rng.normal(0, 0.5, (1, D, H, W))).astype(np.float32)
+    gpt, dt = _t(gp, dev), _t(depth, dev)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    fs = [_t(f, dev).requires_grad_(True) for f in feats]
+    var = warping.variance_cost_volume(fs, gpt, dt, geo)
+    g = torch.randn(var.shape, generator=gen, device=dev)
+    var.backward(g)
+    del var
+    base = [f.detach() for f in fs]
+
+    def forward_side(v, d):
+        with torch.no_grad():
+            plus = warping.variance_cost_volume([f + d if i == v else f for i, f in enumerate(base)], gpt, dt, geo)
+            minus = warping.variance_cost_volume([f - d if i == v else f for i, f in enumerate(base)], gpt, dt, geo)
+            plus -= minus
+            del minus
+            return 0.5 * torch.dot(plus.double().flatten(), g.double().flatten()).item()
+
+    for v in range(V):
+        grad = fs[v].grad
+        assert torch.isfinite(grad).all()
+        d_grad = grad / grad.pow(2).mean().sqrt()                       # unit rms, like the features
+        rhs = torch.dot(grad.double().flatten(), d_grad.double().flatten()).item()
+        lhs = forward_side(v, d_grad)
+        assert rhs > 0 and abs(lhs - rhs) <= 1e-4 * rhs, (v, lhs, rhs)
+        d_rand = torch.randn(grad.shape, generator=gen, device=dev)
+        terms = grad.double() * d_rand.double()
+        rhs, rss = terms.sum().item(), terms.pow(2).sum().sqrt().item()
+        lhs = forward_side(v, d_rand)
+        assert abs(lhs - rhs) <= 1e-3 * rss, (v, lhs, rhs, rss)
+
+
 # ---- BASELINE.json full sizes: properties + oracle spot checks ------------------------------------
 @pytest.mark.parametrize("cfg", [
     dict(V=3, C=32, D=64, H=384, W=768, planes=(0, 31, 63)),      # config 2 (headline metric shape)
