@@ -243,6 +243,30 @@ def side_workloads(dev, stream):
     extra["cfg5_pinhole_3view_768x384x64_c32"] = {"ms": round(ms, 4), "Mvox/s": round(D * H * W / ms / 1e3, 1),
                                                   "note": "through the Python surface (compose + volume allocation included)"}
     del feats, depth
+    # training path of the headline tile: forward + backward of the variance volume through the autograd surface
+    try:
+        V, C, D, H, W = WORKLOADS["cfg2_rpc_3view_768x384x64_c32"]
+        tf_, trpc, tdepth = make_inputs(V, C, D, D, 0, H, W, dev)
+        tf_ = [f.requires_grad_(True) for f in tf_]
+        vol = warping.variance_cost_volume(tf_, trpc, tdepth, "rpc")
+        gout = torch.randn_like(vol)
+        for _ in range(2):
+            warping.variance_cost_volume(tf_, trpc, tdepth, "rpc").backward(gout)
+        del vol
+
+        def step_f():
+            return warping.variance_cost_volume(tf_, trpc, tdepth, "rpc")
+
+        def step_fb():
+            warping.variance_cost_volume(tf_, trpc, tdepth, "rpc").backward(gout)
+        _, ms_f = time_steps(step_f, 10)
+        _, ms_fb = time_steps(step_fb, 10)
+        extra["cfg2_training_costvol_fwd_bwd"] = {"ms_forward": round(ms_f, 3), "ms_forward_backward": round(ms_fb, 3),
+                                                  "ms_backward": round(ms_fb - ms_f, 3), "kernel": "costvol_bwd_kernel<0,2,8>",
+                                                  "note": "smvs_costvol_bwd through torch.autograd (volume allocation and the .grad accumulation included)"}
+        del tf_, gout
+    except Exception as e:
+        extra["cfg2_training_costvol_fwd_bwd"] = {"error": repr(e)[:200]}
     # cfg3: one inference cascade forward (FeatureNet + three stages of variance / RED / regression), 48/32/8 planes
     try:
         from satmvs_amd import rpc_synth

@@ -165,6 +165,21 @@ int smvs_rpc_geo_consistency(const float* depth_ref, const double* rpc_ref, cons
                              unsigned char* mask, float* depth_reproj, double* x_src, double* y_src,
                              double* x_back, double* y_back, void* stream);
 
+/* ---- GroupNorm(1, C) of the recurrent regulariser, training path -------------------------------------
+ * reference: modules/module.py:15-20 (three nn.GroupNorm(1, C, 1e-5) per ConvGRU cell) and :38-52 (sigmoid / tanh of
+ * the normalised gates); differentiated by train.py:284.  x (B,C,HW) float32 with batch stride x_batch_stride elements
+ * (>= C*HW: the two gate halves of a (B,2C,H,W) tensor are normalised where they lie); act 0 none, 1 sigmoid, 2 tanh:
+ *   y = act((x - mean_b) * rstd_b * gamma_c + beta_c),   mean / variance over the C*HW values of sample b.
+ * mean_rstd (B,2) float32 out (kept for the backward); workspace: 2*B doubles (forward), 2*B*C + 2*B doubles
+ * (backward), caller-owned, contents irrelevant on entry.  Backward: dx (batch stride dx_batch_stride), dgamma (C),
+ * dbeta (C) are overwritten; y = the forward's output (needed when act != 0).  Statistics and the reductions of the
+ * backward are accumulated in float64. */
+int smvs_groupnorm1_fwd(const float* x, long long x_batch_stride, const float* gamma, const float* beta, float eps,
+                        int act, float* y, float* mean_rstd, double* workspace, int B, int C, int HW, void* stream);
+int smvs_groupnorm1_bwd(const float* dy, const float* x, long long x_batch_stride, const float* y, const float* gamma,
+                        const float* mean_rstd, int act, float* dx, long long dx_batch_stride, float* dgamma,
+                        float* dbeta, double* workspace, int B, int C, int HW, void* stream);
+
 /* ---- regression ----------------------------------------------------------------------------------
  * Train path: softmax over D + expected height + max probability,
  *   networks/casred.py:58-62 and modules/module.py:433-439 (depth_regression).

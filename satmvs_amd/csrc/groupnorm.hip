@@ -1,0 +1,231 @@
+// groupnorm.hip -- GroupNorm(1, C) (+ the gate's sigmoid / tanh) forward and backward for the TRAINING path of the
+// recurrent regulariser: /root/reference/modules/module.py:15-20 (three nn.GroupNorm(1, C, 1e-5) per ConvGRU cell),
+// :38-52 (sigmoid(norm(r)), sigmoid(norm(u)), tanh(norm(candidate))), differentiated by train.py:284.
+//
+// Why it exists: with ONE group a sample is one "row" of C*H*W values, and torch's RowwiseMomentsCUDAKernel gives a row
+// to ONE workgroup: 152 us per call at the cascade's sizes, 5280 calls per training step = 45 % of the step's kernel
+// time (profiles/r03_train_step.txt), with ComputeInternalGradients the same way in the backward.  Here every pass is
+// spread over the whole chip:
+//   forward   stats: (chunks, B) workgroups sum x and x^2 in float64, one float64 atomic pair per workgroup
+//             apply: y = act((x - mean) * rstd * gamma_c + beta_c), one (b, c) row segment per workgroup
+//   backward  rows:  per (b, c): S1 = sum dz, S2 = sum dz * xhat   (dz = dy * act'(y)), float64 atomics per workgroup
+//             finish: per b: A = sum_c gamma_c S1, Q = sum_c gamma_c S2; dgamma_c = sum_b S2, dbeta_c = sum_b S1
+//             dx:    dx = rstd * (dz * gamma_c - A/N - xhat * Q/N)
+// The inference pipelines do not come here: red.hip folds the statistics into the producing convolution.
+#include "smvs_device.h"
+#include "smvs_host.h"
+
+namespace smvs {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_ELEMS = 4096;                     // elements of one workgroup's segment (16 per thread)
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// sum of (a, b) over the workgroup; valid in thread 0
+__device__ __forceinline__ void block_sum2(double& a, double& b)
+{
+    __shared__ double part[2][GN_THREADS / 64];
+    a = wave_sum(a); b = wave_sum(b);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { part[0][wave] = a; part[1][wave] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = part[0][0]; b = part[1][0];
+#pragma unroll
+        for (int w = 1; w < GN_THREADS / 64; ++w) { a += part[0][w]; b += part[1][w]; }
+    }
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act)
+{
+    if (act == 1) return 1.0f / (1.0f + expf(-v));
+    if (act == 2) return tanhf(v);
+    return v;
+}
+__device__ __forceinline__ float act_bwd(float dy, float y, int act)
+{
+    if (act == 1) return dy * (y * (1.0f - y));
+    if (act == 2) return dy * (1.0f - y * y);
+    return dy;
+}
+
+// x: (B, C, HW) with batch stride xbs (elements) -- the gate halves of a (B, 2C, H, W) tensor are normalised in place
+__global__ __launch_bounds__(GN_THREADS)
+void gn1_stats_kernel(const float* __restrict__ x, long long xbs, long long n, double* __restrict__ sums)
+{
+    const int b = blockIdx.y;
+    const float* xp = x + (size_t)b * xbs;
+    const long long i0 = (long long)blockIdx.x * GN_ELEMS;
+    const long long i1 = min(i0 + GN_ELEMS, n);
+    double s = 0.0, q = 0.0;
+    if ((((uintptr_t)xp) & 15) == 0 && ((i1 - i0) & 3) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(xp + i0);
+        for (int i = threadIdx.x; i < (int)((i1 - i0) >> 2); i += GN_THREADS) {
+            const float4 v = x4[i];
+            s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+            q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        }
+    } else {
+        for (long long i = i0 + threadIdx.x; i < i1; i += GN_THREADS) {
+            const double v = xp[i];
+            s += v; q += v * v;
+        }
+    }
+    block_sum2(s, q);
+    if (threadIdx.x == 0) { unsafeAtomicAdd(sums + 2 * b, s); unsafeAtomicAdd(sums + 2 * b + 1, q); }
+}
+
+__device__ __forceinline__ void mean_rstd_of(const double* sums, int b, long long n, float eps, float& mean, float& rstd)
+{
+    const double m = sums[2 * b] / (double)n;
+    const double var = fmax(sums[2 * b + 1] / (double)n - m * m, 0.0);
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// grid (segments of HW, B*C)
+__global__ __launch_bounds__(GN_THREADS)
+void gn1_apply_kernel(const float* __restrict__ x, long long xbs, const float* __restrict__ gamma, const float* __restrict__ beta,
+                      const double* __restrict__ sums, float eps, int act, float* __restrict__ y, float* __restrict__ mean_rstd,
+                      int C, int HW)
+{
+    const int row = blockIdx.y, b = row / C, c = row - b * C;
+    float mean, rstd;
+    mean_rstd_of(sums, b, (long long)C * HW, eps, mean, rstd);
+    if (c == 0 && blockIdx.x == 0 && threadIdx.x == 0) { mean_rstd[2 * b] = mean; mean_rstd[2 * b + 1] = rstd; }
+    const float g = gamma[c] * rstd, o = beta[c] - mean * g;            // y = x * g + o
+    const float* xp = x + (size_t)b * xbs + (size_t)c * HW;
+    float* yp = y + ((size_t)b * C + c) * HW;
+    const int i0 = blockIdx.x * GN_ELEMS, i1 = min(i0 + GN_ELEMS, HW);
+    if (((((uintptr_t)xp) | ((uintptr_t)yp)) & 15) == 0 && ((i1 - i0) & 3) == 0 && (i0 & 3) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(xp + i0);
+        float4* y4 = reinterpret_cast<float4*>(yp + i0);
+        for (int i = threadIdx.x; i < ((i1 - i0) >> 2); i += GN_THREADS) {
+            const float4 v = x4[i];
+            float4 r;
+            r.x = act_fwd(fmaf(v.x, g, o), act); r.y = act_fwd(fmaf(v.y, g, o), act);
+            r.z = act_fwd(fmaf(v.z, g, o), act); r.w = act_fwd(fmaf(v.w, g, o), act);
+            y4[i] = r;
+        }
+    } else {
+        for (int i = i0 + threadIdx.x; i < i1; i += GN_THREADS) yp[i] = act_fwd(fmaf(xp[i], g, o), act);
+    }
+}
+
+// grid (segments of HW, B*C): S1 = sum dz, S2 = sum dz * xhat of one (b, c) row
+__global__ __launch_bounds__(GN_THREADS)
+void gn1_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__ x, long long xbs, const float* __restrict__ y,
+                         const float* __restrict__ mean_rstd, int act, double* __restrict__ rows, int C, int HW)
+{
+    const int row = blockIdx.y, b = row / C, c = row - b * C;
+    const float mean = mean_rstd[2 * b], rstd = mean_rstd[2 * b + 1];
+    const float* xp = x + (size_t)b * xbs + (size_t)c * HW;
+    const float* dp = dy + ((size_t)b * C + c) * HW;
+    const float* yp = y + ((size_t)b * C + c) * HW;
+    const int i0 = blockIdx.x * GN_ELEMS, i1 = min(i0 + GN_ELEMS, HW);
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = i0 + threadIdx.x; i < i1; i += GN_THREADS) {
+        const float dz = act_bwd(dp[i], act ? yp[i] : 0.0f, act);
+        s1 += (double)dz;
+        s2 += (double)dz * (double)((xp[i] - mean) * rstd);
+    }
+    block_sum2(s1, s2);
+    if (threadIdx.x == 0) { unsafeAtomicAdd(rows + 2 * row, s1); unsafeAtomicAdd(rows + 2 * row + 1, s2); }
+}
+
+// one workgroup: coef[b] = {A/N, Q/N}, dgamma, dbeta
+__global__ __launch_bounds__(GN_THREADS)
+void gn1_bwd_finish_kernel(const double* __restrict__ rows, const float* __restrict__ gamma, double* __restrict__ coef,
+                           float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, int HW)
+{
+    for (int b = 0; b < B; ++b) {
+        double a = 0.0, q = 0.0;
+        for (int c = threadIdx.x; c < C; c += GN_THREADS) {
+            a += (double)gamma[c] * rows[2 * (b * C + c)];
+            q += (double)gamma[c] * rows[2 * (b * C + c) + 1];
+        }
+        __syncthreads();                                     // block_sum2's staging is reused across samples
+        block_sum2(a, q);
+        if (threadIdx.x == 0) { coef[2 * b] = a / ((double)C * HW); coef[2 * b + 1] = q / ((double)C * HW); }
+    }
+    for (int c = threadIdx.x; c < C; c += GN_THREADS) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int b = 0; b < B; ++b) { s1 += rows[2 * (b * C + c)]; s2 += rows[2 * (b * C + c) + 1]; }
+        dbeta[c] = (float)s1; dgamma[c] = (float)s2;
+    }
+}
+
+// grid (segments of HW, B*C)
+__global__ __launch_bounds__(GN_THREADS)
+void gn1_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x, long long xbs, const float* __restrict__ y,
+                       const float* __restrict__ gamma, const float* __restrict__ mean_rstd, const double* __restrict__ coef,
+                       int act, float* __restrict__ dx, long long dxbs, int C, int HW)
+{
+    const int row = blockIdx.y, b = row / C, c = row - b * C;
+    const float mean = mean_rstd[2 * b], rstd = mean_rstd[2 * b + 1];
+    const float a = (float)coef[2 * b], q = (float)coef[2 * b + 1], g = gamma[c];
+    const float* xp = x + (size_t)b * xbs + (size_t)c * HW;
+    const float* dp = dy + ((size_t)b * C + c) * HW;
+    const float* yp = y + ((size_t)b * C + c) * HW;
+    float* op = dx + (size_t)b * dxbs + (size_t)c * HW;
+    const int i0 = blockIdx.x * GN_ELEMS, i1 = min(i0 + GN_ELEMS, HW);
+    for (int i = i0 + threadIdx.x; i < i1; i += GN_THREADS) {
+        const float dz = act_bwd(dp[i], act ? yp[i] : 0.0f, act);
+        const float xh = (xp[i] - mean) * rstd;
+        op[i] = rstd * (dz * g - a - xh * q);
+    }
+}
+
+}  // namespace smvs
+
+extern "C" SMVS_EXPORT int smvs_groupnorm1_fwd(const float* x, long long x_batch_stride, const float* gamma, const float* beta, float eps,
+                                               int act, float* y, float* mean_rstd, double* workspace, int B, int C, int HW, void* stream)
+{
+    using namespace smvs;
+    if (!x || !gamma || !beta || !y || !mean_rstd || !workspace) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (B < 1 || C < 1 || HW < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
+    if (act < 0 || act > 2) return fail(SMVS_ERR_ARG, "act must be 0 (none), 1 (sigmoid) or 2 (tanh)");
+    if (x_batch_stride < (long long)C * HW) return fail(SMVS_ERR_ARG, "batch stride smaller than one sample");
+    if ((long long)B * C > 65535 || B > 65535) return fail(SMVS_ERR_ARG, "B*C exceeds the grid limit 65535");
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)C * HW;
+    if (hipMemsetAsync(workspace, 0, sizeof(double) * 2 * B, st) != hipSuccess) return fail(SMVS_ERR_LAUNCH, "groupnorm workspace clear");
+    hipLaunchKernelGGL(gn1_stats_kernel, dim3((unsigned)((n + GN_ELEMS - 1) / GN_ELEMS), B), dim3(GN_THREADS), 0, st, x, x_batch_stride, n, workspace);
+    hipLaunchKernelGGL(gn1_apply_kernel, dim3((HW + GN_ELEMS - 1) / GN_ELEMS, B * C), dim3(GN_THREADS), 0, st, x, x_batch_stride, gamma, beta,
+                       workspace, eps, act, y, mean_rstd, C, HW);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "groupnorm1_fwd launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
+}
+
+extern "C" SMVS_EXPORT int smvs_groupnorm1_bwd(const float* dy, const float* x, long long x_batch_stride, const float* y, const float* gamma,
+                                               const float* mean_rstd, int act, float* dx, long long dx_batch_stride, float* dgamma,
+                                               float* dbeta, double* workspace, int B, int C, int HW, void* stream)
+{
+    using namespace smvs;
+    if (!dy || !x || !gamma || !mean_rstd || !dx || !dgamma || !dbeta || !workspace) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (act != 0 && !y) return fail(SMVS_ERR_ARG, "the activation's backward needs the forward output y");
+    if (B < 1 || C < 1 || HW < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
+    if (act < 0 || act > 2) return fail(SMVS_ERR_ARG, "act must be 0 (none), 1 (sigmoid) or 2 (tanh)");
+    if (x_batch_stride < (long long)C * HW || dx_batch_stride < (long long)C * HW) return fail(SMVS_ERR_ARG, "batch stride smaller than one sample");
+    if ((long long)B * C > 65535) return fail(SMVS_ERR_ARG, "B*C exceeds the grid limit 65535");
+    hipStream_t st = (hipStream_t)stream;
+    double* rows = workspace;                                // (B*C, 2)
+    double* coef = workspace + 2 * (size_t)B * C;            // (B, 2)
+    if (hipMemsetAsync(rows, 0, sizeof(double) * 2 * B * C, st) != hipSuccess) return fail(SMVS_ERR_LAUNCH, "groupnorm workspace clear");
+    const float* yy = y ? y : dy;
+    const dim3 grid((HW + GN_ELEMS - 1) / GN_ELEMS, B * C);
+    hipLaunchKernelGGL(gn1_bwd_rows_kernel, grid, dim3(GN_THREADS), 0, st, dy, x, x_batch_stride, yy, mean_rstd, act, rows, C, HW);
+    hipLaunchKernelGGL(gn1_bwd_finish_kernel, dim3(1), dim3(GN_THREADS), 0, st, rows, gamma, coef, dgamma, dbeta, B, C, HW);
+    hipLaunchKernelGGL(gn1_bwd_dx_kernel, grid, dim3(GN_THREADS), 0, st, dy, x, x_batch_stride, yy, gamma, mean_rstd, coef, act, dx,
+                       dx_batch_stride, C, HW);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "groupnorm1_bwd launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
+}

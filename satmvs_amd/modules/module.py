@@ -191,6 +191,60 @@ class ConvTransReLU(nn.Module):
 
 
 # ---- recurrent regulariser (RED) ------------------------------------------------------------------------
+class _GroupNorm1Fn(torch.autograd.Function):
+    """act(GroupNorm(1, C)(x)) through smvs_groupnorm1_fwd / _bwd (csrc/groupnorm.hip).  x may be a channel slice of a
+    wider tensor (the gate halves of the 2C-channel gate convolution): only its batch stride has to be regular."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, act):
+        dev = _lib.require_device(x, weight, bias)
+        B, C, H, W = x.shape
+        if x.dtype != torch.float32 or x.stride(1) != H * W or x.stride(2) != W or x.stride(3) != 1 or (B > 1 and x.stride(0) < C * H * W):
+            x = x.float().contiguous()
+        xbs = x.stride(0) if B > 1 else C * H * W
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        y = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
+        stats = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        ws = torch.empty((2 * B,), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("smvs_groupnorm1_fwd", _lib.ptr(x), xbs, _lib.ptr(w), _lib.ptr(b), float(eps), int(act), _lib.ptr(y),
+                      _lib.ptr(stats), _lib.ptr(ws), B, C, H * W, _lib.current_stream(dev))
+        ctx.save_for_backward(x, w, y, stats)
+        ctx.meta = (xbs, int(act))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y, stats = ctx.saved_tensors
+        xbs, act = ctx.meta
+        B, C, H, W = y.shape
+        dev = y.device
+        dy = dy.float().contiguous()
+        dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
+        dg = torch.empty((C,), dtype=torch.float32, device=dev)
+        db = torch.empty((C,), dtype=torch.float32, device=dev)
+        ws = torch.empty((2 * B * C + 2 * B,), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("smvs_groupnorm1_bwd", _lib.ptr(dy), _lib.ptr(x), xbs, _lib.ptr(y), _lib.ptr(w), _lib.ptr(stats), act,
+                      _lib.ptr(dx), C * H * W, _lib.ptr(dg), _lib.ptr(db), _lib.ptr(ws), B, C, H * W, _lib.current_stream(dev))
+        return dx, dg, db, None, None
+
+
+class GroupNorm1(nn.GroupNorm):
+    """nn.GroupNorm(1, C, eps) -- same parameters, same state_dict keys (reference: module.py:15-20) -- whose forward can take
+    the gate's activation along ("sigmoid" / "tanh").  On the GPU with gradients enabled it runs the native kernels: with one
+    group a sample is a single row for torch's RowwiseMoments / ComputeInternalGradients kernels (one workgroup each: 45 % of
+    the training step's kernel time, profiles/r03_train_step.txt).  CPU tensors take torch's composite."""
+
+    _ACT = {None: 0, "sigmoid": 1, "tanh": 2}
+
+    def forward(self, x, act=None):
+        if x.is_cuda and x.dim() == 4 and self.num_groups == 1 and self.affine:
+            return _GroupNorm1Fn.apply(x, self.weight, self.bias, self.eps, self._ACT[act])
+        y = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
+        return torch.sigmoid(y) if act == "sigmoid" else torch.tanh(y) if act == "tanh" else y
+
+
 class ConvGRUCell2(nn.Module):
     """3x3 convolutional GRU with GroupNorm(1, C) on every gate.  reference: module.py:6-58."""
 
@@ -199,10 +253,10 @@ class ConvGRUCell2(nn.Module):
         cat_ch = input_channel + output_channel
         self.output_channel = output_channel
         self.gate_conv = nn.Conv2d(cat_ch, output_channel * 2, kernel_size, padding=1)
-        self.reset_gate_norm = nn.GroupNorm(1, output_channel, 1e-5, True)
-        self.update_gate_norm = nn.GroupNorm(1, output_channel, 1e-5, True)
+        self.reset_gate_norm = GroupNorm1(1, output_channel, 1e-5, True)
+        self.update_gate_norm = GroupNorm1(1, output_channel, 1e-5, True)
         self.output_conv = nn.Conv2d(cat_ch, output_channel, kernel_size, padding=1)
-        self.output_norm = nn.GroupNorm(1, output_channel, 1e-5, True)
+        self.output_norm = GroupNorm1(1, output_channel, 1e-5, True)
         self.activation = nn.Tanh()
 
     def forward(self, x, h=None):
@@ -210,9 +264,9 @@ class ConvGRUCell2(nn.Module):
             h = torch.zeros((x.shape[0], self.output_channel, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device)
         gates = self.gate_conv(torch.cat((x, h), dim=1))
         r, u = torch.split(gates, gates.shape[1] // 2, 1)
-        r = torch.sigmoid(self.reset_gate_norm(r))
-        u = torch.sigmoid(self.update_gate_norm(u))
-        cand = self.activation(self.output_norm(self.output_conv(torch.cat((x, r * h), dim=1))))
+        r = self.reset_gate_norm(r, "sigmoid")
+        u = self.update_gate_norm(u, "sigmoid")
+        cand = self.output_norm(self.output_conv(torch.cat((x, r * h), dim=1)), "tanh")
         new_h = u * h + (1 - u) * cand
         return new_h, new_h
 

@@ -1,0 +1,109 @@
+"""One training step (reference: train.py:267-302 -- model forward, cas_mvsnet_loss, loss.backward(), optimizer.step())
+captured in a HIP graph and replayed.
+
+Why: the eager step is a chain of ~32 000 kernel launches (88 planes x the ConvGRU stack, forward and backward); at the
+3-view 768x384 tile the GPU needs ~150 ms for them and the host ~310 ms to issue them (profiles/r03_train_step.txt).  A HIP
+graph issues the whole step with one call: the step takes what the GPU takes.  The native operators are capturable as they
+are -- they launch on torch's current stream, take their scratch from torch's allocator and never synchronise.
+
+    step = GraphedTrainStep(model, optimizer, loss_fn)          # optimizer built with capturable=True
+    for sample in loader:
+        loss, outputs = step(sample["imgs"], sample["proj"], sample["depth_values"], sample["depth"], sample["mask"])
+
+`loss_fn(outputs, *extra)` gets the model's output dict and the extra positional arguments of the call (ground truth, masks:
+tensors or dicts / lists of tensors).  Arguments are copied into static buffers; a call with other shapes re-captures.
+Returned tensors are the graph's static outputs: valid until the next call.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def _map(obj, fn):
+    if torch.is_tensor(obj):
+        return fn(obj)
+    if isinstance(obj, dict):
+        return {k: _map(v, fn) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_map(v, fn) for v in obj)
+    return obj
+
+
+def _zip_copy(dst, src):
+    if torch.is_tensor(dst):
+        dst.copy_(src, non_blocking=True)
+    elif isinstance(dst, dict):
+        for k in dst:
+            _zip_copy(dst[k], src[k])
+    elif isinstance(dst, (list, tuple)):
+        for d, s in zip(dst, src):
+            _zip_copy(d, s)
+
+
+def _signature(obj):
+    if torch.is_tensor(obj):
+        return (tuple(obj.shape), obj.dtype)
+    if isinstance(obj, dict):
+        return tuple((k, _signature(v)) for k, v in sorted(obj.items()))
+    if isinstance(obj, (list, tuple)):
+        return tuple(_signature(v) for v in obj)
+    return obj
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer, loss_fn, warmup=3):
+        if not all(g.get("capturable", False) for g in optimizer.param_groups):
+            raise ValueError("GraphedTrainStep needs an optimizer built with capturable=True (its step counters live on the GPU)")
+        self.model, self.optimizer, self.loss_fn, self.warmup = model, optimizer, loss_fn, int(warmup)
+        self._sig = None
+        self._graph = None
+
+    def _eager(self, args):
+        self.optimizer.zero_grad(set_to_none=True)
+        out = self.model(*args[:3])
+        loss = self.loss_fn(out, *args[3:])
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach(), _map(out, lambda t: t.detach())
+
+    def _capture(self, args):
+        dev = args[0].device
+        self._static = _map(args, lambda t: t.detach().clone())
+        # the warm-up steps (allocator, MIOpen's find, lazily created optimizer state) must not train: parameters, buffers and
+        # optimizer state are put back IN PLACE afterwards -- the graph holds their addresses
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        saved_p = [p.detach().clone() for p in params]
+        saved_b = [b.detach().clone() for b in self.model.buffers()]
+        saved_s = {id(t): t.detach().clone() for st in self.optimizer.state.values() for t in st.values() if torch.is_tensor(t)}
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                self._eager(self._static)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        with torch.no_grad():
+            for p, s in zip(params, saved_p):
+                p.copy_(s)
+            for b, s in zip(self.model.buffers(), saved_b):
+                b.copy_(s)
+            for st in self.optimizer.state.values():
+                for t in st.values():
+                    if torch.is_tensor(t):
+                        if id(t) in saved_s:
+                            t.copy_(saved_s[id(t)])
+                        else:
+                            t.zero_()                        # state created by the warm-up: torch's optimizers start from zeros
+        torch.cuda.synchronize(dev)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._out = self._eager(self._static)
+
+    def __call__(self, *args):
+        sig = _signature(args)
+        if sig != self._sig:
+            self._capture(args)
+            self._sig = sig
+        else:
+            _zip_copy(self._static, args)
+        self._graph.replay()
+        return self._out

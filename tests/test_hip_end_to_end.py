@@ -349,6 +349,45 @@ def test_sharded_pred_equals_unsharded_on_one_gpu(dev, golden):
     assert torch.equal(a["depth"], b["depth"]) and torch.equal(a["photometric_confidence"], b["photometric_confidence"])
 
 
+@pytest.mark.parametrize("shape,act,sliced", [
+    ((2, 8, 37, 50), "sigmoid", True),          # gate half of a 16-channel tensor, batch 2, odd plane size (scalar path)
+    ((1, 16, 48, 96), "tanh", False),           # vector path
+    ((1, 8, 192, 384), "sigmoid", True),        # several segments per row
+    ((3, 64, 12, 24), None, False),             # coarsest level: many channels, tiny planes
+])
+def test_groupnorm1_native_matches_torch(dev, shape, act, sliced):
+    """smvs_groupnorm1_fwd / _bwd (the training path's GroupNorm(1, C) + gate activation, csrc/groupnorm.hip) against
+    torch's group_norm + sigmoid / tanh under autograd: outputs 1e-6, input / weight / bias gradients 2e-5 of their
+    scale (float64 statistics here, float32 there)."""
+    from satmvs_amd.modules.module import GroupNorm1
+    B, C, H, W = shape
+    torch.manual_seed(3)
+    full = (torch.randn((B, 2 * C if sliced else C, H, W), device=dev) * 1.7 + 0.3)
+    gn = GroupNorm1(1, C, 1e-5, True).to(dev)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.uniform_(-0.5, 0.5)
+    gout = torch.randn((B, C, H, W), device=dev)
+    res = []
+    for native in (True, False):
+        src = full.clone().requires_grad_(True)
+        x = src[:, C:] if sliced else src
+        gn.zero_grad()
+        if native:
+            y = gn(x, act)
+        else:
+            y = torch.nn.functional.group_norm(x, 1, gn.weight, gn.bias, 1e-5)
+            y = torch.sigmoid(y) if act == "sigmoid" else torch.tanh(y) if act == "tanh" else y
+        y.backward(gout)
+        res.append((y.detach(), src.grad.clone(), gn.weight.grad.clone(), gn.bias.grad.clone()))
+    (y0, dx0, dw0, db0), (y1, dx1, dw1, db1) = res
+    assert float((y0 - y1).abs().max()) <= 2e-6
+    for a, b in ((dx0, dx1), (dw0, dw1), (db0, db1)):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7
+    if sliced:
+        assert float(dx0[:, :C].abs().max()) == 0.0             # the other half of the gate tensor gets no gradient from this norm
+
+
 def test_training_step_runs_and_gradients_flow(dev, golden):
     """One optimisation-free training step through the native volume: loss.backward() reaches the
     feature extractor through smvs_costvol_bwd (train.py:279-285 analogue)."""
@@ -410,6 +449,57 @@ def test_training_step_matches_reference(dev, golden):
     for (name, (s1, s2)) in zip(g["grad_names"], g["grad_sums"]):
         n = float(grads[str(name)].double().norm())
         assert abs(n - np.sqrt(s2)) <= 1e-3 * np.sqrt(s2) + 1e-6 * nmax, name
+
+
+def test_graphed_training_step_matches_eager(dev, golden):
+    """satmvs_amd.train_graph.GraphedTrainStep: the whole step (forward, loss, backward, RMSprop) captured in one HIP graph.
+    Same seed, same sample: the first replay's loss equals the eager step's to 1e-6 and its gradients to 2e-4 of their
+    scale (atomics), the warm-up inside the capture leaves parameters / BatchNorm buffers / optimizer state untouched, a
+    second replay trains on (different loss), and a new sample is picked up through the static buffers."""
+    import torch.nn.functional as F
+    from satmvs_amd.networks import casred
+    from satmvs_amd.train_graph import GraphedTrainStep
+    g = golden("cascade")
+    nd = [int(v) for v in g["ndepths"]]
+    imgs, proj, dv = _inputs(g, dev)
+    gts = {s: torch.full_like(torch.from_numpy(g["red." + s + ".depth"]).to(dev), 30.0) for s in ("stage1", "stage2", "stage3")}
+
+    def loss_fn(out, gt):
+        return sum(w * F.smooth_l1_loss(out[s]["depth"], gt[s], reduction="mean") for s, w in (("stage1", 0.5), ("stage2", 1.0), ("stage3", 2.0)))
+
+    def make():
+        torch.manual_seed(0)
+        net = casred.CascadeREDNet("rpc", min_interval=2.5, ndepths=nd).to(dev).train()
+        return net, torch.optim.RMSprop(net.parameters(), lr=1e-3, alpha=0.9, capturable=True)
+
+    net_e, opt_e = make()
+    opt_e.zero_grad(set_to_none=True)
+    loss_e = loss_fn(net_e(imgs, proj, dv), gts)
+    loss_e.backward()
+    grads_e = {k: p.grad.clone() for k, p in net_e.named_parameters()}
+    opt_e.step()
+
+    net_g, opt_g = make()
+    before = {k: v.clone() for k, v in net_g.state_dict().items()}
+    step = GraphedTrainStep(net_g, opt_g, loss_fn)
+    step._capture((imgs, proj, dv, gts))
+    for k, v in net_g.state_dict().items():
+        assert torch.equal(v, before[k]), "the capture's warm-up changed %s" % k
+    step._sig = None
+    loss_g, out_g = step(imgs, proj, dv, gts)
+    loss_g, loss_e = float(loss_g), float(loss_e.detach())      # the returned tensors are the graph's: read before the next call
+    assert abs(loss_g - loss_e) <= 1e-6 * abs(loss_e)
+    for k, p in net_g.named_parameters():
+        scale = float(grads_e[k].abs().max())
+        assert float((p.grad - grads_e[k]).abs().max()) <= 2e-4 * scale + 1e-9, k
+    assert set(out_g) >= {"stage1", "stage2", "stage3"}
+    loss2, _ = step(imgs, proj, dv, gts)                         # second replay: the parameters moved
+    loss2 = float(loss2)
+    assert loss2 != loss_g and np.isfinite(loss2)
+    gts2 = {s: t + 5.0 for s, t in gts.items()}                  # another sample, same shapes: no re-capture, other loss
+    graph = step._graph
+    loss3, _ = step(imgs, proj, dv, gts2)
+    assert step._graph is graph and abs(float(loss3) - loss2) > 1.0
 
 
 def test_native_modules_match_composites_at_ragged_shapes(dev):

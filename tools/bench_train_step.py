@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""One training step of CascadeREDNet (train.py:267-302: forward, cas_mvsnet_loss, backward, RMSprop) on a synthetic 3-view
+768x384 tile, planes 48/32/8: what the native cost-volume forward/backward leave to the PyTorch composites.
+    python tools/bench_train_step.py [steps]"""
+import os, sys, time
+import numpy as np
+import torch
+import torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from satmvs_amd import rpc_synth
+from satmvs_amd.networks.casred import CascadeREDNet
+
+dev = torch.device("cuda:0")
+H, W, nd = 384, 768, [48, 32, 8]
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+torch.manual_seed(0)
+net = CascadeREDNet("rpc", min_interval=2.5, ndepths=nd).to(dev).train()
+opt = torch.optim.RMSprop(net.parameters(), lr=1e-3, alpha=0.9)               # train.py:128
+imgs = torch.randn(1, 3, 3, H, W, device=dev)
+rpc = rpc_synth.make_view_rpcs(3, H, W, seed=0)[None]
+pm = {"stage1": torch.from_numpy(rpc_synth.rescale_rpc(rpc, 4)).to(dev), "stage2": torch.from_numpy(rpc_synth.rescale_rpc(rpc, 2)).to(dev),
+      "stage3": torch.from_numpy(rpc).to(dev)}
+dv = torch.tensor([[0.0, 400.0]], device=dev)
+gt = {s: torch.full((1, H // k, W // k), 200.0, device=dev) for s, k in (("stage1", 4), ("stage2", 2), ("stage3", 1))}
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    out = net(imgs, pm, dv)
+    loss = sum(w * F.smooth_l1_loss(out[s]["depth"], gt[s], reduction="mean") for s, w in (("stage1", 0.5), ("stage2", 1.0), ("stage3", 2.0)))
+    t1 = time.perf_counter()
+    loss.backward()
+    opt.step()
+    return loss, t1
+
+
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+ts, tf = [], []
+for _ in range(steps):
+    t0 = time.perf_counter()
+    loss, t1 = step()
+    torch.cuda.synchronize()
+    ts.append((time.perf_counter() - t0) * 1e3)
+ts.sort()
+print("training step, 3-view 768x384, planes %s: median %.1f ms (min %.1f, max %.1f), loss %.4f, peak memory %.2f GB"
+      % (nd, ts[len(ts) // 2], ts[0], ts[-1], float(loss), torch.cuda.max_memory_allocated() / 2 ** 30))
