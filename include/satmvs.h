@@ -170,7 +170,7 @@ int smvs_rpc_geo_consistency(const float* depth_ref, const double* rpc_ref, cons
  * the normalised gates); differentiated by train.py:284.  x (B,C,HW) float32 with batch stride x_batch_stride elements
  * (>= C*HW: the two gate halves of a (B,2C,H,W) tensor are normalised where they lie); act 0 none, 1 sigmoid, 2 tanh:
  *   y = act((x - mean_b) * rstd_b * gamma_c + beta_c),   mean / variance over the C*HW values of sample b.
- * mean_rstd (B,2) float32 out (kept for the backward); workspace: 2*B doubles (forward), 2*B*C + 2*B doubles
+ * mean_rstd (B,2) float32 out (kept for the backward); workspace: 2*B doubles (forward), 2*B*C doubles
  * (backward), caller-owned, contents irrelevant on entry.  Backward: dx (batch stride dx_batch_stride), dgamma (C),
  * dbeta (C) are overwritten; y = the forward's output (needed when act != 0).  Statistics and the reductions of the
  * backward are accumulated in float64. */

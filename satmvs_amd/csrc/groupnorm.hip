@@ -9,8 +9,8 @@
 //   forward   stats: (chunks, B) workgroups sum x and x^2 in float64, one float64 atomic pair per workgroup
 //             apply: y = act((x - mean) * rstd * gamma_c + beta_c), one (b, c) row segment per workgroup
 //   backward  rows:  per (b, c): S1 = sum dz, S2 = sum dz * xhat   (dz = dy * act'(y)), float64 atomics per workgroup
-//             finish: per b: A = sum_c gamma_c S1, Q = sum_c gamma_c S2; dgamma_c = sum_b S2, dbeta_c = sum_b S1
-//             dx:    dx = rstd * (dz * gamma_c - A/N - xhat * Q/N)
+//             dx:    every workgroup folds A = sum_c gamma_c S1, Q = sum_c gamma_c S2 of its sample, then
+//                    dx = rstd * (dz * gamma_c - A/N - xhat * Q/N); workgroup 0 also writes dgamma_c = sum_b S2, dbeta_c = sum_b S1
 // The inference pipelines do not come here: red.hip folds the statistics into the producing convolution.
 #include "smvs_device.h"
 #include "smvs_host.h"
@@ -130,6 +130,19 @@ void gn1_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__
     const float* yp = y + ((size_t)b * C + c) * HW;
     const int i0 = blockIdx.x * GN_ELEMS, i1 = min(i0 + GN_ELEMS, HW);
     double s1 = 0.0, s2 = 0.0;
+    if (((((uintptr_t)xp) | ((uintptr_t)dp) | ((uintptr_t)yp)) & 15) == 0 && ((i1 - i0) & 3) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(xp + i0);
+        const float4* d4 = reinterpret_cast<const float4*>(dp + i0);
+        const float4* y4 = reinterpret_cast<const float4*>(yp + i0);
+        for (int i = threadIdx.x; i < ((i1 - i0) >> 2); i += GN_THREADS) {
+            const float4 xv = x4[i], dv = d4[i];
+            float4 yv = dv;
+            if (act) yv = y4[i];
+            const float z0 = act_bwd(dv.x, yv.x, act), z1 = act_bwd(dv.y, yv.y, act), z2 = act_bwd(dv.z, yv.z, act), z3 = act_bwd(dv.w, yv.w, act);
+            s1 += (double)((z0 + z1) + (z2 + z3));
+            s2 += (double)((z0 * ((xv.x - mean) * rstd) + z1 * ((xv.y - mean) * rstd)) + (z2 * ((xv.z - mean) * rstd) + z3 * ((xv.w - mean) * rstd)));
+        }
+    } else
     for (int i = i0 + threadIdx.x; i < i1; i += GN_THREADS) {
         const float dz = act_bwd(dp[i], act ? yp[i] : 0.0f, act);
         s1 += (double)dz;
@@ -139,42 +152,54 @@ void gn1_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__
     if (threadIdx.x == 0) { unsafeAtomicAdd(rows + 2 * row, s1); unsafeAtomicAdd(rows + 2 * row + 1, s2); }
 }
 
-// one workgroup: coef[b] = {A/N, Q/N}, dgamma, dbeta
-__global__ __launch_bounds__(GN_THREADS)
-void gn1_bwd_finish_kernel(const double* __restrict__ rows, const float* __restrict__ gamma, double* __restrict__ coef,
-                           float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, int HW)
-{
-    for (int b = 0; b < B; ++b) {
-        double a = 0.0, q = 0.0;
-        for (int c = threadIdx.x; c < C; c += GN_THREADS) {
-            a += (double)gamma[c] * rows[2 * (b * C + c)];
-            q += (double)gamma[c] * rows[2 * (b * C + c) + 1];
-        }
-        __syncthreads();                                     // block_sum2's staging is reused across samples
-        block_sum2(a, q);
-        if (threadIdx.x == 0) { coef[2 * b] = a / ((double)C * HW); coef[2 * b + 1] = q / ((double)C * HW); }
-    }
-    for (int c = threadIdx.x; c < C; c += GN_THREADS) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int b = 0; b < B; ++b) { s1 += rows[2 * (b * C + c)]; s2 += rows[2 * (b * C + c) + 1]; }
-        dbeta[c] = (float)s1; dgamma[c] = (float)s2;
-    }
-}
-
 // grid (segments of HW, B*C)
 __global__ __launch_bounds__(GN_THREADS)
 void gn1_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x, long long xbs, const float* __restrict__ y,
-                       const float* __restrict__ gamma, const float* __restrict__ mean_rstd, const double* __restrict__ coef,
-                       int act, float* __restrict__ dx, long long dxbs, int C, int HW)
+                       const float* __restrict__ gamma, const float* __restrict__ mean_rstd, const double* __restrict__ rows,
+                       int act, float* __restrict__ dx, long long dxbs, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                       int B, int C, int HW)
 {
     const int row = blockIdx.y, b = row / C, c = row - b * C;
+    // every workgroup folds the sample's C row sums itself (C <= a few hundred doubles from L2): no launch in between
+    double a_ = 0.0, q_ = 0.0;
+    for (int k = threadIdx.x; k < C; k += GN_THREADS) {
+        a_ += (double)gamma[k] * rows[2 * (b * C + k)];
+        q_ += (double)gamma[k] * rows[2 * (b * C + k) + 1];
+    }
+    __shared__ float coef[2];
+    block_sum2(a_, q_);
+    if (threadIdx.x == 0) { coef[0] = (float)(a_ / ((double)C * HW)); coef[1] = (float)(q_ / ((double)C * HW)); }
+    __syncthreads();
+    if (row == 0 && blockIdx.x == 0) {                       // parameter gradients: sums over the batch, written once
+        for (int k = threadIdx.x; k < C; k += GN_THREADS) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int bb = 0; bb < B; ++bb) { s1 += rows[2 * (bb * C + k)]; s2 += rows[2 * (bb * C + k) + 1]; }
+            dbeta[k] = (float)s1; dgamma[k] = (float)s2;
+        }
+    }
     const float mean = mean_rstd[2 * b], rstd = mean_rstd[2 * b + 1];
-    const float a = (float)coef[2 * b], q = (float)coef[2 * b + 1], g = gamma[c];
+    const float a = coef[0], q = coef[1], g = gamma[c];
     const float* xp = x + (size_t)b * xbs + (size_t)c * HW;
     const float* dp = dy + ((size_t)b * C + c) * HW;
     const float* yp = y + ((size_t)b * C + c) * HW;
     float* op = dx + (size_t)b * dxbs + (size_t)c * HW;
     const int i0 = blockIdx.x * GN_ELEMS, i1 = min(i0 + GN_ELEMS, HW);
+    if (((((uintptr_t)xp) | ((uintptr_t)dp) | ((uintptr_t)yp) | ((uintptr_t)op)) & 15) == 0 && ((i1 - i0) & 3) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(xp + i0);
+        const float4* d4 = reinterpret_cast<const float4*>(dp + i0);
+        const float4* y4 = reinterpret_cast<const float4*>(yp + i0);
+        float4* o4 = reinterpret_cast<float4*>(op + i0);
+        for (int i = threadIdx.x; i < ((i1 - i0) >> 2); i += GN_THREADS) {
+            const float4 xv = x4[i], dv = d4[i];
+            float4 yv = dv, r;
+            if (act) yv = y4[i];
+            r.x = rstd * (act_bwd(dv.x, yv.x, act) * g - a - ((xv.x - mean) * rstd) * q);
+            r.y = rstd * (act_bwd(dv.y, yv.y, act) * g - a - ((xv.y - mean) * rstd) * q);
+            r.z = rstd * (act_bwd(dv.z, yv.z, act) * g - a - ((xv.z - mean) * rstd) * q);
+            r.w = rstd * (act_bwd(dv.w, yv.w, act) * g - a - ((xv.w - mean) * rstd) * q);
+            o4[i] = r;
+        }
+    } else
     for (int i = i0 + threadIdx.x; i < i1; i += GN_THREADS) {
         const float dz = act_bwd(dp[i], act ? yp[i] : 0.0f, act);
         const float xh = (xp[i] - mean) * rstd;
@@ -217,14 +242,12 @@ extern "C" SMVS_EXPORT int smvs_groupnorm1_bwd(const float* dy, const float* x, 
     if ((long long)B * C > 65535) return fail(SMVS_ERR_ARG, "B*C exceeds the grid limit 65535");
     hipStream_t st = (hipStream_t)stream;
     double* rows = workspace;                                // (B*C, 2)
-    double* coef = workspace + 2 * (size_t)B * C;            // (B, 2)
     if (hipMemsetAsync(rows, 0, sizeof(double) * 2 * B * C, st) != hipSuccess) return fail(SMVS_ERR_LAUNCH, "groupnorm workspace clear");
     const float* yy = y ? y : dy;
     const dim3 grid((HW + GN_ELEMS - 1) / GN_ELEMS, B * C);
     hipLaunchKernelGGL(gn1_bwd_rows_kernel, grid, dim3(GN_THREADS), 0, st, dy, x, x_batch_stride, yy, mean_rstd, act, rows, C, HW);
-    hipLaunchKernelGGL(gn1_bwd_finish_kernel, dim3(1), dim3(GN_THREADS), 0, st, rows, gamma, coef, dgamma, dbeta, B, C, HW);
-    hipLaunchKernelGGL(gn1_bwd_dx_kernel, grid, dim3(GN_THREADS), 0, st, dy, x, x_batch_stride, yy, gamma, mean_rstd, coef, act, dx,
-                       dx_batch_stride, C, HW);
+    hipLaunchKernelGGL(gn1_bwd_dx_kernel, grid, dim3(GN_THREADS), 0, st, dy, x, x_batch_stride, yy, gamma, mean_rstd, rows, act, dx,
+                       dx_batch_stride, dgamma, dbeta, B, C, HW);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "groupnorm1_bwd launch: %s", hipGetErrorString(e));
     return SMVS_OK;

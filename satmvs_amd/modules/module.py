@@ -223,7 +223,7 @@ class _GroupNorm1Fn(torch.autograd.Function):
         dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
         dg = torch.empty((C,), dtype=torch.float32, device=dev)
         db = torch.empty((C,), dtype=torch.float32, device=dev)
-        ws = torch.empty((2 * B * C + 2 * B,), dtype=torch.float64, device=dev)
+        ws = torch.empty((2 * B * C,), dtype=torch.float64, device=dev)
         with torch.cuda.device(dev):
             _lib.call("smvs_groupnorm1_bwd", _lib.ptr(dy), _lib.ptr(x), xbs, _lib.ptr(y), _lib.ptr(w), _lib.ptr(stats), act,
                       _lib.ptr(dx), C * H * W, _lib.ptr(dg), _lib.ptr(db), _lib.ptr(ws), B, C, H * W, _lib.current_stream(dev))

@@ -12,7 +12,8 @@ are -- they launch on torch's current stream, take their scratch from torch's al
 
 `loss_fn(outputs, *extra)` gets the model's output dict and the extra positional arguments of the call (ground truth, masks:
 tensors or dicts / lists of tensors).  Arguments are copied into static buffers; a call with other shapes re-captures.
-Returned tensors are the graph's static outputs: valid until the next call.
+Returned tensors are the graph's static outputs: valid until the next call.  Python scalars the step reads (a float learning
+rate, loss weights) are baked into the graph: call recapture() after changing them (e.g. when a scheduler steps the rate).
 """
 from __future__ import annotations
 
@@ -97,6 +98,11 @@ class GraphedTrainStep:
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._out = self._eager(self._static)
+
+    def recapture(self):
+        """Forget the captured graph: the next call captures again (after a change of learning rate, loss weights, ...)."""
+        self._sig = None
+        self._graph = None
 
     def __call__(self, *args):
         sig = _signature(args)

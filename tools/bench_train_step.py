@@ -15,7 +15,7 @@ H, W, nd = 384, 768, [48, 32, 8]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 torch.manual_seed(0)
 net = CascadeREDNet("rpc", min_interval=2.5, ndepths=nd).to(dev).train()
-opt = torch.optim.RMSprop(net.parameters(), lr=1e-3, alpha=0.9)               # train.py:128
+opt = torch.optim.RMSprop(net.parameters(), lr=1e-3, alpha=0.9)               # train.py:135
 imgs = torch.randn(1, 3, 3, H, W, device=dev)
 rpc = rpc_synth.make_view_rpcs(3, H, W, seed=0)[None]
 pm = {"stage1": torch.from_numpy(rpc_synth.rescale_rpc(rpc, 4)).to(dev), "stage2": torch.from_numpy(rpc_synth.rescale_rpc(rpc, 2)).to(dev),
