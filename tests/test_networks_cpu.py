@@ -120,3 +120,39 @@ def test_pack_cache_never_serves_a_freed_models_weights():
     M._PACK_CACHE[(key[0], key[1], (b.data_ptr(), b._version))] = M._PACK_CACHE.pop(key)   # simulate address reuse
     p2 = M._packed("k", "cpu", [b], build_for(b))
     assert len(built) == 2 and float(p2.sum()) == 16.0
+
+
+def test_groupnorm1_is_a_drop_in_for_nn_groupnorm_on_the_host():
+    """modules.module.GroupNorm1 (the ConvGRU cells' norm, native on the GPU): same parameters and state_dict keys as the
+    reference's nn.GroupNorm(1, C, 1e-5, True) (module.py:15-20), same values on CPU tensors, activation argument included."""
+    from satmvs_amd.modules.module import ConvGRUCell2, GroupNorm1
+    torch.manual_seed(1)
+    a, b = GroupNorm1(1, 8, 1e-5, True), torch.nn.GroupNorm(1, 8, 1e-5, True)
+    assert list(a.state_dict()) == list(b.state_dict()) == ["weight", "bias"]
+    with torch.no_grad():
+        a.weight.uniform_(0.5, 1.5); a.bias.uniform_(-1, 1)
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(2, 8, 5, 7)
+    assert torch.equal(a(x), b(x))
+    assert torch.equal(a(x, "sigmoid"), torch.sigmoid(b(x)))
+    assert torch.equal(a(x, "tanh"), torch.tanh(b(x)))
+    cell = ConvGRUCell2(4, 8, 3)
+    assert [k for k in cell.state_dict() if "norm" in k] == ["reset_gate_norm.weight", "reset_gate_norm.bias", "update_gate_norm.weight",
+                                                             "update_gate_norm.bias", "output_norm.weight", "output_norm.bias"]
+
+
+def test_graphed_train_step_host_logic():
+    """satmvs_amd.train_graph: argument signatures (what triggers a re-capture), nested copies into the static buffers, and the
+    capturable-optimizer requirement -- the capture itself needs a GPU (tests/test_hip_end_to_end.py)."""
+    from satmvs_amd import train_graph as tg
+    a = {"stage1": torch.zeros(1, 2, 3), "stage2": [torch.zeros(4), torch.zeros(5, dtype=torch.float64)]}
+    b = {"stage1": torch.ones(1, 2, 3), "stage2": [torch.ones(4), torch.ones(5, dtype=torch.float64)]}
+    assert tg._signature((a, 3)) == tg._signature((b, 3))
+    assert tg._signature((a,)) != tg._signature(({"stage1": torch.zeros(1, 2, 4), "stage2": a["stage2"]},))
+    assert tg._signature((a,)) != tg._signature(({"stage1": a["stage1"], "stage2": [torch.zeros(4), torch.zeros(5)]},))
+    static = tg._map(a, lambda t: t.clone())
+    tg._zip_copy(static, b)
+    assert float(static["stage1"].sum()) == 6.0 and float(static["stage2"][1].sum()) == 5.0 and float(a["stage1"].sum()) == 0.0
+    lin = torch.nn.Linear(2, 2)
+    with pytest.raises(ValueError, match="capturable"):
+        tg.GraphedTrainStep(lin, torch.optim.RMSprop(lin.parameters(), lr=1e-3), lambda out: out.sum())
