@@ -60,6 +60,9 @@ struct CostVolBwdParams {
 #ifndef SMVS_BWD_ABLATE
 #define SMVS_BWD_ABLATE 0              // timing experiments only (wrong results): 1 no flush atomics, 2 no box adds, 4 no reference atomic
 #endif
+#ifndef SMVS_BWD_DCH8_SRC
+#define SMVS_BWD_DCH8_SRC 4           // up to this many source views a lane keeps 8 planes of taps (2 beyond: the register scheme only); measured 3 / 4 views: 4.01 -> 3.66, 6.78 -> 5.88 ms against 4-plane chunks
+#endif
 #ifndef SMVS_BWD_LDS
 #define SMVS_BWD_LDS 1                 // 0: never take the boxed path (A/B)
 #endif
@@ -592,7 +595,7 @@ template <int GEO, int NSRC>
 static hipError_t launch_bwd_n(CostVolBwdParams p, hipStream_t st)
 {
     // planes per lane: the taps of a chunk live in registers (5 per tap)
-    constexpr int DCH = NSRC <= 2 ? 8 : NSRC <= 4 ? 4 : 2;
+    constexpr int DCH = NSRC <= SMVS_BWD_DCH8_SRC ? 8 : NSRC <= 4 ? 4 : 2;
     p.dch = DCH < p.D ? DCH : p.D;
     p.dct = (p.D + DCH - 1) / DCH;
     const long long nb = (long long)p.xt * p.yt * p.dct * p.B;

@@ -9,12 +9,17 @@ from satmvs_amd.modules.warping import variance_cost_volume
 dev = torch.device("cuda:0")
 # heights: the headline span for cfg2; the cascade's own spacings for the stage shapes (stage 1: the whole range on 48 planes,
 # stage 2: 32 planes 5 m apart, stage 3: 8 planes 2.5 m apart) and, last, a spacing whose boxes overflow (register scheme)
+VIEWS = {"5-view C32 768x384x32": 5, "4-view C32 768x384x32": 4, "2-view C32 768x384x32": 2, "7-view C16 384x192x16": 7}
 for name, (C, H, W, D, s, lo, hi) in {"cfg2 C32 768x384x64": (32, 384, 768, 64, 1, 0.0, 400.0),
                                       "stage1 C32 192x96x48": (32, 96, 192, 48, 4, 0.0, 400.0),
                                       "stage2 C16 384x192x32": (16, 192, 384, 32, 2, 150.0, 305.0),
                                       "stage3 C8 768x384x8": (8, 384, 768, 8, 1, 190.0, 207.5),
-                                      "overflow C8 768x384x8, 57 m planes": (8, 384, 768, 8, 1, 0.0, 400.0)}.items():
-    V = 3
+                                      "overflow C8 768x384x8, 57 m planes": (8, 384, 768, 8, 1, 0.0, 400.0),
+                                      "5-view C32 768x384x32": (32, 384, 768, 32, 1, 0.0, 200.0),
+                                      "4-view C32 768x384x32": (32, 384, 768, 32, 1, 0.0, 200.0),
+                                      "2-view C32 768x384x32": (32, 384, 768, 32, 1, 0.0, 200.0),
+                                      "7-view C16 384x192x16": (16, 192, 384, 16, 2, 100.0, 200.0)}.items():
+    V = VIEWS.get(name, 3)
     torch.manual_seed(0)
     feats = [torch.randn(1, C, H, W, device=dev, requires_grad=True) for _ in range(V)]
     proj = torch.from_numpy(rpc_synth.rescale_rpc(rpc_synth.make_view_rpcs(V, 384, 768, seed=0)[None], s)).to(dev)
