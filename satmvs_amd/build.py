@@ -28,16 +28,29 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    """Compile every HIP source into one shared library.  Returns its path."""
+def build(force=False, verbose=False, extra_flags=(), jobs=None):
+    """Compile every HIP source (one hipcc process each, in parallel) and link them into one shared library.  Returns its path."""
     if not force and not _stale():
         return LIB
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    cflags = [f for f in FLAGS if f != "-shared"] + list(extra_flags)
+    with tempfile.TemporaryDirectory(prefix="obj_", dir=LIB_DIR) as tmp:
+        def compile_one(src):
+            obj = os.path.join(tmp, src + ".o")
+            cmd = [hipcc] + cflags + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            return obj
+        with ThreadPoolExecutor(max_workers=jobs or min(len(SOURCES), os.cpu_count() or 1)) as pool:
+            objs = list(pool.map(compile_one, SOURCES))
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return LIB
 
 
