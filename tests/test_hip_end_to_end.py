@@ -478,6 +478,8 @@ def test_graphed_training_step_matches_eager(dev, golden):
     loss_e.backward()
     grads_e = {k: p.grad.clone() for k, p in net_e.named_parameters()}
     opt_e.step()
+    opt_e.zero_grad(set_to_none=True)
+    loss_e2 = float(loss_fn(net_e(imgs, proj, dv), gts).detach())      # the eager run's SECOND step: the optimizer state has to match too
 
     net_g, opt_g = make()
     before = {k: v.clone() for k, v in net_g.state_dict().items()}
@@ -496,6 +498,9 @@ def test_graphed_training_step_matches_eager(dev, golden):
     loss2, _ = step(imgs, proj, dv, gts)                         # second replay: the parameters moved
     loss2 = float(loss2)
     assert loss2 != loss_g and np.isfinite(loss2)
+    # RMSprop's first update is lr * g / (sqrt(0.1) |g|): parameters whose gradient is round-off noise move by +-lr/0.32 in either
+    # run, with no first-order effect on the loss
+    assert abs(loss2 - loss_e2) <= 1e-3 * abs(loss_e2), (loss2, loss_e2)
     gts2 = {s: t + 5.0 for s, t in gts.items()}                  # another sample, same shapes: no re-capture, other loss
     graph = step._graph
     loss3, _ = step(imgs, proj, dv, gts2)
