@@ -137,7 +137,10 @@ int smvs_homo_compose(const double* src_proj, const double* ref_proj, double* ou
 /* ---- backward of the fused volume (train.py:284 loss.backward through casred.py:22-53) -------
  * grad_var (B,C,D,H,W) -> grad_ref (B,C,H,W) and grad_src[s] (B,C,H,W), all ACCUMULATED with
  * float32 atomics (zero-filled by the caller; grad_src is a HOST array of n_src device pointers).  geo_kind 0 = rpc (B,V,170), 1 = homography
- * (B,n_src,4,4).  Recomputes the taps instead of saving a warped volume. */
+ * (B,n_src,4,4).  Recomputes the taps instead of saving a warped volume.  Where the taps of a wave's 32 x 2 pixels x 8
+ * planes fall into a 64 x 8-cell box of every source view (up to four source views) the contributions are summed in
+ * float64 in LDS first and reach memory as one float32 atomic per touched cell; summation order is not fixed either way
+ * (atomics), values differ from a sequential float32 sum by rounding only.  Limits: C*H*W*4 < 2 GiB, H, W <= 32766. */
 int smvs_costvol_bwd(int geo_kind, const float* grad_var, const float* ref_fea, const float* const* src_fea,
                      int n_src, const double* geo, const float* depth, int depth_is_4d,
                      float* grad_ref, float* const* grad_src,
