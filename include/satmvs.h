@@ -183,6 +183,16 @@ int smvs_groupnorm1_bwd(const float* dy, const float* x, long long x_batch_strid
                         const float* mean_rstd, int act, float* dx, long long dx_batch_stride, float* dgamma,
                         float* dbeta, double* workspace, int B, int C, int HW, void* stream);
 
+/* The ConvGRU cell's element-wise steps (modules/module.py:43-44 and :57), training path, one launch each way:
+ *   smvs_gru_mul_cat:  out (B, Cx+Ch, HW) = cat(x (B,Cx,HW), r * h (B,Ch,HW));   backward: dr = dcat[:, Cx:] * h, dh = dcat[:, Cx:] * r
+ *                      (dx is the first Cx channels of dcat as they are)
+ *   smvs_gru_blend:    out = u * h + (1 - u) * y over n contiguous floats (pointers 16-byte aligned);
+ *                      backward: du = dy (h - y), dh = dy u, dcand = dy (1 - u). */
+int smvs_gru_mul_cat_fwd(const float* x, const float* r, const float* h, float* out, int B, int Cx, int Ch, int HW, void* stream);
+int smvs_gru_mul_cat_bwd(const float* dcat, const float* r, const float* h, float* dr, float* dh, int B, int Cx, int Ch, int HW, void* stream);
+int smvs_gru_blend_fwd(const float* u, const float* h, const float* y, float* out, long long n, void* stream);
+int smvs_gru_blend_bwd(const float* dy, const float* u, const float* h, const float* y, float* du, float* dh, float* dcand, long long n, void* stream);
+
 /* ---- regression ----------------------------------------------------------------------------------
  * Train path: softmax over D + expected height + max probability,
  *   networks/casred.py:58-62 and modules/module.py:433-439 (depth_regression).

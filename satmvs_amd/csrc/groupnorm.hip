@@ -252,3 +252,129 @@ extern "C" SMVS_EXPORT int smvs_groupnorm1_bwd(const float* dy, const float* x, 
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "groupnorm1_bwd launch: %s", hipGetErrorString(e));
     return SMVS_OK;
 }
+
+// ---- the ConvGRU cell's element-wise steps, training path -----------------------------------------------------------
+// /root/reference/modules/module.py:43-44  f = cat((x, r * h), 1)   and  :57  output = u * h + (1 - u) * y.
+// As torch operators these are 2 + 4 launches forward and ~10 backward per cell and plane -- of a training step whose cost IS
+// its number of launches (32 000 per step, profiles/r03_train_step.txt); here one launch each way.
+namespace smvs {
+
+constexpr int GE_THREADS = 256;
+
+__global__ __launch_bounds__(GE_THREADS)
+void gru_blend_fwd_kernel(const float* __restrict__ u, const float* __restrict__ h, const float* __restrict__ y, float* __restrict__ out, long long n4, long long n)
+{
+    const long long i = (long long)blockIdx.x * GE_THREADS + threadIdx.x;
+    if (i < n4) {
+        const float4 a = reinterpret_cast<const float4*>(u)[i], b = reinterpret_cast<const float4*>(h)[i], c = reinterpret_cast<const float4*>(y)[i];
+        float4 r;
+        r.x = a.x * b.x + (1.0f - a.x) * c.x; r.y = a.y * b.y + (1.0f - a.y) * c.y;
+        r.z = a.z * b.z + (1.0f - a.z) * c.z; r.w = a.w * b.w + (1.0f - a.w) * c.w;
+        reinterpret_cast<float4*>(out)[i] = r;
+    }
+    const long long t = 4 * n4 + i;                          // tail (n not a multiple of 4), first workgroup only
+    if (blockIdx.x == 0 && t < n) out[t] = u[t] * h[t] + (1.0f - u[t]) * y[t];
+}
+
+__global__ __launch_bounds__(GE_THREADS)
+void gru_blend_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ u, const float* __restrict__ h, const float* __restrict__ y,
+                          float* __restrict__ du, float* __restrict__ dh, float* __restrict__ dc, long long n4, long long n)
+{
+    const long long i = (long long)blockIdx.x * GE_THREADS + threadIdx.x;
+    if (i < n4) {
+        const float4 g = reinterpret_cast<const float4*>(dy)[i], a = reinterpret_cast<const float4*>(u)[i];
+        const float4 b = reinterpret_cast<const float4*>(h)[i], c = reinterpret_cast<const float4*>(y)[i];
+        float4 r;
+        r.x = g.x * (b.x - c.x); r.y = g.y * (b.y - c.y); r.z = g.z * (b.z - c.z); r.w = g.w * (b.w - c.w);
+        reinterpret_cast<float4*>(du)[i] = r;
+        r.x = g.x * a.x; r.y = g.y * a.y; r.z = g.z * a.z; r.w = g.w * a.w;
+        reinterpret_cast<float4*>(dh)[i] = r;
+        r.x = g.x * (1.0f - a.x); r.y = g.y * (1.0f - a.y); r.z = g.z * (1.0f - a.z); r.w = g.w * (1.0f - a.w);
+        reinterpret_cast<float4*>(dc)[i] = r;
+    }
+    const long long t = 4 * n4 + i;
+    if (blockIdx.x == 0 && t < n) { du[t] = dy[t] * (h[t] - y[t]); dh[t] = dy[t] * u[t]; dc[t] = dy[t] * (1.0f - u[t]); }
+}
+
+// out (B, Cx + Ch, HW) = cat(x (B, Cx, HW), r * h (B, Ch, HW)); grid (segments of a sample, B)
+__global__ __launch_bounds__(GE_THREADS)
+void gru_mul_cat_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ h, float* __restrict__ out,
+                            long long nx, long long nh)
+{
+    const int b = blockIdx.y;
+    const long long i = (long long)blockIdx.x * GE_THREADS + threadIdx.x;
+    float* o = out + (size_t)b * (nx + nh);
+    if (i < nx) o[i] = x[(size_t)b * nx + i];
+    else if (i < nx + nh) { const size_t k = (size_t)b * nh + (i - nx); o[i] = r[k] * h[k]; }
+}
+
+// dr = dcat[:, Cx:] * h, dh = dcat[:, Cx:] * r
+__global__ __launch_bounds__(GE_THREADS)
+void gru_mul_cat_bwd_kernel(const float* __restrict__ dcat, const float* __restrict__ r, const float* __restrict__ h, float* __restrict__ dr,
+                            float* __restrict__ dh, long long nx, long long nh)
+{
+    const int b = blockIdx.y;
+    const long long i = (long long)blockIdx.x * GE_THREADS + threadIdx.x;
+    if (i < nh) {
+        const size_t k = (size_t)b * nh + i;
+        const float g = dcat[(size_t)b * (nx + nh) + nx + i];
+        dr[k] = g * h[k]; dh[k] = g * r[k];
+    }
+}
+
+}  // namespace smvs
+
+extern "C" SMVS_EXPORT int smvs_gru_blend_fwd(const float* u, const float* h, const float* y, float* out, long long n, void* stream)
+{
+    using namespace smvs;
+    if (!u || !h || !y || !out) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (n < 1) return fail(SMVS_ERR_ARG, "non-positive size");
+    if ((((uintptr_t)u) | ((uintptr_t)h) | ((uintptr_t)y) | ((uintptr_t)out)) & 15) return fail(SMVS_ERR_ARG, "pointers must be 16-byte aligned");
+    const long long n4 = n / 4, nb = (n4 + GE_THREADS - 1) / GE_THREADS;
+    hipLaunchKernelGGL(gru_blend_fwd_kernel, dim3((unsigned)(nb > 0 ? nb : 1)), dim3(GE_THREADS), 0, (hipStream_t)stream, u, h, y, out, n4, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "gru_blend_fwd launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
+}
+
+extern "C" SMVS_EXPORT int smvs_gru_blend_bwd(const float* dy, const float* u, const float* h, const float* y, float* du, float* dh, float* dcand,
+                                              long long n, void* stream)
+{
+    using namespace smvs;
+    if (!dy || !u || !h || !y || !du || !dh || !dcand) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (n < 1) return fail(SMVS_ERR_ARG, "non-positive size");
+    if ((((uintptr_t)dy) | ((uintptr_t)u) | ((uintptr_t)h) | ((uintptr_t)y) | ((uintptr_t)du) | ((uintptr_t)dh) | ((uintptr_t)dcand)) & 15)
+        return fail(SMVS_ERR_ARG, "pointers must be 16-byte aligned");
+    const long long n4 = n / 4, nb = (n4 + GE_THREADS - 1) / GE_THREADS;
+    hipLaunchKernelGGL(gru_blend_bwd_kernel, dim3((unsigned)(nb > 0 ? nb : 1)), dim3(GE_THREADS), 0, (hipStream_t)stream, dy, u, h, y, du, dh, dcand, n4, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "gru_blend_bwd launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
+}
+
+extern "C" SMVS_EXPORT int smvs_gru_mul_cat_fwd(const float* x, const float* r, const float* h, float* out, int B, int Cx, int Ch, int HW, void* stream)
+{
+    using namespace smvs;
+    if (!x || !r || !h || !out) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (B < 1 || Cx < 0 || Ch < 1 || HW < 1 || B > 65535) return fail(SMVS_ERR_ARG, "bad dimension");
+    const long long nx = (long long)Cx * HW, nh = (long long)Ch * HW;
+    hipLaunchKernelGGL(gru_mul_cat_fwd_kernel, dim3((unsigned)((nx + nh + GE_THREADS - 1) / GE_THREADS), B), dim3(GE_THREADS), 0, (hipStream_t)stream,
+                       x, r, h, out, nx, nh);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "gru_mul_cat_fwd launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
+}
+
+extern "C" SMVS_EXPORT int smvs_gru_mul_cat_bwd(const float* dcat, const float* r, const float* h, float* dr, float* dh, int B, int Cx, int Ch, int HW,
+                                                void* stream)
+{
+    using namespace smvs;
+    if (!dcat || !r || !h || !dr || !dh) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (B < 1 || Cx < 0 || Ch < 1 || HW < 1 || B > 65535) return fail(SMVS_ERR_ARG, "bad dimension");
+    const long long nx = (long long)Cx * HW, nh = (long long)Ch * HW;
+    hipLaunchKernelGGL(gru_mul_cat_bwd_kernel, dim3((unsigned)((nh + GE_THREADS - 1) / GE_THREADS), B), dim3(GE_THREADS), 0, (hipStream_t)stream,
+                       dcat, r, h, dr, dh, nx, nh);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "gru_mul_cat_bwd launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
+}

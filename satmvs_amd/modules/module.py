@@ -230,6 +230,58 @@ class _GroupNorm1Fn(torch.autograd.Function):
         return dx, dg, db, None, None
 
 
+class _GruMulCatFn(torch.autograd.Function):
+    """cat((x, r * h), 1) in one launch each way (reference: module.py:43-44)."""
+
+    @staticmethod
+    def forward(ctx, x, r, h):
+        dev = _lib.require_device(x, r, h)
+        x, r, h = x.float().contiguous(), r.float().contiguous(), h.float().contiguous()
+        B, Cx, H, W = x.shape
+        Ch = h.shape[1]
+        out = torch.empty((B, Cx + Ch, H, W), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("smvs_gru_mul_cat_fwd", _lib.ptr(x), _lib.ptr(r), _lib.ptr(h), _lib.ptr(out), B, Cx, Ch, H * W, _lib.current_stream(dev))
+        ctx.save_for_backward(r, h)
+        ctx.cx = Cx
+        return out
+
+    @staticmethod
+    def backward(ctx, dcat):
+        r, h = ctx.saved_tensors
+        B, Ch, H, W = h.shape
+        dcat = dcat.float().contiguous()
+        dr, dh = torch.empty_like(r), torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            _lib.call("smvs_gru_mul_cat_bwd", _lib.ptr(dcat), _lib.ptr(r), _lib.ptr(h), _lib.ptr(dr), _lib.ptr(dh), B, ctx.cx, Ch, H * W,
+                      _lib.current_stream(h.device))
+        return dcat[:, :ctx.cx], dr, dh
+
+
+class _GruBlendFn(torch.autograd.Function):
+    """u * h + (1 - u) * y in one launch each way (reference: module.py:57)."""
+
+    @staticmethod
+    def forward(ctx, u, h, y):
+        dev = _lib.require_device(u, h, y)
+        u, h, y = u.float().contiguous(), h.float().contiguous(), y.float().contiguous()
+        out = torch.empty_like(h)
+        with torch.cuda.device(dev):
+            _lib.call("smvs_gru_blend_fwd", _lib.ptr(u), _lib.ptr(h), _lib.ptr(y), _lib.ptr(out), h.numel(), _lib.current_stream(dev))
+        ctx.save_for_backward(u, h, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, h, y = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        du, dh, dc = torch.empty_like(u), torch.empty_like(h), torch.empty_like(y)
+        with torch.cuda.device(h.device):
+            _lib.call("smvs_gru_blend_bwd", _lib.ptr(dy), _lib.ptr(u), _lib.ptr(h), _lib.ptr(y), _lib.ptr(du), _lib.ptr(dh), _lib.ptr(dc), h.numel(),
+                      _lib.current_stream(h.device))
+        return du, dh, dc
+
+
 class GroupNorm1(nn.GroupNorm):
     """nn.GroupNorm(1, C, eps) -- same parameters, same state_dict keys (reference: module.py:15-20) -- whose forward can take
     the gate's activation along ("sigmoid" / "tanh").  On the GPU with gradients enabled it runs the native kernels: with one
@@ -266,8 +318,12 @@ class ConvGRUCell2(nn.Module):
         r, u = torch.split(gates, gates.shape[1] // 2, 1)
         r = self.reset_gate_norm(r, "sigmoid")
         u = self.update_gate_norm(u, "sigmoid")
-        cand = self.output_norm(self.output_conv(torch.cat((x, r * h), dim=1)), "tanh")
-        new_h = u * h + (1 - u) * cand
+        if x.is_cuda:                                             # the cell's element-wise steps: one native launch each way
+            cand = self.output_norm(self.output_conv(_GruMulCatFn.apply(x, r, h)), "tanh")
+            new_h = _GruBlendFn.apply(u, h, cand)
+        else:
+            cand = self.output_norm(self.output_conv(torch.cat((x, r * h), dim=1)), "tanh")
+            new_h = u * h + (1 - u) * cand
         return new_h, new_h
 
 

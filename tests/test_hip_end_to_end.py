@@ -388,6 +388,39 @@ def test_groupnorm1_native_matches_torch(dev, shape, act, sliced):
         assert float(dx0[:, :C].abs().max()) == 0.0             # the other half of the gate tensor gets no gradient from this norm
 
 
+@pytest.mark.parametrize("B,cin,ch,H,W", [(1, 8, 8, 33, 50), (2, 16, 16, 24, 48), (1, 64, 64, 12, 24), (2, 32, 8, 7, 9)])
+def test_convgru_cell_native_elementwise_matches_torch(dev, B, cin, ch, H, W):
+    """ConvGRUCell2 on the GPU (native GroupNorm + activation, cat(x, r*h) and the u-blend as one launch each way) against the
+    reference's operator sequence (module.py:22-58) written with torch operators on the same parameters: output 2e-6,
+    gradients w.r.t. x, h and every parameter 5e-5 of their scale."""
+    import torch.nn.functional as F
+    from satmvs_amd.modules.module import ConvGRUCell2
+    torch.manual_seed(11)
+    cell = ConvGRUCell2(cin, ch, 3).to(dev)
+    x0, h0 = torch.randn(B, cin, H, W, device=dev), torch.randn(B, ch, H, W, device=dev)
+    gout = torch.randn(B, ch, H, W, device=dev)
+
+    def reference(x, h):
+        f = cell.gate_conv(torch.cat((x, h), 1))
+        r, u = torch.split(f, ch, 1)
+        r = torch.sigmoid(F.group_norm(r, 1, cell.reset_gate_norm.weight, cell.reset_gate_norm.bias, 1e-5))
+        u = torch.sigmoid(F.group_norm(u, 1, cell.update_gate_norm.weight, cell.update_gate_norm.bias, 1e-5))
+        o = cell.output_conv(torch.cat((x, r * h), 1))
+        y = torch.tanh(F.group_norm(o, 1, cell.output_norm.weight, cell.output_norm.bias, 1e-5))
+        return u * h + (1 - u) * y
+
+    res = []
+    for fn in (lambda a, b: cell(a, b)[0], reference):
+        x, h = x0.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+        cell.zero_grad()
+        out = fn(x, h)
+        out.backward(gout)
+        res.append([out.detach(), x.grad.clone(), h.grad.clone()] + [p.grad.clone() for p in cell.parameters()])
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-6
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert float((a - b).abs().max()) <= 5e-5 * float(b.abs().max()) + 1e-7
+
+
 def test_training_step_runs_and_gradients_flow(dev, golden):
     """One optimisation-free training step through the native volume: loss.backward() reaches the
     feature extractor through smvs_costvol_bwd (train.py:279-285 analogue)."""
