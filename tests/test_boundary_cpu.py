@@ -278,3 +278,36 @@ def test_generated_heights_python_composite_matches_reference(golden):
     assert torch.equal(planes, stage1_planes(torch.from_numpy(g["dv"]), 8))
     t = stage_hypotheses(torch.from_numpy(g["prev_a"]), None, 6, 5.0, (H, W), (H // 2, W // 2), torch.float32, "cpu", 1)
     assert isinstance(t, torch.Tensor) and np.array_equal(t.numpy(), g["r_a"])          # CPU: the composite, not a generator
+
+
+def test_round3_training_entry_points_validate_arguments(lib):
+    """smvs_groupnorm1_* / smvs_gru_* (training path) and smvs_costvol_bwd reject null pointers, bad activations, strides,
+    alignments and sizes before any HIP call."""
+    from satmvs_amd import _lib
+    d = C.c_void_p(4096)
+    odd = C.c_void_p(4100)
+    with pytest.raises(_lib.SatMVSNativeError, match="null pointer"):
+        _lib.call("smvs_groupnorm1_fwd", None, 64, d, d, 1e-5, 0, d, d, d, 1, 8, 8, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="act must be"):
+        _lib.call("smvs_groupnorm1_fwd", d, 64, d, d, 1e-5, 3, d, d, d, 1, 8, 8, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="batch stride"):
+        _lib.call("smvs_groupnorm1_fwd", d, 63, d, d, 1e-5, 1, d, d, d, 2, 8, 8, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="grid limit"):
+        _lib.call("smvs_groupnorm1_fwd", d, 64 * 8, d, d, 1e-5, 1, d, d, d, 70000, 8, 8, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="needs the forward output"):
+        _lib.call("smvs_groupnorm1_bwd", d, d, 64, None, d, d, 2, d, 64, d, d, d, 1, 8, 8, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="batch stride"):
+        _lib.call("smvs_groupnorm1_bwd", d, d, 64, d, d, d, 2, d, 8, d, d, d, 1, 8, 8, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="16-byte aligned"):
+        _lib.call("smvs_gru_blend_fwd", d, odd, d, d, 64, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="non-positive"):
+        _lib.call("smvs_gru_blend_bwd", d, d, d, d, d, d, d, 0, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="null pointer"):
+        _lib.call("smvs_gru_mul_cat_fwd", d, None, d, d, 1, 8, 8, 64, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="bad dimension"):
+        _lib.call("smvs_gru_mul_cat_bwd", d, d, d, d, d, 1, 8, 0, 64, None)
+    arr = (C.c_void_p * 2)(4096, 4096)
+    with pytest.raises(_lib.SatMVSNativeError, match="border-tap encoding"):
+        _lib.call("smvs_costvol_bwd", 0, d, d, arr, 2, d, d, 1, d, arr, 1, 1, 1, 40000, 8, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="n_src"):
+        _lib.call("smvs_costvol_bwd", 0, d, d, arr, 8, d, d, 1, d, arr, 1, 1, 1, 8, 8, None)
