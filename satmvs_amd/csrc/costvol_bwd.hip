@@ -58,7 +58,7 @@ struct CostVolBwdParams {
 #define SMVS_BWD_OCC 2                 // waves per SIMD the kernel is compiled for
 #endif
 #ifndef SMVS_BWD_ABLATE
-#define SMVS_BWD_ABLATE 0              // timing experiments only (wrong results): 1 no flush atomics, 2 no box adds, 4 no reference atomic
+#define SMVS_BWD_ABLATE 0              // timing experiments only (wrong results): 1 no flush atomics, 2 no box adds, 4 no reference atomic, 16 geometry only
 #endif
 #ifndef SMVS_BWD_DCH8_SRC
 #define SMVS_BWD_DCH8_SRC 4           // up to this many source views a lane keeps 8 planes of taps (2 beyond: the register scheme only); measured 3 / 4 views: 4.01 -> 3.66, 6.78 -> 5.88 ms against 4-plane chunks
