@@ -191,6 +191,32 @@ class ConvTransReLU(nn.Module):
 
 
 # ---- recurrent regulariser (RED) ------------------------------------------------------------------------
+# debugging switch: SMVS_TRAIN_COMPOSITE=1 keeps the ConvGRU cells' GroupNorm / element-wise steps on torch's own
+# operators (A/B against the native ones; the cost-volume operators are native either way)
+_TRAIN_COMPOSITE_ONLY = os.environ.get("SMVS_TRAIN_COMPOSITE", "0") == "1"
+
+
+_FIND_WARNED = False
+
+
+def guard_miopen_find():
+    """Training forwards of the RED networks switch `torch.backends.cudnn.benchmark` off (the reference's train.py:21 turns it on).
+    On this image (ROCm 7.0 / PyTorch 2.10, MI355X) MIOpen's exhaustive search costs ~7 minutes per process for this network, and a
+    training forward at the 768x384 tile ended in a GPU memory access fault in 3 of 3 runs with the search on and the native
+    element-wise operators in the graph (0 of 1 with torch's own operators, 0 of 1 with serialised launches;
+    tools/debug_cudnn_benchmark.py) -- not root-caused.  MIOpen's default (immediate-mode) choices are what every test, fixture and
+    timing of this repository uses."""
+    global _FIND_WARNED
+    if torch.backends.cudnn.benchmark and not _TRAIN_COMPOSITE_ONLY:
+        torch.backends.cudnn.benchmark = False
+        if not _FIND_WARNED:
+            _FIND_WARNED = True
+            import warnings
+            warnings.warn("satmvs_amd: torch.backends.cudnn.benchmark switched off for training (MIOpen's exhaustive search: ~7 min per "
+                          "process here and implicated in a GPU memory fault, see satmvs_amd.modules.module.guard_miopen_find); "
+                          "SMVS_TRAIN_COMPOSITE=1 keeps it on together with torch's own GroupNorm / element-wise operators")
+
+
 class _GroupNorm1Fn(torch.autograd.Function):
     """act(GroupNorm(1, C)(x)) through smvs_groupnorm1_fwd / _bwd (csrc/groupnorm.hip).  x may be a channel slice of a
     wider tensor (the gate halves of the 2C-channel gate convolution): only its batch stride has to be regular."""
@@ -211,6 +237,7 @@ class _GroupNorm1Fn(torch.autograd.Function):
                       _lib.ptr(stats), _lib.ptr(ws), B, C, H * W, _lib.current_stream(dev))
         ctx.save_for_backward(x, w, y, stats)
         ctx.meta = (xbs, int(act))
+        ctx.ws = ws                                            # stays allocated while the graph lives: nothing the kernels touch is freed in flight
         return y
 
     @staticmethod
@@ -291,7 +318,7 @@ class GroupNorm1(nn.GroupNorm):
     _ACT = {None: 0, "sigmoid": 1, "tanh": 2}
 
     def forward(self, x, act=None):
-        if x.is_cuda and x.dim() == 4 and self.num_groups == 1 and self.affine:
+        if x.is_cuda and x.dim() == 4 and self.num_groups == 1 and self.affine and not _TRAIN_COMPOSITE_ONLY:
             return _GroupNorm1Fn.apply(x, self.weight, self.bias, self.eps, self._ACT[act])
         y = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
         return torch.sigmoid(y) if act == "sigmoid" else torch.tanh(y) if act == "tanh" else y
@@ -318,7 +345,7 @@ class ConvGRUCell2(nn.Module):
         r, u = torch.split(gates, gates.shape[1] // 2, 1)
         r = self.reset_gate_norm(r, "sigmoid")
         u = self.update_gate_norm(u, "sigmoid")
-        if x.is_cuda:                                             # the cell's element-wise steps: one native launch each way
+        if x.is_cuda and not _TRAIN_COMPOSITE_ONLY:               # the cell's element-wise steps: one native launch each way
             cand = self.output_norm(self.output_conv(_GruMulCatFn.apply(x, r, h)), "tanh")
             new_h = _GruBlendFn.apply(u, h, cand)
         else:

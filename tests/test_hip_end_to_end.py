@@ -421,6 +421,35 @@ def test_convgru_cell_native_elementwise_matches_torch(dev, B, cin, ch, H, W):
         assert float((a - b).abs().max()) <= 5e-5 * float(b.abs().max()) + 1e-7
 
 
+def test_training_forward_switches_miopen_find_off(dev, golden):
+    """The reference's train.py:21 sets cudnn.benchmark = True; the RED training forward switches it off with a warning
+    (satmvs_amd.modules.module.guard_miopen_find: ~7 min of exhaustive search per process on this image, and implicated in a
+    GPU memory fault).  Inference forwards leave the flag alone."""
+    import warnings
+    from satmvs_amd.modules import module
+    from satmvs_amd.networks import casred
+    g = golden("cascade")
+    nd = [int(v) for v in g["ndepths"]]
+    imgs, proj, dv = _inputs(g, dev)
+    saved = torch.backends.cudnn.benchmark
+    try:
+        torch.manual_seed(0)
+        net = casred.CascadeREDNet("rpc", min_interval=2.5, ndepths=nd).to(dev)
+        torch.backends.cudnn.benchmark = True
+        with torch.no_grad():
+            net.eval()(imgs, proj, dv)
+        assert torch.backends.cudnn.benchmark is True
+        module._FIND_WARNED = False
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            out = net.train()(imgs, proj, dv)
+        assert torch.backends.cudnn.benchmark is False
+        assert any("cudnn.benchmark switched off" in str(x.message) for x in w)
+        assert torch.isfinite(out["stage3"]["depth"]).all()
+    finally:
+        torch.backends.cudnn.benchmark = saved
+
+
 def test_training_step_runs_and_gradients_flow(dev, golden):
     """One optimisation-free training step through the native volume: loss.backward() reaches the
     feature extractor through smvs_costvol_bwd (train.py:279-285 analogue)."""

@@ -10,6 +10,7 @@ from satmvs_amd import rpc_synth
 from satmvs_amd.networks.casred import CascadeREDNet
 
 dev = torch.device("cuda:0")
+torch.backends.cudnn.benchmark = os.environ.get("SMVS_CUDNN_BENCHMARK", "0") == "1"      # train.py:21 sets it; MIOpen then searches per shape
 H, W, nd = 384, 768, [48, 32, 8]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 torch.manual_seed(0)
