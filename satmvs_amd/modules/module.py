@@ -194,6 +194,7 @@ class ConvTransReLU(nn.Module):
 # debugging switch: SMVS_TRAIN_COMPOSITE=1 keeps the ConvGRU cells' GroupNorm / element-wise steps on torch's own
 # operators (A/B against the native ones; the cost-volume operators are native either way)
 _TRAIN_COMPOSITE_ONLY = os.environ.get("SMVS_TRAIN_COMPOSITE", "0") == "1"
+_TRAIN_COMPOSITE_MASK = 7 if _TRAIN_COMPOSITE_ONLY else int(os.environ.get("SMVS_TRAIN_COMPOSITE_MASK", "0"))   # bisecting: 1 GroupNorm, 2 cat(x, r*h), 4 u-blend
 
 
 _FIND_WARNED = False
@@ -203,7 +204,7 @@ def guard_miopen_find():
     """Training forwards of the RED networks switch `torch.backends.cudnn.benchmark` off (the reference's train.py:21 turns it on).
     On this image (ROCm 7.0 / PyTorch 2.10, MI355X) MIOpen's exhaustive search costs ~7 minutes per process for this network, and a
     training forward at the 768x384 tile ended in a GPU memory access fault in 3 of 3 runs with the search on and the native
-    element-wise operators in the graph (0 of 1 with torch's own operators, 0 of 1 with serialised launches;
+    element-wise operators in the graph (0 of 1 with torch's own operators, 0 of 1 with only one of the two native operator groups, 0 of 1 with serialised launches;
     tools/debug_cudnn_benchmark.py) -- not root-caused.  MIOpen's default (immediate-mode) choices are what every test, fixture and
     timing of this repository uses."""
     global _FIND_WARNED
@@ -318,7 +319,7 @@ class GroupNorm1(nn.GroupNorm):
     _ACT = {None: 0, "sigmoid": 1, "tanh": 2}
 
     def forward(self, x, act=None):
-        if x.is_cuda and x.dim() == 4 and self.num_groups == 1 and self.affine and not _TRAIN_COMPOSITE_ONLY:
+        if x.is_cuda and x.dim() == 4 and self.num_groups == 1 and self.affine and not (_TRAIN_COMPOSITE_MASK & 1):
             return _GroupNorm1Fn.apply(x, self.weight, self.bias, self.eps, self._ACT[act])
         y = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
         return torch.sigmoid(y) if act == "sigmoid" else torch.tanh(y) if act == "tanh" else y
@@ -345,12 +346,10 @@ class ConvGRUCell2(nn.Module):
         r, u = torch.split(gates, gates.shape[1] // 2, 1)
         r = self.reset_gate_norm(r, "sigmoid")
         u = self.update_gate_norm(u, "sigmoid")
-        if x.is_cuda and not _TRAIN_COMPOSITE_ONLY:               # the cell's element-wise steps: one native launch each way
-            cand = self.output_norm(self.output_conv(_GruMulCatFn.apply(x, r, h)), "tanh")
-            new_h = _GruBlendFn.apply(u, h, cand)
-        else:
-            cand = self.output_norm(self.output_conv(torch.cat((x, r * h), dim=1)), "tanh")
-            new_h = u * h + (1 - u) * cand
+        native = x.is_cuda                                        # the cell's element-wise steps: one native launch each way
+        xc = _GruMulCatFn.apply(x, r, h) if native and not (_TRAIN_COMPOSITE_MASK & 2) else torch.cat((x, r * h), dim=1)
+        cand = self.output_norm(self.output_conv(xc), "tanh")
+        new_h = _GruBlendFn.apply(u, h, cand) if native and not (_TRAIN_COMPOSITE_MASK & 4) else u * h + (1 - u) * cand
         return new_h, new_h
 
 
