@@ -101,9 +101,16 @@ def version():
     return load().smvs_version().decode()
 
 
+_TRACE_CALLS = os.environ.get("SMVS_TRACE_CALLS", "0") == "1"
+
+
 def call(name, *args):
     """Invoke an entry point; non-zero return -> SatMVSNativeError(smvs_last_error())."""
     lib = load()
+    if _TRACE_CALLS:                                         # SMVS_TRACE_CALLS=1: every native call with its pointer arguments, to stderr
+        import sys
+        sys.stderr.write("smvs-call %s %s\n" % (name, " ".join(hex(a.value or 0) if isinstance(a, C.c_void_p) else str(a) if isinstance(a, (int, float)) else "arr" for a in args)))
+        sys.stderr.flush()
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise SatMVSNativeError("%s failed (code %d): %s" % (name, rc, lib.smvs_last_error().decode()))

@@ -202,20 +202,43 @@ _FIND_WARNED = False
 
 def guard_miopen_find():
     """Training forwards of the RED networks switch `torch.backends.cudnn.benchmark` off (the reference's train.py:21 turns it on).
-    On this image (ROCm 7.0 / PyTorch 2.10, MI355X) MIOpen's exhaustive search costs ~7 minutes per process for this network, and a
-    training forward at the 768x384 tile ended in a GPU memory access fault in 3 of 3 runs with the search on and the native
-    element-wise operators in the graph (0 of 1 with torch's own operators, 0 of 1 with only one of the two native operator groups, 0 of 1 with serialised launches;
-    tools/debug_cudnn_benchmark.py) -- not root-caused.  MIOpen's default (immediate-mode) choices are what every test, fixture and
-    timing of this repository uses."""
+    On this image (ROCm 7.0 / PyTorch 2.10, MI355X) MIOpen's search costs ~7 minutes per process for this network, and the training
+    forward at the 768x384 tile ends in a GPU memory access fault with it on: 5 of 5 whole-model runs, also with torch's own
+    GroupNorm / element-wise operators (SMVS_TRAIN_COMPOSITE=1); never with serialised launches; the RED stack alone at the same
+    sizes passes with either set of operators.  The faulting address is 2 MB aligned and is none of the pointers any native call of
+    the run received (SMVS_TRACE_CALLS=1: the two cost-volume calls of stages 1-2 precede it) -- i.e. a released allocator segment
+    that a queued kernel still uses; which kernel was not isolated within the round's GPU budget (tools/debug_cudnn_benchmark.py).
+    MIOpen's default (immediate-mode) choices are what every test, fixture and timing of this repository uses;
+    SMVS_ALLOW_MIOPEN_FIND=1 leaves the flag alone."""
     global _FIND_WARNED
-    if torch.backends.cudnn.benchmark and not _TRAIN_COMPOSITE_ONLY:
+    if torch.backends.cudnn.benchmark and os.environ.get("SMVS_ALLOW_MIOPEN_FIND", "0") != "1":
         torch.backends.cudnn.benchmark = False
         if not _FIND_WARNED:
             _FIND_WARNED = True
             import warnings
-            warnings.warn("satmvs_amd: torch.backends.cudnn.benchmark switched off for training (MIOpen's exhaustive search: ~7 min per "
-                          "process here and implicated in a GPU memory fault, see satmvs_amd.modules.module.guard_miopen_find); "
-                          "SMVS_TRAIN_COMPOSITE=1 keeps it on together with torch's own GroupNorm / element-wise operators")
+            warnings.warn("satmvs_amd: torch.backends.cudnn.benchmark switched off for training (MIOpen's search: ~7 min per process here, "
+                          "and the training forward ends in a GPU memory fault with it on -- see "
+                          "satmvs_amd.modules.module.guard_miopen_find; SMVS_ALLOW_MIOPEN_FIND=1 leaves the flag alone)")
+
+
+# Scratch of the GroupNorm kernels (a few float64 sums): ONE buffer per (device, stream) that lives as long as the process -- no
+# allocation per call, and nothing the kernels use is handed back to the caching allocator while they are still queued.
+# Superseded buffers are kept, never freed (growth is rare).
+_GN_SCRATCH = {}
+_GN_SCRATCH_OLD = []
+_GN_SCRATCH_LOCK = threading.Lock()
+
+
+def _gn_scratch(dev, doubles):
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    with _GN_SCRATCH_LOCK:
+        buf = _GN_SCRATCH.get(key)
+        if buf is None or buf.numel() < doubles:
+            if buf is not None:
+                _GN_SCRATCH_OLD.append(buf)
+            buf = torch.empty((max(8192, 2 * doubles),), dtype=torch.float64, device=dev)
+            _GN_SCRATCH[key] = buf
+    return buf
 
 
 class _GroupNorm1Fn(torch.autograd.Function):
@@ -232,13 +255,12 @@ class _GroupNorm1Fn(torch.autograd.Function):
         w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
         y = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
         stats = torch.empty((B, 2), dtype=torch.float32, device=dev)
-        ws = torch.empty((2 * B,), dtype=torch.float64, device=dev)
+        ws = _gn_scratch(dev, 2 * B)
         with torch.cuda.device(dev):
             _lib.call("smvs_groupnorm1_fwd", _lib.ptr(x), xbs, _lib.ptr(w), _lib.ptr(b), float(eps), int(act), _lib.ptr(y),
                       _lib.ptr(stats), _lib.ptr(ws), B, C, H * W, _lib.current_stream(dev))
         ctx.save_for_backward(x, w, y, stats)
         ctx.meta = (xbs, int(act))
-        ctx.ws = ws                                            # stays allocated while the graph lives: nothing the kernels touch is freed in flight
         return y
 
     @staticmethod
@@ -251,7 +273,7 @@ class _GroupNorm1Fn(torch.autograd.Function):
         dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
         dg = torch.empty((C,), dtype=torch.float32, device=dev)
         db = torch.empty((C,), dtype=torch.float32, device=dev)
-        ws = torch.empty((2 * B * C,), dtype=torch.float64, device=dev)
+        ws = _gn_scratch(dev, 2 * B * C)
         with torch.cuda.device(dev):
             _lib.call("smvs_groupnorm1_bwd", _lib.ptr(dy), _lib.ptr(x), xbs, _lib.ptr(y), _lib.ptr(w), _lib.ptr(stats), act,
                       _lib.ptr(dx), C * H * W, _lib.ptr(dg), _lib.ptr(db), _lib.ptr(ws), B, C, H * W, _lib.current_stream(dev))
