@@ -102,6 +102,7 @@ def version():
 
 
 _TRACE_CALLS = os.environ.get("SMVS_TRACE_CALLS", "0") == "1"
+_SYNC_CALLS = os.environ.get("SMVS_SYNC_CALLS", "0") == "1"
 
 
 def call(name, *args):
@@ -114,6 +115,8 @@ def call(name, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise SatMVSNativeError("%s failed (code %d): %s" % (name, rc, lib.smvs_last_error().decode()))
+    if _SYNC_CALLS:                                          # SMVS_SYNC_CALLS=1: wait for every native call (debugging: nothing native is in flight afterwards)
+        torch.cuda.synchronize()
 
 
 def current_stream(device):

@@ -203,11 +203,11 @@ _FIND_WARNED = False
 def guard_miopen_find():
     """Training forwards of the RED networks switch `torch.backends.cudnn.benchmark` off (the reference's train.py:21 turns it on).
     On this image (ROCm 7.0 / PyTorch 2.10, MI355X) MIOpen's search costs ~7 minutes per process for this network, and the training
-    forward at the 768x384 tile ends in a GPU memory access fault with it on: 5 of 5 whole-model runs, also with torch's own
-    GroupNorm / element-wise operators (SMVS_TRAIN_COMPOSITE=1); never with serialised launches; the RED stack alone at the same
-    sizes passes with either set of operators.  The faulting address is 2 MB aligned and is none of the pointers any native call of
-    the run received (SMVS_TRACE_CALLS=1: the two cost-volume calls of stages 1-2 precede it) -- i.e. a released allocator segment
-    that a queued kernel still uses; which kernel was not isolated within the round's GPU budget (tools/debug_cudnn_benchmark.py).
+    forward at the 768x384 tile ends in a GPU memory access fault with it on: 6 of 6 whole-model runs -- also with torch's own
+    GroupNorm / element-wise operators (SMVS_TRAIN_COMPOSITE=1) AND a device-wide synchronize after every native call
+    (SMVS_SYNC_CALLS=1), i.e. with no kernel of this library running or queued: the fault is inside the search (MIOpen's candidate
+    kernels / workspace handling), not in the native operators.  It never shows with serialised launches; the address is 2 MB aligned
+    and none of the pointers a native call received (SMVS_TRACE_CALLS=1).  tools/debug_cudnn_benchmark.py reproduces it.
     MIOpen's default (immediate-mode) choices are what every test, fixture and timing of this repository uses;
     SMVS_ALLOW_MIOPEN_FIND=1 leaves the flag alone."""
     global _FIND_WARNED
