@@ -267,6 +267,27 @@ def side_workloads(dev, stream):
         del tf_, gout
     except Exception as e:
         extra["cfg2_training_costvol_fwd_bwd"] = {"error": repr(e)[:200]}
+    # height error against the reference path on identical inputs -- the reference's own outputs for its seeded
+    # Infer_CascadeREDNet are committed as a fixture (tests/golden/cascade.npz: data, generated by tests/golden/gen_golden.py)
+    try:
+        from satmvs_amd import rpc_synth as _rs
+        from satmvs_amd.networks.casred import Infer_CascadeREDNet as _Net
+        gz = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "cascade.npz"))
+        torch.manual_seed(int(gz["red.seed"]))
+        gnet = _Net("rpc", min_interval=2.5, ndepths=[int(v) for v in gz["ndepths"]]).to(dev).eval()
+        grpc = gz["rpc"]
+        gpm = {"stage1": torch.from_numpy(_rs.rescale_rpc(grpc, 4)).to(dev), "stage2": torch.from_numpy(_rs.rescale_rpc(grpc, 2)).to(dev),
+               "stage3": torch.from_numpy(grpc).to(dev)}
+        with torch.no_grad():
+            gout = gnet(torch.from_numpy(gz["imgs"]).to(dev), gpm, torch.from_numpy(gz["dv"]).to(dev))
+        rec = {"fixture": "tests/golden/cascade.npz (the reference's Infer_CascadeREDNet outputs, same seed and inputs)", "target_m": 1e-3}
+        for st in ("stage1", "stage2", "stage3"):
+            d = np.abs(gout[st]["depth"].cpu().numpy().astype(np.float64) - gz["redinf.%s.depth" % st].astype(np.float64))
+            rec[st] = {"max_abs_m": float("%.3g" % d.max()), "mae_m": float("%.3g" % d.mean())}
+        extra["height_parity_vs_reference"] = rec
+        del gnet, gout
+    except Exception as e:
+        extra["height_parity_vs_reference"] = {"error": repr(e)[:200]}
     # cfg3: one inference cascade forward (FeatureNet + three stages of variance / RED / regression), 48/32/8 planes
     try:
         from satmvs_amd import rpc_synth
