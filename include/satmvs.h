@@ -183,6 +183,17 @@ int smvs_groupnorm1_bwd(const float* dy, const float* x, long long x_batch_strid
                         const float* mean_rstd, int act, float* dx, long long dx_batch_stride, float* dgamma,
                         float* dbeta, double* workspace, int B, int C, int HW, void* stream);
 
+/* Both gate norms of a ConvGRU cell in one call (modules/module.py:15-16, :37-40): x (B, 2C, HW) contiguous = the gate
+ * convolution's output; channels [0, C) are normalised with (gamma, beta), channels [C, 2C) with (gamma2, beta2), each half
+ * over its own C*HW values, then the activation.  y and dx (B, 2C, HW); mean_rstd (2B, 2) (sample 2b + half); workspace
+ * 4*B doubles (forward), 4*B*C (backward). */
+int smvs_groupnorm1_pair_fwd(const float* x, const float* gamma, const float* beta, const float* gamma2, const float* beta2,
+                             float eps, int act, float* y, float* mean_rstd, double* workspace, int B, int C, int HW,
+                             void* stream);
+int smvs_groupnorm1_pair_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* gamma2,
+                             const float* mean_rstd, int act, float* dx, float* dgamma, float* dbeta, float* dgamma2,
+                             float* dbeta2, double* workspace, int B, int C, int HW, void* stream);
+
 /* The ConvGRU cell's element-wise steps (modules/module.py:43-44 and :57), training path, one launch each way:
  *   smvs_gru_mul_cat:  out (B, Cx+Ch, HW) = cat(x (B,Cx,HW), r * h (B,Ch,HW));   backward: dr = dcat[:, Cx:] * h, dh = dcat[:, Cx:] * r
  *                      (dx is the first Cx channels of dcat as they are)

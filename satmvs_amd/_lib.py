@@ -36,6 +36,8 @@ _SIGNATURES = {
     "smvs_gru_mul_cat_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "smvs_gru_blend_fwd": [_vp, _vp, _vp, _vp, C.c_longlong, _vp],
     "smvs_gru_blend_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_longlong, _vp],
+    "smvs_groupnorm1_pair_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "smvs_groupnorm1_pair_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "smvs_groupnorm1_fwd": [_vp, C.c_longlong, _vp, _vp, _f, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "smvs_groupnorm1_bwd": [_vp, _vp, C.c_longlong, _vp, _vp, _vp, _i, _vp, C.c_longlong, _vp, _vp, _vp, _i, _i, _i, _vp],
     "smvs_rpc_costvol_fwd_gen": [_vp, _vp, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp],

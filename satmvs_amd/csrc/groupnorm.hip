@@ -92,6 +92,7 @@ __device__ __forceinline__ void mean_rstd_of(const double* sums, int b, long lon
 // grid (segments of HW, B*C)
 __global__ __launch_bounds__(GN_THREADS)
 void gn1_apply_kernel(const float* __restrict__ x, long long xbs, const float* __restrict__ gamma, const float* __restrict__ beta,
+                      const float* __restrict__ gamma2, const float* __restrict__ beta2,
                       const double* __restrict__ sums, float eps, int act, float* __restrict__ y, float* __restrict__ mean_rstd,
                       int C, int HW)
 {
@@ -99,7 +100,8 @@ void gn1_apply_kernel(const float* __restrict__ x, long long xbs, const float* _
     float mean, rstd;
     mean_rstd_of(sums, b, (long long)C * HW, eps, mean, rstd);
     if (c == 0 && blockIdx.x == 0 && threadIdx.x == 0) { mean_rstd[2 * b] = mean; mean_rstd[2 * b + 1] = rstd; }
-    const float g = gamma[c] * rstd, o = beta[c] - mean * g;            // y = x * g + o
+    const bool second = gamma2 != nullptr && (b & 1);                   // pair form: odd samples are the second half of a (B, 2C, HW) tensor
+    const float g = (second ? gamma2 : gamma)[c] * rstd, o = (second ? beta2 : beta)[c] - mean * g;            // y = x * g + o
     const float* xp = x + (size_t)b * xbs + (size_t)c * HW;
     float* yp = y + ((size_t)b * C + c) * HW;
     const int i0 = blockIdx.x * GN_ELEMS, i1 = min(i0 + GN_ELEMS, HW);
@@ -155,16 +157,18 @@ void gn1_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__
 // grid (segments of HW, B*C)
 __global__ __launch_bounds__(GN_THREADS)
 void gn1_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x, long long xbs, const float* __restrict__ y,
-                       const float* __restrict__ gamma, const float* __restrict__ mean_rstd, const double* __restrict__ rows,
-                       int act, float* __restrict__ dx, long long dxbs, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                       int B, int C, int HW)
+                       const float* __restrict__ gamma, const float* __restrict__ gamma2, const float* __restrict__ mean_rstd,
+                       const double* __restrict__ rows, int act, float* __restrict__ dx, long long dxbs, float* __restrict__ dgamma,
+                       float* __restrict__ dbeta, float* __restrict__ dgamma2, float* __restrict__ dbeta2, int B, int C, int HW)
 {
     const int row = blockIdx.y, b = row / C, c = row - b * C;
     // every workgroup folds the sample's C row sums itself (C <= a few hundred doubles from L2): no launch in between
+    const bool pair = gamma2 != nullptr;                     // odd samples: second parameter set
+    const float* gm = (pair && (b & 1)) ? gamma2 : gamma;
     double a_ = 0.0, q_ = 0.0;
     for (int k = threadIdx.x; k < C; k += GN_THREADS) {
-        a_ += (double)gamma[k] * rows[2 * (b * C + k)];
-        q_ += (double)gamma[k] * rows[2 * (b * C + k) + 1];
+        a_ += (double)gm[k] * rows[2 * (b * C + k)];
+        q_ += (double)gm[k] * rows[2 * (b * C + k) + 1];
     }
     __shared__ float coef[2];
     block_sum2(a_, q_);
@@ -172,13 +176,17 @@ void gn1_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x
     __syncthreads();
     if (row == 0 && blockIdx.x == 0) {                       // parameter gradients: sums over the batch, written once
         for (int k = threadIdx.x; k < C; k += GN_THREADS) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int bb = 0; bb < B; ++bb) { s1 += rows[2 * (bb * C + k)]; s2 += rows[2 * (bb * C + k) + 1]; }
+            double s1 = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0;
+            for (int bb = 0; bb < B; ++bb) {
+                if (pair && (bb & 1)) { t1 += rows[2 * (bb * C + k)]; t2 += rows[2 * (bb * C + k) + 1]; }
+                else { s1 += rows[2 * (bb * C + k)]; s2 += rows[2 * (bb * C + k) + 1]; }
+            }
             dbeta[k] = (float)s1; dgamma[k] = (float)s2;
+            if (pair) { dbeta2[k] = (float)t1; dgamma2[k] = (float)t2; }
         }
     }
     const float mean = mean_rstd[2 * b], rstd = mean_rstd[2 * b + 1];
-    const float a = coef[0], q = coef[1], g = gamma[c];
+    const float a = coef[0], q = coef[1], g = gm[c];
     const float* xp = x + (size_t)b * xbs + (size_t)c * HW;
     const float* dp = dy + ((size_t)b * C + c) * HW;
     const float* yp = y + ((size_t)b * C + c) * HW;
@@ -209,48 +217,85 @@ void gn1_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x
 
 }  // namespace smvs
 
-extern "C" SMVS_EXPORT int smvs_groupnorm1_fwd(const float* x, long long x_batch_stride, const float* gamma, const float* beta, float eps,
-                                               int act, float* y, float* mean_rstd, double* workspace, int B, int C, int HW, void* stream)
+namespace smvs {
+
+static int gn_fwd(const float* x, long long xbs, const float* gamma, const float* beta, const float* gamma2, const float* beta2, float eps, int act,
+                  float* y, float* mean_rstd, double* workspace, int B, int C, int HW, void* stream)
 {
-    using namespace smvs;
     if (!x || !gamma || !beta || !y || !mean_rstd || !workspace) return fail(SMVS_ERR_ARG, "null pointer argument");
     if (B < 1 || C < 1 || HW < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
     if (act < 0 || act > 2) return fail(SMVS_ERR_ARG, "act must be 0 (none), 1 (sigmoid) or 2 (tanh)");
-    if (x_batch_stride < (long long)C * HW) return fail(SMVS_ERR_ARG, "batch stride smaller than one sample");
+    if (xbs < (long long)C * HW) return fail(SMVS_ERR_ARG, "batch stride smaller than one sample");
     if ((long long)B * C > 65535 || B > 65535) return fail(SMVS_ERR_ARG, "B*C exceeds the grid limit 65535");
     hipStream_t st = (hipStream_t)stream;
     const long long n = (long long)C * HW;
     if (hipMemsetAsync(workspace, 0, sizeof(double) * 2 * B, st) != hipSuccess) return fail(SMVS_ERR_LAUNCH, "groupnorm workspace clear");
-    hipLaunchKernelGGL(gn1_stats_kernel, dim3((unsigned)((n + GN_ELEMS - 1) / GN_ELEMS), B), dim3(GN_THREADS), 0, st, x, x_batch_stride, n, workspace);
-    hipLaunchKernelGGL(gn1_apply_kernel, dim3((HW + GN_ELEMS - 1) / GN_ELEMS, B * C), dim3(GN_THREADS), 0, st, x, x_batch_stride, gamma, beta,
+    hipLaunchKernelGGL(gn1_stats_kernel, dim3((unsigned)((n + GN_ELEMS - 1) / GN_ELEMS), B), dim3(GN_THREADS), 0, st, x, xbs, n, workspace);
+    hipLaunchKernelGGL(gn1_apply_kernel, dim3((HW + GN_ELEMS - 1) / GN_ELEMS, B * C), dim3(GN_THREADS), 0, st, x, xbs, gamma, beta, gamma2, beta2,
                        workspace, eps, act, y, mean_rstd, C, HW);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "groupnorm1_fwd launch: %s", hipGetErrorString(e));
     return SMVS_OK;
 }
 
-extern "C" SMVS_EXPORT int smvs_groupnorm1_bwd(const float* dy, const float* x, long long x_batch_stride, const float* y, const float* gamma,
-                                               const float* mean_rstd, int act, float* dx, long long dx_batch_stride, float* dgamma,
-                                               float* dbeta, double* workspace, int B, int C, int HW, void* stream)
+static int gn_bwd(const float* dy, const float* x, long long xbs, const float* y, const float* gamma, const float* gamma2, const float* mean_rstd, int act,
+                  float* dx, long long dxbs, float* dgamma, float* dbeta, float* dgamma2, float* dbeta2, double* workspace, int B, int C, int HW,
+                  void* stream)
 {
-    using namespace smvs;
     if (!dy || !x || !gamma || !mean_rstd || !dx || !dgamma || !dbeta || !workspace) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (gamma2 && (!dgamma2 || !dbeta2)) return fail(SMVS_ERR_ARG, "null pointer argument");
     if (act != 0 && !y) return fail(SMVS_ERR_ARG, "the activation's backward needs the forward output y");
     if (B < 1 || C < 1 || HW < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
     if (act < 0 || act > 2) return fail(SMVS_ERR_ARG, "act must be 0 (none), 1 (sigmoid) or 2 (tanh)");
-    if (x_batch_stride < (long long)C * HW || dx_batch_stride < (long long)C * HW) return fail(SMVS_ERR_ARG, "batch stride smaller than one sample");
+    if (xbs < (long long)C * HW || dxbs < (long long)C * HW) return fail(SMVS_ERR_ARG, "batch stride smaller than one sample");
     if ((long long)B * C > 65535) return fail(SMVS_ERR_ARG, "B*C exceeds the grid limit 65535");
     hipStream_t st = (hipStream_t)stream;
     double* rows = workspace;                                // (B*C, 2)
     if (hipMemsetAsync(rows, 0, sizeof(double) * 2 * B * C, st) != hipSuccess) return fail(SMVS_ERR_LAUNCH, "groupnorm workspace clear");
     const float* yy = y ? y : dy;
     const dim3 grid((HW + GN_ELEMS - 1) / GN_ELEMS, B * C);
-    hipLaunchKernelGGL(gn1_bwd_rows_kernel, grid, dim3(GN_THREADS), 0, st, dy, x, x_batch_stride, yy, mean_rstd, act, rows, C, HW);
-    hipLaunchKernelGGL(gn1_bwd_dx_kernel, grid, dim3(GN_THREADS), 0, st, dy, x, x_batch_stride, yy, gamma, mean_rstd, rows, act, dx,
-                       dx_batch_stride, dgamma, dbeta, B, C, HW);
+    hipLaunchKernelGGL(gn1_bwd_rows_kernel, grid, dim3(GN_THREADS), 0, st, dy, x, xbs, yy, mean_rstd, act, rows, C, HW);
+    hipLaunchKernelGGL(gn1_bwd_dx_kernel, grid, dim3(GN_THREADS), 0, st, dy, x, xbs, yy, gamma, gamma2, mean_rstd, rows, act, dx, dxbs, dgamma, dbeta,
+                       dgamma2, dbeta2, B, C, HW);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "groupnorm1_bwd launch: %s", hipGetErrorString(e));
     return SMVS_OK;
+}
+
+}  // namespace smvs
+
+extern "C" SMVS_EXPORT int smvs_groupnorm1_fwd(const float* x, long long x_batch_stride, const float* gamma, const float* beta, float eps,
+                                               int act, float* y, float* mean_rstd, double* workspace, int B, int C, int HW, void* stream)
+{
+    return smvs::gn_fwd(x, x_batch_stride, gamma, beta, nullptr, nullptr, eps, act, y, mean_rstd, workspace, B, C, HW, stream);
+}
+
+extern "C" SMVS_EXPORT int smvs_groupnorm1_bwd(const float* dy, const float* x, long long x_batch_stride, const float* y, const float* gamma,
+                                               const float* mean_rstd, int act, float* dx, long long dx_batch_stride, float* dgamma,
+                                               float* dbeta, double* workspace, int B, int C, int HW, void* stream)
+{
+    return smvs::gn_bwd(dy, x, x_batch_stride, y, gamma, nullptr, mean_rstd, act, dx, dx_batch_stride, dgamma, dbeta, nullptr, nullptr, workspace, B, C,
+                        HW, stream);
+}
+
+// The gate pair of a ConvGRU cell in one call: x (B, 2C, HW) contiguous = the gate convolution's output; channels [0, C) are normalised with
+// (gamma, beta), channels [C, 2C) with (gamma2, beta2), each half over its own C*HW values (two nn.GroupNorm(1, C): module.py:15-16, :37-40).
+// Internally 2B samples of C channels at stride C*HW.  mean_rstd (2B, 2); workspace 4*B doubles (forward), 4*B*C (backward).
+extern "C" SMVS_EXPORT int smvs_groupnorm1_pair_fwd(const float* x, const float* gamma, const float* beta, const float* gamma2, const float* beta2,
+                                                    float eps, int act, float* y, float* mean_rstd, double* workspace, int B, int C, int HW,
+                                                    void* stream)
+{
+    if (!gamma2 || !beta2) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
+    return smvs::gn_fwd(x, (long long)C * HW, gamma, beta, gamma2, beta2, eps, act, y, mean_rstd, workspace, 2 * B, C, HW, stream);
+}
+
+extern "C" SMVS_EXPORT int smvs_groupnorm1_pair_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* gamma2,
+                                                    const float* mean_rstd, int act, float* dx, float* dgamma, float* dbeta, float* dgamma2,
+                                                    float* dbeta2, double* workspace, int B, int C, int HW, void* stream)
+{
+    if (!gamma2) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
+    return smvs::gn_bwd(dy, x, (long long)C * HW, y, gamma, gamma2, mean_rstd, act, dx, (long long)C * HW, dgamma, dbeta, dgamma2, dbeta2, workspace,
+                        2 * B, C, HW, stream);
 }
 
 // ---- the ConvGRU cell's element-wise steps, training path -----------------------------------------------------------

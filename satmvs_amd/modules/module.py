@@ -280,6 +280,42 @@ class _GroupNorm1Fn(torch.autograd.Function):
         return dx, dg, db, None, None
 
 
+class _GroupNormPairFn(torch.autograd.Function):
+    """act(GroupNorm(1, C)) of BOTH halves of the gate convolution's output (B, 2C, H, W), each half with its own affine
+    parameters, in one native call each way (smvs_groupnorm1_pair_fwd / _bwd; reference: module.py:34-40)."""
+
+    @staticmethod
+    def forward(ctx, gates, w1, b1, w2, b2, eps, act):
+        dev = _lib.require_device(gates, w1, b1, w2, b2)
+        x = gates.float().contiguous()
+        B, C2, H, W = x.shape
+        C = C2 // 2
+        ws_ = [t.detach().float().contiguous() for t in (w1, b1, w2, b2)]
+        y = torch.empty_like(x)
+        stats = torch.empty((2 * B, 2), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("smvs_groupnorm1_pair_fwd", _lib.ptr(x), _lib.ptr(ws_[0]), _lib.ptr(ws_[1]), _lib.ptr(ws_[2]), _lib.ptr(ws_[3]), float(eps),
+                      int(act), _lib.ptr(y), _lib.ptr(stats), _lib.ptr(_gn_scratch(dev, 4 * B)), B, C, H * W, _lib.current_stream(dev))
+        ctx.save_for_backward(x, ws_[0], ws_[2], y, stats)
+        ctx.act = int(act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, y, stats = ctx.saved_tensors
+        B, C2, H, W = x.shape
+        C = C2 // 2
+        dev = x.device
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(x)
+        g = torch.empty((4, C), dtype=torch.float32, device=dev)              # dgamma, dbeta, dgamma2, dbeta2
+        with torch.cuda.device(dev):
+            _lib.call("smvs_groupnorm1_pair_bwd", _lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(stats), ctx.act,
+                      _lib.ptr(dx), _lib.ptr(g[0]), _lib.ptr(g[1]), _lib.ptr(g[2]), _lib.ptr(g[3]), _lib.ptr(_gn_scratch(dev, 4 * B * C)),
+                      B, C, H * W, _lib.current_stream(dev))
+        return dx, g[0], g[1], g[2], g[3], None, None
+
+
 class _GruMulCatFn(torch.autograd.Function):
     """cat((x, r * h), 1) in one launch each way (reference: module.py:43-44)."""
 
@@ -365,9 +401,13 @@ class ConvGRUCell2(nn.Module):
         if h is None:
             h = torch.zeros((x.shape[0], self.output_channel, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device)
         gates = self.gate_conv(torch.cat((x, h), dim=1))
-        r, u = torch.split(gates, gates.shape[1] // 2, 1)
-        r = self.reset_gate_norm(r, "sigmoid")
-        u = self.update_gate_norm(u, "sigmoid")
+        if x.is_cuda and not (_TRAIN_COMPOSITE_MASK & 1):           # both gate norms + sigmoids: one native call each way
+            rn, un = self.reset_gate_norm, self.update_gate_norm
+            r, u = torch.split(_GroupNormPairFn.apply(gates, rn.weight, rn.bias, un.weight, un.bias, rn.eps, 1), gates.shape[1] // 2, 1)
+        else:
+            r, u = torch.split(gates, gates.shape[1] // 2, 1)
+            r = self.reset_gate_norm(r, "sigmoid")
+            u = self.update_gate_norm(u, "sigmoid")
         native = x.is_cuda                                        # the cell's element-wise steps: one native launch each way
         xc = _GruMulCatFn.apply(x, r, h) if native and not (_TRAIN_COMPOSITE_MASK & 2) else torch.cat((x, r * h), dim=1)
         cand = self.output_norm(self.output_conv(xc), "tanh")

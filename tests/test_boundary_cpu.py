@@ -298,6 +298,10 @@ def test_round3_training_entry_points_validate_arguments(lib):
         _lib.call("smvs_groupnorm1_bwd", d, d, 64, None, d, d, 2, d, 64, d, d, d, 1, 8, 8, None)
     with pytest.raises(_lib.SatMVSNativeError, match="batch stride"):
         _lib.call("smvs_groupnorm1_bwd", d, d, 64, d, d, d, 2, d, 8, d, d, d, 1, 8, 8, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="null pointer"):
+        _lib.call("smvs_groupnorm1_pair_fwd", d, d, d, None, d, 1e-5, 1, d, d, d, 1, 8, 8, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="null pointer"):
+        _lib.call("smvs_groupnorm1_pair_bwd", d, d, d, d, d, d, 1, d, d, d, None, d, d, 1, 8, 8, None)
     with pytest.raises(_lib.SatMVSNativeError, match="16-byte aligned"):
         _lib.call("smvs_gru_blend_fwd", d, odd, d, d, 64, None)
     with pytest.raises(_lib.SatMVSNativeError, match="non-positive"):
