@@ -173,10 +173,10 @@ int smvs_rpc_geo_consistency(const float* depth_ref, const double* rpc_ref, cons
  * the normalised gates); differentiated by train.py:284.  x (B,C,HW) float32 with batch stride x_batch_stride elements
  * (>= C*HW: the two gate halves of a (B,2C,H,W) tensor are normalised where they lie); act 0 none, 1 sigmoid, 2 tanh:
  *   y = act((x - mean_b) * rstd_b * gamma_c + beta_c),   mean / variance over the C*HW values of sample b.
- * mean_rstd (B,2) float32 out (kept for the backward); workspace: 2*B doubles (forward), 2*B*C doubles
+ * mean_rstd (B,2) float32 out (kept for the backward); workspace: 2*B*ceil(C*HW/4096) doubles (forward), 2*B*C*ceil(HW/4096) doubles
  * (backward), caller-owned, contents irrelevant on entry.  Backward: dx (batch stride dx_batch_stride), dgamma (C),
  * dbeta (C) are overwritten; y = the forward's output (needed when act != 0).  Statistics and the reductions of the
- * backward are accumulated in float64. */
+ * backward are accumulated in float64, without atomics (fixed order: deterministic). */
 int smvs_groupnorm1_fwd(const float* x, long long x_batch_stride, const float* gamma, const float* beta, float eps,
                         int act, float* y, float* mean_rstd, double* workspace, int B, int C, int HW, void* stream);
 int smvs_groupnorm1_bwd(const float* dy, const float* x, long long x_batch_stride, const float* y, const float* gamma,
@@ -186,7 +186,7 @@ int smvs_groupnorm1_bwd(const float* dy, const float* x, long long x_batch_strid
 /* Both gate norms of a ConvGRU cell in one call (modules/module.py:15-16, :37-40): x (B, 2C, HW) contiguous = the gate
  * convolution's output; channels [0, C) are normalised with (gamma, beta), channels [C, 2C) with (gamma2, beta2), each half
  * over its own C*HW values, then the activation.  y and dx (B, 2C, HW); mean_rstd (2B, 2) (sample 2b + half); workspace
- * 4*B doubles (forward), 4*B*C (backward). */
+ * as for smvs_groupnorm1_* with 2B samples (4*B*ceil(C*HW/4096) / 4*B*C*ceil(HW/4096) doubles). */
 int smvs_groupnorm1_pair_fwd(const float* x, const float* gamma, const float* beta, const float* gamma2, const float* beta2,
                              float eps, int act, float* y, float* mean_rstd, double* workspace, int B, int C, int HW,
                              void* stream);

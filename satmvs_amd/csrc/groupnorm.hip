@@ -6,11 +6,13 @@
 // to ONE workgroup: 152 us per call at the cascade's sizes, 5280 calls per training step = 45 % of the step's kernel
 // time (profiles/r03_train_step.txt), with ComputeInternalGradients the same way in the backward.  Here every pass is
 // spread over the whole chip:
-//   forward   stats: (chunks, B) workgroups sum x and x^2 in float64, one float64 atomic pair per workgroup
-//             apply: y = act((x - mean) * rstd * gamma_c + beta_c), one (b, c) row segment per workgroup
-//   backward  rows:  per (b, c): S1 = sum dz, S2 = sum dz * xhat   (dz = dy * act'(y)), float64 atomics per workgroup
+//   forward   stats: (chunks, B) workgroups sum x and x^2 of a 4096-element chunk in float64 and write the pair to the scratch
+//             apply: every workgroup folds its sample's chunk pairs (a few hundred doubles from L2), then
+//                    y = act((x - mean) * rstd * gamma_c + beta_c), one (b, c) row segment per workgroup
+//   backward  rows:  per (b, c, segment): S1 = sum dz, S2 = sum dz * xhat   (dz = dy * act'(y)), written to the scratch
 //             dx:    every workgroup folds A = sum_c gamma_c S1, Q = sum_c gamma_c S2 of its sample, then
 //                    dx = rstd * (dz * gamma_c - A/N - xhat * Q/N); workgroup 0 also writes dgamma_c = sum_b S2, dbeta_c = sum_b S1
+// No atomics and no clearing of the scratch: every partial sum has one writer, the folds run in a fixed order (deterministic).
 // The inference pipelines do not come here: red.hip folds the statistics into the producing convolution.
 #include "smvs_device.h"
 #include "smvs_host.h"
@@ -57,7 +59,7 @@ __device__ __forceinline__ float act_bwd(float dy, float y, int act)
 
 // x: (B, C, HW) with batch stride xbs (elements) -- the gate halves of a (B, 2C, H, W) tensor are normalised in place
 __global__ __launch_bounds__(GN_THREADS)
-void gn1_stats_kernel(const float* __restrict__ x, long long xbs, long long n, double* __restrict__ sums)
+void gn1_stats_kernel(const float* __restrict__ x, long long xbs, long long n, double* __restrict__ partial)
 {
     const int b = blockIdx.y;
     const float* xp = x + (size_t)b * xbs;
@@ -78,27 +80,36 @@ void gn1_stats_kernel(const float* __restrict__ x, long long xbs, long long n, d
         }
     }
     block_sum2(s, q);
-    if (threadIdx.x == 0) { unsafeAtomicAdd(sums + 2 * b, s); unsafeAtomicAdd(sums + 2 * b + 1, q); }
+    if (threadIdx.x == 0) { double* o = partial + 2 * ((size_t)b * gridDim.x + blockIdx.x); o[0] = s; o[1] = q; }
 }
 
-__device__ __forceinline__ void mean_rstd_of(const double* sums, int b, long long n, float eps, float& mean, float& rstd)
+// every thread of the workgroup gets the sample's mean and 1/sqrt(var + eps) from the nblk chunk pairs of the stats pass
+__device__ __forceinline__ void mean_rstd_of(const double* partial, int b, int nblk, long long n, float eps, float& mean, float& rstd)
 {
-    const double m = sums[2 * b] / (double)n;
-    const double var = fmax(sums[2 * b + 1] / (double)n - m * m, 0.0);
-    mean = (float)m;
-    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    __shared__ float mr[2];
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += GN_THREADS) { s += partial[2 * ((size_t)b * nblk + i)]; q += partial[2 * ((size_t)b * nblk + i) + 1]; }
+    block_sum2(s, q);
+    if (threadIdx.x == 0) {
+        const double m = s / (double)n;
+        const double var = fmax(q / (double)n - m * m, 0.0);
+        mr[0] = (float)m;
+        mr[1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    mean = mr[0]; rstd = mr[1];
 }
 
 // grid (segments of HW, B*C)
 __global__ __launch_bounds__(GN_THREADS)
 void gn1_apply_kernel(const float* __restrict__ x, long long xbs, const float* __restrict__ gamma, const float* __restrict__ beta,
                       const float* __restrict__ gamma2, const float* __restrict__ beta2,
-                      const double* __restrict__ sums, float eps, int act, float* __restrict__ y, float* __restrict__ mean_rstd,
+                      const double* __restrict__ partial, int nblk, float eps, int act, float* __restrict__ y, float* __restrict__ mean_rstd,
                       int C, int HW)
 {
     const int row = blockIdx.y, b = row / C, c = row - b * C;
     float mean, rstd;
-    mean_rstd_of(sums, b, (long long)C * HW, eps, mean, rstd);
+    mean_rstd_of(partial, b, nblk, (long long)C * HW, eps, mean, rstd);
     if (c == 0 && blockIdx.x == 0 && threadIdx.x == 0) { mean_rstd[2 * b] = mean; mean_rstd[2 * b + 1] = rstd; }
     const bool second = gamma2 != nullptr && (b & 1);                   // pair form: odd samples are the second half of a (B, 2C, HW) tensor
     const float g = (second ? gamma2 : gamma)[c] * rstd, o = (second ? beta2 : beta)[c] - mean * g;            // y = x * g + o
@@ -151,7 +162,7 @@ void gn1_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__
         s2 += (double)dz * (double)((xp[i] - mean) * rstd);
     }
     block_sum2(s1, s2);
-    if (threadIdx.x == 0) { unsafeAtomicAdd(rows + 2 * row, s1); unsafeAtomicAdd(rows + 2 * row + 1, s2); }
+    if (threadIdx.x == 0) { double* o = rows + 2 * ((size_t)row * gridDim.x + blockIdx.x); o[0] = s1; o[1] = s2; }
 }
 
 // grid (segments of HW, B*C)
@@ -165,10 +176,12 @@ void gn1_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x
     // every workgroup folds the sample's C row sums itself (C <= a few hundred doubles from L2): no launch in between
     const bool pair = gamma2 != nullptr;                     // odd samples: second parameter set
     const float* gm = (pair && (b & 1)) ? gamma2 : gamma;
+    const int nseg = gridDim.x;                              // partial pairs per (b, c) row, in the order the rows pass wrote them
     double a_ = 0.0, q_ = 0.0;
-    for (int k = threadIdx.x; k < C; k += GN_THREADS) {
-        a_ += (double)gm[k] * rows[2 * (b * C + k)];
-        q_ += (double)gm[k] * rows[2 * (b * C + k) + 1];
+    for (int j = threadIdx.x; j < C * nseg; j += GN_THREADS) {
+        const double g_ = (double)gm[j / nseg];
+        a_ += g_ * rows[2 * ((size_t)b * C * nseg + j)];
+        q_ += g_ * rows[2 * ((size_t)b * C * nseg + j) + 1];
     }
     __shared__ float coef[2];
     block_sum2(a_, q_);
@@ -177,10 +190,12 @@ void gn1_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x
     if (row == 0 && blockIdx.x == 0) {                       // parameter gradients: sums over the batch, written once
         for (int k = threadIdx.x; k < C; k += GN_THREADS) {
             double s1 = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0;
-            for (int bb = 0; bb < B; ++bb) {
-                if (pair && (bb & 1)) { t1 += rows[2 * (bb * C + k)]; t2 += rows[2 * (bb * C + k) + 1]; }
-                else { s1 += rows[2 * (bb * C + k)]; s2 += rows[2 * (bb * C + k) + 1]; }
-            }
+            for (int bb = 0; bb < B; ++bb)
+                for (int sg = 0; sg < nseg; ++sg) {
+                    const double* r_ = rows + 2 * (((size_t)bb * C + k) * nseg + sg);
+                    if (pair && (bb & 1)) { t1 += r_[0]; t2 += r_[1]; }
+                    else { s1 += r_[0]; s2 += r_[1]; }
+                }
             dbeta[k] = (float)s1; dgamma[k] = (float)s2;
             if (pair) { dbeta2[k] = (float)t1; dgamma2[k] = (float)t2; }
         }
@@ -229,10 +244,10 @@ static int gn_fwd(const float* x, long long xbs, const float* gamma, const float
     if ((long long)B * C > 65535 || B > 65535) return fail(SMVS_ERR_ARG, "B*C exceeds the grid limit 65535");
     hipStream_t st = (hipStream_t)stream;
     const long long n = (long long)C * HW;
-    if (hipMemsetAsync(workspace, 0, sizeof(double) * 2 * B, st) != hipSuccess) return fail(SMVS_ERR_LAUNCH, "groupnorm workspace clear");
-    hipLaunchKernelGGL(gn1_stats_kernel, dim3((unsigned)((n + GN_ELEMS - 1) / GN_ELEMS), B), dim3(GN_THREADS), 0, st, x, xbs, n, workspace);
+    const int nblk = (int)((n + GN_ELEMS - 1) / GN_ELEMS);
+    hipLaunchKernelGGL(gn1_stats_kernel, dim3((unsigned)nblk, B), dim3(GN_THREADS), 0, st, x, xbs, n, workspace);
     hipLaunchKernelGGL(gn1_apply_kernel, dim3((HW + GN_ELEMS - 1) / GN_ELEMS, B * C), dim3(GN_THREADS), 0, st, x, xbs, gamma, beta, gamma2, beta2,
-                       workspace, eps, act, y, mean_rstd, C, HW);
+                       workspace, nblk, eps, act, y, mean_rstd, C, HW);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "groupnorm1_fwd launch: %s", hipGetErrorString(e));
     return SMVS_OK;
@@ -250,8 +265,7 @@ static int gn_bwd(const float* dy, const float* x, long long xbs, const float* y
     if (xbs < (long long)C * HW || dxbs < (long long)C * HW) return fail(SMVS_ERR_ARG, "batch stride smaller than one sample");
     if ((long long)B * C > 65535) return fail(SMVS_ERR_ARG, "B*C exceeds the grid limit 65535");
     hipStream_t st = (hipStream_t)stream;
-    double* rows = workspace;                                // (B*C, 2)
-    if (hipMemsetAsync(rows, 0, sizeof(double) * 2 * B * C, st) != hipSuccess) return fail(SMVS_ERR_LAUNCH, "groupnorm workspace clear");
+    double* rows = workspace;                                // (B*C, segments, 2)
     const float* yy = y ? y : dy;
     const dim3 grid((HW + GN_ELEMS - 1) / GN_ELEMS, B * C);
     hipLaunchKernelGGL(gn1_bwd_rows_kernel, grid, dim3(GN_THREADS), 0, st, dy, x, xbs, yy, mean_rstd, act, rows, C, HW);
@@ -280,7 +294,7 @@ extern "C" SMVS_EXPORT int smvs_groupnorm1_bwd(const float* dy, const float* x, 
 
 // The gate pair of a ConvGRU cell in one call: x (B, 2C, HW) contiguous = the gate convolution's output; channels [0, C) are normalised with
 // (gamma, beta), channels [C, 2C) with (gamma2, beta2), each half over its own C*HW values (two nn.GroupNorm(1, C): module.py:15-16, :37-40).
-// Internally 2B samples of C channels at stride C*HW.  mean_rstd (2B, 2); workspace 4*B doubles (forward), 4*B*C (backward).
+// Internally 2B samples of C channels at stride C*HW.  mean_rstd (2B, 2); workspace as smvs_groupnorm1_* with 2B samples.
 extern "C" SMVS_EXPORT int smvs_groupnorm1_pair_fwd(const float* x, const float* gamma, const float* beta, const float* gamma2, const float* beta2,
                                                     float eps, int act, float* y, float* mean_rstd, double* workspace, int B, int C, int HW,
                                                     void* stream)

@@ -255,7 +255,7 @@ class _GroupNorm1Fn(torch.autograd.Function):
         w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
         y = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
         stats = torch.empty((B, 2), dtype=torch.float32, device=dev)
-        ws = _gn_scratch(dev, 2 * B)
+        ws = _gn_scratch(dev, 2 * B * ((C * H * W + 4095) // 4096))
         with torch.cuda.device(dev):
             _lib.call("smvs_groupnorm1_fwd", _lib.ptr(x), xbs, _lib.ptr(w), _lib.ptr(b), float(eps), int(act), _lib.ptr(y),
                       _lib.ptr(stats), _lib.ptr(ws), B, C, H * W, _lib.current_stream(dev))
@@ -273,7 +273,7 @@ class _GroupNorm1Fn(torch.autograd.Function):
         dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
         dg = torch.empty((C,), dtype=torch.float32, device=dev)
         db = torch.empty((C,), dtype=torch.float32, device=dev)
-        ws = _gn_scratch(dev, 2 * B * C)
+        ws = _gn_scratch(dev, 2 * B * C * ((H * W + 4095) // 4096))
         with torch.cuda.device(dev):
             _lib.call("smvs_groupnorm1_bwd", _lib.ptr(dy), _lib.ptr(x), xbs, _lib.ptr(y), _lib.ptr(w), _lib.ptr(stats), act,
                       _lib.ptr(dx), C * H * W, _lib.ptr(dg), _lib.ptr(db), _lib.ptr(ws), B, C, H * W, _lib.current_stream(dev))
@@ -295,7 +295,7 @@ class _GroupNormPairFn(torch.autograd.Function):
         stats = torch.empty((2 * B, 2), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.call("smvs_groupnorm1_pair_fwd", _lib.ptr(x), _lib.ptr(ws_[0]), _lib.ptr(ws_[1]), _lib.ptr(ws_[2]), _lib.ptr(ws_[3]), float(eps),
-                      int(act), _lib.ptr(y), _lib.ptr(stats), _lib.ptr(_gn_scratch(dev, 4 * B)), B, C, H * W, _lib.current_stream(dev))
+                      int(act), _lib.ptr(y), _lib.ptr(stats), _lib.ptr(_gn_scratch(dev, 4 * B * ((C * H * W + 4095) // 4096))), B, C, H * W, _lib.current_stream(dev))
         ctx.save_for_backward(x, ws_[0], ws_[2], y, stats)
         ctx.act = int(act)
         return y
@@ -311,7 +311,7 @@ class _GroupNormPairFn(torch.autograd.Function):
         g = torch.empty((4, C), dtype=torch.float32, device=dev)              # dgamma, dbeta, dgamma2, dbeta2
         with torch.cuda.device(dev):
             _lib.call("smvs_groupnorm1_pair_bwd", _lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(stats), ctx.act,
-                      _lib.ptr(dx), _lib.ptr(g[0]), _lib.ptr(g[1]), _lib.ptr(g[2]), _lib.ptr(g[3]), _lib.ptr(_gn_scratch(dev, 4 * B * C)),
+                      _lib.ptr(dx), _lib.ptr(g[0]), _lib.ptr(g[1]), _lib.ptr(g[2]), _lib.ptr(g[3]), _lib.ptr(_gn_scratch(dev, 4 * B * C * ((H * W + 4095) // 4096))),
                       B, C, H * W, _lib.current_stream(dev))
         return dx, g[0], g[1], g[2], g[3], None, None
 
