@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Random shapes / view counts / channel counts / geometries / height spans through the fused variance-volume kernels against the
+CPU oracle (bit comparison, as tests/test_hip_parity.py::test_costvol_vs_oracle):  python tools/fuzz_costvol_fwd.py [n] [seed]"""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import oracle as orc
+from satmvs_amd.modules import warping
+import test_hip_parity as T
+
+orc.build()
+dev = torch.device("cuda:0")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+tot_bad, worst = 0, 0.0
+for it in range(n):
+    V = int(rng.integers(2, 9)); C = int(rng.choice([1, 3, 8, 10, 16, 24, 32, 40])); D = int(rng.integers(1, 20))
+    H = int(rng.integers(3, 100)); W = int(rng.integers(3, 200)); B = int(rng.integers(1, 3))
+    geo = "rpc" if rng.random() < 0.7 else "pinhole"
+    jitter = bool(rng.random() < 0.6)
+    feats, gp, depth = T._inputs(B, V, C, D, H, W, seed=int(rng.integers(0, 10000)), jitter=jitter, geo=geo)
+    r = rng.random()
+    if r < 0.25:                                                # boxes overflow
+        lo, hi = (0.0, float(rng.uniform(2000, 40000))) if geo == "rpc" else (300.0, float(rng.uniform(900, 3000)))
+        depth = np.broadcast_to(np.linspace(lo, hi, D, dtype=np.float32).reshape(1, D, 1, 1), (B, D, H, W)).copy()
+    elif r < 0.35 and depth.ndim == 4:                          # some hypotheses are NaN / far outside
+        depth = depth.copy()
+        depth[..., ::3, ::5] = np.nan
+        depth[..., 1::4, 2::7] = 1e9
+    d0 = int(rng.integers(0, D)); d1 = int(rng.integers(d0 + 1, D + 1))
+    want = orc.costvol_variance(feats, gp, depth, geo, d_begin=d0, d_end=d1)[:, :, d0:d1]
+    got = warping.variance_cost_volume([torch.from_numpy(f).to(dev) for f in feats], torch.from_numpy(gp).to(dev), torch.from_numpy(depth).to(dev), geo,
+                                       d_begin=d0, d_end=d1).cpu().numpy()
+    same = (got == want) | (np.isnan(got) & np.isnan(want))
+    nbad = int((~same).sum())
+    tot_bad += nbad
+    if nbad:
+        diff = float(np.nanmax(np.abs(got.astype(np.float64) - want.astype(np.float64))))
+        worst = max(worst, diff)
+        if nbad > max(1, 1e-4 * got.size) or not diff <= 2e-4:
+            print("MISMATCH it=%d B=%d V=%d C=%d D=%d[%d:%d] H=%d W=%d geo=%s jitter=%s: %d of %d differ, max %.3g" % (it, B, V, C, D, d0, d1, H, W, geo, jitter, nbad, got.size, diff))
+print("%d cases: %d differing voxels in total, largest difference %.3g" % (n, tot_bad, worst))
