@@ -1,11 +1,12 @@
 #!/usr/bin/env python
 """Random shapes / view counts / geometries / height spans through smvs_costvol_bwd against autograd through the per-view warp
-operators (the comparison of tests/test_hip_parity.py::test_costvol_backward_matrix):  python tools/fuzz_costvol_bwd.py [n] [seed]"""
+operators (the comparison of tests/test_hip_parity.py::test_costvol_backward_matrix):  python tests/fuzz/fuzz_costvol_bwd.py [n] [seed]"""
 import os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from satmvs_amd.modules import warping
 import test_hip_parity as T
 

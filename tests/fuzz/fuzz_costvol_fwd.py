@@ -1,10 +1,10 @@
 #!/usr/bin/env python
 """Random shapes / view counts / channel counts / geometries / height spans through the fused variance-volume kernels against the
-CPU oracle (bit comparison, as tests/test_hip_parity.py::test_costvol_vs_oracle):  python tools/fuzz_costvol_fwd.py [n] [seed]"""
+CPU oracle (bit comparison, as tests/test_hip_parity.py::test_costvol_vs_oracle):  python tests/fuzz/fuzz_costvol_fwd.py [n] [seed]"""
 import os, sys
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import oracle as orc
 from satmvs_amd.modules import warping

@@ -1,10 +1,10 @@
 #!/usr/bin/env python
 """Random shapes through the smaller operators of the path against the CPU oracle: rpc_warping / homo_warping (bits), softmax and
-window regressions, streaming regression, in-kernel height hypotheses (bits).   python tools/fuzz_ops.py [n] [seed]"""
+window regressions, streaming regression, in-kernel height hypotheses (bits).   python tests/fuzz/fuzz_ops.py [n] [seed]"""
 import os, sys
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import oracle as orc
 from satmvs_amd.modules import module as M
