@@ -241,6 +241,11 @@ def _gn_scratch(dev, doubles):
     return buf
 
 
+def _f32c_fast(t):
+    """float32 contiguous tensor with the cheapest possible host path (these run ~10^4 times per eager training step)."""
+    return t if (t.dtype is torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
 class _GroupNorm1Fn(torch.autograd.Function):
     """act(GroupNorm(1, C)(x)) through smvs_groupnorm1_fwd / _bwd (csrc/groupnorm.hip).  x may be a channel slice of a
     wider tensor (the gate halves of the 2C-channel gate convolution): only its batch stride has to be regular."""
@@ -252,7 +257,7 @@ class _GroupNorm1Fn(torch.autograd.Function):
         if x.dtype != torch.float32 or x.stride(1) != H * W or x.stride(2) != W or x.stride(3) != 1 or (B > 1 and x.stride(0) < C * H * W):
             x = x.float().contiguous()
         xbs = x.stride(0) if B > 1 else C * H * W
-        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        w, b = _f32c_fast(weight.detach()), _f32c_fast(bias.detach())
         y = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
         stats = torch.empty((B, 2), dtype=torch.float32, device=dev)
         ws = _gn_scratch(dev, 2 * B * ((C * H * W + 4095) // 4096))
@@ -269,7 +274,7 @@ class _GroupNorm1Fn(torch.autograd.Function):
         xbs, act = ctx.meta
         B, C, H, W = y.shape
         dev = y.device
-        dy = dy.float().contiguous()
+        dy = _f32c_fast(dy)
         dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
         dg = torch.empty((C,), dtype=torch.float32, device=dev)
         db = torch.empty((C,), dtype=torch.float32, device=dev)
@@ -287,10 +292,10 @@ class _GroupNormPairFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gates, w1, b1, w2, b2, eps, act):
         dev = _lib.require_device(gates, w1, b1, w2, b2)
-        x = gates.float().contiguous()
+        x = _f32c_fast(gates)
         B, C2, H, W = x.shape
         C = C2 // 2
-        ws_ = [t.detach().float().contiguous() for t in (w1, b1, w2, b2)]
+        ws_ = [_f32c_fast(t.detach()) for t in (w1, b1, w2, b2)]
         y = torch.empty_like(x)
         stats = torch.empty((2 * B, 2), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
@@ -306,7 +311,7 @@ class _GroupNormPairFn(torch.autograd.Function):
         B, C2, H, W = x.shape
         C = C2 // 2
         dev = x.device
-        dy = dy.float().contiguous()
+        dy = _f32c_fast(dy)
         dx = torch.empty_like(x)
         g = torch.empty((4, C), dtype=torch.float32, device=dev)              # dgamma, dbeta, dgamma2, dbeta2
         with torch.cuda.device(dev):
@@ -322,7 +327,7 @@ class _GruMulCatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, r, h):
         dev = _lib.require_device(x, r, h)
-        x, r, h = x.float().contiguous(), r.float().contiguous(), h.float().contiguous()
+        x, r, h = _f32c_fast(x), _f32c_fast(r), _f32c_fast(h)
         B, Cx, H, W = x.shape
         Ch = h.shape[1]
         out = torch.empty((B, Cx + Ch, H, W), dtype=torch.float32, device=dev)
@@ -336,7 +341,7 @@ class _GruMulCatFn(torch.autograd.Function):
     def backward(ctx, dcat):
         r, h = ctx.saved_tensors
         B, Ch, H, W = h.shape
-        dcat = dcat.float().contiguous()
+        dcat = _f32c_fast(dcat)
         dr, dh = torch.empty_like(r), torch.empty_like(h)
         with torch.cuda.device(h.device):
             _lib.call("smvs_gru_mul_cat_bwd", _lib.ptr(dcat), _lib.ptr(r), _lib.ptr(h), _lib.ptr(dr), _lib.ptr(dh), B, ctx.cx, Ch, H * W,
@@ -350,7 +355,7 @@ class _GruBlendFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, h, y):
         dev = _lib.require_device(u, h, y)
-        u, h, y = u.float().contiguous(), h.float().contiguous(), y.float().contiguous()
+        u, h, y = _f32c_fast(u), _f32c_fast(h), _f32c_fast(y)
         out = torch.empty_like(h)
         with torch.cuda.device(dev):
             _lib.call("smvs_gru_blend_fwd", _lib.ptr(u), _lib.ptr(h), _lib.ptr(y), _lib.ptr(out), h.numel(), _lib.current_stream(dev))
@@ -360,7 +365,7 @@ class _GruBlendFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         u, h, y = ctx.saved_tensors
-        dy = dy.float().contiguous()
+        dy = _f32c_fast(dy)
         du, dh, dc = torch.empty_like(u), torch.empty_like(h), torch.empty_like(y)
         with torch.cuda.device(h.device):
             _lib.call("smvs_gru_blend_bwd", _lib.ptr(dy), _lib.ptr(u), _lib.ptr(h), _lib.ptr(y), _lib.ptr(du), _lib.ptr(dh), _lib.ptr(dc), h.numel(),
