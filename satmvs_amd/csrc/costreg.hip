@@ -175,6 +175,9 @@ void conv3d_kernel(const Conv3Args a)
 // the halo for lanes 0 and 63.  Row validity is wave-uniform, so the row offset rides in the scalar offset and
 // the 27-entry per-lane offset table disappears.  With the loads cheap the kernel turns VALU-bound, so the 8
 // output channels are 4 register pairs on v_pk_fma_f32 (weight pairs straight from SGPRs).
+// COT = output channels a lane computes: 8, or 2 for the single-channel `prob` layer (same packed weights: the first pair of each
+// group of 8 -- with 8 the prob layer spent 7/8 of its arithmetic on padding channels).
+template <int COT>
 __global__ __launch_bounds__(256)
 void conv3d_s1_kernel(const Conv3Args a)
 {
@@ -201,9 +204,9 @@ void conv3d_s1_kernel(const Conv3Args a)
         }
     const BufRsrc rs = make_rsrc(a.in + (size_t)b * a.Cin * vol_i, (uint32_t)((size_t)a.Cin * vol_i * 4));
     typedef const f32x2 __attribute__((address_space(4))) * cw3p_t;
-    f32x2 acc2[CR_COT / 2];
+    f32x2 acc2[COT / 2];
 #pragma unroll
-    for (int j = 0; j < CR_COT / 2; ++j) acc2[j] = (f32x2)(0.0f);
+    for (int j = 0; j < COT / 2; ++j) acc2[j] = (f32x2)(0.0f);
     const cw3_t wbase = (cw3_t)(uintptr_t)(a.w + (size_t)cog * a.Cin * 27 * CR_COT);
     for (int ci = 0; ci < a.Cin; ++ci) {
         const int choff = (int)((size_t)ci * vol_i * 4);
@@ -223,7 +226,7 @@ void conv3d_s1_kernel(const Conv3Args a)
             const f32x2 t0 = {l, c[r]};
             const f32x2 t1 = {rr, rr};
 #pragma unroll
-            for (int j = 0; j < CR_COT / 2; ++j) {
+            for (int j = 0; j < COT / 2; ++j) {
                 acc2[j] = __builtin_elementwise_fma(__builtin_shufflevector(t0, t0, 0, 0), wc[(r * 3 + 0) * (CR_COT / 2) + j], acc2[j]);
                 acc2[j] = __builtin_elementwise_fma(__builtin_shufflevector(t0, t0, 1, 1), wc[(r * 3 + 1) * (CR_COT / 2) + j], acc2[j]);
                 acc2[j] = __builtin_elementwise_fma(__builtin_shufflevector(t1, t1, 0, 0), wc[(r * 3 + 2) * (CR_COT / 2) + j], acc2[j]);
@@ -233,14 +236,14 @@ void conv3d_s1_kernel(const Conv3Args a)
     if (!active) return;
     const size_t vol_o = (size_t)a.Do * a.Ho * a.Wo;
     const size_t pos = ((size_t)od * a.Ho + oy) * a.Wo + ox;
-    float sk[CR_COT];                            // skip values first, all in flight together (see conv3d_kernel)
+    float sk[COT];                               // skip values first, all in flight together (see conv3d_kernel)
 #pragma unroll
-    for (int j = 0; j < CR_COT; ++j) {
+    for (int j = 0; j < COT; ++j) {
         const int co = cog * CR_COT + j;
         sk[j] = a.skip ? a.skip[((size_t)b * a.Cout + (co < a.Cout ? co : 0)) * vol_o + pos] : 0.0f;
     }
 #pragma unroll
-    for (int j = 0; j < CR_COT; ++j) {
+    for (int j = 0; j < COT; ++j) {
         const int co = cog * CR_COT + j;
         if (co < a.Cout) {
             const float av = (j & 1) ? acc2[j >> 1].y : acc2[j >> 1].x;
@@ -548,7 +551,8 @@ SMVS_EXPORT int smvs_costreg_fwd(const float* packed, const float* vol, float* o
         } else {
             dim3 grd((a.Wo + 63) / 64, (a.Ho * a.Do + 3) / 4, B * ncog);
             static const bool gather = tune_int("SMVS_CONV3D_GATHER", 0) == 1;
-            if (l.stride == 1 && !gather) hipLaunchKernelGGL(conv3d_s1_kernel, grd, dim3(256), 0, st, a);
+            if (l.stride == 1 && !gather && l.cout <= 2) hipLaunchKernelGGL(conv3d_s1_kernel<2>, grd, dim3(256), 0, st, a);
+            else if (l.stride == 1 && !gather) hipLaunchKernelGGL(conv3d_s1_kernel<CR_COT>, grd, dim3(256), 0, st, a);
             else if (l.stride == 1)       hipLaunchKernelGGL(conv3d_kernel<1>, grd, dim3(256), 0, st, a);
             else               hipLaunchKernelGGL(conv3d_kernel<2>, grd, dim3(256), 0, st, a);
         }
