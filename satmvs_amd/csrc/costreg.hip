@@ -25,6 +25,7 @@
 namespace smvs {
 
 constexpr int CR_COT = 8;
+constexpr int CR_S1_TILE = 62;                // outputs of a wave of the stride-1 row kernel (64 loaded columns minus the two halo lanes)
 constexpr int CR_NL = 11;                    // conv0,1,2,3,4,5,6, conv7,9,11 (transposed), prob
 
 struct CrLayer { int cin, cout, stride, transposed, bn, relu; };
@@ -170,9 +171,10 @@ void conv3d_kernel(const Conv3Args a)
 
 // Stride-1 3x3x3 correlation for the full-resolution layers (conv0, prob): the direct kernel above is bound by the
 // texture-address path -- 27 gathers per channel, the +-1 x-taps unaligned (8 clocks each on this part).  Here a
-// wave owns 64 consecutive x of one (d,y) row: per input row ONE aligned coalesced load gives the centre taps,
-// the x-1 / x+1 taps come from the neighbouring lanes (DPP wave shift), and a second, two-lane load supplies
-// the halo for lanes 0 and 63.  Row validity is wave-uniform, so the row offset rides in the scalar offset and
+// wave loads 64 consecutive x of one (d,y) row with ONE coalesced load per input row and computes the 62 inner ones: the
+// x-1 / x+1 taps come from the neighbouring lanes (DPP wave shift), lanes 0 and 63 only carry the halo (round 3; before,
+// a wave computed 64 outputs and fetched the halo with a second, two-lane load per row: the kernel was bound by the issue
+// of those loads -- 18 instead of 9 per input channel).  Row validity is wave-uniform, so the row offset rides in the scalar offset and
 // the 27-entry per-lane offset table disappears.  With the loads cheap the kernel turns VALU-bound, so the 8
 // output channels are 4 register pairs on v_pk_fma_f32 (weight pairs straight from SGPRs).
 // COT = output channels a lane computes: 8, or 2 for the single-channel `prob` layer (same packed weights: the first pair of each
@@ -182,18 +184,16 @@ __global__ __launch_bounds__(256)
 void conv3d_s1_kernel(const Conv3Args a)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x0 = blockIdx.x * 64, ox = x0 + lane;
+    const int ox = blockIdx.x * CR_S1_TILE - 1 + lane;      // lanes 1..62 own an output, lanes 0 / 63 are the west / east halo
     const int yz = blockIdx.y * 4 + wave;
     const int oy = yz % a.Ho, od = yz / a.Ho;
     const int ncog = (a.Cout + CR_COT - 1) / CR_COT;
     const int cog = blockIdx.z % ncog, b = blockIdx.z / ncog;
     if (od >= a.Do) return;                                  // wave-uniform
-    const bool active = ox < a.Wo;
+    const bool active = lane >= 1 && lane <= CR_S1_TILE && ox < a.Wo;
     const int HWi = a.Hi * a.Wi;
     const size_t vol_i = (size_t)a.Di * HWi;
-    const uint32_t vc = active ? (uint32_t)ox * 4u : SMVS_OOB;
-    const uint32_t vh = lane == 0 ? (x0 > 0 ? (uint32_t)(x0 - 1) * 4u : SMVS_OOB)
-                      : lane == 63 ? (x0 + 64 < a.Wi ? (uint32_t)(x0 + 64) * 4u : SMVS_OOB) : SMVS_OOB;
+    const uint32_t vc = (ox >= 0 && ox < a.Wi) ? (uint32_t)ox * 4u : SMVS_OOB;     // zero padding / beyond the row: the range check returns 0
     int rowoff[9];                                           // (kd,ky) -> byte offset of the input row, wave-uniform
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd)
@@ -211,18 +211,17 @@ void conv3d_s1_kernel(const Conv3Args a)
     for (int ci = 0; ci < a.Cin; ++ci) {
         const int choff = (int)((size_t)ci * vol_i * 4);
         const cw3p_t wc = (cw3p_t)(wbase + (size_t)ci * 27 * CR_COT);
-        float c[9], h[9];
+        float c[9];
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             const int so = rowoff[r] >= 0 ? choff + rowoff[r] : (int)SMVS_OOB;      // scalar select
             c[r] = llvm_raw_buffer_load_f32(rs.v, (int)vc, so, 0);
-            h[r] = llvm_raw_buffer_load_f32(rs.v, (int)vh, so, 0);
         }
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            // lane i <- lane i-1 (wave_shr:1, lane 0 keeps its halo) ; lane i <- lane i+1 (wave_shl:1, lane 63 keeps its halo)
-            const float l = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, h[r]), __builtin_bit_cast(int, c[r]), 0x138, 0xf, 0xf, false));
-            const float rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, h[r]), __builtin_bit_cast(int, c[r]), 0x130, 0xf, 0xf, false));
+            // lane i <- lane i-1 (wave_shr:1) ; lane i <- lane i+1 (wave_shl:1); lanes 0 / 63 get 0 and produce no output
+            const float l = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c[r]), 0x138, 0xf, 0xf, false));
+            const float rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c[r]), 0x130, 0xf, 0xf, false));
             const f32x2 t0 = {l, c[r]};
             const f32x2 t1 = {rr, rr};
 #pragma unroll
@@ -550,9 +549,10 @@ SMVS_EXPORT int smvs_costreg_fwd(const float* packed, const float* vol, float* o
                 hipLaunchKernelGGL(convT3d_kernel, grd, dim3(256), 0, st, a);
         } else {
             dim3 grd((a.Wo + 63) / 64, (a.Ho * a.Do + 3) / 4, B * ncog);
+            const dim3 grd1((a.Wo + CR_S1_TILE - 1) / CR_S1_TILE, (a.Ho * a.Do + 3) / 4, B * ncog);
             static const bool gather = tune_int("SMVS_CONV3D_GATHER", 0) == 1;
-            if (l.stride == 1 && !gather && l.cout <= 2) hipLaunchKernelGGL(conv3d_s1_kernel<2>, grd, dim3(256), 0, st, a);
-            else if (l.stride == 1 && !gather) hipLaunchKernelGGL(conv3d_s1_kernel<CR_COT>, grd, dim3(256), 0, st, a);
+            if (l.stride == 1 && !gather && l.cout <= 2) hipLaunchKernelGGL(conv3d_s1_kernel<2>, grd1, dim3(256), 0, st, a);
+            else if (l.stride == 1 && !gather) hipLaunchKernelGGL(conv3d_s1_kernel<CR_COT>, grd1, dim3(256), 0, st, a);
             else if (l.stride == 1)       hipLaunchKernelGGL(conv3d_kernel<1>, grd, dim3(256), 0, st, a);
             else               hipLaunchKernelGGL(conv3d_kernel<2>, grd, dim3(256), 0, st, a);
         }
