@@ -50,6 +50,20 @@ const char* smvs_last_error(void);
  * of later calls on the caller's stream (slower, but legal inside hipStreamBeginCapture / hipGraph capture);
  * any other value restores the default.  Process-wide, thread-safe; returns the previous setting (0 or 2). */
 int smvs_red_set_streams(int n);
+/* Arithmetic of the variance build (smvs_*_costvol_fwd[_gen], and the plane pipelines that call them).
+ *   SMVS_ARITH_EXACT  the reference's float32 rounding sequence operation for operation (sum, sum of squares, two true
+ *                     divisions by the view count, mean^2, subtract: networks/casred.py:26-53): bit-identical to the
+ *                     CPU oracle; what every bit-level test runs.
+ *   SMVS_ARITH_FUSED  (default) the same float64 geometry, float32 tap coordinates and bilinear weights, but the variance
+ *                     is taken of the differences to the ref feature with its constant factors folded into the weights
+ *                     (11 instead of 22 packed operations per plane and channel pair at 3 views).  Differs from the
+ *                     reference by float32 rounding only -- |delta| <= 1e-5 * max(1, |v|) on the volume (SURVEY.md
+ *                     section 8c), regressed heights within north_star's 1e-3 m -- and is the closer of the two to a float64
+ *                     evaluation (tests/test_fused_arith.py).
+ * Process-wide, thread-safe, takes effect for later calls; returns the previous mode, or -1 for an unknown one. */
+enum { SMVS_ARITH_EXACT = 0, SMVS_ARITH_FUSED = 1 };
+int smvs_set_arith(int mode);
+int smvs_get_arith(void);
 /* Releases what the library keeps between calls (the pooled helper streams and events of the plane pipelines).
  * Call with no library work in flight, e.g. before unloading; later calls re-create what they need.  Returns SMVS_OK. */
 int smvs_shutdown(void);

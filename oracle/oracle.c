@@ -123,7 +123,7 @@ ORC_API void orc_rpc_project(const double *rpc170, const double *a, const double
 /* ---- sampler: F.grid_sample(bilinear, zeros, align_corners=False) fed with a grid that was
  *      normalised with the align_corners=True formula (modules/warping.py:350-359).
  *      px/py are the float32 pixel coordinates (samp.float(), line.float()). ------------------ */
-typedef struct { int x0, y0; float nw, ne, sw, se; int m_nw, m_ne, m_sw, m_se; } tap_t;
+typedef struct { int x0, y0; float nw, ne, sw, se; int m_nw, m_ne, m_sw, m_se; float fw, fn; } tap_t;
 
 static inline tap_t make_tap(float px, float py, int H, int W)
 {
@@ -137,6 +137,7 @@ static inline tap_t make_tap(float px, float py, int H, int W)
     float xw = floorf(x), yn = floorf(y);
     float w = x - xw, e = 1.0f - w, n = y - yn, s = 1.0f - n;
     t.nw = s * e; t.ne = s * w; t.sw = n * e; t.se = n * w;
+    t.fw = w; t.fn = n;
     /* bounds tested in float so NaN / huge coordinates fall out as "outside" */
     int xin0 = (xw >= 0.0f) && (xw <= (float)(W - 1));
     int xin1 = (xw >= -1.0f) && (xw <= (float)(W - 2));
@@ -311,6 +312,7 @@ static inline tap_t make_tap_norm(float gx, float gy, int H, int W)
     float xw = floorf(x), yn = floorf(y);
     float w = x - xw, e = 1.0f - w, n = y - yn, s = 1.0f - n;
     t.nw = s * e; t.ne = s * w; t.sw = n * e; t.se = n * w;
+    t.fw = w; t.fn = n;
     int xin0 = (xw >= 0.0f) && (xw <= (float)(W - 1));
     int xin1 = (xw >= -1.0f) && (xw <= (float)(W - 2));
     int yin0 = (yn >= 0.0f) && (yn <= (float)(H - 1));
@@ -383,6 +385,59 @@ ORC_API void orc_costvol_variance(const float *const *feats, const double *geo_p
                         float m = sum / fV;                     /* div_(num_views) */
                         float q = sq / fV;
                         out[((((size_t)b * C + c) * D + d) * H + y) * W + x] = q - m * m;
+                    }
+                }
+            }
+    }
+}
+
+/* The same volume evaluated in float64 from the reference's float32 tap positions: the bilinear weights are the exact
+ * products of the float32 fractions, the warped values, their sum / sum of squares and the variance are float64.  This is
+ * the real-number function that BOTH the reference's float32 sequence and the library's fused arithmetic
+ * (SMVS_ARITH_FUSED) approximate; tests/test_fused_arith.py measures each against it.  `scale` receives sum(x^2)/V, the
+ * magnitude the float32 rounding errors of the reference's sequence are proportional to.  Not a reference function. */
+ORC_API void orc_costvol_variance_f64(const float *const *feats, const double *geo_params, int geo,
+                                      const float *depth, int depth_is_4d, double *out, double *scale,
+                                      int B, int V, int C, int D, int H, int W)
+{
+    size_t HW = (size_t)H * W;
+    for (int b = 0; b < B; ++b) {
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int d = 0; d < D; ++d)
+            for (int y = 0; y < H; ++y) {
+                tap_t taps[16];
+                for (int x = 0; x < W; ++x) {
+                    double h = height_at(depth, depth_is_4d, b, d, y, x, D, H, W);
+                    for (int v = 1; v < V; ++v) {
+                        if (geo == 0) {
+                            float px, py;
+                            const double *r = geo_params + (size_t)b * V * RPC_LEN;
+                            rpc_chain(r, r + (size_t)v * RPC_LEN, x, y, h, &px, &py);
+                            taps[v] = make_tap(px, py, H, W);
+                        } else {
+                            float gx, gy;
+                            homo_chain(geo_params + ((size_t)b * (V - 1) + (v - 1)) * 16, x, y, h, H, W, &gx, &gy);
+                            taps[v] = make_tap_norm(gx, gy, H, W);
+                        }
+                    }
+                    for (int c = 0; c < C; ++c) {
+                        double r = (double)feats[0][((size_t)b * C + c) * HW + (size_t)y * W + x];
+                        double sum = r, sq = r * r;
+                        for (int v = 1; v < V; ++v) {
+                            const tap_t *t = &taps[v];
+                            const float *p = feats[v] + ((size_t)b * C + c) * HW + (ptrdiff_t)t->y0 * W + t->x0;
+                            double fw = (double)t->fw, fn = (double)t->fn;
+                            double wv = (t->m_nw ? (double)p[0] : 0.0) * ((1.0 - fn) * (1.0 - fw))
+                                      + (t->m_ne ? (double)p[1] : 0.0) * ((1.0 - fn) * fw)
+                                      + (t->m_sw ? (double)p[W] : 0.0) * (fn * (1.0 - fw))
+                                      + (t->m_se ? (double)p[W + 1] : 0.0) * (fn * fw);
+                            sum += wv;
+                            sq += wv * wv;
+                        }
+                        size_t o = ((((size_t)b * C + c) * D + d) * H + y) * W + x;
+                        double m = sum / V;
+                        out[o] = sq / V - m * m;
+                        scale[o] = sq / V;
                     }
                 }
             }

@@ -147,6 +147,28 @@ def costvol_variance(features, geo_params, depth, geo_model="rpc", d_begin=0, d_
     return out
 
 
+def costvol_variance_f64(features, geo_params, depth, geo_model="rpc"):
+    """float64 evaluation of the variance volume from the reference's float32 tap positions (orc_costvol_variance_f64):
+    returns (variance, sum(x^2)/V), both float64 (B,C,D,H,W).  What the float32 sequences approximate; not a reference function."""
+    feats = [_f32(f) for f in features]
+    V = len(feats)
+    B, Cc, H, W = feats[0].shape
+    D = depth.shape[1]
+    depth, is4 = _depth_args(depth, B, D, H, W)
+    if geo_model == "rpc":
+        gp = _f64(geo_params)
+        geo = 0
+    else:
+        P = _f64(geo_params)
+        gp = _f64(np.stack([homo_compose(P[:, v], P[:, 0]) for v in range(1, V)], axis=1))
+        geo = 1
+    out = np.zeros((B, Cc, D, H, W), np.float64)
+    scale = np.zeros((B, Cc, D, H, W), np.float64)
+    ptrs = (C.c_void_p * V)(*[f.ctypes.data for f in feats])
+    lib().orc_costvol_variance_f64(ptrs, _p(gp), geo, _p(depth), is4, _p(out), _p(scale), B, V, Cc, D, H, W)
+    return out, scale
+
+
 def softmax_regress(reg, depth):
     reg = _f32(reg)
     B, D, H, W = reg.shape

@@ -6,3 +6,14 @@ soft-argmin height, as hand-written HIP kernels for gfx950 behind a C ABI (inclu
 See DESIGN.md for the path, data layout and roofline, INTEGRATION.md for the reference-side binding.
 """
 __version__ = "0.1.0"
+
+
+def set_arith(mode):
+    """"fused" (default) or "exact": arithmetic of the variance build -- see include/satmvs.h, smvs_set_arith."""
+    from . import _lib
+    return _lib.set_arith(mode)
+
+
+def get_arith():
+    from . import _lib
+    return _lib.get_arith()

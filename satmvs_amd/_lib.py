@@ -61,7 +61,9 @@ _SIZE_FUNCS = {"smvs_red_packed_floats": [_i], "smvs_red_workspace_bytes": [_i] 
                "smvs_red_pred_workspace_bytes": [_i] * 4, "smvs_costreg_packed_floats": [_i],
                "smvs_costreg_workspace_bytes": [_i] * 5, "smvs_featnet_packed_floats": [_i] * 2,
                "smvs_featnet_workspace_bytes": [_i] * 5}
-EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SIZE_FUNCS) + ["smvs_version", "smvs_last_error", "smvs_red_set_streams", "smvs_shutdown"])
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SIZE_FUNCS) + ["smvs_version", "smvs_last_error", "smvs_red_set_streams", "smvs_shutdown",
+                                                                    "smvs_set_arith", "smvs_get_arith"])
+ARITH_MODES = {"exact": 0, "fused": 1}      # SMVS_ARITH_EXACT / SMVS_ARITH_FUSED of include/satmvs.h
 
 _lib = None
 
@@ -95,8 +97,31 @@ def load():
         lib.smvs_red_set_streams.restype = C.c_int
         lib.smvs_shutdown.argtypes = []
         lib.smvs_shutdown.restype = C.c_int
+    if hasattr(lib, "smvs_set_arith"):
+        lib.smvs_set_arith.argtypes = [_i]
+        lib.smvs_set_arith.restype = C.c_int
+        lib.smvs_get_arith.argtypes = []
+        lib.smvs_get_arith.restype = C.c_int
+        mode = os.environ.get("SMVS_ARITH")                 # the library itself never reads the environment
+        if mode:
+            if mode not in ARITH_MODES:
+                raise ValueError("SMVS_ARITH must be one of %s, got %r" % (sorted(ARITH_MODES), mode))
+            lib.smvs_set_arith(ARITH_MODES[mode])
     _lib = lib
     return lib
+
+
+def set_arith(mode):
+    """Arithmetic of the variance build: "exact" = the reference's float32 rounding sequence (bit-identical to the oracle),
+    "fused" = the library default (contract tolerance, include/satmvs.h).  Process-wide; returns the previous mode's name."""
+    if mode not in ARITH_MODES:
+        raise ValueError("arith mode must be one of %s, got %r" % (sorted(ARITH_MODES), mode))
+    prev = load().smvs_set_arith(ARITH_MODES[mode])
+    return "exact" if prev == 0 else "fused"
+
+
+def get_arith():
+    return "exact" if load().smvs_get_arith() == 0 else "fused"
 
 
 def version():

@@ -762,6 +762,174 @@ __device__ __forceinline__ f32x2 pk_variance(const f32x2& t, const f32x2& s)
     return v;
 }
 
+// ---- contract-tolerance ("fused") arithmetic of the cost-volume build: smvs_set_arith(SMVS_ARITH_FUSED) --------------
+// The variance of V values is shift invariant, so it is taken of the DIFFERENCES to the ref feature, d_s = warped_s - ref
+// (d_ref = 0), which come out of the bilinear chain for free when the chain starts as fma(c_nw, w_nw, -ref):
+//   var = (sum d_s^2) / V - ((sum d_s) / V)^2.
+// The constant factors ride on the tap weights (scaled once per tap in the geometry phase, i.e. once per 16 channel pairs)
+// and on the ref feature (once per channel pair and 8 planes):
+//   2 sources (3 views), weights * sqrt(2)/3:  var = da^2 - da db + db^2          = fma(da, da - db, db*db)     3 operations
+//   1 source  (2 views), weights * 1/2:        var = d*d                                                         1 operation
+//   S >= 3 sources,      weights * 1/sqrt(V):  var = T - S*S/V, S = sum d, T = sum d^2  = fma(-(S*rV), S, T)    2 S + 1 operations
+// against 14 (2 sources) for the reference's sequence  sum, sum of squares, two true divisions, mean^2, subtract.  The
+// float64 geometry, the float32 tap coordinates and the unscaled weights are those of the exact instance bit for bit; the
+// result differs from the reference's by rounding only, and is the more accurate of the two: the reference's
+// meansq - mean^2 cancels, the difference form does not (tests/test_fused_arith.py measures both against a float64
+// evaluation).  The reference sequence stays available (SMVS_ARITH_EXACT) and is what every bit-level test runs.
+// scalar form (direct-gather kernel and the staged kernel's oversized-box path); same operations as the packed blocks
+template <int NSRC>
+__device__ __forceinline__ float fused_variance(const float (&d)[NSRC], float rV)
+{
+    if constexpr (NSRC == 1) return d[0] * d[0];
+    else if constexpr (NSRC == 2) return fmaf(d[0], d[0] - d[1], d[1] * d[1]);
+    else {
+        float S = d[0] + d[1];
+        float T = d[0] * d[0];
+        T = fmaf(d[1], d[1], T);
+#pragma unroll
+        for (int s = 2; s < NSRC; ++s) { S = S + d[s]; T = fmaf(d[s], d[s], T); }
+        const float p = S * rV;
+        return fmaf(-p, S, T);
+    }
+}
+
+// d = c_nw*w_nw - rk, + c_ne*w_ne, + c_sw*w_sw, + c_se*w_se with the scaled weights ((1-fn)*k)*(1-fw), ...
+__device__ __forceinline__ float fused_tap_diff(const BufRsrc& rs, const Tap& t, int choff, float kw, float rk)
+{
+    const float sk = (1.0f - t.fn) * kw, nk = t.fn * kw, e = 1.0f - t.fw;
+    const float a = llvm_raw_buffer_load_f32(rs.v, (int)t.o_nw, choff, 0);
+    const float b = llvm_raw_buffer_load_f32(rs.v, (int)t.o_ne, choff, 0);
+    const float c = llvm_raw_buffer_load_f32(rs.v, (int)t.o_sw, choff, 0);
+    const float d = llvm_raw_buffer_load_f32(rs.v, (int)t.o_se, choff, 0);
+    float r = fmaf(a, sk * e, -rk);
+    r = fmaf(b, sk * t.fw, r);
+    r = fmaf(c, nk * e, r);
+    r = fmaf(d, nk * t.fw, r);
+    return r;
+}
+
+// rk = ref * k for a channel pair (kv = {k, .}); trailing wait state: the next reader may be anything
+__device__ __forceinline__ f32x2 pk_scale_lo(const f32x2& r, const f32x2& kv)
+{
+    f32x2 o;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\ts_nop 0" : "=v"(o) : "v"(r), "v"(kv));
+    return o;
+}
+
+// Bilinear chains of two sources on differences, a = sum c_a w_a - rk, b = sum c_b w_b - rk, interleaved so that no packed
+// result is read in the slot behind its producer; the TAIL of the previous unit (pa, pb: its two differences) rides in the
+// gaps.  Tails:
+//   SMVS_TAIL_VAR3  (2 sources)   e = pa - pb; f = pb*pb; var = fma(pa, e, f)
+//   SMVS_TAIL_ACC0  (first unit of a plane, more to come)   S = pa + pb; T = pa*pa; T = fma(pb, pb, T)
+//   SMVS_TAIL_ACC   (middle unit)  S += pa; T = fma(pa, pa, T); S += pb; T = fma(pb, pb, T)
+//   SMVS_TAIL_FIN   (last unit of a plane)  the same, then p = S*rV; var = fma(-p, S, T)
+#define SMVS_FB_A0 "v_pk_fma_f32 %[a], %[a0], %[wan], %[rk] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+#define SMVS_FB_B0 "v_pk_fma_f32 %[b], %[b0], %[wbn], %[rk] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+#define SMVS_FB_A1 "v_pk_fma_f32 %[a], %[a1], %[wan], %[a] op_sel:[0,1,0]\n\t"
+#define SMVS_FB_B1 "v_pk_fma_f32 %[b], %[b1], %[wbn], %[b] op_sel:[0,1,0]\n\t"
+#define SMVS_FB_A2 "v_pk_fma_f32 %[a], %[a2], %[was], %[a] op_sel_hi:[1,0,1]\n\t"
+#define SMVS_FB_B2 "v_pk_fma_f32 %[b], %[b2], %[wbs], %[b] op_sel_hi:[1,0,1]\n\t"
+#define SMVS_FB_A3 "v_pk_fma_f32 %[a], %[a3], %[was], %[a] op_sel:[0,1,0]\n\t"
+#define SMVS_FB_B3 "v_pk_fma_f32 %[b], %[b3], %[wbs], %[b] op_sel:[0,1,0]\n\t"
+#define SMVS_FB_INPUTS [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [wan] "v"(wan), [was] "v"(was), \
+                       [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3), [wbn] "v"(wbn), [wbs] "v"(wbs), [rk] "v"(rk)
+#define SMVS_FB_ARGS const f32x2& a0, const f32x2& a1, const f32x2& a2, const f32x2& a3, const f32x2& wan, const f32x2& was, \
+                     const f32x2& b0, const f32x2& b1, const f32x2& b2, const f32x2& b3, const f32x2& wbn, const f32x2& wbs, const f32x2& rk
+
+__device__ __forceinline__ void pk_fbil2(f32x2& a, f32x2& b, SMVS_FB_ARGS)
+{
+    asm volatile(SMVS_FB_A0 SMVS_FB_B0 SMVS_FB_A1 SMVS_FB_B1 SMVS_FB_A2 SMVS_FB_B2 SMVS_FB_A3 SMVS_FB_B3
+                 : [a] "=&v"(a), [b] "=&v"(b) : SMVS_FB_INPUTS);
+}
+
+__device__ __forceinline__ void pk_fbil2_var3(f32x2& a, f32x2& b, f32x2& var, const f32x2& pa, const f32x2& pb, SMVS_FB_ARGS)
+{
+    f32x2 e, f;
+    asm volatile(SMVS_FB_A0 SMVS_FB_B0
+                 "v_pk_add_f32 %[e], %[pa], %[pb] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 SMVS_FB_A1 SMVS_FB_B1
+                 "v_pk_mul_f32 %[f], %[pb], %[pb]\n\t"
+                 SMVS_FB_A2 SMVS_FB_B2
+                 "v_pk_fma_f32 %[var], %[pa], %[e], %[f]\n\t"
+                 SMVS_FB_A3 SMVS_FB_B3
+                 : [a] "=&v"(a), [b] "=&v"(b), [var] "=&v"(var), [e] "=&v"(e), [f] "=&v"(f)
+                 : SMVS_FB_INPUTS, [pa] "v"(pa), [pb] "v"(pb));
+}
+
+__device__ __forceinline__ f32x2 pk_var3_tail(const f32x2& pa, const f32x2& pb)
+{
+    f32x2 e, f, var;
+    asm volatile("s_nop 0\n\t"
+                 "v_pk_add_f32 %[e], %[pa], %[pb] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_mul_f32 %[f], %[pb], %[pb]\n\t"
+                 "s_nop 0\n\t"
+                 "v_pk_fma_f32 %[var], %[pa], %[e], %[f]"
+                 : [var] "=&v"(var), [e] "=&v"(e), [f] "=&v"(f) : [pa] "v"(pa), [pb] "v"(pb));
+    return var;
+}
+
+__device__ __forceinline__ void pk_fbil2_acc0(f32x2& a, f32x2& b, f32x2& S, f32x2& T, const f32x2& pa, const f32x2& pb, SMVS_FB_ARGS)
+{
+    asm volatile(SMVS_FB_A0 SMVS_FB_B0
+                 "v_pk_add_f32 %[S], %[pa], %[pb]\n\t"
+                 SMVS_FB_A1 SMVS_FB_B1
+                 "v_pk_mul_f32 %[T], %[pa], %[pa]\n\t"
+                 SMVS_FB_A2 SMVS_FB_B2
+                 "v_pk_fma_f32 %[T], %[pb], %[pb], %[T]\n\t"
+                 SMVS_FB_A3 SMVS_FB_B3
+                 : [a] "=&v"(a), [b] "=&v"(b), [S] "=&v"(S), [T] "=&v"(T)
+                 : SMVS_FB_INPUTS, [pa] "v"(pa), [pb] "v"(pb));
+}
+
+__device__ __forceinline__ void pk_fbil2_acc(f32x2& a, f32x2& b, f32x2& S, f32x2& T, const f32x2& pa, const f32x2& pb, SMVS_FB_ARGS)
+{
+    asm volatile(SMVS_FB_A0 SMVS_FB_B0
+                 "v_pk_add_f32 %[S], %[S], %[pa]\n\t"
+                 SMVS_FB_A1 SMVS_FB_B1
+                 "v_pk_fma_f32 %[T], %[pa], %[pa], %[T]\n\t"
+                 SMVS_FB_A2 SMVS_FB_B2
+                 "v_pk_add_f32 %[S], %[S], %[pb]\n\t"
+                 SMVS_FB_A3 SMVS_FB_B3
+                 "v_pk_fma_f32 %[T], %[pb], %[pb], %[T]"
+                 : [a] "=&v"(a), [b] "=&v"(b), [S] "+v"(S), [T] "+v"(T)
+                 : SMVS_FB_INPUTS, [pa] "v"(pa), [pb] "v"(pb));
+}
+
+// rvv = {1/V, V}
+__device__ __forceinline__ void pk_fbil2_fin(f32x2& a, f32x2& b, f32x2& var, f32x2& S, f32x2& T, const f32x2& pa, const f32x2& pb,
+                                             const f32x2& rvv, SMVS_FB_ARGS)
+{
+    f32x2 p;
+    asm volatile(SMVS_FB_A0 SMVS_FB_B0
+                 "v_pk_add_f32 %[S], %[S], %[pa]\n\t"
+                 SMVS_FB_A1 SMVS_FB_B1
+                 "v_pk_fma_f32 %[T], %[pa], %[pa], %[T]\n\t"
+                 SMVS_FB_A2 SMVS_FB_B2
+                 "v_pk_add_f32 %[S], %[S], %[pb]\n\t"
+                 SMVS_FB_A3 SMVS_FB_B3
+                 "v_pk_fma_f32 %[T], %[pb], %[pb], %[T]\n\t"
+                 "v_pk_mul_f32 %[p], %[S], %[rvv] op_sel_hi:[1,0]\n\t"
+                 "s_nop 0\n\t"
+                 "v_pk_fma_f32 %[var], %[p], %[S], %[T] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+                 : [a] "=&v"(a), [b] "=&v"(b), [var] "=&v"(var), [p] "=&v"(p), [S] "+v"(S), [T] "+v"(T)
+                 : SMVS_FB_INPUTS, [pa] "v"(pa), [pb] "v"(pb), [rvv] "v"(rvv));
+}
+
+__device__ __forceinline__ f32x2 pk_fin_tail(f32x2& S, f32x2& T, const f32x2& pa, const f32x2& pb, const f32x2& rvv)
+{
+    f32x2 p, var;
+    asm volatile("s_nop 0\n\t"
+                 "v_pk_add_f32 %[S], %[S], %[pa]\n\t"
+                 "v_pk_fma_f32 %[T], %[pa], %[pa], %[T]\n\t"
+                 "v_pk_add_f32 %[S], %[S], %[pb]\n\t"
+                 "v_pk_fma_f32 %[T], %[pb], %[pb], %[T]\n\t"
+                 "v_pk_mul_f32 %[p], %[S], %[rvv] op_sel_hi:[1,0]\n\t"
+                 "s_nop 0\n\t"
+                 "v_pk_fma_f32 %[var], %[p], %[S], %[T] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+                 : [var] "=&v"(var), [p] "=&v"(p), [S] "+v"(S), [T] "+v"(T) : [pa] "v"(pa), [pb] "v"(pb), [rvv] "v"(rvv));
+    return var;
+}
+
 __device__ __forceinline__ f32x2 div_by_views2(f32x2 x, float v, float rv)
 {
     const f32x2 q0 = x * rv;

@@ -8,6 +8,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# The bit-level suite runs the reference-rounding instance of the variance build (smvs_set_arith, include/satmvs.h); the
+# library's default, the fused arithmetic, is covered at the contract tolerances by tests/test_fused_arith.py and by the
+# reference-golden end-to-end tests that take the `arith` fixture (both modes).  Through the environment so that test
+# subprocesses (fuzzers, shard ranks, DataParallel workers) start in the same mode.
+os.environ.setdefault("SMVS_ARITH", "exact")
 
 
 def pytest_configure(config):
@@ -31,3 +36,12 @@ def oracle():
     from oracle import oracle as orc
     orc.build()
     return orc
+
+
+@pytest.fixture(params=["exact", "fused"])
+def arith(request):
+    """Runs the test once per arithmetic of the variance build; leaves the suite's mode ("exact") behind."""
+    from satmvs_amd import _lib
+    _lib.set_arith(request.param)
+    yield request.param
+    _lib.set_arith(os.environ.get("SMVS_ARITH", "exact"))

@@ -47,7 +47,7 @@ def _inputs(g, dev):
 
 
 @pytest.mark.parametrize("tag", ["red", "redinf", "casmvs", "ucs"])
-def test_cascade_forward_matches_reference(dev, golden, tag):
+def test_cascade_forward_matches_reference(dev, golden, tag, arith):
     g = golden("cascade")
     nd = [int(v) for v in g["ndepths"]]
     seed_tag = "red" if tag == "redinf" else tag
@@ -73,7 +73,7 @@ def test_cascade_forward_matches_reference(dev, golden, tag):
 
 
 @pytest.mark.parametrize("tag", ["red", "redinf", "ucs"])
-def test_cascade_forward_pinhole_matches_reference(dev, golden, tag):
+def test_cascade_forward_pinhole_matches_reference(dev, golden, tag, arith):
     """BASELINE cfg5 family: geo_model="pinhole" end to end (homography cost volume; for the RED networks the
     native plane pipeline with geo_kind 1) against the reference's outputs, heights within 1e-3."""
     from satmvs_amd.networks import casred, ucs
@@ -257,7 +257,7 @@ def test_featnet_native_matches_reference(dev, golden, oracle, arch):
         np.testing.assert_allclose(y2[k].cpu().numpy(), y[k].cpu().numpy(), rtol=0, atol=2e-6)
 
 
-def test_pred_path_matches_reference(dev, golden):
+def test_pred_path_matches_reference(dev, golden, arith):
     """compute_depth_when_pred (plane loop, recurrent state, streaming float64 regression)."""
     from satmvs_amd.modules.module import slice_RED_Regularization
     from satmvs_amd.networks.casred import compute_depth_when_pred
@@ -269,7 +269,7 @@ def test_pred_path_matches_reference(dev, golden):
     np.testing.assert_allclose(out["photometric_confidence"].cpu().numpy(), g["pred_conf"], rtol=1e-4, atol=1e-6)
 
 
-def test_train_path_matches_reference(dev, golden):
+def test_train_path_matches_reference(dev, golden, arith):
     from satmvs_amd.modules.module import RED_Regularization
     from satmvs_amd.networks.casred import compute_depth_when_train
     g = golden("red_pred")
@@ -466,7 +466,7 @@ def test_training_step_runs_and_gradients_flow(dev, golden):
     assert np.isfinite(gnorm) and gnorm > 0
 
 
-def test_training_step_matches_reference(dev, golden):
+def test_training_step_matches_reference(dev, golden, arith):
     """One training step against the reference's own (train.py:267-302 without the optimiser; fixture
     tests/golden/train_step.npz = CascadeREDNet.train() -> cas_mvsnet_loss -> backward, run on the CPU by
     gen_golden.py::gen_train): same seed => same weights, native cost-volume forward AND backward under the PyTorch

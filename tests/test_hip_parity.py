@@ -357,7 +357,7 @@ def test_generated_heights_ucs(dev, golden, oracle):
                                                            M.window_depth_regression(reg, dv, lamb=1.5)))
 
 
-def test_photo_consistent_peaky_problem(dev, golden):
+def test_photo_consistent_peaky_problem(dev, golden, arith):
     """Photo-consistent features + peaky regulariser (gen_golden.py::gen_photo): heights within 1e-3 m of the
     reference's; and the check means something -- moving one source image by 0.05 px moves the heights by far more."""
     from satmvs_amd.modules import module as M
@@ -378,7 +378,7 @@ def test_photo_consistent_peaky_problem(dev, golden):
     assert float((depth2 - depth).abs().max()) > 0.05          # 50x the tolerance: the golden is sensitive to the warp
 
 
-def test_costvol_backward_matches_reference_gradients(dev, golden):
+def test_costvol_backward_matches_reference_gradients(dev, golden, arith):
     """d loss / d features through the native forward + smvs_costvol_bwd against gradients captured from the
     reference's own differentiable path (gen_golden.py::gen_grad: grid_sample backward, in-place variance
     accumulation, softmax, depth_regression).  float32 atomics sum in another order: rtol 2e-4 on the gradient scale."""
