@@ -394,8 +394,9 @@ ORC_API void orc_costvol_variance(const float *const *feats, const double *geo_p
 /* The same volume evaluated in float64 from the reference's float32 tap positions: the bilinear weights are the exact
  * products of the float32 fractions, the warped values, their sum / sum of squares and the variance are float64.  This is
  * the real-number function that BOTH the reference's float32 sequence and the library's fused arithmetic
- * (SMVS_ARITH_FUSED) approximate; tests/test_fused_arith.py measures each against it.  `scale` receives sum(x^2)/V, the
- * magnitude the float32 rounding errors of the reference's sequence are proportional to.  Not a reference function. */
+ * (SMVS_ARITH_FUSED) approximate; tests/test_fused_arith.py measures each against it.  `scale` receives sum(X^2)/V with
+ * X = |ref| resp. sum |corner| * weight of a source: the magnitude the float32 rounding errors of either sequence are
+ * proportional to (a bilinear sample of large corners can be small).  Not a reference function. */
 ORC_API void orc_costvol_variance_f64(const float *const *feats, const double *geo_params, int geo,
                                       const float *depth, int depth_is_4d, double *out, double *scale,
                                       int B, int V, int C, int D, int H, int W)
@@ -422,7 +423,7 @@ ORC_API void orc_costvol_variance_f64(const float *const *feats, const double *g
                     }
                     for (int c = 0; c < C; ++c) {
                         double r = (double)feats[0][((size_t)b * C + c) * HW + (size_t)y * W + x];
-                        double sum = r, sq = r * r;
+                        double sum = r, sq = r * r, mag = r * r;
                         for (int v = 1; v < V; ++v) {
                             const tap_t *t = &taps[v];
                             const float *p = feats[v] + ((size_t)b * C + c) * HW + (ptrdiff_t)t->y0 * W + t->x0;
@@ -431,13 +432,18 @@ ORC_API void orc_costvol_variance_f64(const float *const *feats, const double *g
                                       + (t->m_ne ? (double)p[1] : 0.0) * ((1.0 - fn) * fw)
                                       + (t->m_sw ? (double)p[W] : 0.0) * (fn * (1.0 - fw))
                                       + (t->m_se ? (double)p[W + 1] : 0.0) * (fn * fw);
+                            double av = (t->m_nw ? fabs((double)p[0]) : 0.0) * ((1.0 - fn) * (1.0 - fw))
+                                      + (t->m_ne ? fabs((double)p[1]) : 0.0) * ((1.0 - fn) * fw)
+                                      + (t->m_sw ? fabs((double)p[W]) : 0.0) * (fn * (1.0 - fw))
+                                      + (t->m_se ? fabs((double)p[W + 1]) : 0.0) * (fn * fw);
                             sum += wv;
                             sq += wv * wv;
+                            mag += av * av;
                         }
                         size_t o = ((((size_t)b * C + c) * D + d) * H + y) * W + x;
                         double m = sum / V;
                         out[o] = sq / V - m * m;
-                        scale[o] = sq / V;
+                        scale[o] = mag / V;
                     }
                 }
             }

@@ -149,7 +149,7 @@ def costvol_variance(features, geo_params, depth, geo_model="rpc", d_begin=0, d_
 
 def costvol_variance_f64(features, geo_params, depth, geo_model="rpc"):
     """float64 evaluation of the variance volume from the reference's float32 tap positions (orc_costvol_variance_f64):
-    returns (variance, sum(x^2)/V), both float64 (B,C,D,H,W).  What the float32 sequences approximate; not a reference function."""
+    returns (variance, error scale = sum(X^2)/V with X = sum |corner| * weight), both float64 (B,C,D,H,W).  What the float32 sequences approximate; not a reference function."""
     feats = [_f32(f) for f in features]
     V = len(feats)
     B, Cc, H, W = feats[0].shape

@@ -357,7 +357,7 @@ def test_generated_heights_ucs(dev, golden, oracle):
                                                            M.window_depth_regression(reg, dv, lamb=1.5)))
 
 
-def test_photo_consistent_peaky_problem(dev, golden, arith):
+def test_photo_consistent_peaky_problem(dev, golden, oracle, arith):
     """Photo-consistent features + peaky regulariser (gen_golden.py::gen_photo): heights within 1e-3 m of the
     reference's; and the check means something -- moving one source image by 0.05 px moves the heights by far more."""
     from satmvs_amd.modules import module as M
@@ -373,7 +373,21 @@ def test_photo_consistent_peaky_problem(dev, golden, arith):
         rpc2[0, 1, SAMP_OFF] += 0.05
         var2 = warping.variance_cost_volume(feats, _t(rpc2, dev), dv, "rpc")
         depth2, _ = M.softmax_depth_regression(-lam * var2.mean(1), dv)
-    assert np.abs(depth.cpu().numpy() - g["depth"]).max() <= 1e-3
+    if arith == "exact":
+        assert np.abs(depth.cpu().numpy() - g["depth"]).max() <= 1e-3
+    else:
+        # lam = 2e6 amplifies the ROUNDING NOISE of the variance into the height: the reference's own golden sits 1.16e-3 m from
+        # a float64 evaluation of its formula on the same float32 taps (oracle.costvol_variance_f64 -> softmax -> expectation,
+        # all float64).  The fused arithmetic does not reproduce that noise; it is held to 1e-3 m (measured 2.4e-4) of the
+        # float64 evaluation, and lands as far from the golden as the golden is from float64.
+        truth, _ = oracle.costvol_variance_f64([g["feats"][v] for v in range(g["feats"].shape[0])], g["rpc"], g["depth_values"], "rpc")
+        reg = -lam * truth.mean(1)
+        p = np.exp(reg - reg.max(1, keepdims=True))
+        h64 = (p / p.sum(1, keepdims=True) * g["depth_values"].astype(np.float64)).sum(1)
+        ref_noise = np.abs(g["depth"] - h64).max()
+        assert 1e-3 < ref_noise < 1.3e-3                        # the golden's own distance from float64
+        assert np.abs(depth.cpu().numpy() - h64).max() <= 1e-3 / 2
+        assert np.abs(depth.cpu().numpy() - g["depth"]).max() <= ref_noise + 1e-3 / 2
     np.testing.assert_allclose(conf.cpu().numpy(), g["conf"], rtol=0, atol=5e-4)
     assert float((depth2 - depth).abs().max()) > 0.05          # 50x the tolerance: the golden is sensitive to the warp
 
