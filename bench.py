@@ -124,7 +124,7 @@ def kernel_source_hash():
     """sha256 over the sources of the dominant kernel: ties profiles/pmc_traffic.json to the code it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("costvol.hip", "smvs_device.h"):
+    for f in ("costvol.hip", "costvol_fused.hip", "costvol_kernels.h", "smvs_device.h"):
         with open(os.path.join(ROOT, "satmvs_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -173,7 +173,8 @@ def kernel_name(V, C, planes=4):
     if direct:
         return "costvol_fwd_kernel<rpc,%d,%d>" % (V - 1, C)
     dp = 1 if planes == 1 else 2 if (planes == 2 or V - 1 > 4) else 8 if (planes % 8 == 0 and V - 1 <= 2 and C == 32) else 4
-    return "costvol_dma_kernel<rpc,%d,%d,%d>" % (V - 1, C, dp)
+    from satmvs_amd import _lib
+    return "costvol_dma_kernel<rpc,%d,%d,%d,%s>" % (V - 1, C, dp, _lib.get_arith())
 
 
 def side_workloads(dev, stream):
@@ -230,7 +231,39 @@ def side_workloads(dev, stream):
         "roofline_frac": round(bpv * D * H * W / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "ms_plain_heights_interleaved": round(ms_plain, 4),
         "note": "same tile, heights = plane + N(0, 2 m) per pixel; timed alternating with plain-height launches (same thermal state)"}
-    del plain
+    # the other arithmetic instance on the same tile (smvs_set_arith): launches ALTERNATE with the default's, and the two volumes
+    # are compared voxel by voxel
+    default_mode = _lib.get_arith()
+    other = "exact" if default_mode == "fused" else "fused"
+    out2 = torch.empty_like(out)
+
+    def launch_mode(mode, dst):
+        _lib.set_arith(mode)
+        _lib.call("smvs_rpc_costvol_fwd", _lib.ptr(feats[0]), srcs, V - 1, _lib.ptr(rpc), _lib.ptr(plain), 1,
+                  _lib.ptr(dst), 1, C, D, H, W, 0, D, D, 0, stream)
+    try:
+        for _ in range(20):
+            launch_mode(default_mode, out); launch_mode(other, out2)
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(40)]
+        torch.cuda.synchronize()
+        for a, b, c in evs:
+            a.record(); launch_mode(default_mode, out); b.record(); launch_mode(other, out2); c.record()
+        torch.cuda.synchronize()
+        ms_def = float(np.mean([a.elapsed_time(b) for a, b, c in evs]))
+        ms_oth = float(np.mean([b.elapsed_time(c) for a, b, c in evs]))
+        dmax = float((out - out2).abs().max())
+        rel = float(((out - out2).abs() / out2.abs().clamp_min(1.0)).max())
+        extra["cfg2_%s_arithmetic_768x384x64_c32" % other] = {
+            "ms": round(ms_oth, 4), "Mvox/s": round(D * H * W / ms_oth / 1e3, 1),
+            "roofline_frac": round(bpv * D * H * W / (ms_oth * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "ms_%s_interleaved" % default_mode: round(ms_def, 4),
+            "max_abs_difference_between_the_two_volumes": float("%.3g" % dmax),
+            "max_difference_over_1e-5_max(1,|v|)": float("%.3g" % (rel / 1e-5)),
+            "note": "smvs_set_arith(%s): %s; same tile, launches alternating with the default (%s) instance" % (
+                other, "the reference's float32 rounding sequence, bit-identical to the oracle" if other == "exact" else "fused arithmetic", default_mode)}
+    finally:
+        _lib.set_arith(default_mode)
+    del plain, out2
     del feats, out, depth
     # cfg5: pinhole (homography) volume, 3-view 768x384x64, C=32
     V, C, D, H, W = 3, 32, 64, 384, 768
@@ -488,7 +521,8 @@ def main():
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 features / f64 RPC geometry", "data": "synthetic",
-            "config": {"workload": args.workload, "views": V, "channels": C, "planes_per_gpu": D_local,
+            "config": {"workload": args.workload, "arithmetic": _lib.get_arith() + " (smvs_set_arith; the library default is fused: float64 geometry and float32 taps "
+                       "bit-identical to the reference's, variance within 1e-5 max(1,|v|) of it; the exact instance is timed under extra)", "views": V, "channels": C, "planes_per_gpu": D_local,
                        "planes_total": D, "H": H, "W": W, "depth_values": "per-voxel (B,D,H,W)",
                        "sharding": "height planes of one tile split over the ranks, regression partials exchanged each step (overlapping the next step's build when N > 1)",
                        "prewarm_seconds": args.prewarm_seconds},

@@ -182,7 +182,7 @@ void costvol_fwd_kernel(const CostVolParams p)
 // ---- geometry shared by the staged (LDS) kernel ----------------------------------------------------
 constexpr int WV_TX = 32, WV_TY = 2;          // ref pixels per wave
 #ifndef SMVS_WG_WAVES
-#define SMVS_WG_WAVES 4
+#define SMVS_WG_WAVES 2
 #endif
 constexpr int WV_WAVES = SMVS_WG_WAVES;       // waves per workgroup, stacked in y: 32 x 8 pixels
 
