@@ -382,7 +382,8 @@ class GroupNorm1(nn.GroupNorm):
     _ACT = {None: 0, "sigmoid": 1, "tanh": 2}
 
     def forward(self, x, act=None):
-        if x.is_cuda and x.dim() == 4 and self.num_groups == 1 and self.affine and not (_TRAIN_COMPOSITE_MASK & 1):
+        if (x.is_cuda and x.dtype is torch.float32 and x.dim() == 4 and self.num_groups == 1 and self.affine
+                and x.shape[0] * x.shape[1] <= 65535 and not (_TRAIN_COMPOSITE_MASK & 1)):
             return _GroupNorm1Fn.apply(x, self.weight, self.bias, self.eps, self._ACT[act])
         y = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
         return torch.sigmoid(y) if act == "sigmoid" else torch.tanh(y) if act == "tanh" else y
@@ -406,17 +407,23 @@ class ConvGRUCell2(nn.Module):
         if h is None:
             h = torch.zeros((x.shape[0], self.output_channel, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device)
         gates = self.gate_conv(torch.cat((x, h), dim=1))
-        if x.is_cuda and not (_TRAIN_COMPOSITE_MASK & 1):           # both gate norms + sigmoids: one native call each way
+        # the native element-wise paths are float32 kernels with 16-byte vector accesses and 16-bit grid limits: anything else
+        # (a .double() model, exotic channel counts that leave a gate half unaligned, B*C > 65535) takes torch's operators
+        native = (x.is_cuda and x.dtype is torch.float32 and h.dtype is torch.float32 and gates.dtype is torch.float32
+                  and x.shape[0] * gates.shape[1] <= 65535)
+        if native and not (_TRAIN_COMPOSITE_MASK & 1):              # both gate norms + sigmoids: one native call each way
             rn, un = self.reset_gate_norm, self.update_gate_norm
             r, u = torch.split(_GroupNormPairFn.apply(gates, rn.weight, rn.bias, un.weight, un.bias, rn.eps, 1), gates.shape[1] // 2, 1)
         else:
             r, u = torch.split(gates, gates.shape[1] // 2, 1)
             r = self.reset_gate_norm(r, "sigmoid")
             u = self.update_gate_norm(u, "sigmoid")
-        native = x.is_cuda                                        # the cell's element-wise steps: one native launch each way
+        # the cell's element-wise steps: one native launch each way
         xc = _GruMulCatFn.apply(x, r, h) if native and not (_TRAIN_COMPOSITE_MASK & 2) else torch.cat((x, r * h), dim=1)
         cand = self.output_norm(self.output_conv(xc), "tanh")
-        new_h = _GruBlendFn.apply(u, h, cand) if native and not (_TRAIN_COMPOSITE_MASK & 4) else u * h + (1 - u) * cand
+        blend_native = native and not (_TRAIN_COMPOSITE_MASK & 4) and all(
+            t.data_ptr() % 16 == 0 or not t.is_contiguous() for t in (u, h, cand))       # non-contiguous operands are copied (aligned) first
+        new_h = _GruBlendFn.apply(u, h, cand) if blend_native else u * h + (1 - u) * cand
         return new_h, new_h
 
 
@@ -551,7 +558,7 @@ class _REDCore(nn.Module):
         mode-dependent layers), and a plane the kernels support; anything else takes the PyTorch composite."""
         if os.environ.get("SMVS_RED_TORCH") == "1":        # A/B switch: force the stock PyTorch composite
             return False
-        if not cost.is_cuda or self.base_channels != 8 or cost.dim() != 4:
+        if not cost.is_cuda or cost.dtype is not torch.float32 or self.base_channels != 8 or cost.dim() != 4:
             return False
         if _autograd_needed(cost, _tensors_by_path(self, self._PARAM_ORDER)):
             return False
