@@ -150,11 +150,7 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
     constexpr int BS = (TAPS == 27) ? 9 : 9;               // steps per batch (TAPS is a multiple of 9)
     constexpr int NB = TAPS / BS;                          // batches per channel pair
     const int ncip = Cin / 2, per = ncip / KS;
-#ifdef SMVS_HACK_KDIV                         // timing experiment only (wrong results): what a shorter K chain on the widest level would buy
-    const int q_end = per * NB / (Cin >= 128 ? SMVS_HACK_KDIV : 1);
-#else
     const int q_end = per * NB;
-#endif
     struct Batch { float x[BS]; float w[NT][BS]; float sx; };
     // explicit variants so that every off[] / register index is a compile-time constant
 #define SMVS_LOAD_BATCH(G, BT, Q)                                                                        \

@@ -582,9 +582,6 @@ void conv_jobs_kernel(const ConvJobs J)
     for (int i = 1; i < 4; ++i)
         if (i < J.n && bid >= J.j[i].blk0) l = i;
     const ConvJob& jb = J.j[l];
-#ifdef SMVS_HACK_SKIP_LEVEL                     // timing experiment only (wrong results): which level's job bounds the level-batched launch
-    if ((SMVS_HACK_SKIP_LEVEL >> l) & 1) return;
-#endif
     bid -= jb.blk0;
     const int bx = bid % jb.gx, t = bid / jb.gx;
     if (jb.kind == 4) mfma_conv_body<9, 1, 4, 1>(jb.m, bid, 0, smem);        // MFMA, throughput regime: a (tile, cout tile) unit per wave

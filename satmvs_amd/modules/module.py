@@ -198,47 +198,48 @@ _TRAIN_COMPOSITE_MASK = 7 if _TRAIN_COMPOSITE_ONLY else int(os.environ.get("SMVS
 
 
 _FIND_WARNED = False
+_FIND_SWITCHED_OFF = False
 
 
 def guard_miopen_find():
-    """Training forwards of the RED networks switch `torch.backends.cudnn.benchmark` off (the reference's train.py:21 turns it on).
-    On this image (ROCm 7.0 / PyTorch 2.10, MI355X) MIOpen's search costs ~7 minutes per process for this network, and the training
-    forward at the 768x384 tile ends in a GPU memory access fault with it on: 6 of 6 whole-model runs -- also with torch's own
-    GroupNorm / element-wise operators (SMVS_TRAIN_COMPOSITE=1) AND a device-wide synchronize after every native call
-    (SMVS_SYNC_CALLS=1), i.e. with no kernel of this library running or queued: the fault is inside the search (MIOpen's candidate
-    kernels / workspace handling), not in the native operators.  It never shows with serialised launches; the address is 2 MB aligned
-    and none of the pointers a native call received (SMVS_TRACE_CALLS=1).  tools/debug_cudnn_benchmark.py reproduces it.
-    MIOpen's default (immediate-mode) choices are what every test, fixture and timing of this repository uses;
-    SMVS_ALLOW_MIOPEN_FIND=1 leaves the flag alone."""
-    global _FIND_WARNED
+    """Training forwards of the RED cascades switch `torch.backends.cudnn.benchmark` off (the reference's train.py:21 turns it on)
+    and restore_miopen_find() puts it back at the next inference forward.
+
+    On this image (ROCm 7.0 / PyTorch 2.10, MI355X) MIOpen's exhaustive search ends the training forward of this network at the
+    768x384 tile in a GPU memory access fault -- in a process that never maps this library: tools/miopen_find_repro.py builds the
+    same forward from torch operators only (torch convolutions, F.group_norm, F.grid_sample), checks /proc/self/maps, and faults in
+    stage 2 after ~70 s (profiles/r04_miopen_find_repro.txt; round 3 saw the same with the native operators serialised and
+    synchronised, 6 of 6 runs).  The fault is inside the search (its candidate kernels / workspaces), and where it does not fault
+    the search costs ~7 minutes per process.  MIOpen's default (immediate-mode) choices are what every test, fixture and timing
+    of this repository uses.  Only the RED cascades call this (the fault was reproduced for them); SMVS_ALLOW_MIOPEN_FIND=1
+    leaves the flag alone."""
+    global _FIND_WARNED, _FIND_SWITCHED_OFF
     if torch.backends.cudnn.benchmark and os.environ.get("SMVS_ALLOW_MIOPEN_FIND", "0") != "1":
         torch.backends.cudnn.benchmark = False
+        _FIND_SWITCHED_OFF = True
         if not _FIND_WARNED:
             _FIND_WARNED = True
             import warnings
-            warnings.warn("satmvs_amd: torch.backends.cudnn.benchmark switched off for training (MIOpen's search: ~7 min per process here, "
-                          "and the training forward ends in a GPU memory fault with it on -- see "
-                          "satmvs_amd.modules.module.guard_miopen_find; SMVS_ALLOW_MIOPEN_FIND=1 leaves the flag alone)")
+            warnings.warn("satmvs_amd: torch.backends.cudnn.benchmark switched off while the RED cascade trains (MIOpen's search faults in "
+                          "this network's training forward on this ROCm build, with or without this library in the process -- see "
+                          "satmvs_amd.modules.module.guard_miopen_find; it is restored at the next inference forward; "
+                          "SMVS_ALLOW_MIOPEN_FIND=1 leaves the flag alone)")
 
 
-# Scratch of the GroupNorm kernels (a few float64 sums): ONE buffer per (device, stream) that lives as long as the process -- no
-# allocation per call, and nothing the kernels use is handed back to the caching allocator while they are still queued.
-# Superseded buffers are kept, never freed (growth is rare).
-_GN_SCRATCH = {}
-_GN_SCRATCH_OLD = []
-_GN_SCRATCH_LOCK = threading.Lock()
+def restore_miopen_find():
+    """Inference forward after a guarded training forward: give the caller's cudnn.benchmark = True back."""
+    global _FIND_SWITCHED_OFF
+    if _FIND_SWITCHED_OFF:
+        _FIND_SWITCHED_OFF = False
+        torch.backends.cudnn.benchmark = True
 
 
 def _gn_scratch(dev, doubles):
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    with _GN_SCRATCH_LOCK:
-        buf = _GN_SCRATCH.get(key)
-        if buf is None or buf.numel() < doubles:
-            if buf is not None:
-                _GN_SCRATCH_OLD.append(buf)
-            buf = torch.empty((max(8192, 2 * doubles),), dtype=torch.float64, device=dev)
-            _GN_SCRATCH[key] = buf
-    return buf
+    """Scratch of the GroupNorm kernels (float64 partial sums, written by one kernel and folded by the next on the same stream):
+    a fresh torch allocation per call.  The caching allocator makes that cheap in eager mode, keeps a block that queued kernels
+    still use from being handed out on another stream, and inside a HIP-graph capture takes it from that graph's own pool -- no
+    buffer outlives the graph it was captured in."""
+    return torch.empty((max(64, doubles),), dtype=torch.float64, device=dev)
 
 
 def _f32c_fast(t):

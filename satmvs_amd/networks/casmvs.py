@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..modules.depth_range import stage_hypotheses
-from ..modules.module import CostRegNet, FeatureNet, depth_regression, guard_miopen_find, window_depth_regression
+from ..modules.module import CostRegNet, FeatureNet, depth_regression, window_depth_regression
 from ..modules.warping import variance_cost_volume
 
 Align_Corners_Range = False
@@ -53,8 +53,6 @@ class CascadeMVSNet(nn.Module):
         self.DepthNet = DepthNet()
 
     def forward(self, imgs, proj_matrices, depth_values):
-        if self.training and imgs.is_cuda:
-            guard_miopen_find()                             # see modules/module.py: MIOpen's search is switched off for training
         features = self.feature.forward_views(imgs)
         h, w = int(imgs.shape[3]), int(imgs.shape[4])
         outputs = {}

@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..modules.depth_range import GeneratedHeights, stage_hypotheses
-from ..modules.module import (FeatureNet, RED_Regularization, StreamingRegression, guard_miopen_find, slice_RED_Regularization,
+from ..modules.module import (FeatureNet, RED_Regularization, StreamingRegression, guard_miopen_find, restore_miopen_find, slice_RED_Regularization,
                               softmax_depth_regression)
 from ..modules.warping import variance_cost_volume
 
@@ -100,8 +100,8 @@ class _CascadeRED(nn.Module):
 
     def forward(self, imgs, proj_matrices, depth_values):
         """imgs (B,V,3,H,W); proj_matrices {"stageK": (B,V,170)|(B,V,4,4)|QC dicts}; depth_values (B,2)."""
-        if self.training and imgs.is_cuda:
-            guard_miopen_find()
+        if imgs.is_cuda:
+            guard_miopen_find() if self.training else restore_miopen_find()
         features = self.feature.forward_views(imgs)
         img_h, img_w = int(imgs.shape[3]), int(imgs.shape[4])
         outputs = {}

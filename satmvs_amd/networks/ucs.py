@@ -9,7 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..modules.depth_range import GeneratedHeights, uncertainty_aware_samples
-from ..modules.module import CostRegNet, FeatureNet, guard_miopen_find, window_depth_regression
+from ..modules.module import CostRegNet, FeatureNet, window_depth_regression
 from ..modules.warping import variance_cost_volume
 
 
@@ -37,8 +37,6 @@ class UCSNet(nn.Module):
             for i in range(self.num_stage)])
 
     def forward(self, imgs, proj_matrices, depth_values):
-        if self.training and imgs.is_cuda:
-            guard_miopen_find()                             # see modules/module.py: MIOpen's search is switched off for training
         features = self.feature_extraction.forward_views(imgs)
         outputs = {}
         depth, exp_var = None, None

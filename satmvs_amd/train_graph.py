@@ -12,8 +12,11 @@ are -- they launch on torch's current stream, take their scratch from torch's al
 
 `loss_fn(outputs, *extra)` gets the model's output dict and the extra positional arguments of the call (ground truth, masks:
 tensors or dicts / lists of tensors).  Arguments are copied into static buffers; a call with other shapes re-captures.
-Returned tensors are the graph's static outputs: valid until the next call.  Python scalars the step reads (a float learning
-rate, loss weights) are baked into the graph: call recapture() after changing them (e.g. when a scheduler steps the rate).
+Returned tensors are the graph's static outputs: valid until the next call.  Python scalars the step reads are baked into the
+graph.  The optimizer's are watched: every call compares the param groups' scalar hyper-parameters (lr, weight_decay, momentum,
+alpha, eps, betas, ...) with what was captured and re-captures when one changed -- the reference's loop steps a MultiStepLR
+every iteration (train.py:287), so a milestone costs one re-capture instead of silently training on at the old rate.  Scalars
+inside loss_fn (loss weights) are the caller's: recapture() after changing them.
 """
 from __future__ import annotations
 
@@ -41,6 +44,16 @@ def _zip_copy(dst, src):
             _zip_copy(d, s)
 
 
+def _hyper(optimizer):
+    """Python-scalar hyper-parameters of every param group (tensors -- a capturable tensor lr -- live on the GPU and need no watch)."""
+    out = []
+    for g in optimizer.param_groups:
+        out.append(tuple((k, v) for k, v in sorted(g.items())
+                         if k != "params" and (isinstance(v, (int, float, bool, type(None))) or
+                                               (isinstance(v, tuple) and all(isinstance(x, (int, float)) for x in v)))))
+    return tuple(out)
+
+
 def _signature(obj):
     if torch.is_tensor(obj):
         return (tuple(obj.shape), obj.dtype)
@@ -58,6 +71,8 @@ class GraphedTrainStep:
         self.model, self.optimizer, self.loss_fn, self.warmup = model, optimizer, loss_fn, int(warmup)
         self._sig = None
         self._graph = None
+        self._hyper_captured = None
+        self.captures = 0                                     # how many times a graph was captured (shape / hyper-parameter changes)
 
     def _eager(self, args):
         self.optimizer.zero_grad(set_to_none=True)
@@ -98,6 +113,8 @@ class GraphedTrainStep:
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._out = self._eager(self._static)
+        self._hyper_captured = _hyper(self.optimizer)
+        self.captures += 1
 
     def recapture(self):
         """Forget the captured graph: the next call captures again (after a change of learning rate, loss weights, ...)."""
@@ -106,7 +123,8 @@ class GraphedTrainStep:
 
     def __call__(self, *args):
         sig = _signature(args)
-        if sig != self._sig:
+        if sig != self._sig or _hyper(self.optimizer) != self._hyper_captured:
+            self._graph = None                                # release the old graph (and its private pool) before capturing again
             self._capture(args)
             self._sig = sig
         else:

@@ -423,8 +423,9 @@ def test_convgru_cell_native_elementwise_matches_torch(dev, B, cin, ch, H, W):
 
 def test_training_forward_switches_miopen_find_off(dev, golden):
     """The reference's train.py:21 sets cudnn.benchmark = True; the RED training forward switches it off with a warning
-    (satmvs_amd.modules.module.guard_miopen_find: ~7 min of exhaustive search per process on this image, and implicated in a
-    GPU memory fault).  Inference forwards leave the flag alone."""
+    (satmvs_amd.modules.module.guard_miopen_find: MIOpen's search faults in this network's training forward on this image, with or
+    without this library in the process -- profiles/r04_miopen_find_repro.txt).  Inference forwards leave the flag alone, and the
+    first one after a guarded training forward restores it."""
     import warnings
     from satmvs_amd.modules import module
     from satmvs_amd.networks import casred
@@ -446,7 +447,11 @@ def test_training_forward_switches_miopen_find_off(dev, golden):
         assert torch.backends.cudnn.benchmark is False
         assert any("cudnn.benchmark switched off" in str(x.message) for x in w)
         assert torch.isfinite(out["stage3"]["depth"]).all()
+        with torch.no_grad():                                   # the next inference forward hands the caller's setting back
+            net.eval()(imgs, proj, dv)
+        assert torch.backends.cudnn.benchmark is True
     finally:
+        module._FIND_SWITCHED_OFF = False
         torch.backends.cudnn.benchmark = saved
 
 
@@ -567,6 +572,17 @@ def test_graphed_training_step_matches_eager(dev, golden):
     graph = step._graph
     loss3, _ = step(imgs, proj, dv, gts2)
     assert step._graph is graph and abs(float(loss3) - loss2) > 1.0
+    # a scheduler stepping the rate (the reference's MultiStepLR, train.py:287): the change is noticed and the step re-captured
+    n = step.captures
+    before = {k: p.detach().clone() for k, p in net_g.named_parameters()}
+    for grp in opt_g.param_groups:
+        grp["lr"] = 0.0
+    step(imgs, proj, dv, gts2)
+    assert step.captures == n + 1 and step._graph is not graph
+    for k, p in net_g.named_parameters():
+        assert torch.equal(p, before[k]), "a step at lr = 0 moved %s: the old rate was replayed" % k
+    step(imgs, proj, dv, gts2)
+    assert step.captures == n + 1                               # unchanged hyper-parameters: plain replay
 
 
 def test_native_modules_match_composites_at_ragged_shapes(dev):
