@@ -19,6 +19,8 @@
 //     channels) four ways and reduce through LDS: 4x the waves in flight for the same tile.
 // Epilogue (wave 0): bias / BatchNorm scale-shift, ReLU, skip add, GroupNorm statistics.
 #pragma once
+#include <type_traits>
+
 #include "smvs_device.h"
 
 namespace smvs {
@@ -33,6 +35,123 @@ constexpr int MFMA9_WSLOT = 12;              // 9-tap weights: a lane's 9 taps p
 #define SMVS_MFMA_PREFETCH 2                 // 9-tap kernels, one cout tile per workgroup: channel pairs in flight per wave
 #endif
 
+// ---- element-wise ConvGRU stage computed by the CONSUMING convolution (RED plane loop, red.hip) ------------------------------
+// The plane loop of the RED regulariser is a chain of dependent launches whose cost is their number, not their work
+// (DESIGN.md section 6): gate convolution -> gate apply -> candidate convolution -> combine.  GroupNorm(1, C) needs the statistics
+// of the WHOLE convolution output before an element can be normalised, so the element-wise stages cannot move into their
+// producer's epilogue; they can move into their CONSUMER, which starts after the producer's launch boundary anyway: the
+// consuming convolution computes the stage once per input tile (+ the 3x3 halo) into LDS and reads its hidden-state operand
+// (the B half of the concatenated input) from there.  2 dependent launches per plane instead of 4:
+//   mode FUSE_APPLY    candidate convolution:  B = sigmoid(GN(reset gate)) * h                            (module.py:34-44)
+//   mode FUSE_COMBINE  NEXT plane's gate convolution:  B = h' = u h + (1 - u) tanh(GN(candidate)), u = sigmoid(GN(update gate));
+//                      the workgroups of output-channel group 0 also store h' (new state + the decoder's snapshot)   (module.py:45-57)
+// Same float32 operations as gru_gate_apply_kernel / gru_combine_kernel (red.hip), so the bits do not change.
+enum { FUSE_NONE = 0, FUSE_APPLY = 1, FUSE_COMBINE = 2 };
+struct FuseB {
+    int mode, HC, nslot;
+    const float* gates;                      // raw gate convolution (B, 2 HC, h, w) of the plane the stage belongs to
+    const float* cand;                       // raw candidate convolution (B, HC, h, w)                      (combine)
+    const float* h;                          // hidden state the stage reads (B, HC, h, w)
+    float* h_out; float* hsnap;              // where the new state goes (another buffer than h), and its copy for the decoder   (combine)
+    const double *stats_g, *stats_o;         // [b][reset, update][nslot][2] and [b][nslot][2] partial sums
+    const float *gw, *gb, *ow, *ob;          // affine of the gate norm used (reset: apply, update: combine) and of the output norm
+    double* zero; int zero_n;                // statistics buffer of a later plane, cleared by workgroup 0 of the job (or null)
+};
+
+// sigmoid / tanh of the ConvGRU gates on the hardware's exp2 and reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each): 6-7 instructions
+// instead of libm's ~40 -- the fused launches evaluate them 3-12 times per element (tile halos, one tile per output-channel
+// group), and the stand-alone element-wise kernels use the same two functions so that a plane's bits do not depend on the path.
+// |error| <= 2e-7 absolute (tolerance of the regulariser against the reference: 2e-5).
+__device__ __forceinline__ float fuse_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fuse_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+// mean / rstd of one norm group from its 64 partial (sum, sumsq) slots, by ONE wave (lane = slot); same arithmetic as
+// gn_coeffs (red.hip)
+__device__ __forceinline__ void fuse_gn_coeffs(const double* st, double n, float& mean, float& rstd)
+{
+    const int l = threadIdx.x & 63;
+    double a = st[l * 2], q = st[l * 2 + 1];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); q += __shfl_xor(q, m, 64); }
+    const double mu = a / n;
+    double var = q / n - mu * mu;
+    var = var < 0.0 ? 0.0 : var;
+    mean = (float)mu;
+    rstd = (float)(1.0 / sqrt(var + (double)1e-5f));
+}
+
+// Fill the LDS tile [HC][TH][TW] (rows y0 .. y0+TH-1, columns x0 .. x0+TW-1 of sample b; zeros outside the image) with the
+// stage's output.  Called by the NWF waves that share the tile (wf = this wave's index among them); the caller synchronises.
+// writer: this workgroup stores the new state for the tile's interior (rows y0+1 .. y0+TH-2, columns x0+1 .. x0+TW-2).
+// A thread takes E elements per round and issues ALL their loads before the first use: on these small grids a wave sees
+// the full memory latency of every dependent access, and an element at a time cost one round trip each (measured: the
+// fused launches took 38 us instead of 13).
+// TH, TW are compile-time: the index arithmetic is four integer divisions per element, ~35 instructions each by a run-time divisor.
+template <int NWF, int E, int TH, int TW>
+__device__ __forceinline__ void fuse_fill_tile(const FuseB& f, int b, int Hh, int Ww, int y0, int x0, float* tile, int wf, bool writer)
+{
+#ifndef SMVS_FUSE_ABLATE
+#define SMVS_FUSE_ABLATE 0                    // profiling builds only (wrong results): 1 no fill at all, 2 no operand loads, 4 no gate arithmetic, 8 no statistics
+#endif
+    if (SMVS_FUSE_ABLATE & 1) return;
+    const int HC = f.HC, HW = Hh * Ww;
+    constexpr int per = TH * TW;
+    const int tot = HC * per;
+    const int lane = threadIdx.x & 63;
+    const bool comb = f.mode == FUSE_COMBINE;
+    const float* gsrc = f.gates + ((size_t)b * 2 * HC + (comb ? HC : 0)) * HW;     // update half (combine) / reset half (apply)
+    const float* csrc = comb ? f.cand + (size_t)b * HC * HW : f.h;
+    const float* hsrc = f.h + (size_t)b * HC * HW;
+    float mg = 0.0f, sg = 0.0f, mo = 0.0f, so = 0.0f;
+    bool have = false;
+    const int rounds = (tot + NWF * 64 * E - 1) / (NWF * 64 * E);           // wave-uniform trip count (the statistics use wave shuffles)
+    for (int it = 0; it < rounds; ++it) {
+        const int base = wf * 64 + lane + it * NWF * 64 * E;
+        int c[E], p[E];
+        bool in[E];
+        float vg[E], vh[E], vc[E];
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            const int i = base + u * NWF * 64;
+            const int ii = i < tot ? i : 0;
+            const int cc = ii / per, r = ii - cc * per, ty = r / TW, tx = r - ty * TW;
+            const int y = y0 + ty, x = x0 + tx;
+            in[u] = i < tot && y >= 0 && y < Hh && x >= 0 && x < Ww;
+            c[u] = cc;
+            p[u] = in[u] ? y * Ww + x : 0;
+            const size_t e = (size_t)cc * HW + p[u];
+            if (SMVS_FUSE_ABLATE & 2) { vg[u] = 0.1f * (float)u; vh[u] = 0.5f; vc[u] = 0.25f; }
+            else { vg[u] = gsrc[e]; vh[u] = hsrc[e]; vc[u] = comb ? csrc[e] : 0.0f; }
+        }
+        if (!have && !(SMVS_FUSE_ABLATE & 8)) {                // statistics: loaded behind the first round's operands
+            const double n = (double)HC * HW;
+            fuse_gn_coeffs(f.stats_g + ((size_t)b * 2 + (comb ? 1 : 0)) * f.nslot * 2, n, mg, sg);
+            if (comb) fuse_gn_coeffs(f.stats_o + (size_t)b * f.nslot * 2, n, mo, so);
+            have = true;
+        }
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            const int i = base + u * NWF * 64;
+            const int cc = c[u];
+            float v;
+            const float g = (SMVS_FUSE_ABLATE & 4) ? vg[u] : fuse_sigmoid(fmaf((vg[u] - mg) * sg, f.gw[cc], f.gb[cc]));
+            if (!comb) v = g * vh[u];
+            else {
+                const float yv = (SMVS_FUSE_ABLATE & 4) ? vc[u] : fuse_tanh(fmaf((vc[u] - mo) * so, f.ow[cc], f.ob[cc]));
+                v = g * vh[u] + (1.0f - g) * yv;
+                if (writer && in[u]) {
+                    const int r = i - cc * per, ty = r / TW, tx = r - ty * TW;
+                    if (ty >= 1 && ty < TH - 1 && tx >= 1 && tx < TW - 1) {
+                        const size_t e = ((size_t)b * HC + cc) * HW + p[u];
+                        f.h_out[e] = v; f.hsnap[e] = v;
+                    }
+                }
+            }
+            if (i < tot) tile[i] = in[u] ? v : 0.0f;
+        }
+    }
+}
+
 struct MfmaConvArgs {
     const float* inA; int CA;                // first CA input channels (must be even)
     const float* inB; int CB;                // next CB channels (concat input), or null/0
@@ -46,7 +165,9 @@ struct MfmaConvArgs {
     int Di, Hi, Wi, Do, Ho, Wo;              // 2-D: Di = Do = 1
     float scaleA;                            // multiplies the A-tensor inputs (-1 feeds -cost)
     int ntiles;                              // tiles of 32 positions in the launch (KS < NW variants: decode / bound of the flat unit index)
+    FuseB fuse;                              // 9-tap kernels of the RED plane loop: the B operand computed into LDS (mode != FUSE_NONE)
 };
+constexpr int MFMA_FUSE_TW = 34, MFMA_FUSE_TH = 3;           // LDS tile of one unit's B operand: 3 rows x (32 + 2) columns per channel
 
 // W pack kernel: src (Cout, Cin, TAPS) [conv] -> dst [cip][p][nt][h][32]
 // step p of channel pair cip covers kk = 2p + h in the 2*TAPS-long (ci0 taps..., ci1 taps...) list.
@@ -91,9 +212,12 @@ __device__ __forceinline__ unsigned long long mfma_now() { unsigned long long t 
 //   wave -- all prologue -- and three of four waves idle through the epilogue (MFMA pipe 20 % busy,
 //   profiles/r03_mfma_utilisation.txt); KS = 1 / 2 gives 144-288 MFMAs per wave at 4-5 resident waves per SIMD.
 // smem: (NW - NW/KS)*NT*16*64 floats.
-template <int TAPS, int NT, int NW, int KS = NW>
-__device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, int by, float* smem)
+// FUSE (9 taps only): the B operand is a.fuse's element-wise stage, computed into `tile` (LDS, NW/KS tiles of
+// CB * MFMA_FUSE_TH * MFMA_FUSE_TW floats) before the K loop.
+template <int TAPS, int NT, int NW, int KS = NW, bool FUSE = false>
+__device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, int by, float* smem, float* tile = nullptr)
 {
+    static_assert(!FUSE || TAPS == 9, "fused element-wise stages exist for the 2-D kernels only");
     static_assert(NW % KS == 0, "waves per unit");
     constexpr int TW = NW / KS;                            // units per workgroup
     constexpr int KD = TAPS == 27 ? 3 : 1;
@@ -224,15 +348,31 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
         struct Batch9 { mf32x3 x[3]; mf32x4 w[NT][2]; float w8[NT]; float sx; };   // no dead load components: the compiler would reuse them
                                                                                     // as scratch and then has to wait for the load in flight
         Batch9 bb[NPF];
-        auto load9 = [&](Batch9& B, int q) {
-            const int cip = kw * per + q;
+        const float* tl = nullptr;                                 // this unit's LDS tile of the B operand (FUSE)
+        if constexpr (FUSE) {
+            tl = tile + (size_t)tw * a.CB * (MFMA_FUSE_TH * MFMA_FUSE_TW);
+            if (unit_ok)
+                fuse_fill_tile<KS, 16, MFMA_FUSE_TH, MFMA_FUSE_TW>(a.fuse, b, a.Hi, a.Wi, oy - 1, x0 - 1, const_cast<float*>(tl), kw, nt0 == 0);
+            if (a.fuse.zero && bx == 0 && by == 0)
+                for (int i = threadIdx.x; i < a.fuse.zero_n; i += NW * 64) a.fuse.zero[i] = 0.0;
+            __syncthreads();
+        }
+        // X operand of channel pair cip: from memory (A half; B half when not fused) or from the LDS tile (fused B half)
+        auto load9 = [&](Batch9& B, int cip, auto lds_tag) {
+            constexpr bool LDS = decltype(lds_tag)::value;
             const bool fromA = 2 * cip < a.CA;                      // wave-uniform: scalar selects
-            const int choff = (int)((size_t)(fromA ? 2 * cip : 2 * cip - a.CA) * vol_i * 4);
-            i32x4 rx;
-            rx.x = fromA ? rA.v.x : rB.v.x; rx.y = fromA ? rA.v.y : rB.v.y;
-            rx.z = fromA ? rA.v.z : rB.v.z; rx.w = rA.v.w;
+            if constexpr (LDS) {
+                const float* tc = tl + (size_t)(2 * cip - a.CA + h) * (MFMA_FUSE_TH * MFMA_FUSE_TW) + j;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) B.x[ky] = llvm_raw_buffer_load_v3f32(rx, (int)roff[ky], choff, 0);
+                for (int ky = 0; ky < 3; ++ky) { B.x[ky].x = tc[ky * MFMA_FUSE_TW]; B.x[ky].y = tc[ky * MFMA_FUSE_TW + 1]; B.x[ky].z = tc[ky * MFMA_FUSE_TW + 2]; }
+            } else {
+                const int choff = (int)((size_t)(fromA ? 2 * cip : 2 * cip - a.CA) * vol_i * 4);
+                i32x4 rx;
+                rx.x = fromA ? rA.v.x : rB.v.x; rx.y = fromA ? rA.v.y : rB.v.y;
+                rx.z = fromA ? rA.v.z : rB.v.z; rx.w = rA.v.w;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) B.x[ky] = llvm_raw_buffer_load_v3f32(rx, (int)roff[ky], choff, 0);
+            }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int wo = (cip * nt_all + nt0 + n) * (64 * MFMA9_WSLOT * 4);
@@ -242,15 +382,17 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
             }
             B.sx = fromA ? a.scaleA : 1.0f;                         // applied at MMA time: no wait on the loads here
         };
-        auto mma9 = [&](const Batch9& B) {
+        auto mma9 = [&](const Batch9& B, auto lds_tag) {
+            constexpr bool LDS = decltype(lds_tag)::value;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 // loaded columns start at max(ix0, 0): shift right by one where the west tap is padding, drop the east one
+                // (the LDS tile carries its zero padding itself)
                 const float l0 = B.x[ky].x, l1 = B.x[ky].y, l2 = B.x[ky].z;
                 float xv[3];
-                xv[0] = padL ? 0.0f : l0;
-                xv[1] = padL ? l0 : l1;
-                xv[2] = padR ? 0.0f : (padL ? l1 : l2);
+                xv[0] = LDS ? l0 : (padL ? 0.0f : l0);
+                xv[1] = LDS ? l1 : (padL ? l0 : l1);
+                xv[2] = LDS ? l2 : (padR ? 0.0f : (padL ? l1 : l2));
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int p = ky * 3 + kx;
@@ -264,17 +406,28 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
         // of outstanding operations unknown at the join, and the compiler then waits with vmcnt(0) before every batch of
         // MFMAs -- i.e. also for the batch it has just issued, and the prefetch hides nothing (that was the case until
         // round 2: ~1900 clocks per batch against 576 of MFMA issue).
+        // Channel pairs [c_lo, c_hi) of this wave, in order (the accumulation order is the unfused kernel's)
+        auto run = [&](int c_lo, int c_hi, auto lds_tag) {
 #pragma unroll
-        for (int i = 0; i < NPF - 1; ++i) load9(bb[i], min(i, q_end - 1));
-        SMVS_MT(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mt1 = mfma_now();)
-        for (int q = 0; q < q_end; q += NPF) {
+            for (int i = 0; i < NPF - 1; ++i) load9(bb[i], min(c_lo + i, c_hi - 1), lds_tag);
+            for (int q = c_lo; q < c_hi; q += NPF) {
 #pragma unroll
-            for (int i = 0; i < NPF; ++i) {
-                load9(bb[(i + NPF - 1) % NPF], min(q + i + NPF - 1, q_end - 1));
-                __builtin_amdgcn_sched_barrier(0);
-                if (q + i < q_end) mma9(bb[i]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < NPF; ++i) {
+                    load9(bb[(i + NPF - 1) % NPF], min(q + i + NPF - 1, c_hi - 1), lds_tag);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (q + i < c_hi) mma9(bb[i], lds_tag);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+        };
+        const int c_lo = kw * per, c_hi = c_lo + q_end;
+        if constexpr (FUSE) {
+            const int cA = a.CA / 2;
+            if (c_lo < min(c_hi, cA)) run(c_lo, min(c_hi, cA), std::false_type());
+            if (max(c_lo, cA) < c_hi) run(max(c_lo, cA), c_hi, std::true_type());
+        } else {
+            SMVS_MT(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mt1 = mfma_now();)
+            run(c_lo, c_hi, std::false_type());
         }
     }
 #undef SMVS_LOAD_BATCH
@@ -282,6 +435,7 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
 
     // ---- split-K reduction through LDS: waves 1..3 publish, wave 0 sums and finishes -----------------
     SMVS_MT(asm volatile("s_nop 7\n s_nop 7" ::: "memory"); const unsigned long long mt2 = mfma_now();)
+    if (FUSE) __syncthreads();                // the B tile shares its LDS with the partial accumulators: every wave is out of its K loop
     if (KS > 1) {
         if (kw > 0) {
 #pragma unroll

@@ -166,9 +166,14 @@ constexpr int WLDS_MAX_CIN = 64;
 constexpr int CONV_PART_FLOATS = 3 * COT * 64;
 constexpr int WLDS_FLOATS = SMVS_WLDS ? WLDS_MAX_CIN * 9 * COT : 0;
 constexpr int CONV_SMEM_FLOATS = CONV_PART_FLOATS + WLDS_FLOATS;
-template <int STRIDE, bool SPLIT>
-__device__ __forceinline__ void conv3x3_body(const ConvArgs& a, int bx, int by, int bz, float* smem)
+// FUSE (stride 1): the B operand is the element-wise ConvGRU stage `fz` (mfma_conv.h: FuseB), computed by the workgroup
+// into `tile` (LDS, CB x CONV_FUSE_TH(SPLIT) x CONV_FUSE_TW floats) before the channel loop.
+constexpr int CONV_FUSE_TW = 66;
+constexpr int conv_fuse_th(bool split) { return split ? 3 : 6; }
+template <int STRIDE, bool SPLIT, bool FUSE = false>
+__device__ __forceinline__ void conv3x3_body(const ConvArgs& a, int bx, int by, int bz, float* smem, const FuseB* fz = nullptr, float* tile = nullptr)
 {
+    static_assert(!FUSE || STRIDE == 1, "fused element-wise stages feed the stride-1 ConvGRU convolutions");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ox = bx * 64 + lane;
     const int oy = SPLIT ? by : by * 4 + wave;
@@ -221,63 +226,98 @@ __device__ __forceinline__ void conv3x3_body(const ConvArgs& a, int bx, int by, 
 
     const int per = SPLIT ? (Cin + 3) / 4 : Cin;
     const int c0 = SPLIT ? wave * per : 0, c1 = SPLIT ? min(Cin, c0 + per) : Cin;
-#define SMVS_CONV_LOAD(V, CC)                                                                          \
-    {                                                                                                  \
-        const bool fa_ = (CC) < a.CA;                              /* wave-uniform: scalar selects */ \
-        i32x4 rx_;                                                                                     \
-        rx_.x = fa_ ? rA.v.x : rB.v.x; rx_.y = fa_ ? rA.v.y : rB.v.y;                                  \
-        rx_.z = fa_ ? rA.v.z : rB.v.z; rx_.w = rA.v.w;                                                 \
-        const int co_ = fa_ ? (CC) * csA * 4 : ((CC) - a.CA) * HWi * 4;                                \
-        if (ROWS) { _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) V.r[k_] = llvm_raw_buffer_load_v3f32(rx_, (int)roff[k_], co_, 0); } \
-        else { _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_) V.t[k_] = llvm_raw_buffer_load_f32(rx_, (int)off[k_], co_, 0); } \
+    constexpr int FTH = conv_fuse_th(SPLIT);
+    if constexpr (FUSE) {
+        fuse_fill_tile<4, 8, FTH, CONV_FUSE_TW>(*fz, b, a.Hi, a.Wi, (SPLIT ? by : by * 4) - 1, bx * 64 - 1, tile, wave, cog == 0);
+        if (fz->zero && bx == 0 && by == 0 && bz == 0)
+            for (int i = threadIdx.x; i < fz->zero_n; i += 256) fz->zero[i] = 0.0;
+        __syncthreads();
     }
-#define SMVS_CONV_TAPS(V, CC)                                                                          \
-    float t_[9];                                                                                       \
-    {                                                                                                  \
-        const float sc_ = (CC) < a.CA ? a.scaleA : 1.0f;                                               \
-        if (ROWS) {                                                                                    \
-            _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) {                                         \
-                float l0_ = V.r[k_].x, l1_ = V.r[k_].y, l2_ = V.r[k_].z;                               \
-                if (anypad) { l2_ = padR ? 0.0f : (padL ? l1_ : l2_); l1_ = padL ? l0_ : l1_; l0_ = padL ? 0.0f : l0_; } \
-                t_[3 * k_] = l0_ * sc_; t_[3 * k_ + 1] = l1_ * sc_; t_[3 * k_ + 2] = l2_ * sc_;         \
-            }                                                                                          \
-        } else {                                                                                       \
-            _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_) t_[k_] = V.t[k_] * sc_;                   \
-        }                                                                                              \
-    }
-#define SMVS_CONV_FMA(V, CC)                                                                           \
-    { SMVS_CONV_TAPS(V, CC)                                                                            \
-      if (WL) {                                                                                        \
-        const float* wc_ = wl + (CC) * 9 * COT;                                                        \
-        _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_)                                               \
-            _Pragma("unroll") for (int j_ = 0; j_ < COT; ++j_) acc[j_] = fmaf(t_[k_], wc_[k_ * COT + j_], acc[j_]); \
-    } else {                                                                                           \
-        const cw_t wc_ = wbase + (size_t)(CC) * 9 * COT;                                               \
-        _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_)                                               \
-            _Pragma("unroll") for (int j_ = 0; j_ < COT; ++j_) acc[j_] = fmaf(t_[k_], wc_[k_ * COT + j_], acc[j_]); \
-    } }
     // NPF-1 channels of taps are in flight while one is multiplied.
     constexpr int NPF = SMVS_CONV_PREFETCH;
     struct Taps { mf32x3 r[ROWS ? 3 : 1]; float t[ROWS ? 1 : 9]; };   // one of the two is used (compile-time)
     Taps v[NPF];
+    // taps of input channel cc: from memory (A half; B half when not fused) or from the LDS tile (fused B half)
+    auto load = [&](Taps& V, int cc, auto lds_tag) {
+        constexpr bool LDS = decltype(lds_tag)::value;
+        if constexpr (LDS) {
+            const float* tc = tile + (size_t)(cc - a.CA) * (FTH * CONV_FUSE_TW) + (SPLIT ? 0 : wave) * CONV_FUSE_TW + lane;
+            if (ROWS) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { V.r[k].x = tc[k * CONV_FUSE_TW]; V.r[k].y = tc[k * CONV_FUSE_TW + 1]; V.r[k].z = tc[k * CONV_FUSE_TW + 2]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) V.t[k] = tc[(k / 3) * CONV_FUSE_TW + k % 3];
+            }
+        } else {
+            const bool fa = cc < a.CA;                                 // wave-uniform: scalar selects
+            i32x4 rx;
+            rx.x = fa ? rA.v.x : rB.v.x; rx.y = fa ? rA.v.y : rB.v.y;
+            rx.z = fa ? rA.v.z : rB.v.z; rx.w = rA.v.w;
+            const int co = fa ? cc * csA * 4 : (cc - a.CA) * HWi * 4;
+            if (ROWS) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) V.r[k] = llvm_raw_buffer_load_v3f32(rx, (int)roff[k], co, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) V.t[k] = llvm_raw_buffer_load_f32(rx, (int)off[k], co, 0);
+            }
+        }
+    };
+    auto fma = [&](const Taps& V, int cc, auto lds_tag) {
+        constexpr bool LDS = decltype(lds_tag)::value;
+        float t[9];
+        const float sc = cc < a.CA ? a.scaleA : 1.0f;
+        if (ROWS) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float l0 = V.r[k].x, l1 = V.r[k].y, l2 = V.r[k].z;
+                if (!LDS && anypad) { l2 = padR ? 0.0f : (padL ? l1 : l2); l1 = padL ? l0 : l1; l0 = padL ? 0.0f : l0; }   // (the LDS tile carries its zero padding)
+                t[3 * k] = l0 * sc; t[3 * k + 1] = l1 * sc; t[3 * k + 2] = l2 * sc;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) t[k] = V.t[k] * sc;
+        }
+        if (WL) {
+            const float* wc = wl + cc * 9 * COT;
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int j = 0; j < COT; ++j) acc[j] = fmaf(t[k], wc[k * COT + j], acc[j]);
+        } else {
+            const cw_t wc = wbase + (size_t)cc * 9 * COT;
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int j = 0; j < COT; ++j) acc[j] = fmaf(t[k], wc[k * COT + j], acc[j]);
+        }
+    };
     // The loads are UNCONDITIONAL (past the end: the last channel again, unused) -- a load under a branch makes the
     // compiler wait with vmcnt(0) before every multiply block, and the prefetch hides nothing (mfma_conv.h).
-    const int cl = max(c1 - 1, 0);
+    // Channels [lo, hi) of this wave in order (the accumulation order is the unfused kernel's).
+    auto run = [&](int lo, int hi, auto lds_tag) {
+        const int cl = max(hi - 1, lo);
 #pragma unroll
-    for (int i = 0; i < NPF - 1; ++i) SMVS_CONV_LOAD(v[i], min(c0 + i, cl))
-    for (int cc = c0; cc < c1; cc += NPF) {
+        for (int i = 0; i < NPF - 1; ++i) load(v[i], min(lo + i, cl), lds_tag);
+        for (int cc = lo; cc < hi; cc += NPF) {
 #pragma unroll
-        for (int i = 0; i < NPF; ++i) {
-            SMVS_CONV_LOAD(v[(i + NPF - 1) % NPF], min(cc + i + NPF - 1, cl))
-            __builtin_amdgcn_sched_barrier(0);
-            if (cc + i < c1) SMVS_CONV_FMA(v[i], cc + i)
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < NPF; ++i) {
+                load(v[(i + NPF - 1) % NPF], min(cc + i + NPF - 1, cl), lds_tag);
+                __builtin_amdgcn_sched_barrier(0);
+                if (cc + i < hi) fma(v[i], cc + i, lds_tag);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+    };
+    if constexpr (FUSE) {
+        if (c0 < min(c1, a.CA)) run(c0, min(c1, a.CA), std::false_type());
+        if (max(c0, a.CA) < c1) run(max(c0, a.CA), c1, std::true_type());
+    } else {
+        run(c0, c1, std::false_type());
     }
-#undef SMVS_CONV_LOAD
-#undef SMVS_CONV_FMA
-#undef SMVS_CONV_TAPS
 
+    if (FUSE) __syncthreads();                // the B tile shares its LDS with the scratch below: every wave is out of its channel loop
     if (SPLIT) {
         float (*part)[COT][64] = (float (*)[COT][64])smem;
         if (wave > 0) {
@@ -460,10 +500,11 @@ void convT3x3s2_kernel(const ConvArgs a)
 // regression update of the pred loop (networks/casred.py:218-231, float64 accumulators) in its epilogue: the plane
 // never goes to memory unless the caller wants the regularised volume.  lane = one pixel, 72 taps in flight.
 struct OutConvArgs {
-    const float* in;                         // (B,8,H,W)
+    const float* in;                         // (NP*B,8,H,W): sample = plane * B + batch
+    int NP;                                  // planes of the chunk (height hypotheses d .. d+NP-1), folded in plane order
     const float* w;                          // packed [8][9][COT], output channel 0
     const float* bias;
-    float* reg; size_t reg_bstride;          // regularised plane (floats between samples), or null
+    float* reg; size_t reg_bstride, reg_pstride;   // regularised planes (floats between batch samples / between planes), or null
     double *exp_sum, *depth_img, *max_prob;  // (B,H,W) accumulators, or null (no regression update)
     const float* depth; int hmode; HeightGen hg; int D, d;
     int B, H, W;
@@ -476,41 +517,47 @@ void out_conv_regress_kernel(const OutConvArgs a)
     const int ox = blockIdx.x * 64 + lane, oy = blockIdx.y * 4 + wave, b = blockIdx.z;
     const bool active = ox < a.W && oy < a.H;
     const int HW = a.H * a.W;
-    const BufRsrc rA = make_rsrc(a.in + (size_t)b * 8 * HW, (uint32_t)(8 * HW) * 4u);
-    float v[8][9];
+    uint32_t off[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int iy = oy - 1 + k / 3, ix = ox - 1 + k % 3;
-        const uint32_t off = (active && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? (uint32_t)(iy * a.W + ix) * 4u : SMVS_OOB;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[c][k] = llvm_raw_buffer_load_f32(rA.v, (int)off, c * HW * 4, 0);
+        off[k] = (active && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? (uint32_t)(iy * a.W + ix) * 4u : SMVS_OOB;
     }
     const cw_t w = (cw_t)(uintptr_t)a.w;
-    float acc = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-#pragma unroll
-        for (int k = 0; k < 9; ++k) acc = fmaf(v[c][k], w[(c * 9 + k) * COT], acc);
-    if (!active) return;
-    const float r = acc + a.bias[0];
     const int pix = oy * a.W + ox;
-    if (a.reg) a.reg[(size_t)b * a.reg_bstride + pix] = r;
-    if (a.exp_sum) {
-        const size_t i = (size_t)b * HW + pix;
-        const double pr = exp((double)r);
-        double hv;
-        if (a.hmode == HEIGHT_GENERATED) {
-            HeightPix hpx;
-            hg_prepare(a.hg, b, oy, ox, hpx);
-            hv = (double)hg_height(a.hg, hpx, a.d);
-        } else {
-            hv = a.hmode == HEIGHT_TENSOR ? (double)a.depth[((size_t)b * a.D + a.d) * HW + pix] : (double)a.depth[(size_t)b * a.D + a.d];
+    const size_t i = (size_t)b * HW + (active ? pix : 0);
+    // the regression accumulators are read once, folded over the chunk's planes in plane order, and written once
+    double m = 0.0, di = 0.0, es = 0.0;
+    if (a.exp_sum && active) { m = a.max_prob[i]; di = a.depth_img[i]; es = a.exp_sum[i]; }
+    HeightPix hpx;
+    if (a.exp_sum && a.hmode == HEIGHT_GENERATED && active) hg_prepare(a.hg, b, oy, ox, hpx);
+    for (int pl = 0; pl < a.NP; ++pl) {
+        const BufRsrc rA = make_rsrc(a.in + ((size_t)pl * a.B + b) * 8 * HW, (uint32_t)(8 * HW) * 4u);
+        float v[8][9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c][k] = llvm_raw_buffer_load_f32(rA.v, (int)off[k], c * HW * 4, 0);
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = fmaf(v[c][k], w[(c * 9 + k) * COT], acc);
+        if (!active) continue;
+        const float r = acc + a.bias[0];
+        const int d = a.d + pl;
+        if (a.reg) a.reg[(size_t)b * a.reg_bstride + (size_t)pl * a.reg_pstride + pix] = r;
+        if (a.exp_sum) {
+            const double pr = exp((double)r);
+            double hv;
+            if (a.hmode == HEIGHT_GENERATED) hv = (double)hg_height(a.hg, hpx, d);
+            else hv = a.hmode == HEIGHT_TENSOR ? (double)a.depth[((size_t)b * a.D + d) * HW + pix] : (double)a.depth[(size_t)b * a.D + d];
+            m = (m < pr) ? pr : m;
+            di = fma(hv, pr, di);
+            es = es + pr;
         }
-        const double m = a.max_prob[i], di = a.depth_img[i], es = a.exp_sum[i];   // three loads in flight, then the stores (the pointers may alias as far as the compiler knows)
-        a.max_prob[i] = (m < pr) ? pr : m;
-        a.depth_img[i] = fma(hv, pr, di);
-        a.exp_sum[i] = es + pr;
     }
+    if (a.exp_sum && active) { a.max_prob[i] = m; a.depth_img[i] = di; a.exp_sum[i] = es; }
 }
 
 // ---- GRU element-wise stages -------------------------------------------------------------------------------------
@@ -557,7 +604,7 @@ __device__ __forceinline__ void gn_coeffs2(const double* st0, const double* st1,
     m0 = lds2[0][0]; r0 = lds2[0][1]; m1 = lds2[1][0]; r1 = lds2[1][1];
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return fuse_sigmoid(x); }     // the same functions as the fused launches (mfma_conv.h)
 
 // ---- level-batched launches ------------------------------------------------------------------------------------------
 // The four ConvGRU levels of a plane do not depend on each other (only the decoder crosses levels), and each of
@@ -568,6 +615,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 struct ConvJob {
     ConvArgs a; MfmaConvArgs m;              // kind 0/1: a (direct, unsplit / channel-split); kind 2: m (MFMA, one cout tile per workgroup)
     int kind, gx, gy, blk0;                  // grid (gx, gy, rest) flattened; workgroups [blk0, next job's blk0)
+    FuseB fuse;                              // fused launches: the element-wise stage this convolution computes for its B operand (direct kinds; MFMA kinds: m.fuse)
 };
 struct ConvJobs { ConvJob j[4]; int n; };
 
@@ -591,11 +639,41 @@ void conv_jobs_kernel(const ConvJobs J)
     else conv3x3_body<1, false>(jb.a, bx, t % jb.gy, t / jb.gy, smem);
 }
 
+// Fused launches (conv_jobs_fused_kernel): the convolution computes the element-wise ConvGRU stage that feeds its B operand
+// into LDS first (mfma_conv.h: FuseB) -- 2 dependent launches per plane instead of 4.  LDS: the job bodies' own scratch +
+// the largest B tile (MFMA, 64 channels x 3 x 34; direct 16 x 3 x 66 / 8 x 6 x 66).
+constexpr int FUSE_TILE_FLOATS = 64 * MFMA_FUSE_TH * MFMA_FUSE_TW;
+__host__ __device__ inline int fuse_tile_floats(int kind, int CB)
+{
+    return kind == 0 ? CB * conv_fuse_th(false) * CONV_FUSE_TW : kind == 1 ? CB * conv_fuse_th(true) * CONV_FUSE_TW
+         : (kind == 3 ? 2 : 1) * CB * MFMA_FUSE_TH * MFMA_FUSE_TW;
+}
+
+__global__ __launch_bounds__(256)
+void conv_jobs_fused_kernel(const ConvJobs J)
+{
+    // one allocation: the B tile is dead when the bodies' scratch (split-K partials, statistics) comes into use
+    __shared__ __attribute__((aligned(16))) float smem[JOBS_SMEM_FLOATS > FUSE_TILE_FLOATS ? JOBS_SMEM_FLOATS : FUSE_TILE_FLOATS];
+    float* tile = smem;
+    int bid = blockIdx.x, l = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < J.n && bid >= J.j[i].blk0) l = i;
+    const ConvJob& jb = J.j[l];
+    bid -= jb.blk0;
+    const int bx = bid % jb.gx, t = bid / jb.gx;
+    if (jb.kind == 3) mfma_conv_body<9, 1, 4, 2, true>(jb.m, bid, 0, smem, tile);
+    else if (jb.kind == 2) mfma_conv_body<9, 1, 4, 4, true>(jb.m, bx, t, smem, tile);
+    else if (jb.kind == 1) conv3x3_body<1, true, true>(jb.a, bx, t % jb.gy, t / jb.gy, smem, &jb.fuse, tile);
+    else conv3x3_body<1, false, true>(jb.a, bx, t % jb.gy, t / jb.gy, smem, &jb.fuse, tile);
+}
+
 struct GruJob {                              // the element-wise stages of one level
     const float* gates;                      // raw gate convolution (B,2HC,h,w): reset half read by the apply stage, update half by the combine stage
     const double *stats_g, *stats_o;         // [b][reset,update][NSLOT][2] ; [b][NSLOT][2]
     const float *rn_w, *rn_b, *un_w, *un_b, *on_w, *on_b;
-    float* h;                                // hidden state (B,HC,h,w), updated in place by the combine stage
+    float* h;                                // hidden state (B,HC,h,w) read by both stages
+    float* h_out;                            // where the combine stage stores the new state (h itself: in place)
     float* rh;                               // r*h for the candidate convolution
     const float* cand;                       // raw candidate convolution
     float* hsnap;                            // copy of the new state for the decoder (which runs while the next plane updates h)
@@ -662,9 +740,9 @@ void gru_combine_kernel(const GruJobs J)
     gn_coeffs2(g.stats_g + ((size_t)b * 2 + 1) * NSLOT * 2, g.stats_o + (size_t)b * NSLOT * 2, (double)HC * HW, 1e-5f, mu, su, m, s, coef);
     if (!valid) return;
     const float u = sigmoidf_(fmaf((vu - mu) * su, wu, bu));
-    const float y = tanhf(fmaf((vc - m) * s, wo, bo));
+    const float y = fuse_tanh(fmaf((vc - m) * s, wo, bo));
     const float hn = u * vh + (1.0f - u) * y;
-    g.h[i] = hn;
+    g.h_out[i] = hn;
     g.hsnap[i] = hn;
 }
 
@@ -688,7 +766,10 @@ struct RedWorkspace {                        // offsets in floats into the calle
     // read (see red_run_planes).  gates / rh / cand (recurrent stream) and sum (decoder stream) live on one stream.
     // e[i] + slot * e_stride[i]: the slots of a chunk are adjacent = one dense batch of CH*B samples.
     int CH, NSL;
-    size_t e[3], e_stride[3], gates[4], rh[4], cand[4], hsnap[NSL_MAX][4], sum[3], stats[2];   // stats: doubles, offset in floats (8-byte aligned)
+    size_t e[3], e_stride[3], gates[4], rh[4], cand[4], hsnap[4], hsnap_stride[4], sum[3], stats[2];   // stats: doubles, offset in floats (8-byte aligned)
+    // hsnap[g] + slot * hsnap_stride[g]: like e, the slots of a chunk are adjacent = one dense batch of CH*B samples for the
+    // decoder, which runs once per CHUNK of planes (planes = batch dimension); sum[] holds a chunk.
+    size_t gates2[4], halt[4];               // fused plane loop: the gate convolution's second buffer, the state's second buffer
     size_t total;
 };
 
@@ -709,12 +790,17 @@ static RedWorkspace red_workspace(int B, int C, int H, int W)
         w.gates[i] = take((size_t)B * 2 * HID[i] * hs[i] * ws[i]);
         w.rh[i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
         w.cand[i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
-        for (int p = 0; p < w.NSL; ++p) w.hsnap[p][i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
+        w.hsnap_stride[i] = (size_t)B * HID[i] * hs[i] * ws[i];
+        w.hsnap[i] = take(w.hsnap_stride[i] * w.NSL);
     }
     for (int i = 0; i < 3; ++i)              // sum[i] = relu(upconv{i+1}(.)) + state{i+1}'  (decoder skip fused into the transposed convolution)
-        w.sum[i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
+        w.sum[i] = take((size_t)w.CH * B * HID[i] * hs[i] * ws[i]);
     for (int p = 0; p < 2; ++p)
         w.stats[p] = take((size_t)B * 4 * 3 * NSLOT * 2 * 2);   // 4 GRUs x (reset, update, output) x NSLOT x (sum, sumsq) doubles
+    for (int i = 0; i < 4; ++i) {
+        w.gates2[i] = take((size_t)B * 2 * HID[i] * hs[i] * ws[i]);
+        w.halt[i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
+    }
     w.total = o;
     return w;
 }
@@ -799,11 +885,13 @@ static int conv_job(ConvJob& j, const ConvArgs& a, int B, const float* wm, int b
     return j.gx * j.gy * B * ncog;
 }
 
-static void launch_convT(const ConvArgs& a, int B, hipStream_t st)
+// Bh: the batch the kernel VARIANT is chosen for (0 = B), see launch_conv
+static void launch_convT(const ConvArgs& a, int B, hipStream_t st, int Bh = 0)
 {
+    if (Bh <= 0) Bh = B;
     const int ncog = (a.Cout + COT - 1) / COT;
     const int wx = (a.Wi + 63) / 64;
-    if (wx * ((a.Hi + 3) / 4) * B * ncog < g_split_below()) {
+    if (wx * ((a.Hi + 3) / 4) * Bh * ncog < g_split_below()) {
         hipLaunchKernelGGL(convT3x3s2_kernel<true>, dim3(wx, a.Hi, B * ncog), dim3(256), 0, st, a);
         return;
     }
@@ -911,10 +999,20 @@ struct RedIssuer {
         sD = multi ? P.dec : r.main;
         for (int g = 0; g < 4; ++g) { hs[g] = r.H >> g; wd[g] = r.W >> g; }
     }
+    // Fused plane loop (2 dependent launches per plane, the element-wise stages computed by the consuming convolutions into
+    // LDS: mfma_conv.h, FuseB).  Built and measured in round 4 -- correct (every RED test passes with it on) and SLOWER:
+    // 80 / 152 us per plane at cascade stages 1 / 2 against 62 / 95 for the four-launch chain (profiles/r04_red_fusion.txt).
+    // The premise was wrong: the two element-wise launches cost 5-8 us of kernel + ~3 us of gap each, not 13 us; computing
+    // their stage per tile (3-12x redundantly: halos, one tile per output-channel group) inside the latency chain of the
+    // convolutions costs 10-33 us per launch, and what bounded the plane was the decoder chain on the other stream.  Kept
+    // for tuning builds (SMVS_RED_FUSED=1); the shipped library never takes this path.
+    bool fused() const { return tune_int("SMVS_RED_FUSED", 0) == 1; }
+    float* state_buf(int g, int k) const { return (k & 1) ? r.wsf + ws.halt[g] : r.state[g]; }     // state entering plane k of this call
+    float* gates_buf(int g, int k) const { return r.wsf + ((k & 1) ? ws.gates2[g] : ws.gates[g]); }
     int CH() const { return ws.CH; }
     double* stats_of(int k) const { return (double*)(r.wsf + ws.stats[k & 1]); }
     float* e_of(int k, int i) const { return r.wsf + ws.e[i] + (size_t)(k % ws.NSL) * ws.e_stride[i]; }
-    float* hsnap_of(int k, int g) const { return r.wsf + ws.hsnap[k % ws.NSL][g]; }
+    float* hsnap_of(int k, int g) const { return r.wsf + ws.hsnap[g] + (size_t)(k % ws.NSL) * ws.hsnap_stride[g]; }
 
     // the variance plane of plane k as a strided view for the convolutions that read it
     void cost_view(int k, ConvArgs& a) const
@@ -994,7 +1092,7 @@ struct RedIssuer {
             u.gates = wsf + ws.gates[g]; u.stats_g = sg; u.stats_o = so;
             u.rn_w = packed + L.rn_w[g]; u.rn_b = packed + L.rn_b[g]; u.un_w = packed + L.un_w[g]; u.un_b = packed + L.un_b[g];
             u.on_w = packed + L.on_w[g]; u.on_b = packed + L.on_b[g];
-            u.h = r.state[g]; u.rh = wsf + ws.rh[g]; u.cand = wsf + ws.cand[g]; u.hsnap = hsnap_of(k, g);
+            u.h = r.state[g]; u.h_out = r.state[g]; u.rh = wsf + ws.rh[g]; u.cand = wsf + ws.cand[g]; u.hsnap = hsnap_of(k, g);
             u.zero_next = stats_next ? stats_next + (size_t)g * B * 3 * NSLOT * 2 : nullptr;
             u.HC = hc; u.HW = hw; u.gx = (int)(((size_t)hc * hw + 255) / 256); u.blk0 = nb_gru;
             nb_gru += u.gx * B;
@@ -1016,40 +1114,153 @@ struct RedIssuer {
         hipLaunchKernelGGL(conv_jobs_kernel, dim3(nb_cand), dim3(256), 0, sR, cand);
         }
         hipLaunchKernelGGL(gru_combine_kernel, dim3(nb_gru), dim3(256), 0, sR, gru);
+        // the decoder runs per chunk: only the chunk's last plane signals it (an event per plane costs the chain ~1 us each)
+        if (multi && ((k + 1) % ws.CH == 0 || d + 1 == d_end)) (void)hipEventRecord(P.state[k % RING], sR);
+        return SMVS_OK;
+    }
+
+    // Fused chain of plane k: L_A = [combine of plane k-1 on load] + gate convolutions, L_B = [gate apply on load] + candidate
+    // convolutions.  The state entering plane k lives in state_buf(., k) (the caller's tensors for even k, the workspace for odd
+    // k): L_A(k) computes it from plane k-1's raw gates / candidates and stores it there (and into the decoder's snapshot of plane
+    // k-1); gate buffers alternate likewise (L_A(k) reads plane k-1's update gate while it writes plane k's gates).
+    // After the last plane issue_final_combine() produces the final state in the caller's tensors.
+    int issue_recurrent_fused(int k)
+    {
+        const int d = d_begin + k;
+        const int B = r.B, C = r.C;
+        float* wsf = r.wsf;
+        const float* packed = r.packed;
+        const int enc_out[3] = {16, 32, 64};
+        double* stats = stats_of(k);
+        double* stats_prev = stats_of(k + 1);                                 // ring of two: plane k-1's = plane k+1's
+        const bool has_next = d + 1 < d_end;
+        if (multi && k % ws.CH == 0) (void)hipStreamWaitEvent(sR, P.enc[k % RING], 0);
+        ConvJobs gate{}, cand{};
+        gate.n = cand.n = 4;
+        int nb_gate = 0, nb_cand = 0;
+        for (int q = 0; q < 4; ++q) {
+            const int g = 3 - q;
+            const int hc = HID[g];
+            const int cx = g == 0 ? C : enc_out[g - 1];
+            const float sx = g == 0 ? -1.0f : 1.0f;
+            const size_t lvl = (size_t)g * B * 3 * NSLOT * 2;
+            double* sg = stats + lvl;
+            double* so = sg + (size_t)B * 2 * NSLOT * 2;
+            FuseB fa{};                                                        // gate convolution: B = h(k) = combine of plane k-1
+            fa.HC = hc; fa.nslot = NSLOT;
+            if (k > 0) {
+                fa.mode = FUSE_COMBINE;
+                fa.gates = gates_buf(g, k - 1); fa.cand = wsf + ws.cand[g]; fa.h = state_buf(g, k - 1);
+                fa.h_out = state_buf(g, k); fa.hsnap = hsnap_of(k - 1, g);
+                fa.stats_g = stats_prev + lvl; fa.stats_o = stats_prev + lvl + (size_t)B * 2 * NSLOT * 2;
+                fa.gw = packed + L.un_w[g]; fa.gb = packed + L.un_b[g]; fa.ow = packed + L.on_w[g]; fa.ob = packed + L.on_b[g];
+            }
+            ConvArgs a{};
+            if (g == 0) cost_view(k, a); else a.inA = e_of(k, g - 1);
+            a.CA = cx; a.scaleA = sx; a.inB = state_buf(g, k); a.CB = hc;
+            a.w = packed + L.gate_w[g]; a.bias = packed + L.gate_b[g]; a.out = gates_buf(g, k); a.stats = sg; a.ngroups = 2;
+            a.Cout = 2 * hc; a.Hi = a.Ho = hs[g]; a.Wi = a.Wo = wd[g];
+            nb_gate += conv_job(gate.j[q], a, B, packed + L.gate_wm[g], nb_gate);
+            gate.j[q].fuse = fa; gate.j[q].m.fuse = fa;
+            FuseB fb{};                                                        // candidate convolution: B = r * h(k)
+            fb.mode = FUSE_APPLY; fb.HC = hc; fb.nslot = NSLOT;
+            fb.gates = gates_buf(g, k); fb.h = state_buf(g, k); fb.stats_g = sg;
+            fb.gw = packed + L.rn_w[g]; fb.gb = packed + L.rn_b[g];
+            // plane k+1's statistics (= plane k-1's buffer: its last reader, L_A(k), is behind us) are cleared by this launch
+            if (has_next && q == 0) { fb.zero = stats_prev; fb.zero_n = B * 4 * 3 * NSLOT * 2; }
+            ConvArgs o{};
+            if (g == 0) cost_view(k, o); else o.inA = e_of(k, g - 1);
+            o.CA = cx; o.scaleA = sx; o.inB = state_buf(g, k); o.CB = hc;
+            o.w = packed + L.out_w[g]; o.bias = packed + L.out_b[g]; o.out = wsf + ws.cand[g]; o.stats = so; o.ngroups = 1;
+            o.Cout = hc; o.Hi = o.Ho = hs[g]; o.Wi = o.Wo = wd[g];
+            nb_cand += conv_job(cand.j[q], o, B, packed + L.out_wm[g], nb_cand);
+            cand.j[q].fuse = fb; cand.j[q].m.fuse = fb;
+        }
+        if (k > 0) hipLaunchKernelGGL(conv_jobs_fused_kernel, dim3(nb_gate), dim3(256), 0, sR, gate);
+        else       hipLaunchKernelGGL(conv_jobs_kernel, dim3(nb_gate), dim3(256), 0, sR, gate);       // plane 0 of the call: the state is the caller's
+        if (multi && k > 0) (void)hipEventRecord(P.state[(k - 1) % RING], sR);                         // plane k-1's snapshots are complete
+        hipLaunchKernelGGL(conv_jobs_fused_kernel, dim3(nb_cand), dim3(256), 0, sR, cand);
+        return SMVS_OK;
+    }
+
+    // the combine stage of the call's last plane: final state into the caller's tensors, snapshots for its decoder
+    int issue_final_combine(int k)
+    {
+        const int B = r.B;
+        float* wsf = r.wsf;
+        const float* packed = r.packed;
+        double* stats = stats_of(k);
+        GruJobs gru{};
+        gru.n = 4; gru.B = B;
+        int nb = 0;
+        for (int q = 0; q < 4; ++q) {
+            const int g = 3 - q;
+            const int hc = HID[g], hw = hs[g] * wd[g];
+            GruJob& u = gru.j[q];
+            double* sg = stats + (size_t)g * B * 3 * NSLOT * 2;
+            u.gates = gates_buf(g, k); u.stats_g = sg; u.stats_o = sg + (size_t)B * 2 * NSLOT * 2;
+            u.un_w = packed + L.un_w[g]; u.un_b = packed + L.un_b[g]; u.on_w = packed + L.on_w[g]; u.on_b = packed + L.on_b[g];
+            u.h = state_buf(g, k); u.h_out = r.state[g]; u.cand = wsf + ws.cand[g]; u.hsnap = hsnap_of(k, g);
+            u.HC = hc; u.HW = hw; u.gx = (int)(((size_t)hc * hw + 255) / 256); u.blk0 = nb;
+            nb += u.gx * B;
+        }
+        hipLaunchKernelGGL(gru_combine_kernel, dim3(nb), dim3(256), 0, sR, gru);
         if (multi) (void)hipEventRecord(P.state[k % RING], sR);
         return SMVS_OK;
     }
 
-    // decoder of plane k from the state snapshots, output convolution, regression update
-    int issue_decoder(int k)
+    // can every job of the fused launches hold its B tile in the kernel's LDS?  (geometry only)
+    bool fused_fits() const
     {
-        const int d = d_begin + k;
-        const int B = r.B;
+        const int enc_out[3] = {16, 32, 64};
+        for (int g = 0; g < 4; ++g) {
+            const int hc = HID[g], cx = g == 0 ? r.C : enc_out[g - 1];
+            for (int pass = 0; pass < 2; ++pass) {
+                ConvArgs a{};
+                ConvJob j{};
+                a.CA = cx; a.CB = hc; a.Cout = pass ? hc : 2 * hc; a.Hi = a.Ho = hs[g]; a.Wi = a.Wo = wd[g];
+                static const float dummy = 0.0f;
+                (void)conv_job(j, a, r.B, &dummy, 0);
+                if (j.kind == 4 || fuse_tile_floats(j.kind, hc) > FUSE_TILE_FLOATS) return false;
+            }
+        }
+        return true;
+    }
+
+    // Decoder of planes [k0, k0+n) (one chunk; k0 a multiple of CH) from their state snapshots, output convolution, regression
+    // update: the planes are the batch dimension of three transposed convolutions and one output-convolution launch -- 4
+    // launches per CHUNK.  (Per plane, as until round 3, the decoder was a second chain of 4 dependent launches beside the
+    // recurrent one and cost it ~10 us of interference per plane; nothing in it depends on the neighbouring planes.)  The kernel
+    // variants are chosen for a full chunk, so a plane's bits do not depend on the range or its chunking.
+    int issue_decoder(int k0, int n)
+    {
+        const int d = d_begin + k0;
+        const int B = r.B, ch = ws.CH;
         float* wsf = r.wsf;
         const float* packed = r.packed;
         const size_t npix = (size_t)B * r.H * r.W;
-        if (multi) (void)hipStreamWaitEvent(sD, P.state[k % RING], 0);
+        if (multi) (void)hipStreamWaitEvent(sD, P.state[(k0 + n - 1) % RING], 0);
         for (int g = 3; g >= 1; --g) {
             // sum[g-1] = relu(upconv{g}(state4' or sum[g])) + state{g}'
             ConvArgs u{};
-            u.inA = g == 3 ? hsnap_of(k, 3) : wsf + ws.sum[g]; u.CA = HID[g]; u.scaleA = 1.0f;
-            u.w = packed + L.up_w[g - 1]; u.out = wsf + ws.sum[g - 1]; u.skip = hsnap_of(k, g - 1); u.Cout = HID[g - 1];
+            u.inA = g == 3 ? hsnap_of(k0, 3) : wsf + ws.sum[g]; u.CA = HID[g]; u.scaleA = 1.0f;
+            u.w = packed + L.up_w[g - 1]; u.out = wsf + ws.sum[g - 1]; u.skip = hsnap_of(k0, g - 1); u.Cout = HID[g - 1];
             u.Hi = hs[g]; u.Wi = wd[g]; u.Ho = hs[g - 1]; u.Wo = wd[g - 1]; u.relu = 1;
-            launch_convT(u, B, sD);
+            launch_convT(u, n * B, sD, ch * B);
         }
         // reg = upconv2d(up1 + state1') : ConvTranspose2d stride 1 == correlation with flipped taps; the regression
-        // update of the pred loop rides in its epilogue
+        // update of the pred loop rides in its epilogue, folded over the chunk's planes in plane order
         OutConvArgs f{};
-        f.in = wsf + ws.sum[0]; f.w = packed + L.up2d_w; f.bias = packed + L.up2d_b;
-        f.B = B; f.H = r.H; f.W = r.W;
-        if (!r.pred) { f.reg = r.reg_out; f.reg_bstride = (size_t)r.H * r.W; }
-        else if (r.reg_volume) { f.reg = r.reg_volume + (size_t)d * r.H * r.W; f.reg_bstride = (size_t)r.D * r.H * r.W; }
+        f.in = wsf + ws.sum[0]; f.NP = n; f.w = packed + L.up2d_w; f.bias = packed + L.up2d_b;
+        f.B = B; f.H = r.H; f.W = r.W; f.d = d;
+        if (!r.pred) { f.reg = r.reg_out; f.reg_bstride = (size_t)r.H * r.W; f.reg_pstride = 0; }
+        else if (r.reg_volume) { f.reg = r.reg_volume + (size_t)d * r.H * r.W; f.reg_bstride = (size_t)r.D * r.H * r.W; f.reg_pstride = (size_t)r.H * r.W; }
         else {
             f.exp_sum = r.acc; f.depth_img = r.acc + npix; f.max_prob = r.acc + 2 * npix;
-            f.depth = r.depth; f.hmode = hmode; f.hg = hg; f.D = r.D; f.d = d;
+            f.depth = r.depth; f.hmode = hmode; f.hg = hg; f.D = r.D;
         }
         hipLaunchKernelGGL(out_conv_regress_kernel, dim3((r.W + 63) / 64, (r.H + 3) / 4, B), dim3(256), 0, sD, f);
-        if (multi) (void)hipEventRecord(P.done[k % RING], sD);
+        if (multi) (void)hipEventRecord(P.done[(k0 + n - 1) % RING], sD);
         return SMVS_OK;
     }
 };
@@ -1065,6 +1276,7 @@ static int red_run_planes(const RedRun& r, int d_begin, int d_end)
     const bool multi = nplanes > 1 && tune_int("SMVS_RED_STREAMS", 2) != 0 && g_red_streams.load(std::memory_order_relaxed) != 0;
     RedIssuer is(r, *pp, multi, d_begin, d_end);
     const RedPipe& P = *pp;
+    const bool fused = is.fused() && is.fused_fits();
     if (r.pred && !r.reg_volume)
         if (int rc0 = resolve_heights(r.depth, r.depth_is_4d, r.gen, r.D, r.H, r.W, is.hmode, is.hg)) return rc0;
     // the first plane's statistics are cleared here; afterwards each level clears the next plane's buffer itself
@@ -1079,9 +1291,18 @@ static int red_run_planes(const RedRun& r, int d_begin, int d_end)
         // this half of the ring was last used by chunk j-2; its last plane leaving the decoder implies all of it
         if (multi && k0 >= 2 * ch) (void)hipStreamWaitEvent(r.main, P.done[(k0 - ch - 1) % RING], 0);
         rc = is.issue_front(k0, n);
-        for (int k = k0; k < k0 + n && !rc; ++k) {
-            rc = is.issue_recurrent(k);
-            if (!rc) rc = is.issue_decoder(k);
+        for (int k = k0; k < k0 + n && !rc; ++k)
+            rc = fused ? is.issue_recurrent_fused(k) : is.issue_recurrent(k);
+        if (rc) break;
+        if (fused) {
+            // (tuning builds) plane k's snapshots come out of plane k+1's first launch: the decoder runs one chunk behind
+            if (k0 > 0) rc = is.issue_decoder(k0 - ch, ch);
+            if (!rc && k0 + n == nplanes) {
+                rc = is.issue_final_combine(nplanes - 1);
+                if (!rc) rc = is.issue_decoder(k0, n);
+            }
+        } else {
+            rc = is.issue_decoder(k0, n);
         }
     }
     if (rc) {
