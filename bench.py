@@ -415,27 +415,37 @@ def cfg4_strong(dev, stream, rank, world, dist, barrier):
 
     ex_stream = torch.cuda.Stream(device=dev) if state is not None else None
 
-    def step():
+    def step(overlap=True):
         if nd > 0:
             _lib.call("smvs_rpc_costvol_fwd", _lib.ptr(feats[0]), srcs, V - 1, _lib.ptr(rpc), _lib.ptr(depth), 1,
                       _lib.ptr(out), 1, C, nd, H, W, 0, nd, nd, 0, stream)
-        if state is not None:                                   # see main(): the exchange trails the step's kernel on its own stream
+        if state is not None and overlap:                       # see main(): the exchange trails the step's kernel on its own stream
             ex_stream.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(ex_stream):
                 shard.allreduce_regression_state(state)
+        elif state is not None:
+            shard.allreduce_regression_state(state)
     for _ in range(3):
         step()
     steps = 10
     elapsed, _ = time_steps(step, steps, barrier)
+    serial_ms = None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        for _ in range(2):
+            step(False)
+        se, _ = time_steps(lambda: step(False), steps, barrier)
+        t = torch.tensor([se], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        serial_ms = float(t.item()) / steps * 1e3
     ms = elapsed / steps * 1e3
     bpv = algorithmic_bytes_per_voxel(V, C, D)
     return {"workload": "cfg4_rpc_5view_1536x768x64_c32", "planes_per_gpu": nd, "ms_per_step": round(ms, 4),
             "Mvox/s": round(D * H * W / ms / 1e3, 1), "scaling": "strong",
             "roofline_frac_aggregate": round(bpv * D * H * W / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
+            "exchange_overlapped": world > 1, "ms_per_step_not_overlapped": None if serial_ms is None else round(serial_ms, 4),
             "note": "whole 64-plane sweep / step time incl. the (3,1,768,1536) f64 slab all-reduce (28 MB) when N > 1"}
 
 
@@ -521,9 +531,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         _, ex_ms = time_steps(lambda: shard.allreduce_regression_state(state), 20, barrier)
+
+        # the same steps with the exchange IN stream order (build -> exchange -> next build): single-tile latency, beside the
+        # tile-stream throughput that `value` reports
+        def step_serial():
+            launch()
+            shard.allreduce_regression_state(state)
+        for _ in range(3):
+            step_serial()
+        serial_elapsed, _ = time_steps(step_serial, min(args.steps, 50), barrier)
+        t = torch.tensor([serial_elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        serial_ms = float(t.item()) / min(args.steps, 50) * 1e3
         exchange = {"op": "reduce-scatter (all_to_all of pixel chunks + rank-ordered local sum,sum,max) + all_gather of the (3,1,%d,%d) f64 regression partials, inside the timed step" % (H, W),
                     "bytes": int(state.numel() * 8), "ms": round(ex_ms, 4),
-                    "overlap": "issued behind the step's kernel on its own stream; the next step's kernel does not wait for it (a stream of tiles)"}
+                    "overlap": "issued behind the step's kernel on its own stream; the next step's kernel does not wait for it (a stream of tiles)",
+                    "ms_per_step_not_overlapped": round(serial_ms, 4),
+                    "device_work": "all_to_all_single out of the slab + smvs_regress_fold (one kernel) + in-place all_gather_into_tensor"}
 
     cfg4 = None
     if not args.no_extra:
@@ -556,6 +580,7 @@ def main():
         }
         if exchange is not None:
             line["exchange"] = exchange
+            line["exchange_overlapped"] = True              # `value` is tile-stream throughput; exchange.ms_per_step_not_overlapped is the single-tile latency
         if not args.no_extra:
             line["extra"] = {"cfg4_strong_scaling": cfg4}
             if world == 1:

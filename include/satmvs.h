@@ -249,6 +249,12 @@ int smvs_stream_regress_step(const float* reg_plane, const float* depth, int dep
  * (networks/casred.py:234-236).  n = B*H*W. */
 int smvs_stream_regress_final(const double* exp_sum, const double* depth_img, const double* max_prob,
                               float* out_depth, float* out_conf, size_t n, void* stream);
+/* Reduce step of the plane-sharded regression's exchange (satmvs_amd/shard.py; north_star's "RCCL all-reduce of the per-plane
+ * cost slab", networks/casred.py:176-236 sharded over height planes): recv holds `world` copies [rank][chunk] (one per rank, in
+ * rank order) of `chunk` consecutive elements, starting at element `first`, of the flattened (3,B,H,W) float64 accumulators
+ * [exp_sum | depth_img | max_prob] (row_len = B*H*W); out[i] = sum over ranks for elements of the first two rows, max for the
+ * third, folded in rank order.  out may be the slab position the following all-gather sends from. */
+int smvs_regress_fold(const double* recv, double* out, int world, size_t chunk, size_t first, size_t row_len, void* stream);
 
 /* ---- recurrent encoder-decoder regulariser (RED), one height plane per call ----------------------
  * Replaces slice_RED_Regularization.forward (modules/module.py:672-693) and the loop body of

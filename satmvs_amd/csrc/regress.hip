@@ -247,6 +247,24 @@ int stream_regress_step(const float* reg_plane, const float* depth, int depth_is
     return check_launch("stream_regress_step");
 }
 
+// The reduce step of the sharded regression's exchange (satmvs_amd/shard.py): rank r receives every rank's copy of chunk r of the
+// flattened (3,B,H,W) float64 accumulators [exp_sum | depth_img | max_prob] and folds them in rank order -- sum for the first two
+// rows, max for the third; element i of the chunk is element first + i of the flattened slab, its row is (first + i) / row_len --
+// straight into the slab position the all-gather sends from.  One launch instead of two torch reductions and two layout copies;
+// the association is fixed (rank 0, 1, 2, ...), so every rank and every run produce the same bits.
+__global__ void regress_fold_kernel(const double* __restrict__ recv, double* __restrict__ out, int world, size_t chunk, size_t first, size_t row_len)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= chunk) return;
+    const bool is_max = (first + i) / row_len >= 2;
+    double v = recv[i];
+    for (int r = 1; r < world; ++r) {
+        const double x = recv[(size_t)r * chunk + i];
+        v = is_max ? (v < x ? x : v) : v + x;
+    }
+    out[i] = v;
+}
+
 }  // namespace smvs
 
 extern "C" {
@@ -306,6 +324,16 @@ SMVS_EXPORT int smvs_stream_regress_final(const double* exp_sum, const double* d
     hipLaunchKernelGGL(smvs::stream_regress_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, exp_sum, depth_img, max_prob, out_depth, out_conf, n);
     return smvs::check_launch("stream_regress_final");
+}
+
+SMVS_EXPORT int smvs_regress_fold(const double* recv, double* out, int world, size_t chunk, size_t first, size_t row_len, void* stream)
+{
+    if (!recv || !out) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
+    if (world < 1 || row_len == 0) return smvs::fail(SMVS_ERR_ARG, "bad world size / row length");
+    if (chunk == 0) return SMVS_OK;
+    hipLaunchKernelGGL(smvs::regress_fold_kernel, dim3((unsigned)((chunk + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       recv, out, world, chunk, first, row_len);
+    return smvs::check_launch("regress_fold");
 }
 
 SMVS_EXPORT int smvs_rpc_project(const double* rpc170, const double* a, const double* b, const double* h,

@@ -33,38 +33,63 @@ def plane_range(num_planes, rank, world):
 def allreduce_regression_state(state, group=None):
     """In-place reduction of the (3,B,H,W) float64 accumulators over the ranks: rows 0,1 summed, row 2 maxed.
 
-    A hand-rolled reduce-scatter + all-gather that carries all three rows at once: every rank sends pixel chunk r of its
-    slab to rank r (all_to_all: on xGMI seven direct point-to-point transfers in parallel, 7/8 of 7 MB out per rank at
-    768x384), folds the chunks it received in rank order (sum, sum, max -- the same association on every run, so the
-    result is deterministic and identical on all ranks), and the reduced chunks are all-gathered.  Two exchange phases of
-    optimal volume instead of the four of two ring all-reduces (round 2), no 8x-volume gather (an all-gather of whole
-    slabs moves 49 MB into every rank)."""
+    A reduce-scatter + all-gather that carries all three rows at once, with no layout copies: the flattened slab is cut into
+    `world` contiguous chunks; every rank sends chunk r of its slab to rank r (all_to_all straight out of the slab: on xGMI
+    seven direct point-to-point transfers in parallel, 7/8 of 7 MB out per rank at 768x384), folds the copies it received in
+    rank order with ONE kernel (smvs_regress_fold: sum, sum, max by the row an element belongs to -- the same association
+    on every rank and run, so the result is deterministic) straight into its chunk of the slab, and the chunks are
+    all-gathered IN PLACE (input = this rank's chunk of the output).  Per exchange on the device: 2 collectives + 1 kernel
+    (round 3: 2 collectives + 6 torch kernels).  A slab whose length the rank count does not divide is padded (one copy in,
+    one out); CPU tensors and the host-staged gloo rehearsal fold with torch operators."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return state
     if state.shape[0] != 3:
         raise ValueError("state must be (3,B,H,W): [exp_sum, depth_img, max_prob]")
-    world = dist.get_world_size(group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     staged = _host_staged(state, group)
-    flat = state.detach().reshape(3, -1)
-    if staged:
-        flat = flat.cpu()
-    n = flat.shape[1]
+    row_len = state[0].numel()
+    n = 3 * row_len
     chunk = (n + world - 1) // world
-    if n != world * chunk:                                 # ragged pixel count: pad the tail chunk (zeros are neutral for the sums; the
-        padded = torch.zeros((3, world * chunk), dtype=flat.dtype, device=flat.device)   # padded max entries are cut off again)
-        padded[:, :n] = flat
-        flat = padded
-    send = flat.view(3, world, chunk).permute(1, 0, 2).contiguous()                     # [destination rank][row][pixel of its chunk]
-    recv = torch.empty_like(send)                                                       # [source rank][row][pixel of MY chunk]
-    dist.all_to_all_single(recv, send, group=group)
-    mine = torch.empty((3, chunk), dtype=flat.dtype, device=flat.device)
-    torch.sum(recv[:, :2], dim=0, out=mine[:2])            # one kernel each; the same reduction order on every rank and run
-    torch.amax(recv[:, 2], dim=0, out=mine[2])
-    gathered = torch.empty((world, 3, chunk), dtype=flat.dtype, device=flat.device)
-    dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)
-    out = gathered.permute(1, 0, 2).reshape(3, world * chunk)[:, :n]
-    state.copy_(out.reshape(state.shape).to(state.device))
+    direct = state.is_contiguous() and n == world * chunk and not staged
+    if direct:
+        flat = state.detach().view(-1)
+    else:
+        flat = torch.zeros((world * chunk,), dtype=state.dtype, device="cpu" if staged else state.device)
+        flat[:n] = state.detach().reshape(-1).to(flat.device)   # zeros pad the tail: neutral for the sums, cut off again for the max row
+    recv = torch.empty((world, chunk), dtype=flat.dtype, device=flat.device)            # [source rank][element of MY chunk]
+    dist.all_to_all_single(recv.view(-1), flat, group=group)
+    mine = flat[rank * chunk:(rank + 1) * chunk]
+    if flat.is_cuda:
+        from . import _lib
+        with torch.cuda.device(flat.device):
+            _lib.call("smvs_regress_fold", _lib.ptr(recv), _lib.ptr(mine), world, chunk, rank * chunk, row_len, _lib.current_stream(flat.device))
+    else:
+        idx = torch.arange(rank * chunk, (rank + 1) * chunk)
+        is_max = (idx // row_len) >= 2
+        acc = recv[0].clone()
+        for r in range(1, world):                              # rank order, like the kernel
+            acc = torch.where(is_max, torch.maximum(acc, recv[r]), acc + recv[r])
+        mine.copy_(acc)
+    dist.all_gather_into_tensor(flat, mine, group=group)       # in place: `mine` is this rank's slice of `flat`
+    if not direct:
+        state.copy_(flat[:n].reshape(state.shape).to(state.device))
     return state
+
+
+def handoff_buffers(cost_regularization, b, h, w, device):
+    """The recurrent hand-off of one tile as ONE message: a flat float32 buffer holding the regression accumulators
+    ((3,B,H,W) float64, first: 8-byte aligned) followed by the four hidden states, and views of it that the plane pipeline
+    updates in place.  Returns (flat, states, accumulator view)."""
+    shapes = [tuple(t.shape) for t in cost_regularization.initial_states(b, h, w, torch.device("meta"))]
+    acc_floats = 2 * 3 * b * h * w
+    sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+    flat = torch.zeros((acc_floats + sum(sizes),), dtype=torch.float32, device=device)
+    acc = flat[:acc_floats].view(torch.float64).view(3, b, h, w)
+    states, o = [], acc_floats
+    for sh, n in zip(shapes, sizes):
+        states.append(flat[o:o + n].view(sh))
+        o += n
+    return flat, states, acc
 
 
 def finish_regression(state):
@@ -90,14 +115,18 @@ def sharded_compute_depth_when_pred(features, proj_matrices, depth_values, num_d
     b, _, h, w = ref.shape
     recurrent = hasattr(cost_regularization, "initial_states")
     chain = recurrent and recurrent_handoff and world > 1
-    states = cost_regularization.initial_states(b, h, w, ref.device) if recurrent else []
     acc = StreamingRegression(b, h, w, ref.device)
-    if chain and rank > 0:
+    flat = None
+    if chain:
         # The recurrence serialises the shards of one tile anyway, so the regression accumulators travel with the four
         # hidden states: rank g continues the float64 sums exactly where rank g-1 stopped and the result is the
-        # single-GPU one bit for bit (a tree reduction would re-associate the float64 additions).
-        for s in states + [acc.state]:
-            _recv(s, _global_rank(group, rank - 1), group)
+        # single-GPU one bit for bit (a tree reduction would re-associate the float64 additions).  States and accumulators
+        # are views of ONE buffer = one message per shard boundary (round 3: five, on RCCL's in-order point-to-point stream).
+        flat, states, acc.state = handoff_buffers(cost_regularization, b, h, w, ref.device)
+        if rank > 0:
+            _recv(flat, _global_rank(group, rank - 1), group)
+    else:
+        states = cost_regularization.initial_states(b, h, w, ref.device) if recurrent else []
     # stages 2-3 of the inference cascades hand over a GeneratedHeights description instead of a (B,D,H,W) tensor
     # (modules/depth_range.py::stage_hypotheses): the native plane pipeline evaluates it per pixel, the composite loop
     # needs the tensor
@@ -117,9 +146,11 @@ def sharded_compute_depth_when_pred(features, proj_matrices, depth_values, num_d
             acc.step(reg, dv, d)
     if chain:
         if rank < world - 1:
-            for s in states + [acc.state]:
-                _send(s.contiguous(), _global_rank(group, rank + 1), group)
-        dist.broadcast(acc.state, src=_global_rank(group, world - 1), group=group)    # the last shard holds the whole sum
+            for t, v in zip(states, handoff_views(flat, states)):
+                if t.data_ptr() != v.data_ptr():                              # the composite loop returns fresh state tensors
+                    v.copy_(t)
+            _send(flat, _global_rank(group, rank + 1), group)
+        _broadcast(acc.state, _global_rank(group, world - 1), group)          # the last shard holds the whole sum
     else:
         allreduce_regression_state(acc.state, group)
     depth, confidence = acc.result()
@@ -154,17 +185,15 @@ def sharded_pred_stream(tiles, num_depth, cost_regularization, geo_model="rpc", 
             native = hasattr(cost_regularization, "native_pred_planes") and cost_regularization._use_native(ref)
             if not native:
                 raise RuntimeError("sharded_pred_stream drives the native RED plane pipeline (GPU tensors, no autograd)")
-        states = cost_regularization.initial_states(b, h, w, ref.device)          # fresh buffers: the previous tile's may still be in flight
         acc = StreamingRegression(b, h, w, ref.device)
+        flat, states, acc.state = handoff_buffers(cost_regularization, b, h, w, ref.device)   # fresh per tile: the previous tile's may still be in flight
         if rank > 0:
-            for s in states + [acc.state]:
-                _recv(s, _global_rank(group, rank - 1), group)
+            _recv(flat, _global_rank(group, rank - 1), group)                   # one message per boundary and tile
         gen = isinstance(depth_values, GeneratedHeights)
         dv = depth_values if gen else depth_values.detach().to(torch.float32).contiguous()
         cost_regularization.native_pred_planes(features, proj_matrices, dv, geo_model, use_qc, states, acc.state, lo, hi)
         if rank < world - 1:
-            for s in states + [acc.state]:
-                pending.append(_isend(s, _global_rank(group, rank + 1), group))
+            pending.append(_isend(flat, _global_rank(group, rank + 1), group))
         finished.append(acc)
     for req, _keep in pending:
         req.wait()
@@ -175,6 +204,16 @@ def sharded_pred_stream(tiles, num_depth, cost_regularization, geo_model="rpc", 
     for a in finished:
         depth, confidence = a.result()
         out.append({"depth": depth, "photometric_confidence": confidence})
+    return out
+
+
+def handoff_views(flat, states):
+    """The state views of a hand-off buffer, in order (shapes taken from `states`)."""
+    o = flat.numel() - sum(int(t.numel()) for t in states)
+    out = []
+    for t in states:
+        out.append(flat[o:o + t.numel()].view(t.shape))
+        o += t.numel()
     return out
 
 

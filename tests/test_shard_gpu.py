@@ -159,3 +159,31 @@ def test_bench_two_rank_rehearsal_on_one_device(tmp_path):
     assert line["exchange"]["bytes"] == 3 * 384 * 768 * 8 and line["exchange"]["ms"] > 0
     assert line["extra"]["cfg4_strong_scaling"]["planes_per_gpu"] == 32
     assert line["value"] > 0 and "cpu_baseline" not in line
+
+
+@pytest.mark.parametrize("world,B,H,W", [(8, 1, 384, 768), (2, 2, 24, 40), (4, 1, 8, 24)])
+def test_regress_fold_kernel_is_the_rank_ordered_sum_sum_max(world, B, H, W):
+    """smvs_regress_fold (the reduce step of shard.allreduce_regression_state on RCCL): rank r's chunk of the flattened
+    (3,B,H,W) slab from `world` received copies, rows 0-1 summed and row 2 maxed in rank order, for every rank's chunk --
+    against the float64 fold in numpy, bit for bit; chunks that straddle the row boundaries included."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import sys
+    sys.path.insert(0, ROOT)
+    from satmvs_amd import _lib
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    row = B * H * W
+    n = 3 * row
+    assert n % world == 0
+    chunk = n // world
+    slabs = rng.standard_normal((world, n))                     # every rank's slab
+    ref = slabs[0].copy()
+    for r in range(1, world):                                   # rank order
+        ref[:2 * row] = ref[:2 * row] + slabs[r, :2 * row]
+        ref[2 * row:] = np.maximum(ref[2 * row:], slabs[r, 2 * row:])
+    out = torch.zeros(n, dtype=torch.float64, device=dev)
+    for rank in range(world):
+        recv = torch.from_numpy(np.ascontiguousarray(slabs[:, rank * chunk:(rank + 1) * chunk])).to(dev)
+        _lib.call("smvs_regress_fold", _lib.ptr(recv), _lib.ptr(out[rank * chunk:]), world, chunk, rank * chunk, row, _lib.current_stream(dev))
+    assert np.array_equal(out.cpu().numpy(), ref)
