@@ -715,10 +715,80 @@ def gen_filter():
     save("filter", **out)
 
 
+def gen_dataset():
+    """dataset/satmvsdataset.py:36-160 (MVSDataset.get_sample / get_pred_sample) + dataset/gen_list.py + read_img / center_image,
+    run AS IS on a small scene folder written by OUR writers (tests/golden/scene/: 3 views x 2 tiles of 32x64 PNG -- one tile
+    single-band --, .rpc, .pfm).  Modules the image lacks are stood in for at import time, nothing of the reference is edited or
+    stored: osgeo.gdal / matplotlib.pyplot (imported, never called on this path) by empty modules, cv2 by a module whose
+    resize(..., INTER_NEAREST) is OpenCV's nearest rule src = floor(dst * scale) in numpy -- so everything the assembler does is
+    pinned by this fixture EXCEPT cv2.resize itself."""
+    import types
+    from PIL import Image
+    from satmvs_amd import data_io
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_NEAREST = 0
+
+    def resize(src, dsize, interpolation=None):
+        assert interpolation == cv2.INTER_NEAREST
+        ow, oh = dsize
+        h, w = src.shape[:2]
+        ys = np.minimum(np.floor(np.arange(oh) * (h / oh)).astype(np.int64), h - 1)
+        xs = np.minimum(np.floor(np.arange(ow) * (w / ow)).astype(np.int64), w - 1)
+        return np.ascontiguousarray(src[ys][:, xs])
+    cv2.resize = resize
+    cv2.setNumThreads = lambda n: None
+    cv2.ocl = types.SimpleNamespace(setUseOpenCL=lambda f: None)
+    sys.modules["cv2"] = cv2
+    osgeo = types.ModuleType("osgeo")
+    osgeo.gdal = types.ModuleType("osgeo.gdal")
+    sys.modules.setdefault("osgeo", osgeo)
+    sys.modules.setdefault("osgeo.gdal", osgeo.gdal)
+    try:
+        import matplotlib.pyplot  # noqa: F401
+    except Exception:
+        mpl = types.ModuleType("matplotlib")
+        mpl.pyplot = types.ModuleType("matplotlib.pyplot")
+        sys.modules["matplotlib"], sys.modules["matplotlib.pyplot"] = mpl, mpl.pyplot
+    from dataset.satmvsdataset import MVSDataset as RefDataset
+
+    scene = os.path.join(HERE, "scene")
+    V, H, W = 3, 32, 64
+    rng = np.random.default_rng(101)
+    for t, tile in enumerate(("tile_a", "tile_b")):
+        rpc = ref_rpcs(V, H, W, seed=102 + t)[0]
+        for v in range(V):
+            for kind in ("image", "rpc", "height"):
+                os.makedirs(os.path.join(scene, kind, str(v)), exist_ok=True)
+            base = rng.integers(0, 256, (H // 4, W // 4, 3)).astype(np.float32)
+            img = np.clip(np.kron(base, np.ones((4, 4, 1), np.float32)) + rng.normal(0, 9, (H, W, 3)), 0, 255).astype(np.uint8)
+            if tile == "tile_b":
+                Image.fromarray(img[:, :, 0], "L").save(os.path.join(scene, "image", str(v), tile + ".png"))     # single-band tile
+            else:
+                Image.fromarray(img, "RGB").save(os.path.join(scene, "image", str(v), tile + ".png"))
+            data_io.save_rpc(os.path.join(scene, "rpc", str(v), tile + ".rpc"), rpc[v])
+            hm = (rpc[v][4] + rpc[v][9] * rng.uniform(-1.3, 1.3, (H, W))).astype(np.float32)                    # some heights outside the range: mask
+            data_io.save_pfm(os.path.join(scene, "height", str(v), tile + ".pfm"), hm)
+    out = {}
+    for mode, ref_view in (("test", 2), ("test", 0), ("pred", 2)):
+        ds = RefDataset(scene, mode, V, ref_view=ref_view)
+        out["%s%d.len" % (mode, ref_view)] = np.int64(len(ds))
+        for i in range(len(ds)):
+            smp = ds[i]
+            key = "%s%d.%s.%s" % (mode, ref_view, smp["out_view"], smp["out_name"])
+            out[key + ".imgs"] = smp["imgs"]
+            out[key + ".depth_values"] = smp["depth_values"]
+            for st in ("stage1", "stage2", "stage3"):
+                out[key + ".cam." + st] = smp["cam_para"][st]
+                if mode != "pred":
+                    out[key + ".depth." + st] = smp["depth"][st]
+                    out[key + ".mask." + st] = smp["mask"][st]
+    save("dataset", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (gen_iccv, gen_project, gen_grid_sample, gen_rpc_warp, gen_qc, gen_homo, gen_costvol, gen_pred,
-               gen_regress, gen_depth_range, gen_ucs_samples, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad, gen_io, gen_filter, gen_train):
+               gen_regress, gen_depth_range, gen_ucs_samples, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad, gen_io, gen_filter, gen_train, gen_dataset):
         if only and fn.__name__[4:] not in only:
             continue
         fn()

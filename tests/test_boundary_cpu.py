@@ -315,3 +315,33 @@ def test_round3_training_entry_points_validate_arguments(lib):
         _lib.call("smvs_costvol_bwd", 0, d, d, arr, 2, d, d, 1, d, arr, 1, 1, 1, 40000, 8, None)
     with pytest.raises(_lib.SatMVSNativeError, match="n_src"):
         _lib.call("smvs_costvol_bwd", 0, d, d, arr, 8, d, d, 1, d, arr, 1, 1, 1, 8, 8, None)
+
+
+def test_dataset_assembler_matches_reference(golden):
+    """satmvs_amd.dataset (PNG views, sample lists, get_sample / get_pred_sample: SURVEY 8f-4) against the reference's own
+    MVSDataset run on the same scene folder (tests/golden/scene/, gen_golden.py::gen_dataset): images, three-scale RPCs,
+    height range, height maps and masks at the three scales -- identical values and dtypes, for ref view 2 (the reference's
+    default, including its height-range quirk), ref view 0 and the all-views "pred" list."""
+    from satmvs_amd.dataset import MVSDataset
+    g = golden("dataset")
+    scene = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene")
+    for mode, ref_view in (("test", 2), ("test", 0), ("pred", 2)):
+        ds = MVSDataset(scene, mode, 3, ref_view=ref_view)
+        assert len(ds) == int(g["%s%d.len" % (mode, ref_view)])
+        for i in range(len(ds)):
+            smp = ds[i]
+            key = "%s%d.%s.%s" % (mode, ref_view, smp["out_view"], smp["out_name"])
+            want = g[key + ".imgs"]
+            assert smp["imgs"].dtype == want.dtype == np.float32 and smp["imgs"].shape == want.shape == (3, 3, 32, 64)
+            assert np.array_equal(smp["imgs"], want), key
+            assert smp["depth_values"].dtype == np.float32 and np.array_equal(smp["depth_values"], g[key + ".depth_values"])
+            for st in ("stage1", "stage2", "stage3"):
+                assert smp["cam_para"][st].dtype == np.float64 and np.array_equal(smp["cam_para"][st], g[key + ".cam." + st]), (key, st)
+                if mode != "pred":
+                    assert smp["depth"][st].dtype == np.float32 and np.array_equal(smp["depth"][st], g[key + ".depth." + st]), (key, st)
+                    assert smp["mask"][st].dtype == np.float32 and np.array_equal(smp["mask"][st], g[key + ".mask." + st]), (key, st)
+            if mode != "pred":
+                assert 0.0 < smp["mask"]["stage3"].mean() < 1.0          # the scene's heights leave the range somewhere: the mask is exercised
+    # a sample feeds the networks as it is: (V,3,H,W) images, per-stage (V,170) RPCs
+    smp = MVSDataset(scene, "pred", 3)[0]
+    assert abs(float(smp["imgs"][0, 0].mean())) < 1e-5 and abs(float(smp["imgs"][0, 0].std()) - 1.0) < 1e-3
