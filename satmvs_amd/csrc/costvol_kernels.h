@@ -256,6 +256,12 @@ constexpr int DM_NBUF = 2;
 #ifndef SMVS_WPS_DP8_FUSED
 #define SMVS_WPS_DP8_FUSED 2          // the same for the fused-arithmetic instance
 #endif
+#ifndef SMVS_WPS_NSRC34_DP2
+#define SMVS_WPS_NSRC34_DP2 2         // 3-4 sources, 1-2 planes per wave (166 VGPRs at 4 sources): waves per SIMD compiled for
+#endif
+#ifndef SMVS_NSRC34_DP
+#define SMVS_NSRC34_DP 4              // planes per wave of a 3-4 source sweep (A/B switch of profiling builds)
+#endif
 #ifndef SMVS_DP8_MINC
 #define SMVS_DP8_MINC 32              // fewest channels for which a sweep that divides into eights takes 8 planes per wave
 #endif
@@ -298,7 +304,7 @@ __device__ __forceinline__ void wait_vmcnt_upto8(int n)
 struct TapD { uint32_t base[DM_NBUF]; f32x2 wn, ws; };       // base[parity] = LDS address of the NW corner; wn = {nw, ne}, ws = {sw, se}
 
 template <int GEO, int NSRC, int CT, int DP, int AR>
-__global__ __launch_bounds__(64 * WV_WAVES, (NSRC <= 2 && DP <= 4 ? SMVS_WAVES_PER_SIMD : NSRC <= 2 ? (AR == AR_FUSED ? SMVS_WPS_DP8_FUSED : SMVS_WPS_DP8) : 2))
+__global__ __launch_bounds__(64 * WV_WAVES, (NSRC <= 2 && DP <= 4 ? SMVS_WAVES_PER_SIMD : NSRC <= 2 ? (AR == AR_FUSED ? SMVS_WPS_DP8_FUSED : SMVS_WPS_DP8) : (NSRC <= 4 && DP <= 2 ? SMVS_WPS_NSRC34_DP2 : 2)))
 void costvol_dma_kernel(const CostVolParams p)
 {
     // Staging layout of one source box and channel pair: [row][channel of the pair][column] dwords, row pitch 2*BW; filled
@@ -843,7 +849,7 @@ static hipError_t launch_staged(CostVolParams p, hipStream_t st)
     dim3 blk(64 * WV_WAVES), grd((unsigned)nb);
 #ifdef SMVS_ONLY_BENCH
     // profiling builds: only the instances the headline bench launches (seconds instead of a minute to compile)
-    if constexpr (GEO == 0 && NSRC == 2 && DP >= 4) { if (p.C == 32) hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 32, DP, AR>), grd, blk, 0, st, p); }
+    if constexpr (GEO == 0 && (NSRC == 2 || NSRC == 4) && DP >= 2) { if (p.C == 32) hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 32, DP, AR>), grd, blk, 0, st, p); }
     return hipGetLastError();
 #else
     switch (p.C) {
@@ -876,6 +882,7 @@ static hipError_t launch_ct(CostVolParams p, hipStream_t st)
 #if SMVS_DP8
             if constexpr (NSRC <= 2 && (GEO == 0 || SMVS_DP8_HOMO)) { if (nd % 8 == 0 && p.C >= SMVS_DP8_MINC) return launch_staged<GEO, NSRC, 8, AR>(p, st); }
 #endif
+            if constexpr (NSRC > 2 && NSRC <= 4 && SMVS_NSRC34_DP == 2) return launch_staged<GEO, NSRC, 2, AR>(p, st);
             if constexpr (NSRC <= 4) return launch_staged<GEO, NSRC, 4, AR>(p, st);
         }
     }

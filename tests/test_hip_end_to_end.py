@@ -656,3 +656,25 @@ def test_native_paths_run_on_dataparallel_replicas(dev, golden):
         for s in ("stage1", "stage2", "stage3"):
             assert torch.equal(got[s]["depth"], want[s]["depth"]), s
             assert torch.equal(got[s]["photometric_confidence"], want[s]["photometric_confidence"]), s
+
+
+def test_scene_folder_to_height_map(dev):
+    """A WHU-TLC-shaped scene folder (tests/golden/scene/: PNG views, .rpc, .pfm) through satmvs_amd.dataset.MVSDataset into the
+    inference cascade: what predict.py does with the reference's loader (predict.py:60-110), end to end from this repository
+    alone.  Random weights: the check is plumbing (shapes, dtypes, keys, finite heights inside the tile's height range)."""
+    from satmvs_amd.dataset import MVSDataset
+    from satmvs_amd.networks import casred
+    scene = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene")
+    ds = MVSDataset(scene, "pred", 3)
+    smp = ds[0]
+    imgs = torch.from_numpy(smp["imgs"])[None].to(dev)
+    proj = {k: torch.from_numpy(v)[None].to(dev) for k, v in smp["cam_para"].items()}
+    dv = torch.from_numpy(smp["depth_values"])[None].to(dev)
+    torch.manual_seed(3)
+    net = casred.Infer_CascadeREDNet("rpc", min_interval=2.5, ndepths=[16, 8, 8]).to(dev).eval()
+    with torch.no_grad():
+        out = net(imgs, proj, dv)
+    h = out["stage3"]["depth"]
+    assert h.shape == (1, 32, 64) and torch.isfinite(h).all()
+    lo, hi = float(dv[0, 0]), float(dv[0, 1])
+    assert lo - 50.0 <= float(h.min()) and float(h.max()) <= hi + 50.0
