@@ -354,9 +354,13 @@ def side_workloads(dev, stream):
                 net(imgs, pm, dv)
                 torch.cuda.synchronize()
                 ts.append((time.perf_counter() - t0) * 1e3)
+            order = [round(t, 2) for t in ts]
             ts.sort()
         rec = {"ms_per_forward": round(ts[len(ts) // 2], 2), "ms_min": round(ts[0], 2), "ms_max": round(ts[-1], 2),
-               "note": "Infer_CascadeREDNet, random weights, B=1, median of 12 forwards"}
+               "ms_in_order": order,
+               "note": "Infer_CascadeREDNet, random weights, B=1, median of 12 forwards (an isolated 2-3x forward among them is this process's "
+                       "history -- the allocator after the preceding side workloads --, not the pipeline: 180 consecutive forwards in a fresh "
+                       "process stay within 7.5-8.1 ms, tools/cascade_outliers.py, profiles/r04_cascade_outliers.txt)"}
         # self-check of what was just timed: the same forward on the stock torch / MIOpen composites (same weights, same inputs)
         try:
             with torch.no_grad():
