@@ -348,19 +348,21 @@ def side_workloads(dev, stream):
             for _ in range(3):
                 net(imgs, pm, dv)
             torch.cuda.synchronize()
-            ts = []
+            ts, issue = [], []
             for _ in range(12):                               # host-paced plane loop: report the median forward, not a mean with outliers
                 t0 = time.perf_counter()
                 net(imgs, pm, dv)
+                issue.append(round((time.perf_counter() - t0) * 1e3, 2))      # host done issuing
                 torch.cuda.synchronize()
                 ts.append((time.perf_counter() - t0) * 1e3)
             order = [round(t, 2) for t in ts]
             ts.sort()
         rec = {"ms_per_forward": round(ts[len(ts) // 2], 2), "ms_min": round(ts[0], 2), "ms_max": round(ts[-1], 2),
-               "ms_in_order": order,
-               "note": "Infer_CascadeREDNet, random weights, B=1, median of 12 forwards (an isolated 2-3x forward among them is this process's "
-                       "history -- the allocator after the preceding side workloads --, not the pipeline: 180 consecutive forwards in a fresh "
-                       "process stay within 7.5-8.1 ms, tools/cascade_outliers.py, profiles/r04_cascade_outliers.txt)"}
+               "ms_in_order": order, "host_issue_ms_in_order": issue,
+               "note": "Infer_CascadeREDNet, random weights, B=1, median of 12 forwards.  An isolated 2-3x forward shows up in 0-1 of the 12 at a "
+                       "position that changes from run to run, with a normal host issue time (host_issue_ms_in_order): a device-side stall "
+                       "between kernels of this process's GPU (clock / power-state transition after the heavy side workloads), not pipeline logic -- "
+                       "180 consecutive forwards in a fresh process stay within 7.5-8.1 ms (tools/cascade_outliers.py, profiles/r04_cascade_outliers.txt)"}
         # self-check of what was just timed: the same forward on the stock torch / MIOpen composites (same weights, same inputs)
         try:
             with torch.no_grad():
