@@ -199,6 +199,12 @@ int smvs_groupnorm1_bwd(const float* dy, const float* x, long long x_batch_strid
                         const float* mean_rstd, int act, float* dx, long long dx_batch_stride, float* dgamma,
                         float* dbeta, double* workspace, int B, int C, int HW, void* stream);
 
+/* Weight and bias gradient of a 3x3, stride-1, pad-1 convolution (the ConvGRU cells' gate_conv / output_conv, modules/module.py:13-14
+ * under loss.backward(), train.py:284):  dw[co][ci][ky][kx] += sum_{b,y,x} dy[b][co][y][x] * x[b][ci][y+ky-1][x+kx-1],
+ * db[co] += sum dy[b][co][y][x].  x (B,Cin,H,W), dy (B,Cout,H,W), dw (Cout,Cin,3,3), db (Cout) or NULL; dw and db are ACCUMULATED
+ * with float atomics -- the caller zero-fills them for a plain gradient. */
+int smvs_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int B, int Cin, int Cout, int H, int W, void* stream);
+
 /* Both gate norms of a ConvGRU cell in one call (modules/module.py:15-16, :37-40): x (B, 2C, HW) contiguous = the gate
  * convolution's output; channels [0, C) are normalised with (gamma, beta), channels [C, 2C) with (gamma2, beta2), each half
  * over its own C*HW values, then the activation.  y and dx (B, 2C, HW); mean_rstd (2B, 2) (sample 2b + half); workspace

@@ -1,0 +1,184 @@
+// conv_wgrad.hip -- weight (and bias) gradient of the 3x3, stride-1, pad-1 convolutions of the ConvGRU cells (training path).
+//
+// Replaces, for gate_conv / output_conv of ConvGRUCell2 (/root/reference/modules/module.py:13-14, :24, :47 under
+// loss.backward(), /root/reference/train.py:284), what autograd gets from MIOpen on this image: per call an im2col, two to four
+// layout transposes, an implicit-GEMM weight-gradient kernel and a col2im / reduction -- ~40 % of the training step's convolution
+// time for ~700 calls per step (profiles/r04_train_step.txt).
+//     dW[co][ci][ky][kx] = sum_{b,y,x} dY[b][co][y][x] * X[b][ci][y+ky-1][x+kx-1]        db[co] = sum dY[b][co][y][x]
+//
+// One WAVE owns (a pair of input channels) x (a group of 8 output channels) x (a 64-pixel-wide column strip) x (a range of rows)
+// and keeps its 2 x 8 x 9 = 144 partial sums in registers, lane = column: per row it loads the new south row of the two input
+// channels (3 shifted dwords each: the 3x3 window slides down through registers, every X row is fetched once per wave) and the 8
+// gradient values, and issues 144 FMAs -- 14 coalesced loads per 144 FMAs, no LDS.  Columns outside the image carry an
+// out-of-range offset (the buffer range check returns 0 = zero padding), rows outside are skipped wave-uniformly.  At the end the
+// 144 sums are reduced over the 64 lanes on the DPP network and lane 63 adds them to dW with float atomics (the caller zeroes
+// dW): the association differs from MIOpen's like any split-K GEMM's does.
+// The bias gradient rides along in the waves of input-channel pair 0.
+#include "smvs_device.h"
+#include "smvs_host.h"
+
+namespace smvs {
+
+struct WgradParams {
+    const float* x; const float* dy; float* dw; float* db;
+    int B, Cin, Cout, H, W;
+    int ncp, ncog, nxs, nrc, rows;      // input-channel pairs, output-channel groups of 8, column strips, row chunks, rows per chunk
+};
+
+// Four registers -> one: the sums over the 64 lanes of a, b, c, d end up in lanes 15 (a), 31 (c), 47 (b), 63 (d) of the result.
+// v_permlane32_swap / v_permlane16_swap (gfx950) exchange half-waves / odd-even 16-lane rows between two registers, so one swap +
+// one add folds two registers into one whose halves (rows) carry the partial sums of different values; the last four steps run
+// inside the 16-lane rows on the DPP network.  152 values cost 38 x (3 swaps + 3 adds + 4 DPP adds) instead of 152 x 6 DPP adds,
+// and leave 38 atomics with four active lanes instead of 152 with one.
+__device__ __forceinline__ float reduce4_rows(float a, float b, float c, float d)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %1\n\t"          // a = {a.lo, b.lo}, b = {a.hi, b.hi}
+                 "v_permlane32_swap_b32 %2, %3\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32 %0, %0, %1\n\t"                  // lanes 0-31: sum pairs of a, lanes 32-63: of b
+                 "v_add_f32 %2, %2, %3\n\t"                  // likewise c | d
+                 "s_nop 1\n\t"
+                 "v_permlane16_swap_b32 %0, %2\n\t"          // %0 = {ab.row0, cd.row0, ab.row2, cd.row2}, %2 = {ab.row1, cd.row1, ab.row3, cd.row3}
+                 "s_nop 1\n\t"
+                 "v_add_f32 %0, %0, %2\n\t"                  // row 0: a, row 1: c, row 2: b, row 3: d -- 16 partial sums each
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    return a;
+}
+
+__global__ __launch_bounds__(256)
+void conv3x3_wgrad_kernel(const WgradParams p)
+{
+    const int lane = threadIdx.x & 63;
+    int unit = blockIdx.x * 4 + (threadIdx.x >> 6);                  // one wave = one unit
+    unit = __builtin_amdgcn_readfirstlane(unit);
+    const int total = p.ncp * p.ncog * p.nxs * p.nrc * p.B;
+    if (unit >= total) return;
+    // row chunk fastest, then column strip, channel pair, output group, batch: neighbouring waves share X / dY rows in L2
+    const int rc = unit % p.nrc; unit /= p.nrc;
+    const int xs = unit % p.nxs; unit /= p.nxs;
+    const int cp = unit % p.ncp; unit /= p.ncp;
+    const int cog = unit % p.ncog;
+    const int b = unit / p.ncog;
+    const int H = p.H, W = p.W, HW = H * W;
+    const int x = xs * 64 + lane;
+    const int y0 = rc * p.rows, y1 = min(y0 + p.rows, H);
+    const int ci0 = 2 * cp;
+    const bool two = ci0 + 1 < p.Cin;                                 // odd channel counts: the last pair has one member
+    // column offsets of the three taps inside a row (bytes), out-of-range where the column is outside the image
+    uint32_t cx[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int xx = x - 1 + k;
+        cx[k] = (x < W && xx >= 0 && xx < W) ? (uint32_t)xx * 4u : SMVS_OOB;
+    }
+    const uint32_t cy = x < W ? (uint32_t)x * 4u : SMVS_OOB;
+    const BufRsrc rx = make_rsrc(p.x + ((size_t)b * p.Cin + ci0) * HW, (uint32_t)((two ? 2 : 1) * HW) * 4u);
+    const int nco = min(8, p.Cout - cog * 8);
+    const BufRsrc ry = make_rsrc(p.dy + ((size_t)b * p.Cout + cog * 8) * HW, (uint32_t)(nco * HW) * 4u);
+
+    float acc[2][8][9];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[c][j][k] = 0.0f;
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.0f;
+
+    // window rows: win[c][r][k] = X[ci0 + c][y - 1 + r][x - 1 + k]; rows outside the image are zeros
+    float win[2][3][3];
+    auto load_row = [&](int yy, float (&dst)[2][3]) {
+        const bool in = yy >= 0 && yy < H;                            // wave-uniform
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                dst[c][k] = in ? llvm_raw_buffer_load_f32(rx.v, (int)cx[k], (c * HW + yy * W) * 4, 0) : 0.0f;
+    };
+    {
+        float r0[2][3], r1[2][3];
+        load_row(y0 - 1, r0);
+        load_row(y0, r1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { win[c][1][k] = r0[c][k]; win[c][2][k] = r1[c][k]; win[c][0][k] = 0.0f; }
+    }
+    // (Requesting the next iteration's rows one iteration ahead was measured and is SLOWER -- 16.9 against 14.3 ms per training
+    //  step over all ConvGRU shapes, 220 VGPRs: the kernel is not bound by the row latency but by its per-wave fixed work.)
+    for (int y = y0; y < y1; ++y) {
+        // slide: rows (y-1, y) move up, the new south row y+1 comes in
+        float south[2][3];
+        load_row(y + 1, south);
+        float g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = llvm_raw_buffer_load_f32(ry.v, (int)cy, (j * HW + y * W) * 4, 0);     // channels beyond Cout: out of range = 0
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { win[c][0][k] = win[c][1][k]; win[c][1][k] = win[c][2][k]; win[c][2][k] = south[c][k]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc[c][j][r * 3 + k] = fmaf(g[j], win[c][r][k], acc[c][j][r * 3 + k]);
+            bsum[j] += g[j];
+        }
+    }
+    // reduce over the lanes four values at a time; lanes 15 / 31 / 47 / 63 publish values 4m + {0, 2, 1, 3}
+    // value index: (c * 8 + j) * 9 + k for the weight gradients, 144 + j for the bias gradient
+    auto value = [&](int i) -> float { return i < 144 ? acc[i / 72][(i % 72) / 9][i % 9] : bsum[i - 144]; };
+    const int q = lane >> 4;
+    const int sel = q == 1 ? 2 : q == 2 ? 1 : q;
+    const bool publisher = (lane & 15) == 15;
+#pragma unroll
+    for (int m = 0; m < 38; ++m) {
+        const float v = reduce4_rows(value(4 * m), value(4 * m + 1), value(4 * m + 2), value(4 * m + 3));
+        const int i = 4 * m + sel;
+        if (publisher) {
+            if (i < 144) {
+                const int c = i / 72, j = (i % 72) / 9, k = i % 9;
+                if (j < nco && (c == 0 || two)) unsafeAtomicAdd(p.dw + ((size_t)(cog * 8 + j) * p.Cin + ci0 + c) * 9 + k, v);
+            } else {
+                const int j = i - 144;
+                if (p.db && cp == 0 && j < nco) unsafeAtomicAdd(p.db + cog * 8 + j, v);
+            }
+        }
+    }
+}
+
+}  // namespace smvs
+
+extern "C" SMVS_EXPORT int smvs_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db,
+                                              int B, int Cin, int Cout, int H, int W, void* stream)
+{
+    using namespace smvs;
+    if (!x || !dy || !dw) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
+    if ((long long)2 * H * W * 4 >= (1ll << 31) || (long long)8 * H * W * 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "plane too large");
+    WgradParams p{};
+    p.x = x; p.dy = dy; p.dw = dw; p.db = db; p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
+    p.ncp = (Cin + 1) / 2; p.ncog = (Cout + 7) / 8; p.nxs = (W + 63) / 64;
+    // rows per wave: long enough to amortise the lane reduction (~3 rows of arithmetic), short enough for >= ~2048 waves
+    const long long base = (long long)p.ncp * p.ncog * p.nxs * B;
+    int rows = H;
+    while (rows > 16 && base * ((H + rows - 1) / rows) < 2048) rows = (rows + 1) / 2;
+    p.rows = rows; p.nrc = (H + rows - 1) / rows;
+    const long long units = base * p.nrc;
+    if (units >= (1ll << 31)) return fail(SMVS_ERR_ARG, "too many work units");
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "conv3x3_wgrad launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
+}

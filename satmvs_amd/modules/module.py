@@ -194,7 +194,7 @@ class ConvTransReLU(nn.Module):
 # debugging switch: SMVS_TRAIN_COMPOSITE=1 keeps the ConvGRU cells' GroupNorm / element-wise steps on torch's own
 # operators (A/B against the native ones; the cost-volume operators are native either way)
 _TRAIN_COMPOSITE_ONLY = os.environ.get("SMVS_TRAIN_COMPOSITE", "0") == "1"
-_TRAIN_COMPOSITE_MASK = 7 if _TRAIN_COMPOSITE_ONLY else int(os.environ.get("SMVS_TRAIN_COMPOSITE_MASK", "0"))   # bisecting: 1 GroupNorm, 2 cat(x, r*h), 4 u-blend
+_TRAIN_COMPOSITE_MASK = 15 if _TRAIN_COMPOSITE_ONLY else int(os.environ.get("SMVS_TRAIN_COMPOSITE_MASK", "0"))   # bisecting: 1 GroupNorm, 2 cat(x, r*h), 4 u-blend, 8 conv weight gradient
 
 
 _FIND_WARNED = False
@@ -374,6 +374,12 @@ class _GruBlendFn(torch.autograd.Function):
         return du, dh, dc
 
 
+try:                                                     # torch's own functional-module context manager (private, stable since 2.0)
+    from torch.nn.utils.stateless import _reparametrize_module as _reparametrize
+except Exception:                                        # pragma: no cover
+    _reparametrize = None
+
+
 class GroupNorm1(nn.GroupNorm):
     """nn.GroupNorm(1, C, eps) -- same parameters, same state_dict keys (reference: module.py:15-20) -- whose forward can take
     the gate's activation along ("sigmoid" / "tanh").  On the GPU with gradients enabled it runs the native kernels: with one
@@ -388,6 +394,48 @@ class GroupNorm1(nn.GroupNorm):
             return _GroupNorm1Fn.apply(x, self.weight, self.bias, self.eps, self._ACT[act])
         y = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
         return torch.sigmoid(y) if act == "sigmoid" else torch.tanh(y) if act == "tanh" else y
+
+
+class _Conv3x3WgradFn(torch.autograd.Function):
+    """A 3x3 / stride 1 / pad 1 nn.Conv2d whose WEIGHT and BIAS gradients come from smvs_conv3x3_wgrad (csrc/conv_wgrad.hip);
+    the forward and the input gradient stay torch's (MIOpen's direct kernels are fine there).  On this image MIOpen computes the
+    weight gradient of these small-channel layers as im2col + layout transposes + implicit GEMM + col2im: ~5 launches per call,
+    ~700 calls per training step of the 48/32/8 cascade (profiles/r04_train_step.txt)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.conv2d(x, weight, bias, stride=1, padding=1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _f32c_fast(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            xc = _f32c_fast(x)
+            B, Cin, H, W = xc.shape
+            Cout = weight.shape[0]
+            nw = weight.numel()
+            buf = torch.zeros((nw + (Cout if ctx.has_bias else 0),), dtype=torch.float32, device=xc.device)    # one fill for both gradients
+            dw = buf[:nw].view(weight.shape)
+            db = buf[nw:] if ctx.has_bias else None
+            with torch.cuda.device(xc.device):
+                _lib.call("smvs_conv3x3_wgrad", _lib.ptr(xc), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
+                          B, Cin, Cout, H, W, _lib.current_stream(xc.device))
+        return dx, dw, db
+
+
+def _conv3x3(conv, x):
+    """conv(x) for the ConvGRU cells' 3x3 convolutions: with the native weight gradient where a gradient is wanted on the GPU."""
+    if (x.is_cuda and x.dtype is torch.float32 and torch.is_grad_enabled() and conv.weight.requires_grad and conv.weight.dtype is torch.float32
+            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and not (_TRAIN_COMPOSITE_MASK & 8) and x.shape[2] * x.shape[3] * 8 * 4 < 2 ** 31):
+        return _Conv3x3WgradFn.apply(x, conv.weight, conv.bias)
+    return conv(x)
 
 
 class ConvGRUCell2(nn.Module):
@@ -407,7 +455,7 @@ class ConvGRUCell2(nn.Module):
     def forward(self, x, h=None):
         if h is None:
             h = torch.zeros((x.shape[0], self.output_channel, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device)
-        gates = self.gate_conv(torch.cat((x, h), dim=1))
+        gates = _conv3x3(self.gate_conv, torch.cat((x, h), dim=1))
         # the native element-wise paths are float32 kernels with 16-byte vector accesses and 16-bit grid limits: anything else
         # (a .double() model, exotic channel counts that leave a gate half unaligned, B*C > 65535) takes torch's operators
         native = (x.is_cuda and x.dtype is torch.float32 and h.dtype is torch.float32 and gates.dtype is torch.float32
@@ -421,7 +469,7 @@ class ConvGRUCell2(nn.Module):
             u = self.update_gate_norm(u, "sigmoid")
         # the cell's element-wise steps: one native launch each way
         xc = _GruMulCatFn.apply(x, r, h) if native and not (_TRAIN_COMPOSITE_MASK & 2) else torch.cat((x, r * h), dim=1)
-        cand = self.output_norm(self.output_conv(xc), "tanh")
+        cand = self.output_norm(_conv3x3(self.output_conv, xc), "tanh")
         blend_native = native and not (_TRAIN_COMPOSITE_MASK & 4) and all(
             t.data_ptr() % 16 == 0 or not t.is_contiguous() for t in (u, h, cand))       # non-contiguous operands are copied (aligned) first
         new_h = _GruBlendFn.apply(u, h, cand) if blend_native else u * h + (1 - u) * cand
@@ -594,10 +642,29 @@ class RED_Regularization(_REDCore):
         b, _, d_num, h, w = volume_variance.shape
         s = self.initial_states(b, h, w, volume_variance.device)
         outs = []
+        planes = self._per_plane_parameters(d_num) if torch.is_grad_enabled() else None
         for d in range(d_num):
-            reg, *s = self.step(volume_variance[:, :, d], *s)
+            if planes is None:
+                reg, *s = self.step(volume_variance[:, :, d], *s)
+            else:
+                with _reparametrize(self, {n: t[d] for n, t in planes.items()}):
+                    reg, *s = self.step(volume_variance[:, :, d], *s)
             outs.append(reg)
         return torch.stack(outs, dim=1).squeeze(2)
+
+    def _per_plane_parameters(self, d_num):
+        """Training: every plane of the loop uses its own VIEW of each parameter (`p.expand(D, ...)` unbound along D: same
+        memory, same values).  Autograd then delivers the D per-plane gradients of a parameter to ONE stack + ONE sum over D
+        (UnbindBackward, ExpandBackward) instead of D-1 `AccumulateGrad` additions per parameter: ~6 000 add launches per
+        training step of the 48/32/8 cascade become ~140 (round 4: graphed step 126 -> see profiles/r04_train_step.txt).
+        Forward values are untouched; the gradient is the same sum in another association.  SMVS_TRAIN_PLANE_VIEWS=0 keeps the
+        plain loop."""
+        if _reparametrize is None or d_num < 2 or os.environ.get("SMVS_TRAIN_PLANE_VIEWS", "1") == "0":
+            return None
+        named = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        if not named:
+            return None
+        return {n: torch.unbind(p.unsqueeze(0).expand(d_num, *p.shape), 0) for n, p in named}
 
 
 class slice_RED_Regularization(_REDCore):

@@ -678,3 +678,28 @@ def test_scene_folder_to_height_map(dev):
     assert h.shape == (1, 32, 64) and torch.isfinite(h).all()
     lo, hi = float(dv[0, 0]), float(dv[0, 1])
     assert lo - 50.0 <= float(h.min()) and float(h.max()) <= hi + 50.0
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W", [(1, 24, 16, 96, 192), (2, 16, 8, 33, 70), (1, 5, 3, 8, 24), (1, 128, 64, 12, 24), (1, 32, 32, 48, 96), (1, 16, 16, 192, 384)])
+def test_conv3x3_native_weight_gradient_matches_torch(dev, B, cin, cout, H, W):
+    """smvs_conv3x3_wgrad (csrc/conv_wgrad.hip) behind satmvs_amd.modules.module._conv3x3: weight and bias gradient of the ConvGRU cells'
+    3x3 convolutions against torch autograd of the same nn.Conv2d -- channel counts that are odd / not multiples of 8, widths that are
+    not multiples of 64, batch 2, the coarse 12x24 level and a full stage-2 plane.  Another summation order (wave-private sums over
+    rows, lane reduction, float atomics over row chunks): 2e-4 of the gradient's scale; forward and input gradient are torch's own."""
+    from satmvs_amd.modules import module as M
+    torch.manual_seed(B * 1000 + cin * 10 + cout)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).to(dev)
+    x = torch.randn(B, cin, H, W, device=dev, requires_grad=True)
+    gy = torch.randn(B, cout, H, W, device=dev)
+    y0 = conv(x)
+    y0.backward(gy)
+    want = (conv.weight.grad.clone(), conv.bias.grad.clone(), x.grad.clone())
+    conv.zero_grad(); x.grad = None
+    y1 = M._conv3x3(conv, x)
+    assert y1.grad_fn is not None and "Conv3x3Wgrad" in type(y1.grad_fn).__name__
+    assert torch.equal(y1, y0)
+    y1.backward(gy)
+    for got, ref, name in ((conv.weight.grad, want[0], "weight"), (conv.bias.grad, want[1], "bias")):
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 2e-4 * scale, (name, float((got - ref).abs().max()), scale)
+    assert torch.allclose(x.grad, want[2], rtol=1e-4, atol=1e-4 * float(want[2].abs().max()))

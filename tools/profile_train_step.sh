@@ -16,7 +16,7 @@ ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
 rows = db.execute("select s.kernel_name, count(*), sum(d.end-d.start)/1e6 from %s d join %s s on d.kernel_id=s.id group by s.kernel_name order by 3 desc" % (kd, ks)).fetchall()
 tot = sum(r[2] for r in rows)
 print("kernel time over 5 steps (2 warm-up + 3 timed): %.1f ms in %d launches; top kernels:" % (tot, sum(r[1] for r in rows)))
-for r in rows[:18]:
+for r in rows[:40]:
     print("  %6.1f ms %5.1f %%  n=%6d  %s" % (r[2], 100 * r[2] / tot, r[1], r[0][:110]))
 PY
 find "$OUT" -name "*.db" -delete
