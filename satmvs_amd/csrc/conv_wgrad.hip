@@ -93,15 +93,25 @@ void conv3x3_wgrad_kernel(const WgradParams p)
 #pragma unroll
     for (int j = 0; j < 8; ++j) bsum[j] = 0.0f;
 
-    // window rows: win[c][r][k] = X[ci0 + c][y - 1 + r][x - 1 + k]; rows outside the image are zeros
+    // window rows: win[c][r][k] = X[ci0 + c][y - 1 + r][x - 1 + k]; rows outside the image are zeros.  Every load is UNCONDITIONAL
+    // (a row outside the image / past the chunk reads through a descriptor with zero records: the range check returns 0) -- a load
+    // under a branch makes the compiler wait with vmcnt(0) at the join, and the prefetch below would hide nothing (mfma_conv.h).
     float win[2][3][3];
     auto load_row = [&](int yy, float (&dst)[2][3]) {
-        const bool in = yy >= 0 && yy < H;                            // wave-uniform
+        i32x4 r = rx.v;
+        r.z = (yy >= 0 && yy < H) ? r.z : 0;                          // wave-uniform scalar select
+        const int so = (yy >= 0 && yy < H) ? yy * W * 4 : 0;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-                dst[c][k] = in ? llvm_raw_buffer_load_f32(rx.v, (int)cx[k], (c * HW + yy * W) * 4, 0) : 0.0f;
+            for (int k = 0; k < 3; ++k) dst[c][k] = llvm_raw_buffer_load_f32(r, (int)cx[k], c * HW * 4 + so, 0);
+    };
+    auto load_g = [&](int yy, float (&dst)[8]) {
+        i32x4 r = ry.v;
+        r.z = yy < y1 ? r.z : 0;
+        const int so = yy < y1 ? yy * W * 4 : 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j] = llvm_raw_buffer_load_f32(r, (int)cy, j * HW * 4 + so, 0);     // channels beyond Cout: out of range = 0
     };
     {
         float r0[2][3], r1[2][3];
@@ -112,15 +122,23 @@ void conv3x3_wgrad_kernel(const WgradParams p)
 #pragma unroll
             for (int k = 0; k < 3; ++k) { win[c][1][k] = r0[c][k]; win[c][2][k] = r1[c][k]; win[c][0][k] = 0.0f; }
     }
-    // (Requesting the next iteration's rows one iteration ahead was measured and is SLOWER -- 16.9 against 14.3 ms per training
-    //  step over all ConvGRU shapes, 220 VGPRs: the kernel is not bound by the row latency but by its per-wave fixed work.)
+    // The south row and the gradient row of iteration y+1 are requested BEFORE iteration y's arithmetic: un-prefetched, a wave pays a
+    // full memory latency per row (measured: ~2 us per row on the full-resolution shapes, a 13 us floor on the small ones).
+    float south_n[2][3], g_n[8];
+    load_row(y0 + 1, south_n);
+    load_g(y0, g_n);
     for (int y = y0; y < y1; ++y) {
-        // slide: rows (y-1, y) move up, the new south row y+1 comes in
-        float south[2][3];
-        load_row(y + 1, south);
-        float g[8];
+        float south[2][3], g[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = llvm_raw_buffer_load_f32(ry.v, (int)cy, (j * HW + y * W) * 4, 0);     // channels beyond Cout: out of range = 0
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) south[c][k] = south_n[c][k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = g_n[j];
+        load_row(y + 2 <= y1 ? y + 2 : H, south_n);                   // (past the chunk: not needed)
+        load_g(y + 1, g_n);
+        __builtin_amdgcn_sched_barrier(0);
+        // slide: rows (y-1, y) move up, the new south row y+1 comes in
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -135,6 +153,7 @@ void conv3x3_wgrad_kernel(const WgradParams p)
                     for (int k = 0; k < 3; ++k) acc[c][j][r * 3 + k] = fmaf(g[j], win[c][r][k], acc[c][j][r * 3 + k]);
             bsum[j] += g[j];
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
     // reduce over the lanes four values at a time; lanes 15 / 31 / 47 / 63 publish values 4m + {0, 2, 1, 3}
     // value index: (c * 8 + j) * 9 + k for the weight gradients, 144 + j for the bias gradient
