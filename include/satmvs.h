@@ -204,6 +204,15 @@ int smvs_groupnorm1_bwd(const float* dy, const float* x, long long x_batch_strid
  * db[co] += sum dy[b][co][y][x].  x (B,Cin,H,W), dy (B,Cout,H,W), dw (Cout,Cin,3,3), db (Cout) or NULL; dw and db are ACCUMULATED
  * with float atomics -- the caller zero-fills them for a plain gradient. */
 int smvs_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int B, int Cin, int Cout, int H, int W, void* stream);
+/* The same correlation with the window tensor read at `stride` 1 or 2 -- the weight gradient of every 3x3 layer of the RED
+ * regulariser (modules/module.py:595-693 under loss.backward()):
+ *   dw[g][c][ky][kx] += sum_{b,y,x} grid[b][g][y][x] * window[b][c][stride*y + ky - 1][stride*x + kx - 1]
+ * grid (B,Cgrid,H,W), window (B,Cwin,stride*H,stride*W), dw (Cgrid,Cwin,3,3); dgrid_sum (Cgrid) += sum of grid, or NULL.
+ *   nn.Conv2d(stride s, pad 1): window = input, grid = output gradient -> dw = weight gradient (Cout,Cin,3,3), dgrid_sum = bias gradient;
+ *   nn.ConvTranspose2d(stride s, pad 1, output_padding s-1): window = output gradient, grid = input -> dw = weight gradient
+ *   (Cin_layer,Cout_layer,3,3) (its bias gradient is the plain sum of the output gradient: not computed here). */
+int smvs_conv3x3_wgrad_strided(const float* window, const float* grid, float* dw, float* dgrid_sum,
+                               int B, int Cwin, int Cgrid, int H, int W, int stride, void* stream);
 
 /* Both gate norms of a ConvGRU cell in one call (modules/module.py:15-16, :37-40): x (B, 2C, HW) contiguous = the gate
  * convolution's output; channels [0, C) are normalised with (gamma, beta), channels [C, 2C) with (gamma2, beta2), each half

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "smvs_stream_regress_final": [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "smvs_regress_fold": [_vp, _vp, _i, _sz, _sz, _sz, _vp],
     "smvs_conv3x3_wgrad": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "smvs_conv3x3_wgrad_strided": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "smvs_red_pack_weights": [_vp, _i, _vp, _vp],
     "smvs_red_step_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 4 + [_vp],
     "smvs_red_pred_planes": [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 7 + [_vp],

@@ -19,9 +19,13 @@
 
 namespace smvs {
 
+// Generalised in round 4 to every 3x3 layer of the RED regulariser: the WINDOW tensor (`x`: Cin channels, read through the 3x3 taps at
+// stride S) and the GRADIENT-side tensor (`dy`: Cout channels, one value per position of the H x W grid) swap roles for the transposed
+// convolutions -- conv (stride 1 / 2): window = layer input, grid = output gradient, dw (Cout,Cin,3,3); ConvTranspose2d (stride 2 or 1,
+// pad 1): window = output gradient, grid = layer input, weight (Cin_layer, Cout_layer, 3, 3) = the same index formula.
 struct WgradParams {
     const float* x; const float* dy; float* dw; float* db;
-    int B, Cin, Cout, H, W;
+    int B, Cin, Cout, H, W;             // H, W: the grid; the window tensor is (B, Cin, S*H, S*W)
     int ncp, ncog, nxs, nrc, rows;      // input-channel pairs, output-channel groups of 8, column strips, row chunks, rows per chunk
 };
 
@@ -51,6 +55,7 @@ __device__ __forceinline__ float reduce4_rows(float a, float b, float c, float d
     return a;
 }
 
+template <int S>
 __global__ __launch_bounds__(256)
 void conv3x3_wgrad_kernel(const WgradParams p)
 {
@@ -66,6 +71,7 @@ void conv3x3_wgrad_kernel(const WgradParams p)
     const int cog = unit % p.ncog;
     const int b = unit / p.ncog;
     const int H = p.H, W = p.W, HW = H * W;
+    const int HX = S * H, WX = S * W, HWX = HX * WX;                  // the window tensor's plane
     const int x = xs * 64 + lane;
     const int y0 = rc * p.rows, y1 = min(y0 + p.rows, H);
     const int ci0 = 2 * cp;
@@ -74,11 +80,11 @@ void conv3x3_wgrad_kernel(const WgradParams p)
     uint32_t cx[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int xx = x - 1 + k;
-        cx[k] = (x < W && xx >= 0 && xx < W) ? (uint32_t)xx * 4u : SMVS_OOB;
+        const int xx = S * x - 1 + k;
+        cx[k] = (x < W && xx >= 0 && xx < WX) ? (uint32_t)xx * 4u : SMVS_OOB;
     }
     const uint32_t cy = x < W ? (uint32_t)x * 4u : SMVS_OOB;
-    const BufRsrc rx = make_rsrc(p.x + ((size_t)b * p.Cin + ci0) * HW, (uint32_t)((two ? 2 : 1) * HW) * 4u);
+    const BufRsrc rx = make_rsrc(p.x + ((size_t)b * p.Cin + ci0) * HWX, (uint32_t)((two ? 2 : 1) * HWX) * 4u);
     const int nco = min(8, p.Cout - cog * 8);
     const BufRsrc ry = make_rsrc(p.dy + ((size_t)b * p.Cout + cog * 8) * HW, (uint32_t)(nco * HW) * 4u);
 
@@ -97,14 +103,14 @@ void conv3x3_wgrad_kernel(const WgradParams p)
     // (a row outside the image / past the chunk reads through a descriptor with zero records: the range check returns 0) -- a load
     // under a branch makes the compiler wait with vmcnt(0) at the join, and the prefetch below would hide nothing (mfma_conv.h).
     float win[2][3][3];
-    auto load_row = [&](int yy, float (&dst)[2][3]) {
+    auto load_row = [&](int yy, float (&dst)[2][3]) {                 // yy: row of the window tensor
         i32x4 r = rx.v;
-        r.z = (yy >= 0 && yy < H) ? r.z : 0;                          // wave-uniform scalar select
-        const int so = (yy >= 0 && yy < H) ? yy * W * 4 : 0;
+        r.z = (yy >= 0 && yy < HX) ? r.z : 0;                         // wave-uniform scalar select
+        const int so = (yy >= 0 && yy < HX) ? yy * WX * 4 : 0;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) dst[c][k] = llvm_raw_buffer_load_f32(r, (int)cx[k], c * HW * 4 + so, 0);
+            for (int k = 0; k < 3; ++k) dst[c][k] = llvm_raw_buffer_load_f32(r, (int)cx[k], c * HWX * 4 + so, 0);
     };
     auto load_g = [&](int yy, float (&dst)[8]) {
         i32x4 r = ry.v;
@@ -113,7 +119,12 @@ void conv3x3_wgrad_kernel(const WgradParams p)
 #pragma unroll
         for (int j = 0; j < 8; ++j) dst[j] = llvm_raw_buffer_load_f32(r, (int)cy, j * HW * 4 + so, 0);     // channels beyond Cout: out of range = 0
     };
-    {
+    // Grid row y reads window rows S*y - 1 .. S*y + 1.  Before iteration y the window holds rows (., S*y - 1, S*y) in slots 1, 2 for
+    // S = 1 (one new row per iteration) resp. row S*y - 1 in slot 2 for S = 2 (two new rows per iteration).
+    // The rows of iteration y+1 and its gradient row are requested BEFORE iteration y's arithmetic: un-prefetched, a wave pays a
+    // full memory latency per row (measured: ~2 us per row on the full-resolution shapes, a 13 us floor on the small ones).
+    float new_n[S][2][3], g_n[8];
+    if (S == 1) {
         float r0[2][3], r1[2][3];
         load_row(y0 - 1, r0);
         load_row(y0, r1);
@@ -121,28 +132,41 @@ void conv3x3_wgrad_kernel(const WgradParams p)
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int k = 0; k < 3; ++k) { win[c][1][k] = r0[c][k]; win[c][2][k] = r1[c][k]; win[c][0][k] = 0.0f; }
+        load_row(y0 + 1, new_n[0]);
+    } else {
+        float r0[2][3];
+        load_row(S * y0 - 1, r0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { win[c][2][k] = r0[c][k]; win[c][0][k] = win[c][1][k] = 0.0f; }
+#pragma unroll
+        for (int q = 0; q < S; ++q) load_row(S * y0 + q, new_n[q]);
     }
-    // The south row and the gradient row of iteration y+1 are requested BEFORE iteration y's arithmetic: un-prefetched, a wave pays a
-    // full memory latency per row (measured: ~2 us per row on the full-resolution shapes, a 13 us floor on the small ones).
-    float south_n[2][3], g_n[8];
-    load_row(y0 + 1, south_n);
     load_g(y0, g_n);
     for (int y = y0; y < y1; ++y) {
-        float south[2][3], g[8];
+        float fresh[S][2][3], g[8];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int q = 0; q < S; ++q)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) south[c][k] = south_n[c][k];
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) fresh[q][c][k] = new_n[q][c][k];
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[j] = g_n[j];
-        load_row(y + 2 <= y1 ? y + 2 : H, south_n);                   // (past the chunk: not needed)
+        // next iteration's rows (past the chunk: not needed -> a row index outside the tensor)
+#pragma unroll
+        for (int q = 0; q < S; ++q) load_row(y + 1 < y1 ? (S == 1 ? y + 2 : S * (y + 1) + q) : HX, new_n[q]);
         load_g(y + 1, g_n);
         __builtin_amdgcn_sched_barrier(0);
-        // slide: rows (y-1, y) move up, the new south row y+1 comes in
+        // slide the window by S rows
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { win[c][0][k] = win[c][1][k]; win[c][1][k] = win[c][2][k]; win[c][2][k] = south[c][k]; }
+            for (int k = 0; k < 3; ++k) {
+                if (S == 1) { win[c][0][k] = win[c][1][k]; win[c][1][k] = win[c][2][k]; win[c][2][k] = fresh[0][c][k]; }
+                else { win[c][0][k] = win[c][2][k]; win[c][1][k] = fresh[0][c][k]; win[c][2][k] = fresh[1][c][k]; }
+            }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
 #pragma unroll
@@ -179,13 +203,13 @@ void conv3x3_wgrad_kernel(const WgradParams p)
 
 }  // namespace smvs
 
-extern "C" SMVS_EXPORT int smvs_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db,
-                                              int B, int Cin, int Cout, int H, int W, void* stream)
+static int wgrad_launch(const float* x, const float* dy, float* dw, float* db, int B, int Cin, int Cout, int H, int W, int stride, void* stream)
 {
     using namespace smvs;
     if (!x || !dy || !dw) return fail(SMVS_ERR_ARG, "null pointer argument");
     if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
-    if ((long long)2 * H * W * 4 >= (1ll << 31) || (long long)8 * H * W * 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "plane too large");
+    if (stride != 1 && stride != 2) return fail(SMVS_ERR_ARG, "stride must be 1 or 2");
+    if ((long long)2 * stride * stride * H * W * 4 >= (1ll << 31) || (long long)8 * H * W * 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "plane too large");
     WgradParams p{};
     p.x = x; p.dy = dy; p.dw = dw; p.db = db; p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
     p.ncp = (Cin + 1) / 2; p.ncog = (Cout + 7) / 8; p.nxs = (W + 63) / 64;
@@ -196,8 +220,21 @@ extern "C" SMVS_EXPORT int smvs_conv3x3_wgrad(const float* x, const float* dy, f
     p.rows = rows; p.nrc = (H + rows - 1) / rows;
     const long long units = base * p.nrc;
     if (units >= (1ll << 31)) return fail(SMVS_ERR_ARG, "too many work units");
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    if (stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    else             hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "conv3x3_wgrad launch: %s", hipGetErrorString(e));
     return SMVS_OK;
+}
+
+extern "C" SMVS_EXPORT int smvs_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db,
+                                              int B, int Cin, int Cout, int H, int W, void* stream)
+{
+    return wgrad_launch(x, dy, dw, db, B, Cin, Cout, H, W, 1, stream);
+}
+
+extern "C" SMVS_EXPORT int smvs_conv3x3_wgrad_strided(const float* window, const float* grid, float* dw, float* dgrid_sum,
+                                                      int B, int Cwin, int Cgrid, int H, int W, int stride, void* stream)
+{
+    return wgrad_launch(window, grid, dw, dgrid_sum, B, Cwin, Cgrid, H, W, stride, stream);
 }

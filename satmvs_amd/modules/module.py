@@ -177,7 +177,7 @@ class ConvReLU(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
 
     def forward(self, x):
-        return F.relu(self.conv(x), inplace=True)
+        return F.relu(_conv3x3(self.conv, x), inplace=True)
 
 
 class ConvTransReLU(nn.Module):
@@ -187,7 +187,7 @@ class ConvTransReLU(nn.Module):
                                        output_padding=output_pad, bias=False)
 
     def forward(self, x):
-        return F.relu(self.conv(x), inplace=True)
+        return F.relu(_conv3x3(self.conv, x), inplace=True)
 
 
 # ---- recurrent regulariser (RED) ------------------------------------------------------------------------
@@ -397,44 +397,56 @@ class GroupNorm1(nn.GroupNorm):
 
 
 class _Conv3x3WgradFn(torch.autograd.Function):
-    """A 3x3 / stride 1 / pad 1 nn.Conv2d whose WEIGHT and BIAS gradients come from smvs_conv3x3_wgrad (csrc/conv_wgrad.hip);
-    the forward and the input gradient stay torch's (MIOpen's direct kernels are fine there).  On this image MIOpen computes the
-    weight gradient of these small-channel layers as im2col + layout transposes + implicit GEMM + col2im: ~5 launches per call,
-    ~700 calls per training step of the 48/32/8 cascade (profiles/r04_train_step.txt)."""
+    """A 3x3 / pad 1 nn.Conv2d (stride 1 or 2) or nn.ConvTranspose2d (stride 2 with output_padding 1, or stride 1) whose WEIGHT and BIAS
+    gradients come from smvs_conv3x3_wgrad_strided (csrc/conv_wgrad.hip); the forward and the input gradient stay torch's (MIOpen's
+    direct kernels are fine there).  On this image MIOpen computes the weight gradient of these small-channel layers as im2col + layout
+    transposes + implicit GEMM + col2im: ~5 launches per call, ~1 300 calls per training step of the 48/32/8 cascade
+    (profiles/r04_train_step.txt)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, stride, transposed):
         ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return F.conv2d(x, weight, bias, stride=1, padding=1)
+        ctx.meta = (bias is not None, int(stride), bool(transposed))
+        if transposed:
+            return F.conv_transpose2d(x, weight, bias, stride=stride, padding=1, output_padding=stride - 1)
+        return F.conv2d(x, weight, bias, stride=stride, padding=1)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
+        has_bias, stride, transposed = ctx.meta
         dy = _f32c_fast(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [stride, stride], [1, 1], [1, 1], transposed, [stride - 1, stride - 1] if transposed else [0, 0],
+                                                     1, [True, False, False])[0]
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             xc = _f32c_fast(x)
-            B, Cin, H, W = xc.shape
-            Cout = weight.shape[0]
+            window, grid = (dy, xc) if transposed else (xc, dy)             # the tensor read through the taps / the one on the output grid
+            B, Cg, H, W = grid.shape
+            Cw = window.shape[1]
             nw = weight.numel()
-            buf = torch.zeros((nw + (Cout if ctx.has_bias else 0),), dtype=torch.float32, device=xc.device)    # one fill for both gradients
+            sums = has_bias and not transposed                              # a convolution's bias gradient = the grid tensor's sums
+            buf = torch.zeros((nw + (Cg if sums else 0),), dtype=torch.float32, device=xc.device)    # one fill for both gradients
             dw = buf[:nw].view(weight.shape)
-            db = buf[nw:] if ctx.has_bias else None
             with torch.cuda.device(xc.device):
-                _lib.call("smvs_conv3x3_wgrad", _lib.ptr(xc), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
-                          B, Cin, Cout, H, W, _lib.current_stream(xc.device))
-        return dx, dw, db
+                _lib.call("smvs_conv3x3_wgrad_strided", _lib.ptr(window), _lib.ptr(grid), _lib.ptr(dw), _lib.ptr(buf[nw:]) if sums else None,
+                          B, Cw, Cg, H, W, stride, _lib.current_stream(xc.device))
+            if has_bias:
+                db = buf[nw:] if sums else dy.sum((0, 2, 3))
+        return dx, dw, db, None, None
 
 
 def _conv3x3(conv, x):
-    """conv(x) for the ConvGRU cells' 3x3 convolutions: with the native weight gradient where a gradient is wanted on the GPU."""
+    """conv(x) for the regulariser's 3x3 layers (nn.Conv2d stride 1 / 2, nn.ConvTranspose2d stride 2 / 1, pad 1): with the native weight
+    gradient where a gradient is wanted on the GPU."""
+    transposed = isinstance(conv, nn.ConvTranspose2d)
+    s = conv.stride[0]
     if (x.is_cuda and x.dtype is torch.float32 and torch.is_grad_enabled() and conv.weight.requires_grad and conv.weight.dtype is torch.float32
-            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
-            and not (_TRAIN_COMPOSITE_MASK & 8) and x.shape[2] * x.shape[3] * 8 * 4 < 2 ** 31):
-        return _Conv3x3WgradFn.apply(x, conv.weight, conv.bias)
+            and conv.kernel_size == (3, 3) and conv.stride in ((1, 1), (2, 2)) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and (not transposed or conv.output_padding == (s - 1, s - 1)) and (transposed or (x.shape[2] % s == 0 and x.shape[3] % s == 0))
+            and not (_TRAIN_COMPOSITE_MASK & 8) and x.shape[2] * x.shape[3] * 8 * 4 * (s * s if transposed else 1) < 2 ** 31):
+        return _Conv3x3WgradFn.apply(x, conv.weight, conv.bias, s, transposed)
     return conv(x)
 
 
@@ -632,7 +644,7 @@ class _REDCore(nn.Module):
         r2, s2 = self.conv_gru2(e1, s2)
         u1 = self.upconv1(u2 + r2)
         r1, s1 = self.conv_gru1(neg, s1)
-        return self.upconv2d(u1 + r1), s1, s2, s3, s4
+        return _conv3x3(self.upconv2d, u1 + r1), s1, s2, s3, s4
 
 
 class RED_Regularization(_REDCore):

@@ -703,3 +703,37 @@ def test_conv3x3_native_weight_gradient_matches_torch(dev, B, cin, cout, H, W):
         scale = float(ref.abs().max())
         assert float((got - ref).abs().max()) <= 2e-4 * scale, (name, float((got - ref).abs().max()), scale)
     assert torch.allclose(x.grad, want[2], rtol=1e-4, atol=1e-4 * float(want[2].abs().max()))
+
+
+@pytest.mark.parametrize("kind,B,cin,cout,H,W,bias", [
+    ("conv_s2", 1, 8, 16, 96, 192, False), ("conv_s2", 2, 16, 32, 24, 48, False), ("conv_s2", 1, 5, 3, 10, 36, True), ("conv_s2", 1, 32, 64, 24, 48, False),
+    ("convT_s2", 1, 16, 8, 48, 96, False), ("convT_s2", 2, 64, 32, 12, 24, False), ("convT_s2", 1, 3, 5, 7, 33, True),
+    ("convT_s1", 1, 8, 1, 96, 192, True), ("convT_s1", 2, 7, 2, 17, 70, True)])
+def test_conv3x3_native_weight_gradient_strided_and_transposed(dev, kind, B, cin, cout, H, W, bias):
+    """smvs_conv3x3_wgrad_strided behind _conv3x3 for the regulariser's other 3x3 layers: the stride-2 encoder convolutions, the stride-2
+    transposed decoder convolutions (output_padding 1) and the stride-1 transposed output layer with its bias -- against torch autograd of
+    the same layer (weight / bias gradient 2e-4 of the gradient's scale, forward bit-identical, input gradient torch's own)."""
+    from satmvs_amd.modules import module as M
+    torch.manual_seed(B * 1000 + cin * 10 + cout)
+    if kind == "conv_s2":
+        conv = torch.nn.Conv2d(cin, cout, 3, stride=2, padding=1, bias=bias).to(dev)
+    elif kind == "convT_s2":
+        conv = torch.nn.ConvTranspose2d(cin, cout, 3, stride=2, padding=1, output_padding=1, bias=bias).to(dev)
+    else:
+        conv = torch.nn.ConvTranspose2d(cin, cout, 3, stride=1, padding=1, output_padding=0, bias=bias).to(dev)
+    x = torch.randn(B, cin, H, W, device=dev, requires_grad=True)
+    y0 = conv(x)
+    gy = torch.randn_like(y0)
+    y0.backward(gy)
+    want = (conv.weight.grad.clone(), conv.bias.grad.clone() if bias else None, x.grad.clone())
+    conv.zero_grad(); x.grad = None
+    y1 = M._conv3x3(conv, x)
+    assert y1.grad_fn is not None and "Conv3x3Wgrad" in type(y1.grad_fn).__name__
+    assert torch.equal(y1, y0)
+    y1.backward(gy)
+    pairs = [(conv.weight.grad, want[0], "weight")] + ([(conv.bias.grad, want[1], "bias")] if bias else [])
+    for got, ref, name in pairs:
+        scale = float(ref.abs().max())
+        assert got.shape == ref.shape
+        assert float((got - ref).abs().max()) <= 2e-4 * scale, (kind, name, float((got - ref).abs().max()), scale)
+    assert torch.allclose(x.grad, want[2], rtol=1e-4, atol=1e-4 * float(want[2].abs().max()))
