@@ -166,6 +166,10 @@ struct MfmaConvArgs {
     float scaleA;                            // multiplies the A-tensor inputs (-1 feeds -cost)
     int ntiles;                              // tiles of 32 positions in the launch (KS < NW variants: decode / bound of the flat unit index)
     FuseB fuse;                              // 9-tap kernels of the RED plane loop: the B operand computed into LDS (mode != FUSE_NONE)
+    // Partial convolutions over a SLICE of a layer's input channels (RED plane loop: the state-independent half of the ConvGRU
+    // convolutions runs ahead of the recurrent chain, red.hip): the layer's packed weights hold wcipN channel pairs (0 = (CA+CB)/2),
+    // this launch uses pairs wcip0 ..; `init` (same shape as out, or null) is added to the sums before statistics / activation.
+    const float* init; int wcip0, wcipN;
 };
 constexpr int MFMA_FUSE_TW = 34, MFMA_FUSE_TH = 3;           // LDS tile of one unit's B operand: 3 rows x (32 + 2) columns per channel
 
@@ -259,7 +263,7 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
     }
     const BufRsrc rA = make_rsrc(a.inA + (size_t)b * a.CA * vol_i, (uint32_t)((size_t)a.CA * vol_i * 4));
     const BufRsrc rB = make_rsrc(a.CB ? a.inB + (size_t)b * a.CB * vol_i : a.inA, (uint32_t)((size_t)a.CB * vol_i * 4));
-    const BufRsrc rW = make_rsrc(a.w, (uint32_t)((size_t)(Cin / 2) * (TAPS == 9 ? MFMA9_WSLOT : TAPS) * nt_all * 64 * 4));
+    const BufRsrc rW = make_rsrc(a.w, (uint32_t)((size_t)(a.wcipN ? a.wcipN : Cin / 2) * (TAPS == 9 ? MFMA9_WSLOT : TAPS) * nt_all * 64 * 4));
 
     f32x16 acc[NT];
 #pragma unroll
@@ -289,7 +293,7 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
         _Pragma("unroll") for (int s_ = 0; s_ < BS; ++s_) {                                              \
             BT.x[s_] = llvm_raw_buffer_load_f32(rx_, (int)off[(G) * BS + s_], choff_, 0);                \
             _Pragma("unroll") for (int n_ = 0; n_ < NT; ++n_)                                            \
-                BT.w[n_][s_] = llvm_raw_buffer_load_f32(rW.v, lane * 4, ((cip_ * TAPS + (G) * BS + s_) * nt_all + nt0 + n_) * 256, 0); \
+                BT.w[n_][s_] = llvm_raw_buffer_load_f32(rW.v, lane * 4, (((cip_ + a.wcip0) * TAPS + (G) * BS + s_) * nt_all + nt0 + n_) * 256, 0); \
         }                                                                                                \
         BT.sx = sx_;                                              /* applied at MMA time: no wait on the loads here */ \
     }
@@ -375,7 +379,7 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                const int wo = (cip * nt_all + nt0 + n) * (64 * MFMA9_WSLOT * 4);
+                const int wo = ((cip + a.wcip0) * nt_all + nt0 + n) * (64 * MFMA9_WSLOT * 4);
                 B.w[n][0] = llvm_raw_buffer_load_v4f32(rW.v, lane * (MFMA9_WSLOT * 4), wo, 0);
                 B.w[n][1] = llvm_raw_buffer_load_v4f32(rW.v, lane * (MFMA9_WSLOT * 4) + 16, wo, 0);
                 B.w8[n] = llvm_raw_buffer_load_f32(rW.v, lane * (MFMA9_WSLOT * 4) + 32, wo, 0);
@@ -466,7 +470,7 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int cb = (nt0 + n) * 32 + 4 * h;                      // channel of register 0; register r: cb + (r&3) + 8*(r>>2)
-        float bi[16], sc[16], sh[16], sk[16];
+        float bi[16], sc[16], sh[16], sk[16], ini[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f), one = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
@@ -481,11 +485,15 @@ __device__ __forceinline__ void mfma_conv_body(const MfmaConvArgs& a, int bx, in
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             sk[r] = (a.skip && pos_ok) ? a.skip[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * vol_o] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            ini[r] = (a.init && pos_ok) ? a.init[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * vol_o] : 0.0f;
         if (pos_ok) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = cb + (r & 3) + 8 * (r >> 2);
                 float v = acc[n][r];
+                if (a.init) v += ini[r];
                 if (a.bias) v += bi[r];
                 if (a.scale) v = fmaf(v, sc[r], sh[r]);
                 if (a.stats) {

@@ -141,6 +141,10 @@ struct ConvArgs {
     // s / inA_bmod) when inA_bmod > 0, else (batch s, plane 0); its first channel starts at
     // inA + batch*inA_bs + plane*inA_ps and channels are inA_cs floats apart.
     size_t inA_cs, inA_bs, inA_ps; int inA_bmod;
+    // Partial convolution over a slice of the layer's input channels (the ConvGRU convolutions split into their state-independent
+    // and state-dependent halves, see issue_front): the packed weights hold CinW input channels (0 = CA + CB), this launch uses
+    // channels wc0 .. wc0 + CA + CB - 1 of them; `init` (same shape as out, or null) is added to the sums before the statistics.
+    const float* init; int wc0, CinW;
 };
 
 typedef const float __attribute__((address_space(4))) * cw_t;
@@ -211,14 +215,20 @@ __device__ __forceinline__ void conv3x3_body(const ConvArgs& a, int bx, int by, 
                                  ((uint32_t)(a.CA - 1) * (uint32_t)csA + (uint32_t)HWi) * 4u);
     const BufRsrc rB = make_rsrc(a.inB ? a.inB + (size_t)b * a.CB * HWi : a.inA, (uint32_t)(a.inB ? a.CB : 0) * (uint32_t)HWi * 4u);
 
-    float acc[COT];
+    float acc[COT], ini[COT];                // ini: the partial sums this launch continues (issued ahead of the channel loop)
 #pragma unroll
-    for (int j = 0; j < COT; ++j) acc[j] = 0.0f;
-    const cw_t wbase = (cw_t)(uintptr_t)(a.w + (size_t)cog * Cin * 9 * COT);
+    for (int j = 0; j < COT; ++j) {
+        acc[j] = 0.0f;
+        const int co = cog * COT + j;
+        ini[j] = (a.init && active && co < a.Cout && (!SPLIT || wave == 0))
+                     ? a.init[(a.out_bstride ? (size_t)b * a.out_bstride + (size_t)co * a.Ho * a.Wo : ((size_t)b * a.Cout + co) * a.Ho * a.Wo) + (size_t)oy * a.Wo + ox] : 0.0f;
+    }
+    const int CinW = a.CinW ? a.CinW : Cin;
+    const cw_t wbase = (cw_t)(uintptr_t)(a.w + ((size_t)cog * CinW + a.wc0) * 9 * COT);
     const float* wl = smem + CONV_PART_FLOATS;
     constexpr bool WL = SPLIT && SMVS_WLDS;
     if (WL) {
-        const float* wg = a.w + (size_t)cog * Cin * 9 * COT;
+        const float* wg = a.w + ((size_t)cog * CinW + a.wc0) * 9 * COT;
         float* wd = smem + CONV_PART_FLOATS;
         for (int i = threadIdx.x * 4; i < Cin * 9 * COT; i += 256 * 4) *(float4*)(wd + i) = *(const float4*)(wg + i);
         __syncthreads();
@@ -336,7 +346,7 @@ __device__ __forceinline__ void conv3x3_body(const ConvArgs& a, int bx, int by, 
     for (int j = 0; j < COT; ++j) {
         const int co = cog * COT + j;
         if (co < a.Cout) {
-            float r = acc[j] + (a.bias ? a.bias[co] : 0.0f);
+            float r = acc[j] + ini[j] + (a.bias ? a.bias[co] : 0.0f);
             if (active) { s1 += r; s2 = fmaf(r, r, s2); }
             if (a.relu) r = fmaxf(r, 0.0f);
             if (active) a.out[(a.out_bstride ? (size_t)b * a.out_bstride + (size_t)co * HWo : ((size_t)b * a.Cout + co) * HWo) + (size_t)oy * a.Wo + ox] = r;
@@ -770,6 +780,9 @@ struct RedWorkspace {                        // offsets in floats into the calle
     // hsnap[g] + slot * hsnap_stride[g]: like e, the slots of a chunk are adjacent = one dense batch of CH*B samples for the
     // decoder, which runs once per CHUNK of planes (planes = batch dimension); sum[] holds a chunk.
     size_t gates2[4], halt[4];               // fused plane loop: the gate convolution's second buffer, the state's second buffer
+    // xg / xc [g] + slot * stride: the state-INDEPENDENT half of the gate / candidate convolutions of a plane (input channels of
+    // the encoder level, bias included), computed by the front for a chunk of planes; the recurrent chain continues them.
+    size_t xg[4], xg_stride[4], xc[4], xc_stride[4];
     size_t total;
 };
 
@@ -800,6 +813,12 @@ static RedWorkspace red_workspace(int B, int C, int H, int W)
     for (int i = 0; i < 4; ++i) {
         w.gates2[i] = take((size_t)B * 2 * HID[i] * hs[i] * ws[i]);
         w.halt[i] = take((size_t)B * HID[i] * hs[i] * ws[i]);
+    }
+    for (int i = 0; i < 4; ++i) {
+        w.xg_stride[i] = (size_t)B * 2 * HID[i] * hs[i] * ws[i];
+        w.xg[i] = take(w.xg_stride[i] * w.NSL);
+        w.xc_stride[i] = (size_t)B * HID[i] * hs[i] * ws[i];
+        w.xc[i] = take(w.xc_stride[i] * w.NSL);
     }
     w.total = o;
     return w;
@@ -834,6 +853,7 @@ static MfmaConvArgs mfma_args(int stride, const ConvArgs& a, const float* wm)
     m.out = a.out; m.stats = a.stats; m.ngroups = a.ngroups; m.nslot = NSLOT;
     m.Cout = a.Cout; m.relu = a.relu; m.stride = stride;
     m.Di = m.Do = 1; m.Hi = a.Hi; m.Wi = a.Wi; m.Ho = a.Ho; m.Wo = a.Wo;
+    m.init = a.init; m.wcip0 = a.wc0 / 2; m.wcipN = a.CinW / 2;
     return m;
 }
 
@@ -861,8 +881,9 @@ static void launch_conv(int stride, const ConvArgs& a, int B, hipStream_t st, co
 }
 
 // one stride-1 convolution as a job of a level-batched launch; returns its workgroup count
-static int conv_job(ConvJob& j, const ConvArgs& a, int B, const float* wm, int blk0)
+static int conv_job(ConvJob& j, const ConvArgs& a, int B, const float* wm, int blk0, int Bh = 0)
 {
+    if (Bh <= 0) Bh = B;                      // the batch the kernel VARIANT is chosen for (see launch_conv)
     j.blk0 = blk0;
     if (wm && !a.inA_cs && mfma_conv_ok(a.CA, a.CB, a.Cout) && !g_red_direct_only()) {
         j.kind = 2; j.m = mfma_args(1, a, wm);
@@ -879,7 +900,7 @@ static int conv_job(ConvJob& j, const ConvArgs& a, int B, const float* wm, int b
     j.a = a;
     const int ncog = (a.Cout + COT - 1) / COT;
     j.gx = (a.Wo + 63) / 64;
-    const bool split = j.gx * ((a.Ho + 3) / 4) * B * ncog < g_split_below() && (!SMVS_WLDS || a.CA + a.CB <= WLDS_MAX_CIN);
+    const bool split = j.gx * ((a.Ho + 3) / 4) * Bh * ncog < g_split_below() && (!SMVS_WLDS || a.CA + a.CB <= WLDS_MAX_CIN);
     j.kind = split ? 1 : 0;
     j.gy = split ? a.Ho : (a.Ho + 3) / 4;
     return j.gx * j.gy * B * ncog;
@@ -920,8 +941,13 @@ struct RedPipe {
 static RedPipe* red_pipe_create()
 {
     RedPipe* p = new RedPipe();
-    bool ok = hipStreamCreateWithFlags(&p->rec, hipStreamNonBlocking) == hipSuccess
-           && hipStreamCreateWithFlags(&p->dec, hipStreamNonBlocking) == hipSuccess;
+    // the recurrent chain bounds the loop: its stream gets the highest queue priority, so that its workgroups are dispatched
+    // ahead of the front's and the decoder's wherever they compete for CUs
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    const int pr = tune_int("SMVS_RED_PRIO", 1);
+    bool ok = (pr ? hipStreamCreateWithPriority(&p->rec, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&p->rec, hipStreamNonBlocking)) == hipSuccess
+           && (pr == 2 ? hipStreamCreateWithPriority(&p->dec, hipStreamNonBlocking, lo) : hipStreamCreateWithFlags(&p->dec, hipStreamNonBlocking)) == hipSuccess;
     for (int r = 0; r < RING && ok; ++r)
         ok = hipEventCreateWithFlags(&p->enc[r], hipEventDisableTiming) == hipSuccess
           && hipEventCreateWithFlags(&p->state[r], hipEventDisableTiming) == hipSuccess
@@ -1013,6 +1039,17 @@ struct RedIssuer {
     double* stats_of(int k) const { return (double*)(r.wsf + ws.stats[k & 1]); }
     float* e_of(int k, int i) const { return r.wsf + ws.e[i] + (size_t)(k % ws.NSL) * ws.e_stride[i]; }
     float* hsnap_of(int k, int g) const { return r.wsf + ws.hsnap[g] + (size_t)(k % ws.NSL) * ws.hsnap_stride[g]; }
+    float* xg_of(int k, int g) const { return r.wsf + ws.xg[g] + (size_t)(k % ws.NSL) * ws.xg_stride[g]; }
+    float* xc_of(int k, int g) const { return r.wsf + ws.xc[g] + (size_t)(k % ws.NSL) * ws.xc_stride[g]; }
+    // The ConvGRU convolutions act on cat(x, h) / cat(x, r*h): their x half does not depend on the recurrent state.  With the
+    // split on, the front computes it (+ bias) for a whole chunk of planes (planes = batch, caller's stream, under the previous
+    // chunk's chain) and the chain's two convolutions per plane walk the hidden channels only (8 of 40 input channels at level 1
+    // of cascade stage 1, half of them at the coarser levels), starting from those sums.  Built and measured in round 4 (every
+    // RED test passes with it on; profiles/r04_red_xsplit.txt): the chain's convolutions get 18.3 -> 13.0 / 15.4 -> 11.8 us
+    // shorter at stage 1, but a convolution over half the channels costs well over half the time (tile set-up, epilogue, the extra
+    // store + load of the partial sums) and the x halves compete with the chain for the CUs: 57 -> 54 us per plane at stage 1,
+    // 98 -> 100 at stage 2, 262 -> 288 at stage 3.  Off; tuning builds: SMVS_RED_XSPLIT=1.
+    bool xsplit() const { return !fused() && tune_int("SMVS_RED_XSPLIT", 0) == 1; }
 
     // the variance plane of plane k as a strided view for the convolutions that read it
     void cost_view(int k, ConvArgs& a) const
@@ -1050,6 +1087,29 @@ struct RedIssuer {
             a.Hi = hs[i]; a.Wi = wd[i]; a.Ho = hs[i + 1]; a.Wo = wd[i + 1]; a.relu = 1;
             launch_conv(2, a, n * B, r.main, r.packed + L.conv_wm[i], r.pred ? ch * B : B);
         }
+        if (xsplit()) {
+            ConvJobs jg{}, jc{};
+            jg.n = jc.n = 4;
+            int nbg = 0, nbc = 0;
+            const int Bh = r.pred ? ch * B : B;
+            for (int q = 0; q < 4; ++q) {
+                const int g = 3 - q, hc = HID[g];
+                const int cx = g == 0 ? C : enc_out[g - 1];
+                for (int pass = 0; pass < 2; ++pass) {
+                    ConvArgs a{};
+                    if (g == 0) { cost_view(k0, a); if (r.pred) { a.inA_ps = (size_t)r.H * r.W; a.inA_bmod = B; } }
+                    else a.inA = e_of(k0, g - 1);
+                    a.CA = cx; a.scaleA = g == 0 ? -1.0f : 1.0f; a.CinW = cx + hc;
+                    a.w = r.packed + (pass ? L.out_w[g] : L.gate_w[g]); a.bias = r.packed + (pass ? L.out_b[g] : L.gate_b[g]);
+                    a.out = pass ? xc_of(k0, g) : xg_of(k0, g);
+                    a.Cout = pass ? hc : 2 * hc; a.Hi = a.Ho = hs[g]; a.Wi = a.Wo = wd[g];
+                    if (pass) nbc += conv_job(jc.j[q], a, n * B, r.packed + L.out_wm[g], nbc, Bh);
+                    else      nbg += conv_job(jg.j[q], a, n * B, r.packed + L.gate_wm[g], nbg, Bh);
+                }
+            }
+            hipLaunchKernelGGL(conv_jobs_kernel, dim3(nbg), dim3(256), 0, r.main, jg);
+            hipLaunchKernelGGL(conv_jobs_kernel, dim3(nbc), dim3(256), 0, r.main, jc);
+        }
         if (multi) (void)hipEventRecord(P.enc[k0 % RING], r.main);
         return SMVS_OK;
     }
@@ -1076,16 +1136,23 @@ struct RedIssuer {
             const float sx = g == 0 ? -1.0f : 1.0f;
             double* sg = stats + (size_t)g * B * 3 * NSLOT * 2;           // [b][reset,update][slot][2], then [b][slot][2] for the output norm
             double* so = sg + (size_t)B * 2 * NSLOT * 2;
+            const bool xs = xsplit();
             ConvArgs a{};
-            if (g == 0) cost_view(k, a); else a.inA = e_of(k, g - 1);
-            a.CA = cx; a.scaleA = sx; a.inB = r.state[g]; a.CB = hc;
-            a.w = packed + L.gate_w[g]; a.bias = packed + L.gate_b[g]; a.out = wsf + ws.gates[g]; a.stats = sg; a.ngroups = 2;
+            if (xs) { a.inA = r.state[g]; a.CA = hc; a.scaleA = 1.0f; a.wc0 = cx; a.CinW = cx + hc; a.init = xg_of(k, g); }
+            else {
+                if (g == 0) cost_view(k, a); else a.inA = e_of(k, g - 1);
+                a.CA = cx; a.scaleA = sx; a.inB = r.state[g]; a.CB = hc; a.bias = packed + L.gate_b[g];
+            }
+            a.w = packed + L.gate_w[g]; a.out = wsf + ws.gates[g]; a.stats = sg; a.ngroups = 2;
             a.Cout = 2 * hc; a.Hi = a.Ho = hs[g]; a.Wi = a.Wo = wd[g];
             nb_gate += conv_job(gate.j[q], a, B, packed + L.gate_wm[g], nb_gate);
             ConvArgs o{};
-            if (g == 0) cost_view(k, o); else o.inA = e_of(k, g - 1);
-            o.CA = cx; o.scaleA = sx; o.inB = wsf + ws.rh[g]; o.CB = hc;
-            o.w = packed + L.out_w[g]; o.bias = packed + L.out_b[g]; o.out = wsf + ws.cand[g]; o.stats = so; o.ngroups = 1;
+            if (xs) { o.inA = wsf + ws.rh[g]; o.CA = hc; o.scaleA = 1.0f; o.wc0 = cx; o.CinW = cx + hc; o.init = xc_of(k, g); }
+            else {
+                if (g == 0) cost_view(k, o); else o.inA = e_of(k, g - 1);
+                o.CA = cx; o.scaleA = sx; o.inB = wsf + ws.rh[g]; o.CB = hc; o.bias = packed + L.out_b[g];
+            }
+            o.w = packed + L.out_w[g]; o.out = wsf + ws.cand[g]; o.stats = so; o.ngroups = 1;
             o.Cout = hc; o.Hi = o.Ho = hs[g]; o.Wi = o.Wo = wd[g];
             nb_cand += conv_job(cand.j[q], o, B, packed + L.out_wm[g], nb_cand);
             GruJob& u = gru.j[q];
