@@ -375,6 +375,120 @@ __device__ __forceinline__ void conv3x3_body(const ConvArgs& a, int bx, int by, 
     }
 }
 
+// Stride-1 correlation, THROUGHPUT regime (the full-resolution levels of the late cascade stages: thousands of workgroups): lane =
+// one output column, R vertically adjacent output rows, COT output channels.  The nine-tap variant above loads 9 dwords per input
+// channel for 9*COT multiply-adds and is bound by the texture path (measured 30-47 us for the 768x384 level-1 gate convolution,
+// 1.36 GFLOP: ~35 TFLOP/s); here the R+2 input rows a lane needs are loaded once and shared by its R outputs: 3(R+2) loads per
+// 9*R*COT multiply-adds.  Same accumulation order per output (channel, tap) as the nine-tap variant: same bits.
+// Workgroup = 64 columns x 4R rows (wave w: rows (4 by + w) R ..).
+template <int R>
+__device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a, int bx, int by, int bz, float* smem)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ox = bx * 64 + lane;
+    const int oy0 = (by * 4 + wave) * R;
+    const int ncog = (a.Cout + COT - 1) / COT;
+    const int cog = bz % ncog, b = bz / ncog;
+    const bool colok = ox < a.Wo;
+    const int Cin = a.CA + a.CB;
+    const int HWi = a.Hi * a.Wi;
+    constexpr int NT = (R + 2) * 3;
+    uint32_t off[NT];
+#pragma unroll
+    for (int rr = 0; rr < R + 2; ++rr)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = oy0 - 1 + rr, ix = ox - 1 + kx;
+            off[rr * 3 + kx] = (colok && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) ? (uint32_t)(iy * a.Wi + ix) * 4u : SMVS_OOB;
+        }
+    const int csA = a.inA_cs ? (int)a.inA_cs : HWi;                 // floats between channels of inA
+    const int bA = a.inA_bmod ? b % a.inA_bmod : b, pA = a.inA_bmod ? b / a.inA_bmod : 0;
+    const BufRsrc rA = make_rsrc(a.inA + (a.inA_cs ? (size_t)bA * a.inA_bs + (size_t)pA * a.inA_ps : (size_t)b * a.CA * HWi),
+                                 ((uint32_t)(a.CA - 1) * (uint32_t)csA + (uint32_t)HWi) * 4u);
+    const BufRsrc rB = make_rsrc(a.inB ? a.inB + (size_t)b * a.CB * HWi : a.inA, (uint32_t)(a.inB ? a.CB : 0) * (uint32_t)HWi * 4u);
+    const int HWo = a.Ho * a.Wo;
+    float acc[R][COT], ini[R][COT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < COT; ++j) {
+            acc[r][j] = 0.0f;
+            const int co = cog * COT + j;
+            ini[r][j] = (a.init && colok && oy0 + r < a.Ho && co < a.Cout)
+                            ? a.init[(a.out_bstride ? (size_t)b * a.out_bstride + (size_t)co * HWo : ((size_t)b * a.Cout + co) * HWo) + (size_t)(oy0 + r) * a.Wo + ox] : 0.0f;
+        }
+    const int CinW = a.CinW ? a.CinW : Cin;
+    const cw_t wbase = (cw_t)(uintptr_t)(a.w + ((size_t)cog * CinW + a.wc0) * 9 * COT);
+    constexpr int NPF = 2;
+    struct Taps { float t[NT]; };
+    Taps v[NPF];
+    auto load = [&](Taps& V, int cc) {
+        const bool fa = cc < a.CA;                                 // wave-uniform: scalar selects
+        i32x4 rx;
+        rx.x = fa ? rA.v.x : rB.v.x; rx.y = fa ? rA.v.y : rB.v.y;
+        rx.z = fa ? rA.v.z : rB.v.z; rx.w = rA.v.w;
+        const int co = fa ? cc * csA * 4 : (cc - a.CA) * HWi * 4;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) V.t[i] = llvm_raw_buffer_load_f32(rx, (int)off[i], co, 0);
+    };
+    auto fma = [&](const Taps& V, int cc) {
+        const float sc = cc < a.CA ? a.scaleA : 1.0f;
+        float t[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) t[i] = V.t[i] * sc;
+        const cw_t wc = wbase + (size_t)cc * 9 * COT;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int j = 0; j < COT; ++j) acc[r][j] = fmaf(t[(r + k / 3) * 3 + k % 3], wc[k * COT + j], acc[r][j]);
+    };
+    // unconditional loads (past the end: the last channel again, unused), see conv3x3_body
+    const int cl = Cin - 1;
+    load(v[0], 0);
+    for (int cc = 0; cc < Cin; cc += NPF) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            load(v[(i + 1) % NPF], min(cc + i + 1, cl));
+            __builtin_amdgcn_sched_barrier(0);
+            if (cc + i < Cin) fma(v[i], cc + i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int oy = oy0 + r;
+        const bool active = colok && oy < a.Ho;
+#pragma unroll
+        for (int j = 0; j < COT; ++j) {
+            const int co = cog * COT + j;
+            if (co < a.Cout) {
+                float q = acc[r][j] + ini[r][j] + (a.bias ? a.bias[co] : 0.0f);
+                if (active) { s1 += q; s2 = fmaf(q, q, s2); }
+                if (a.relu) q = fmaxf(q, 0.0f);
+                if (active) a.out[(a.out_bstride ? (size_t)b * a.out_bstride + (size_t)co * HWo : ((size_t)b * a.Cout + co) * HWo) + (size_t)oy * a.Wo + ox] = q;
+            }
+        }
+    }
+    if (a.stats) {
+        float (*red)[4] = (float (*)[4])smem;
+        s1 = wave_sum_f(s1);
+        s2 = wave_sum_f(s2);
+        const int grp = (a.ngroups == 2 && cog * COT >= a.Cout / 2) ? 1 : 0;
+        const int slot = (bx + by * 7 + cog * 13) % NSLOT;
+        double* st = a.stats + (((size_t)b * a.ngroups + grp) * NSLOT + slot) * 2;
+        if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(st, (double)red[0][0] + (double)red[0][1] + (double)red[0][2] + (double)red[0][3]);
+            atomicAdd(st + 1, (double)red[1][0] + (double)red[1][1] + (double)red[1][2] + (double)red[1][3]);
+        }
+    }
+}
+
 template <int STRIDE, bool SPLIT>
 __global__ __launch_bounds__(256)
 void conv3x3_kernel(const ConvArgs a)
@@ -646,6 +760,8 @@ void conv_jobs_kernel(const ConvJobs J)
     else if (jb.kind == 3) mfma_conv_body<9, 1, 4, 2>(jb.m, bid, 0, smem);   // two units per workgroup, K split in two
     else if (jb.kind == 2) mfma_conv_body<9, 1, 4>(jb.m, bx, t, smem);
     else if (jb.kind == 1) conv3x3_body<1, true>(jb.a, bx, t % jb.gy, t / jb.gy, smem);
+    else if (jb.kind == 6) conv3x3_rows_body<4>(jb.a, bx, t % jb.gy, t / jb.gy, smem);
+    else if (jb.kind == 5) conv3x3_rows_body<2>(jb.a, bx, t % jb.gy, t / jb.gy, smem);
     else conv3x3_body<1, false>(jb.a, bx, t % jb.gy, t / jb.gy, smem);
 }
 
@@ -689,11 +805,42 @@ struct GruJob {                              // the element-wise stages of one l
     float* hsnap;                            // copy of the new state for the decoder (which runs while the next plane updates h)
     double* zero_next;                       // next plane's statistics of this level, cleared by the apply stage
     int HC, HW, gx, blk0;                    // gx workgroups per sample; workgroups [blk0, blk0 + gx*B)
+    int vec;                                 // 1: four elements per thread (HW % 4 == 0 and 16-byte aligned tensors), 0: one
 };
 struct GruJobs { GruJob j[4]; int n, B; };
 
+// E consecutive elements of one channel per thread (E = 4: 16-byte accesses; the job's `vec` says whether its plane size and
+// pointers allow it).  One element per thread made every workgroup pay the statistics reduction (64 float64 slots, a division and
+// a square root: ~1.5 us of latency) for 256 elements of work: at the full-resolution stage the two kernels ran at 1.6 / 2.3 TB/s
+// (23 + 27 us per plane).  Same arithmetic per element: the bits do not depend on E.
+template <int E> struct fvec;
+template <> struct fvec<1> { float v[1]; };
+template <> struct __attribute__((aligned(16))) fvec<4> { float v[4]; };
+
 // gates raw -> rh = sigmoid(GN(r)) * h.  (The update gate is normalised by the combine stage straight from the raw
 // convolution output: writing u here and reading it back there was 2 of this pass's 5 memory streams -- round 3.)
+template <int E>
+__device__ __forceinline__ void gru_gate_apply_body(const GruJob& g, int bx, int b, int nB, float* coef)
+{
+    const int HC = g.HC, HW = g.HW;
+    // element operands first (they do not depend on the norm coefficients): their latency runs under the reduction
+    const size_t jr = ((size_t)bx * blockDim.x + threadIdx.x) * E;     // index inside the sample
+    const bool valid = jr < (size_t)HC * HW;
+    const size_t j = valid ? jr : 0;
+    const int c = (int)(j / HW), p = (int)(j % HW);
+    const size_t i = (size_t)b * HC * HW + j;
+    const fvec<E> vr = *reinterpret_cast<const fvec<E>*>(g.gates + ((size_t)b * 2 * HC + c) * HW + p);
+    const fvec<E> vh = *reinterpret_cast<const fvec<E>*>(g.h + i);
+    const float wr = g.rn_w[c], br = g.rn_b[c];
+    float mr, sr;
+    gn_coeffs(g.stats_g + ((size_t)b * 2 + 0) * NSLOT * 2, (double)HC * HW, 1e-5f, mr, sr, coef);
+    if (!valid) return;
+    fvec<E> o;
+#pragma unroll
+    for (int e = 0; e < E; ++e) o.v[e] = sigmoidf_(fmaf((vr.v[e] - mr) * sr, wr, br)) * vh.v[e];
+    *reinterpret_cast<fvec<E>*>(g.rh + i) = o;
+}
+
 __global__ __launch_bounds__(256)
 void gru_gate_apply_kernel(const GruJobs J)
 {
@@ -705,28 +852,43 @@ void gru_gate_apply_kernel(const GruJobs J)
     const GruJob& g = J.j[l];
     bid -= g.blk0;
     const int bx = bid % g.gx, b = bid / g.gx;
-    const int HC = g.HC, HW = g.HW;
     // the next plane's statistics of this level (other ring entry) are cleared here: every reader of that buffer
     // (an older plane's apply / combine kernels) precedes this kernel on the stream, every writer (the next plane's
     // convolutions) follows it.
     if (g.zero_next && bid == 0)
         for (int i = threadIdx.x; i < J.B * 3 * NSLOT * 2; i += blockDim.x) g.zero_next[i] = 0.0;
-    // element operands first (they do not depend on the norm coefficients): their latency runs under the reduction
-    const size_t jr = (size_t)bx * blockDim.x + threadIdx.x;     // index inside the sample
+    if (g.vec) gru_gate_apply_body<4>(g, bx, b, J.B, coef);
+    else       gru_gate_apply_body<1>(g, bx, b, J.B, coef);
+}
+
+// u = sigmoid(GN(update gate)); h' = u*h + (1-u)*tanh(GN(cand)); state <- h'; hsnap <- h'
+template <int E>
+__device__ __forceinline__ void gru_combine_body(const GruJob& g, int bx, int b, float (*coef)[2])
+{
+    const int HC = g.HC, HW = g.HW;
+    const size_t jr = ((size_t)bx * blockDim.x + threadIdx.x) * E;
     const bool valid = jr < (size_t)HC * HW;
     const size_t j = valid ? jr : 0;
     const int c = (int)(j / HW), p = (int)(j % HW);
     const size_t i = (size_t)b * HC * HW + j;
-    const float vr = g.gates[((size_t)b * 2 * HC + c) * HW + p], vh = g.h[i];
-    const float wr = g.rn_w[c], br = g.rn_b[c];
-    float mr, sr;
-    gn_coeffs(g.stats_g + ((size_t)b * 2 + 0) * NSLOT * 2, (double)HC * HW, 1e-5f, mr, sr, coef);
+    const fvec<E> vc = *reinterpret_cast<const fvec<E>*>(g.cand + i);            // before the reduction: see the apply kernel
+    const fvec<E> vu = *reinterpret_cast<const fvec<E>*>(g.gates + ((size_t)b * 2 * HC + HC + c) * HW + p);
+    const fvec<E> vh = *reinterpret_cast<const fvec<E>*>(g.h + i);
+    const float wu = g.un_w[c], bu = g.un_b[c], wo = g.on_w[c], bo = g.on_b[c];
+    float mu, su, m, s;
+    gn_coeffs2(g.stats_g + ((size_t)b * 2 + 1) * NSLOT * 2, g.stats_o + (size_t)b * NSLOT * 2, (double)HC * HW, 1e-5f, mu, su, m, s, coef);
     if (!valid) return;
-    const float r = sigmoidf_(fmaf((vr - mr) * sr, wr, br));
-    g.rh[i] = r * vh;
+    fvec<E> o;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const float u = sigmoidf_(fmaf((vu.v[e] - mu) * su, wu, bu));
+        const float y = fuse_tanh(fmaf((vc.v[e] - m) * s, wo, bo));
+        o.v[e] = u * vh.v[e] + (1.0f - u) * y;
+    }
+    *reinterpret_cast<fvec<E>*>(g.h_out + i) = o;
+    *reinterpret_cast<fvec<E>*>(g.hsnap + i) = o;
 }
 
-// u = sigmoid(GN(update gate)); h' = u*h + (1-u)*tanh(GN(cand)); state <- h'; hsnap <- h'
 __global__ __launch_bounds__(256)
 void gru_combine_kernel(const GruJobs J)
 {
@@ -738,22 +900,8 @@ void gru_combine_kernel(const GruJobs J)
     const GruJob& g = J.j[l];
     bid -= g.blk0;
     const int bx = bid % g.gx, b = bid / g.gx;
-    const int HC = g.HC, HW = g.HW;
-    const size_t jr = (size_t)bx * blockDim.x + threadIdx.x;
-    const bool valid = jr < (size_t)HC * HW;
-    const size_t j = valid ? jr : 0;
-    const int c = (int)(j / HW), p = (int)(j % HW);
-    const size_t i = (size_t)b * HC * HW + j;
-    const float vc = g.cand[i], vu = g.gates[((size_t)b * 2 * HC + HC + c) * HW + p], vh = g.h[i];   // before the reduction: see the apply kernel
-    const float wu = g.un_w[c], bu = g.un_b[c], wo = g.on_w[c], bo = g.on_b[c];
-    float mu, su, m, s;
-    gn_coeffs2(g.stats_g + ((size_t)b * 2 + 1) * NSLOT * 2, g.stats_o + (size_t)b * NSLOT * 2, (double)HC * HW, 1e-5f, mu, su, m, s, coef);
-    if (!valid) return;
-    const float u = sigmoidf_(fmaf((vu - mu) * su, wu, bu));
-    const float y = fuse_tanh(fmaf((vc - m) * s, wo, bo));
-    const float hn = u * vh + (1.0f - u) * y;
-    g.h_out[i] = hn;
-    g.hsnap[i] = hn;
+    if (g.vec) gru_combine_body<4>(g, bx, b, coef);
+    else       gru_combine_body<1>(g, bx, b, coef);
 }
 
 // ---- host orchestration ----------------------------------------------------------------------------------------------
@@ -903,6 +1051,11 @@ static int conv_job(ConvJob& j, const ConvArgs& a, int B, const float* wm, int b
     const bool split = j.gx * ((a.Ho + 3) / 4) * Bh * ncog < g_split_below() && (!SMVS_WLDS || a.CA + a.CB <= WLDS_MAX_CIN);
     j.kind = split ? 1 : 0;
     j.gy = split ? a.Ho : (a.Ho + 3) / 4;
+    // throughput regime (chosen from ONE sample's geometry): 4 / 2 output rows per lane
+    static const int rows4 = tune_int("SMVS_CONV_ROWS4_FROM", 1024), rows2 = tune_int("SMVS_CONV_ROWS2_FROM", 1024);
+    const int wg1 = j.gx * ((a.Ho + 3) / 4) * ncog;
+    if (!split && wg1 >= rows4) { j.kind = 6; j.gy = (a.Ho + 15) / 16; }
+    else if (!split && wg1 >= rows2) { j.kind = 5; j.gy = (a.Ho + 7) / 8; }
     return j.gx * j.gy * B * ncog;
 }
 
@@ -1161,7 +1314,8 @@ struct RedIssuer {
             u.on_w = packed + L.on_w[g]; u.on_b = packed + L.on_b[g];
             u.h = r.state[g]; u.h_out = r.state[g]; u.rh = wsf + ws.rh[g]; u.cand = wsf + ws.cand[g]; u.hsnap = hsnap_of(k, g);
             u.zero_next = stats_next ? stats_next + (size_t)g * B * 3 * NSLOT * 2 : nullptr;
-            u.HC = hc; u.HW = hw; u.gx = (int)(((size_t)hc * hw + 255) / 256); u.blk0 = nb_gru;
+            u.vec = tune_int("SMVS_GRU_VEC", 1) == 1 && hw % 4 == 0 && ((uintptr_t)u.h | (uintptr_t)u.h_out | (uintptr_t)u.hsnap | (uintptr_t)u.gates | (uintptr_t)u.rh | (uintptr_t)u.cand) % 16 == 0;
+            u.HC = hc; u.HW = hw; u.gx = (int)(((size_t)hc * hw / (u.vec ? 4 : 1) + 255) / 256); u.blk0 = nb_gru;
             nb_gru += u.gx * B;
         }
         if (tune_int("SMVS_RED_SPLIT_JOBS", 0)) {                       // tuning builds: one launch per level, to time the jobs
@@ -1288,7 +1442,7 @@ struct RedIssuer {
                 a.CA = cx; a.CB = hc; a.Cout = pass ? hc : 2 * hc; a.Hi = a.Ho = hs[g]; a.Wi = a.Wo = wd[g];
                 static const float dummy = 0.0f;
                 (void)conv_job(j, a, r.B, &dummy, 0);
-                if (j.kind == 4 || fuse_tile_floats(j.kind, hc) > FUSE_TILE_FLOATS) return false;
+                if (j.kind >= 4 || fuse_tile_floats(j.kind, hc) > FUSE_TILE_FLOATS) return false;
             }
         }
         return true;

@@ -354,6 +354,8 @@ def test_sharded_pred_equals_unsharded_on_one_gpu(dev, golden):
     ((1, 16, 48, 96), "tanh", False),           # vector path
     ((1, 8, 192, 384), "sigmoid", True),        # several segments per row
     ((3, 64, 12, 24), None, False),             # coarsest level: many channels, tiny planes
+    ((1, 8, 384, 768), "sigmoid", True),        # the real tile: level 1 of cascade stage 3 (gate tensor, sliced)
+    ((1, 8, 384, 768), "tanh", False),
 ])
 def test_groupnorm1_native_matches_torch(dev, shape, act, sliced):
     """smvs_groupnorm1_fwd / _bwd (the training path's GroupNorm(1, C) + gate activation, csrc/groupnorm.hip) against
@@ -388,7 +390,8 @@ def test_groupnorm1_native_matches_torch(dev, shape, act, sliced):
         assert float(dx0[:, :C].abs().max()) == 0.0             # the other half of the gate tensor gets no gradient from this norm
 
 
-@pytest.mark.parametrize("B,cin,ch,H,W", [(1, 8, 8, 33, 50), (2, 16, 16, 24, 48), (1, 64, 64, 12, 24), (2, 32, 8, 7, 9)])
+@pytest.mark.parametrize("B,cin,ch,H,W", [(1, 8, 8, 33, 50), (2, 16, 16, 24, 48), (1, 64, 64, 12, 24), (2, 32, 8, 7, 9),
+                                           (1, 8, 8, 384, 768)])      # the real tile: level 1 of cascade stage 3
 def test_convgru_cell_native_elementwise_matches_torch(dev, B, cin, ch, H, W):
     """ConvGRUCell2 on the GPU (native GroupNorm + activation, cat(x, r*h) and the u-blend as one launch each way) against the
     reference's operator sequence (module.py:22-58) written with torch operators on the same parameters: output 2e-6,
