@@ -396,6 +396,34 @@ class GroupNorm1(nn.GroupNorm):
         return torch.sigmoid(y) if act == "sigmoid" else torch.tanh(y) if act == "tanh" else y
 
 
+class _WgradArena:
+    """Zero-initialised gradient buffers for one training forward of a regulariser: ONE fill per forward instead of one per
+    convolution and plane (the native weight-gradient kernel accumulates with atomics into zeroed memory; ~800 fills per training
+    step of the 48/32/8 cascade).  A fresh tensor per forward: nothing aliases across steps; each convolution call takes its slice at
+    forward time and its backward writes there once."""
+    current = None
+
+    def __init__(self, floats, device):
+        self.buf = torch.zeros((floats,), dtype=torch.float32, device=device)
+        self.off = 0
+
+    def take(self, n):
+        n4 = (n + 3) & ~3
+        if self.off + n4 > self.buf.numel():
+            return None
+        v = self.buf[self.off:self.off + n]
+        self.off += n4
+        return v
+
+    def __enter__(self):
+        self.prev, _WgradArena.current = _WgradArena.current, self
+        return self
+
+    def __exit__(self, *exc):
+        _WgradArena.current = self.prev
+        return False
+
+
 class _Conv3x3WgradFn(torch.autograd.Function):
     """A 3x3 / pad 1 nn.Conv2d (stride 1 or 2) or nn.ConvTranspose2d (stride 2 with output_padding 1, or stride 1) whose WEIGHT and BIAS
     gradients come from smvs_conv3x3_wgrad_strided (csrc/conv_wgrad.hip); the forward and the input gradient stay torch's (MIOpen's
@@ -407,6 +435,8 @@ class _Conv3x3WgradFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, transposed):
         ctx.save_for_backward(x, weight)
         ctx.meta = (bias is not None, int(stride), bool(transposed))
+        arena = _WgradArena.current
+        ctx.zeroed = arena.take(weight.numel() + (weight.shape[0] if bias is not None and not transposed else 0)) if arena is not None else None
         if transposed:
             return F.conv_transpose2d(x, weight, bias, stride=stride, padding=1, output_padding=stride - 1)
         return F.conv2d(x, weight, bias, stride=stride, padding=1)
@@ -427,7 +457,9 @@ class _Conv3x3WgradFn(torch.autograd.Function):
             Cw = window.shape[1]
             nw = weight.numel()
             sums = has_bias and not transposed                              # a convolution's bias gradient = the grid tensor's sums
-            buf = torch.zeros((nw + (Cg if sums else 0),), dtype=torch.float32, device=xc.device)    # one fill for both gradients
+            buf, ctx.zeroed = ctx.zeroed, None                              # (a second backward through the same graph gets fresh memory)
+            if buf is None or buf.device != xc.device:
+                buf = torch.zeros((nw + (Cg if sums else 0),), dtype=torch.float32, device=xc.device)    # one fill for both gradients
             dw = buf[:nw].view(weight.shape)
             with torch.cuda.device(xc.device):
                 _lib.call("smvs_conv3x3_wgrad_strided", _lib.ptr(window), _lib.ptr(grid), _lib.ptr(dw), _lib.ptr(buf[nw:]) if sums else None,
@@ -655,13 +687,18 @@ class RED_Regularization(_REDCore):
         s = self.initial_states(b, h, w, volume_variance.device)
         outs = []
         planes = self._per_plane_parameters(d_num) if torch.is_grad_enabled() else None
-        for d in range(d_num):
-            if planes is None:
+        if planes is None:
+            for d in range(d_num):
                 reg, *s = self.step(volume_variance[:, :, d], *s)
-            else:
+                outs.append(reg)
+            return torch.stack(outs, dim=1).squeeze(2)
+        per_plane = sum(((m.weight.numel() + (m.weight.shape[0] if m.bias is not None else 0)) + 3) & ~3
+                        for m in self.modules() if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and m.kernel_size == (3, 3))
+        with _WgradArena(per_plane * d_num if volume_variance.is_cuda else 0, volume_variance.device):
+            for d in range(d_num):
                 with _reparametrize(self, {n: t[d] for n, t in planes.items()}):
                     reg, *s = self.step(volume_variance[:, :, d], *s)
-            outs.append(reg)
+                outs.append(reg)
         return torch.stack(outs, dim=1).squeeze(2)
 
     def _per_plane_parameters(self, d_num):
