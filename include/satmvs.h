@@ -213,6 +213,25 @@ int smvs_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, in
  *   (Cin_layer,Cout_layer,3,3) (its bias gradient is the plain sum of the output gradient: not computed here). */
 int smvs_conv3x3_wgrad_strided(const float* window, const float* grid, float* dw, float* dgrid_sum,
                                int B, int Cwin, int Cgrid, int H, int W, int stride, void* stream);
+/* smvs_conv3x3_wgrad for a convolution over cat(xA, xB) without the concatenated tensor: xA (B,CA,H,W), xB (B,CB,H,W) (CB = 0: xA only;
+ * CA even otherwise), dw (Cout, CA+CB, 3, 3). */
+int smvs_conv3x3_wgrad_cat(const float* xA, int CA, const float* xB, int CB, const float* dy, float* dw, float* db,
+                           int B, int Cout, int H, int W, void* stream);
+
+/* A single 3x3 / stride 1 / pad 1 convolution over cat(xA, xB) on the kernels of the RED plane loop -- the ConvGRU convolutions of the
+ * TRAINING forward (modules/module.py:34-57 under autograd) and their input gradients:
+ *   smvs_conv3x3_packed_floats(cin, cout)  floats of the packed weights
+ *   smvs_conv3x3_pack(w, packed, cin, cout, adjoint)
+ *       adjoint 0: w = nn.Conv2d weight (cout, cin, 3, 3);
+ *       adjoint 1: w = the weight (cin, cout, 3, 3) of the convolution whose INPUT gradient is wanted: the packed correlation maps that
+ *                  layer's output gradient (cin channels) to its input gradient (cout channels)
+ *   smvs_conv3x3_fwd  out (B,Cout,H,W) = correlation of cat(xA (B,CA,H,W), xB (B,CB,H,W) or NULL) with the packed weights (+ bias (Cout) or NULL)
+ * float32; accumulation in input-channel order (direct kernels) or as a k-ordered fmaf chain on v_mfma_f32_32x32x2_f32 (layers with
+ * 32 / 64 / 128 output channels): same class of rounding as torch's direct convolution, 2e-5 relative in the tests. */
+size_t smvs_conv3x3_packed_floats(int cin, int cout);
+int smvs_conv3x3_pack(const float* w, float* packed, int cin, int cout, int adjoint, void* stream);
+int smvs_conv3x3_fwd(const float* xA, int CA, const float* xB, int CB, const float* packed, const float* bias, float* out,
+                     int B, int Cout, int H, int W, void* stream);
 
 /* Both gate norms of a ConvGRU cell in one call (modules/module.py:15-16, :37-40): x (B, 2C, HW) contiguous = the gate
  * convolution's output; channels [0, C) are normalised with (gamma, beta), channels [C, 2C) with (gamma2, beta2), each half

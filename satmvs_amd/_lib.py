@@ -51,6 +51,9 @@ _SIGNATURES = {
     "smvs_regress_fold": [_vp, _vp, _i, _sz, _sz, _sz, _vp],
     "smvs_conv3x3_wgrad": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "smvs_conv3x3_wgrad_strided": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "smvs_conv3x3_wgrad_cat": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "smvs_conv3x3_pack": [_vp, _vp, _i, _i, _i, _vp],
+    "smvs_conv3x3_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "smvs_red_pack_weights": [_vp, _i, _vp, _vp],
     "smvs_red_step_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 4 + [_vp],
     "smvs_red_pred_planes": [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 7 + [_vp],
@@ -63,7 +66,7 @@ _SIGNATURES = {
 _SIZE_FUNCS = {"smvs_red_packed_floats": [_i], "smvs_red_workspace_bytes": [_i] * 4,
                "smvs_red_pred_workspace_bytes": [_i] * 4, "smvs_costreg_packed_floats": [_i],
                "smvs_costreg_workspace_bytes": [_i] * 5, "smvs_featnet_packed_floats": [_i] * 2,
-               "smvs_featnet_workspace_bytes": [_i] * 5}
+               "smvs_featnet_workspace_bytes": [_i] * 5, "smvs_conv3x3_packed_floats": [_i] * 2}
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SIZE_FUNCS) + ["smvs_version", "smvs_last_error", "smvs_red_set_streams", "smvs_shutdown",
                                                                     "smvs_set_arith", "smvs_get_arith"])
 ARITH_MODES = {"exact": 0, "fused": 1}      # SMVS_ARITH_EXACT / SMVS_ARITH_FUSED of include/satmvs.h

@@ -25,6 +25,7 @@ namespace smvs {
 // pad 1): window = output gradient, grid = layer input, weight (Cin_layer, Cout_layer, 3, 3) = the same index formula.
 struct WgradParams {
     const float* x; const float* dy; float* dw; float* db;
+    const float* x2; int CA;            // window tensor given as two operands: channels [0, CA) in x (B,CA,..), the rest in x2 (B,Cin-CA,..); x2 null: all in x (CA = Cin)
     int B, Cin, Cout, H, W;             // H, W: the grid; the window tensor is (B, Cin, S*H, S*W)
     int ncp, ncog, nxs, nrc, rows;      // input-channel pairs, output-channel groups of 8, column strips, row chunks, rows per chunk
 };
@@ -84,7 +85,9 @@ void conv3x3_wgrad_kernel(const WgradParams p)
         cx[k] = (x < W && xx >= 0 && xx < WX) ? (uint32_t)xx * 4u : SMVS_OOB;
     }
     const uint32_t cy = x < W ? (uint32_t)x * 4u : SMVS_OOB;
-    const BufRsrc rx = make_rsrc(p.x + ((size_t)b * p.Cin + ci0) * HWX, (uint32_t)((two ? 2 : 1) * HWX) * 4u);
+    const bool inA = ci0 < p.CA;                                      // (CA is even when there is a second operand: a pair never straddles)
+    const BufRsrc rx = make_rsrc(inA ? p.x + ((size_t)b * p.CA + ci0) * HWX : p.x2 + ((size_t)b * (p.Cin - p.CA) + (ci0 - p.CA)) * HWX,
+                                 (uint32_t)((two ? 2 : 1) * HWX) * 4u);
     const int nco = min(8, p.Cout - cog * 8);
     const BufRsrc ry = make_rsrc(p.dy + ((size_t)b * p.Cout + cog * 8) * HW, (uint32_t)(nco * HW) * 4u);
 
@@ -203,15 +206,18 @@ void conv3x3_wgrad_kernel(const WgradParams p)
 
 }  // namespace smvs
 
-static int wgrad_launch(const float* x, const float* dy, float* dw, float* db, int B, int Cin, int Cout, int H, int W, int stride, void* stream)
+static int wgrad_launch(const float* x, const float* dy, float* dw, float* db, int B, int Cin, int Cout, int H, int W, int stride, void* stream,
+                        const float* x2 = nullptr, int CA = 0)
 {
     using namespace smvs;
     if (!x || !dy || !dw) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (x2 && (CA < 2 || CA >= Cin || (CA & 1))) return fail(SMVS_ERR_ARG, "two-operand window: the first operand needs an even channel count in [2, Cin)");
     if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
     if (stride != 1 && stride != 2) return fail(SMVS_ERR_ARG, "stride must be 1 or 2");
     if ((long long)2 * stride * stride * H * W * 4 >= (1ll << 31) || (long long)8 * H * W * 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "plane too large");
     WgradParams p{};
     p.x = x; p.dy = dy; p.dw = dw; p.db = db; p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
+    p.x2 = x2; p.CA = x2 ? CA : Cin;
     p.ncp = (Cin + 1) / 2; p.ncog = (Cout + 7) / 8; p.nxs = (W + 63) / 64;
     // rows per wave: long enough to amortise the lane reduction (~3 rows of arithmetic), short enough for >= ~2048 waves
     const long long base = (long long)p.ncp * p.ncog * p.nxs * B;
@@ -237,4 +243,11 @@ extern "C" SMVS_EXPORT int smvs_conv3x3_wgrad_strided(const float* window, const
                                                       int B, int Cwin, int Cgrid, int H, int W, int stride, void* stream)
 {
     return wgrad_launch(window, grid, dw, dgrid_sum, B, Cwin, Cgrid, H, W, stride, stream);
+}
+
+extern "C" SMVS_EXPORT int smvs_conv3x3_wgrad_cat(const float* xA, int CA, const float* xB, int CB, const float* dy, float* dw, float* db,
+                                                  int B, int Cout, int H, int W, void* stream)
+{
+    if (CB > 0 && !xB) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
+    return wgrad_launch(xA, dy, dw, db, B, CA + CB, Cout, H, W, 1, stream, CB > 0 ? xB : nullptr, CA);
 }

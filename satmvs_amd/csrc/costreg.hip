@@ -484,7 +484,7 @@ SMVS_EXPORT int smvs_costreg_pack_weights(const float* const* params, int C, flo
         if (cr_use_mfma(L[i])) {
             const int nm = (int)mfma_packed_floats(L[i].cin, L[i].cout, 27);
             hipLaunchKernelGGL(mfma_pack_kernel, dim3((nm + 255) / 256), dim3(256), 0, st, q[0], packed + lay.wm[i],
-                               L[i].cin, L[i].cout, 27);
+                               L[i].cin, L[i].cout, 27, 0);
         }
         const int cp = ((L[i].cout + CR_COT - 1) / CR_COT) * CR_COT;
         hipLaunchKernelGGL(cr_pack_bn_kernel, dim3(1), dim3(64), 0, st, i < 10 ? q[1] : q[0], i < 10 ? q[2] : q[0],

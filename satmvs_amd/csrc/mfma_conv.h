@@ -175,7 +175,9 @@ constexpr int MFMA_FUSE_TW = 34, MFMA_FUSE_TH = 3;           // LDS tile of one 
 
 // W pack kernel: src (Cout, Cin, TAPS) [conv] -> dst [cip][p][nt][h][32]
 // step p of channel pair cip covers kk = 2p + h in the 2*TAPS-long (ci0 taps..., ci1 taps...) list.
-static __global__ void mfma_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int cin, int cout, int taps)
+// adjoint = 1 (9 taps): src is an nn.Conv2d weight (cin, cout, 3, 3) -- of the layer whose ADJOINT (gradient with respect to its input:
+// the correlation of the output gradient with the transposed, tap-flipped weights) is packed: W'[co][ci][t] = src[ci][co][8 - t].
+static __global__ void mfma_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int cin, int cout, int taps, int adjoint)
 {
     const int nt = (cout + 31) / 32;
     if (taps == 9) {                             // [cip][nt][h][32][12]: step p = tap p, k-slot h = channel 2*cip + h
@@ -184,7 +186,7 @@ static __global__ void mfma_pack_kernel(const float* __restrict__ src, float* __
             const int t = i % MFMA9_WSLOT, j = (i / MFMA9_WSLOT) & 31, h = (i / (MFMA9_WSLOT * 32)) & 1;
             const int tl = (i / (MFMA9_WSLOT * 64)) % nt, cip = i / (MFMA9_WSLOT * 64 * nt);
             const int co = tl * 32 + j, ci = 2 * cip + h;
-            dst[i] = (t < 9 && co < cout) ? src[((size_t)co * cin + ci) * 9 + t] : 0.0f;
+            dst[i] = (t < 9 && co < cout) ? (adjoint ? src[((size_t)ci * cout + co) * 9 + (8 - t)] : src[((size_t)co * cin + ci) * 9 + t]) : 0.0f;
         }
         return;
     }

@@ -489,6 +489,14 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a, int bx, int
     }
 }
 
+template <int R>
+__global__ __launch_bounds__(256)
+void conv3x3_rows_kernel(const ConvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float smem[8];
+    conv3x3_rows_body<R>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
 template <int STRIDE, bool SPLIT>
 __global__ __launch_bounds__(256)
 void conv3x3_kernel(const ConvArgs a)
@@ -994,6 +1002,12 @@ static int g_split_below()
                                                             //  24 -> ~16 us unsplit; stage 2 of the cascade 3.13 -> 3.01 ms)
 }
 
+static int g_rows_from()
+{
+    static const int v = tune_int("SMVS_CONV_ROWS4_FROM", 1024);
+    return v;                                               // workgroups (nine-tap kernel, one sample) from which a lane computes 4 output rows
+}
+
 static MfmaConvArgs mfma_args(int stride, const ConvArgs& a, const float* wm)
 {
     MfmaConvArgs m{};
@@ -1024,7 +1038,9 @@ static void launch_conv(int stride, const ConvArgs& a, int B, hipStream_t st, co
         return;
     }
     dim3 grd(wx, (a.Ho + 3) / 4, B * ncog), blk(256);
-    if (stride == 1) hipLaunchKernelGGL((conv3x3_kernel<1, false>), grd, blk, 0, st, a);
+    if (stride == 1 && wx * ((a.Ho + 3) / 4) * ncog >= g_rows_from())          // throughput regime (one sample's geometry): 4 output rows per lane
+        hipLaunchKernelGGL((conv3x3_rows_kernel<4>), dim3(wx, (a.Ho + 15) / 16, B * ncog), blk, 0, st, a);
+    else if (stride == 1) hipLaunchKernelGGL((conv3x3_kernel<1, false>), grd, blk, 0, st, a);
     else             hipLaunchKernelGGL((conv3x3_kernel<2, false>), grd, blk, 0, st, a);
 }
 
@@ -1052,9 +1068,9 @@ static int conv_job(ConvJob& j, const ConvArgs& a, int B, const float* wm, int b
     j.kind = split ? 1 : 0;
     j.gy = split ? a.Ho : (a.Ho + 3) / 4;
     // throughput regime (chosen from ONE sample's geometry): 4 / 2 output rows per lane
-    static const int rows4 = tune_int("SMVS_CONV_ROWS4_FROM", 1024), rows2 = tune_int("SMVS_CONV_ROWS2_FROM", 1024);
+    static const int rows2 = tune_int("SMVS_CONV_ROWS2_FROM", 1 << 30);      // (2 rows per lane: no gain measured at cascade stage 2; tuning builds)
     const int wg1 = j.gx * ((a.Ho + 3) / 4) * ncog;
-    if (!split && wg1 >= rows4) { j.kind = 6; j.gy = (a.Ho + 15) / 16; }
+    if (!split && wg1 >= g_rows_from()) { j.kind = 6; j.gy = (a.Ho + 15) / 16; }
     else if (!split && wg1 >= rows2) { j.kind = 5; j.gy = (a.Ho + 7) / 8; }
     return j.gx * j.gy * B * ncog;
 }
@@ -1590,7 +1606,7 @@ SMVS_EXPORT int smvs_red_pack_weights(const float* const* params, int C, float* 
     };
     auto packm = [&](const float* src, size_t dst, int cin, int cout) {
         const int n = (int)mfma_packed_floats(cin, cout, 9);
-        hipLaunchKernelGGL(mfma_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, packed + dst, cin, cout, 9);
+        hipLaunchKernelGGL(mfma_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, packed + dst, cin, cout, 9, 0);
     };
     const int xin[4] = {C, 16, 32, 64};
     for (int g = 0; g < 4; ++g) {
@@ -1615,6 +1631,59 @@ SMVS_EXPORT int smvs_red_pack_weights(const float* const* params, int C, float* 
     copy(params[47], L.up2d_b, 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "red_pack_weights launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
+}
+
+// ---- a single 3x3 / stride 1 / pad 1 convolution over cat(xA, xB) (training path of the regulariser) ---------------------------
+// The ConvGRU convolutions of the TRAINING forward and their input gradients (modules/module.py:_Conv3x3NativeFn) on the kernels of
+// the plane loop above -- MIOpen's Winograd kernels take ~19 us per call on these shapes (1 400 calls per training step of the
+// 48/32/8 cascade, profiles/r04_train_step.txt), and the concatenation of (x, h) is a launch of its own.
+//   smvs_conv3x3_packed_floats(cin, cout): floats of the packed weights (direct order + the MFMA order where the layer qualifies)
+//   smvs_conv3x3_pack(w, packed, cin, cout, adjoint): adjoint = 0: w = nn.Conv2d weight (cout, cin, 3, 3);
+//       adjoint = 1: w = the weight (cin, cout, 3, 3) of the convolution whose INPUT gradient is computed: the packed correlation maps
+//       its output gradient (cin channels) to its input gradient (cout channels) -- transposed, taps flipped
+//   smvs_conv3x3_fwd: out (B, Cout, H, W) = correlation of cat(xA (B,CA,H,W), xB (B,CB,H,W) or null) with the packed weights (+ bias)
+SMVS_EXPORT size_t smvs_conv3x3_packed_floats(int cin, int cout)
+{
+    using namespace smvs;
+    if (cin < 1 || cout < 1) return 0;
+    return packed_conv_floats(cin, cout) + (mfma_conv_ok(cin, 0, cout) ? mfma_packed_floats(cin, cout, 9) : 0);
+}
+
+SMVS_EXPORT int smvs_conv3x3_pack(const float* w, float* packed, int cin, int cout, int adjoint, void* stream)
+{
+    using namespace smvs;
+    if (!w || !packed) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (cin < 1 || cout < 1) return fail(SMVS_ERR_ARG, "non-positive channel count");
+    hipStream_t st = (hipStream_t)stream;
+    const int n = (int)packed_conv_floats(cin, cout);
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, packed, cin, cout, adjoint ? 2 : 0);
+    if (mfma_conv_ok(cin, 0, cout)) {
+        const int nm = (int)mfma_packed_floats(cin, cout, 9);
+        hipLaunchKernelGGL(mfma_pack_kernel, dim3((nm + 255) / 256), dim3(256), 0, st, w, packed + n, cin, cout, 9, adjoint ? 1 : 0);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "conv3x3_pack launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
+}
+
+SMVS_EXPORT int smvs_conv3x3_fwd(const float* xA, int CA, const float* xB, int CB, const float* packed, const float* bias, float* out,
+                                 int B, int Cout, int H, int W, void* stream)
+{
+    using namespace smvs;
+    if (!xA || !packed || !out || (CB > 0 && !xB)) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (B < 1 || CA < 1 || CB < 0 || Cout < 1 || H < 1 || W < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
+    if ((long long)(CA > CB ? CA : CB) * H * W * 4 >= (1ll << 31) || (long long)Cout * H * W * 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "plane too large");
+    if ((long long)B * ((Cout + COT - 1) / COT) > 65535) return fail(SMVS_ERR_ARG, "batch too large");
+    const int Cin = CA + CB;
+    ConvArgs a{};
+    a.inA = xA; a.CA = CA; a.scaleA = 1.0f; a.inB = CB > 0 ? xB : nullptr; a.CB = CB;
+    a.w = packed; a.bias = bias; a.out = out; a.Cout = Cout; a.Hi = a.Ho = H; a.Wi = a.Wo = W;
+    // the MFMA kernel reads its per-channel vectors as aligned float4 and pairs input channels: both operands even, bias 16-byte aligned
+    const bool mf = mfma_conv_ok(Cin, 0, Cout) && CA % 2 == 0 && (!bias || ((uintptr_t)bias & 15) == 0);
+    launch_conv(1, a, B, (hipStream_t)stream, mf ? packed + packed_conv_floats(Cin, Cout) : nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "conv3x3_fwd launch: %s", hipGetErrorString(e));
     return SMVS_OK;
 }
 

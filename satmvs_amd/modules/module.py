@@ -41,6 +41,14 @@ def _tensors_by_path(module, names):
     return out
 
 
+_PARAM_EPOCH = [0]      # bumped by whoever changes parameters behind autograd's version counters (train_graph: a graph replay runs the
+                        # optimizer step on the device without touching Python), so that no kernel-layout copy outlives the weights
+
+
+def bump_param_epoch():
+    _PARAM_EPOCH[0] += 1
+
+
 _PACK_CACHE = {}        # key -> (packed tensor, weak references to the source storages); module-level so that it survives
 _PACK_CACHE_PER_DEVICE = 16   # DataParallel's per-forward replicas (the device-0 replica shares the parent's storages);
                               # entries are counted per device, so 8 replicas do not evict each other every forward
@@ -55,7 +63,7 @@ def _packed(kind, device, tensors, build):
     to the next model's parameters."""
     from torch.multiprocessing.reductions import StorageWeakRef
     dkey = str(device)
-    key = (kind, dkey) + tuple((t.data_ptr(), t._version) for t in tensors)
+    key = (kind, dkey, _PARAM_EPOCH[0]) + tuple((t.data_ptr(), t._version) for t in tensors)
     with _PACK_CACHE_LOCK:
         hit = _PACK_CACHE.get(key)
         if hit is not None and any(r.expired() for r in hit[1]):
@@ -194,7 +202,7 @@ class ConvTransReLU(nn.Module):
 # debugging switch: SMVS_TRAIN_COMPOSITE=1 keeps the ConvGRU cells' GroupNorm / element-wise steps on torch's own
 # operators (A/B against the native ones; the cost-volume operators are native either way)
 _TRAIN_COMPOSITE_ONLY = os.environ.get("SMVS_TRAIN_COMPOSITE", "0") == "1"
-_TRAIN_COMPOSITE_MASK = 15 if _TRAIN_COMPOSITE_ONLY else int(os.environ.get("SMVS_TRAIN_COMPOSITE_MASK", "0"))   # bisecting: 1 GroupNorm, 2 cat(x, r*h), 4 u-blend, 8 conv weight gradient
+_TRAIN_COMPOSITE_MASK = 31 if _TRAIN_COMPOSITE_ONLY else int(os.environ.get("SMVS_TRAIN_COMPOSITE_MASK", "0"))   # bisecting: 1 GroupNorm, 2 cat(x, r*h), 4 u-blend, 8 conv weight gradient, 16 ConvGRU convolutions (forward + input gradient)
 
 
 _FIND_WARNED = False
@@ -469,6 +477,95 @@ class _Conv3x3WgradFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+_CONV_PACK = {}         # (weight address, adjoint) -> (version, epoch, storage weak reference, packed tensor): one entry per layer and direction
+
+
+def _conv_packed(weight, adjoint):
+    """Kernel-layout copy of a (Cout, Cin, 3, 3) weight for smvs_conv3x3_fwd (adjoint: for the input gradient), packed once per
+    parameter version -- every plane of a training step uses a view of the same parameter."""
+    from torch.multiprocessing.reductions import StorageWeakRef
+    key = (weight.data_ptr(), bool(adjoint), weight.device.index)
+    hit = _CONV_PACK.get(key)
+    if hit is not None and hit[0] == weight._version and hit[1] == _PARAM_EPOCH[0] and not hit[2].expired() and hit[3].shape[0] > 0:
+        return hit[3]
+    cout, cin = weight.shape[0], weight.shape[1]
+    ci, co = (cout, cin) if adjoint else (cin, cout)
+    packed = torch.empty((_lib.load().smvs_conv3x3_packed_floats(ci, co),), dtype=torch.float32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        _lib.call("smvs_conv3x3_pack", _lib.ptr(weight), _lib.ptr(packed), ci, co, 1 if adjoint else 0, _lib.current_stream(weight.device))
+    if len(_CONV_PACK) > 256:
+        _CONV_PACK.clear()
+    _CONV_PACK[key] = (weight._version, _PARAM_EPOCH[0], StorageWeakRef(weight.untyped_storage()), packed)
+    return packed
+
+
+class _Conv3x3CatNativeFn(torch.autograd.Function):
+    """conv2d(cat(xa, xb), weight, bias), 3x3 / stride 1 / pad 1, on the kernels of the RED plane loop (smvs_conv3x3_fwd: direct or
+    MFMA by channel count) -- forward, input gradient (the same kernels on the transposed, tap-flipped weights) and weight / bias
+    gradient (smvs_conv3x3_wgrad_cat), without the concatenated tensor.  xb may be None."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, weight, bias):
+        xa = _f32c_fast(xa)
+        xb = _f32c_fast(xb) if xb is not None else None
+        B, CA, H, W = xa.shape
+        CB = xb.shape[1] if xb is not None else 0
+        Cout = weight.shape[0]
+        out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=xa.device)
+        packed = _conv_packed(weight, False)
+        with torch.cuda.device(xa.device):
+            _lib.call("smvs_conv3x3_fwd", _lib.ptr(xa), CA, _lib.ptr(xb) if xb is not None else None, CB, _lib.ptr(packed),
+                      _lib.ptr(bias) if bias is not None else None, _lib.ptr(out), B, Cout, H, W, _lib.current_stream(xa.device))
+        ctx.save_for_backward(xa, xb, weight)
+        ctx.has_bias = bias is not None
+        arena = _WgradArena.current
+        ctx.zeroed = arena.take(weight.numel() + (Cout if bias is not None else 0)) if arena is not None else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, xb, weight = ctx.saved_tensors
+        dy = _f32c_fast(dy)
+        B, CA, H, W = xa.shape
+        CB = xb.shape[1] if xb is not None else 0
+        Cout = weight.shape[0]
+        dev = xa.device
+        dxa = dxb = dw = db = None
+        with torch.cuda.device(dev):
+            if ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1]):
+                dx = torch.empty((B, CA + CB, H, W), dtype=torch.float32, device=dev)
+                _lib.call("smvs_conv3x3_fwd", _lib.ptr(dy), Cout, None, 0, _lib.ptr(_conv_packed(weight, True)), None, _lib.ptr(dx),
+                          B, CA + CB, H, W, _lib.current_stream(dev))
+                dxa = dx[:, :CA] if ctx.needs_input_grad[0] else None
+                dxb = dx[:, CA:] if xb is not None and ctx.needs_input_grad[1] else None
+            if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+                nw = weight.numel()
+                buf, ctx.zeroed = ctx.zeroed, None
+                if buf is None or buf.device != dev:
+                    buf = torch.zeros((nw + (Cout if ctx.has_bias else 0),), dtype=torch.float32, device=dev)
+                dw = buf[:nw].view(weight.shape)
+                _lib.call("smvs_conv3x3_wgrad_cat", _lib.ptr(xa), CA, _lib.ptr(xb) if xb is not None else None, CB, _lib.ptr(dy), _lib.ptr(dw),
+                          _lib.ptr(buf[nw:]) if ctx.has_bias else None, B, Cout, H, W, _lib.current_stream(dev))
+                db = buf[nw:] if ctx.has_bias else None
+        return dxa, dxb, dw, db
+
+
+def _conv3x3_cat(conv, xa, xb=None):
+    """conv(cat(xa, xb)) for the ConvGRU cells' 3x3 convolutions: fully native under autograd on the GPU (SMVS_TRAIN_COMPOSITE_MASK
+    bit 16 keeps torch's convolution with the native weight gradient, bit 8 torch's convolution alone)."""
+    x_all = (xa,) if xb is None else (xa, xb)
+    if (xa.is_cuda and all(t.dtype is torch.float32 for t in x_all) and torch.is_grad_enabled() and conv.weight.requires_grad
+            and conv.weight.dtype is torch.float32 and conv.weight.is_contiguous() and isinstance(conv, nn.Conv2d)
+            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and not (_TRAIN_COMPOSITE_MASK & 24) and (xb is None or xa.shape[1] % 2 == 0)
+            and max(t.shape[1] for t in x_all) * xa.shape[2] * xa.shape[3] * 4 < 2 ** 31 and conv.weight.shape[0] * xa.shape[2] * xa.shape[3] * 4 < 2 ** 31
+            and sum(t.shape[1] for t in x_all) * xa.shape[2] * xa.shape[3] * 4 < 2 ** 31
+            and xa.shape[0] * ((max(conv.weight.shape[0], conv.weight.shape[1]) + 7) // 8) <= 65535
+            and (conv.bias is None or conv.bias.data_ptr() % 16 == 0)):
+        return _Conv3x3CatNativeFn.apply(xa, xb, conv.weight, conv.bias)
+    return _conv3x3(conv, xa if xb is None else torch.cat((xa, xb), dim=1))
+
+
 def _conv3x3(conv, x):
     """conv(x) for the regulariser's 3x3 layers (nn.Conv2d stride 1 / 2, nn.ConvTranspose2d stride 2 / 1, pad 1): with the native weight
     gradient where a gradient is wanted on the GPU."""
@@ -499,7 +596,7 @@ class ConvGRUCell2(nn.Module):
     def forward(self, x, h=None):
         if h is None:
             h = torch.zeros((x.shape[0], self.output_channel, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device)
-        gates = _conv3x3(self.gate_conv, torch.cat((x, h), dim=1))
+        gates = _conv3x3_cat(self.gate_conv, x, h)
         # the native element-wise paths are float32 kernels with 16-byte vector accesses and 16-bit grid limits: anything else
         # (a .double() model, exotic channel counts that leave a gate half unaligned, B*C > 65535) takes torch's operators
         native = (x.is_cuda and x.dtype is torch.float32 and h.dtype is torch.float32 and gates.dtype is torch.float32
@@ -513,7 +610,7 @@ class ConvGRUCell2(nn.Module):
             u = self.update_gate_norm(u, "sigmoid")
         # the cell's element-wise steps: one native launch each way
         xc = _GruMulCatFn.apply(x, r, h) if native and not (_TRAIN_COMPOSITE_MASK & 2) else torch.cat((x, r * h), dim=1)
-        cand = self.output_norm(_conv3x3(self.output_conv, xc), "tanh")
+        cand = self.output_norm(_conv3x3_cat(self.output_conv, xc), "tanh")
         blend_native = native and not (_TRAIN_COMPOSITE_MASK & 4) and all(
             t.data_ptr() % 16 == 0 or not t.is_contiguous() for t in (u, h, cand))       # non-contiguous operands are copied (aligned) first
         new_h = _GruBlendFn.apply(u, h, cand) if blend_native else u * h + (1 - u) * cand

@@ -22,6 +22,8 @@ from __future__ import annotations
 
 import torch
 
+from .modules.module import bump_param_epoch
+
 
 def _map(obj, fn):
     if torch.is_tensor(obj):
@@ -130,4 +132,5 @@ class GraphedTrainStep:
         else:
             _zip_copy(self._static, args)
         self._graph.replay()
+        bump_param_epoch()                                    # the replay stepped the parameters without touching autograd's version counters
         return self._out

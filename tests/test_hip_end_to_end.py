@@ -708,6 +708,44 @@ def test_conv3x3_native_weight_gradient_matches_torch(dev, B, cin, cout, H, W):
     assert torch.allclose(x.grad, want[2], rtol=1e-4, atol=1e-4 * float(want[2].abs().max()))
 
 
+@pytest.mark.parametrize("B,ca,cb,cout,H,W", [(1, 32, 8, 16, 96, 192), (1, 32, 8, 8, 96, 192), (2, 16, 16, 32, 24, 48), (1, 64, 64, 128, 12, 24),
+                                               (1, 32, 32, 32, 48, 96), (1, 8, 8, 16, 384, 768), (1, 24, 0, 8, 33, 70), (3, 6, 5, 3, 9, 21)])
+def test_conv3x3_cat_native_matches_torch(dev, B, ca, cb, cout, H, W):
+    """smvs_conv3x3_fwd / smvs_conv3x3_pack / smvs_conv3x3_wgrad_cat behind modules.module._conv3x3_cat: the ConvGRU cells' convolution over
+    cat(x, h) without the concatenated tensor -- forward, both input gradients, weight and bias gradient against torch autograd of
+    conv2d(cat(x, h)): direct kernels (16 / 8 outputs), MFMA kernels (32 / 128 outputs; 64-channel adjoint), the 4-rows-per-lane variant at
+    the real tile, a single operand, batch 2 / 3, odd sizes (torch fallback where the first operand's channel count is odd).  2e-5 of
+    each tensor's scale (float32 sums in another order)."""
+    from satmvs_amd.modules import module as M
+    torch.manual_seed(B * 1000 + ca * 10 + cout)
+    conv = torch.nn.Conv2d(ca + cb, cout, 3, padding=1).to(dev)
+    xa = torch.randn(B, ca, H, W, device=dev, requires_grad=True)
+    xb = torch.randn(B, cb, H, W, device=dev, requires_grad=True) if cb else None
+    x_all = [xa] + ([xb] if cb else [])
+    y0 = conv(torch.cat(x_all, 1))
+    gy = torch.randn_like(y0)
+    y0.backward(gy)
+    want = [conv.weight.grad.clone(), conv.bias.grad.clone()] + [t.grad.clone() for t in x_all]
+    conv.zero_grad()
+    for t in x_all:
+        t.grad = None
+    y1 = M._conv3x3_cat(conv, xa, xb)
+    native = ca % 2 == 0 or cb == 0
+    assert ("Conv3x3CatNative" in type(y1.grad_fn).__name__) == native
+    assert float((y1 - y0).abs().max()) <= 2e-5 * float(y0.abs().max())
+    y1.backward(gy)
+    got = [conv.weight.grad, conv.bias.grad] + [t.grad for t in x_all]
+    for g, r, name in zip(got, want, ("weight", "bias", "xa", "xb")):
+        scale = float(r.abs().max())
+        assert g.shape == r.shape
+        assert float((g - r).abs().max()) <= (2e-4 if name in ("weight", "bias") else 2e-5) * scale, (name, float((g - r).abs().max()), scale)
+    # a changed weight (optimizer step) is repacked
+    with torch.no_grad():
+        conv.weight.mul_(0.5)
+    y2 = M._conv3x3_cat(conv, xa, xb)
+    assert float((y2 - conv(torch.cat(x_all, 1))).abs().max()) <= 2e-5 * float(y0.abs().max())
+
+
 @pytest.mark.parametrize("kind,B,cin,cout,H,W,bias", [
     ("conv_s2", 1, 8, 16, 96, 192, False), ("conv_s2", 2, 16, 32, 24, 48, False), ("conv_s2", 1, 5, 3, 10, 36, True), ("conv_s2", 1, 32, 64, 24, 48, False),
     ("convT_s2", 1, 16, 8, 48, 96, False), ("convT_s2", 2, 64, 32, 12, 24, False), ("convT_s2", 1, 3, 5, 7, 33, True),
