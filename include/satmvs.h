@@ -217,6 +217,12 @@ int smvs_conv3x3_wgrad_strided(const float* window, const float* grid, float* dw
  * CA even otherwise), dw (Cout, CA+CB, 3, 3). */
 int smvs_conv3x3_wgrad_cat(const float* xA, int CA, const float* xB, int CB, const float* dy, float* dw, float* db,
                            int B, int Cout, int H, int W, void* stream);
+/* The same sums over a LIST of n tensors (host arrays of n device pointers each; win2 NULL when CB = 0) of Bper samples each -- the planes
+ * of a training step's plane loop, whose activations and gradients are separate allocations: one launch per layer and step instead of one
+ * per layer and plane.  window tensors (Bper, CA [+ CB], stride*H, stride*W), grid tensors (Bper, Cgrid, H, W); dw (Cgrid, CA+CB, 3, 3)
+ * and dgrid_sum (Cgrid, or NULL) are accumulated into (the caller zeroes them). */
+int smvs_conv3x3_wgrad_list(const float* const* win, const float* const* win2, const float* const* grid, int n,
+                            float* dw, float* dgrid_sum, int Bper, int CA, int CB, int Cgrid, int H, int W, int stride, void* stream);
 
 /* A single 3x3 / stride 1 / pad 1 convolution over cat(xA, xB) on the kernels of the RED plane loop -- the ConvGRU convolutions of the
  * TRAINING forward (modules/module.py:34-57 under autograd) and their input gradients:

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "smvs_conv3x3_wgrad": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "smvs_conv3x3_wgrad_strided": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "smvs_conv3x3_wgrad_cat": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "smvs_conv3x3_wgrad_list": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "smvs_conv3x3_pack": [_vp, _vp, _i, _i, _i, _vp],
     "smvs_conv3x3_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "smvs_red_pack_weights": [_vp, _i, _vp, _vp],

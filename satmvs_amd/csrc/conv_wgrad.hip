@@ -23,11 +23,18 @@ namespace smvs {
 // stride S) and the GRADIENT-side tensor (`dy`: Cout channels, one value per position of the H x W grid) swap roles for the transposed
 // convolutions -- conv (stride 1 / 2): window = layer input, grid = output gradient, dw (Cout,Cin,3,3); ConvTranspose2d (stride 2 or 1,
 // pad 1): window = output gradient, grid = layer input, weight (Cin_layer, Cout_layer, 3, 3) = the same index formula.
+constexpr int WGRAD_LIST_MAX = 64;
 struct WgradParams {
     const float* x; const float* dy; float* dw; float* db;
     const float* x2; int CA;            // window tensor given as two operands: channels [0, CA) in x (B,CA,..), the rest in x2 (B,Cin-CA,..); x2 null: all in x (CA = Cin)
     int B, Cin, Cout, H, W;             // H, W: the grid; the window tensor is (B, Cin, S*H, S*W)
     int ncp, ncog, nxs, nrc, rows;      // input-channel pairs, output-channel groups of 8, column strips, row chunks, rows per chunk
+    int nbc, bchunk;                    // batch chunks; a wave walks samples [bc * bchunk, min(B, (bc + 1) * bchunk)) with its sums in registers
+    // The batch as a LIST of nlist tensors of Bper samples each (B = nlist * Bper): the planes of a training step's plane loop, whose
+    // activations and output gradients are separate allocations -- one launch per layer and step instead of one per layer and plane
+    // (a launch on these shapes is a 13 us latency floor; ~1 300 per training step of the 48/32/8 cascade).
+    int nlist, Bper;
+    const float* xl[WGRAD_LIST_MAX]; const float* x2l[WGRAD_LIST_MAX]; const float* dyl[WGRAD_LIST_MAX];
 };
 
 // Four registers -> one: the sums over the 64 lanes of a, b, c, d end up in lanes 15 (a), 31 (c), 47 (b), 63 (d) of the result.
@@ -63,14 +70,15 @@ void conv3x3_wgrad_kernel(const WgradParams p)
     const int lane = threadIdx.x & 63;
     int unit = blockIdx.x * 4 + (threadIdx.x >> 6);                  // one wave = one unit
     unit = __builtin_amdgcn_readfirstlane(unit);
-    const int total = p.ncp * p.ncog * p.nxs * p.nrc * p.B;
+    const int total = p.ncp * p.ncog * p.nxs * p.nrc * p.nbc;
     if (unit >= total) return;
     // row chunk fastest, then column strip, channel pair, output group, batch: neighbouring waves share X / dY rows in L2
     const int rc = unit % p.nrc; unit /= p.nrc;
     const int xs = unit % p.nxs; unit /= p.nxs;
     const int cp = unit % p.ncp; unit /= p.ncp;
     const int cog = unit % p.ncog;
-    const int b = unit / p.ncog;
+    const int bc = unit / p.ncog;
+    const int b0 = bc * p.bchunk, b1 = min(p.B, b0 + p.bchunk);
     const int H = p.H, W = p.W, HW = H * W;
     const int HX = S * H, WX = S * W, HWX = HX * WX;                  // the window tensor's plane
     const int x = xs * 64 + lane;
@@ -86,10 +94,7 @@ void conv3x3_wgrad_kernel(const WgradParams p)
     }
     const uint32_t cy = x < W ? (uint32_t)x * 4u : SMVS_OOB;
     const bool inA = ci0 < p.CA;                                      // (CA is even when there is a second operand: a pair never straddles)
-    const BufRsrc rx = make_rsrc(inA ? p.x + ((size_t)b * p.CA + ci0) * HWX : p.x2 + ((size_t)b * (p.Cin - p.CA) + (ci0 - p.CA)) * HWX,
-                                 (uint32_t)((two ? 2 : 1) * HWX) * 4u);
     const int nco = min(8, p.Cout - cog * 8);
-    const BufRsrc ry = make_rsrc(p.dy + ((size_t)b * p.Cout + cog * 8) * HW, (uint32_t)(nco * HW) * 4u);
 
     float acc[2][8][9];
 #pragma unroll
@@ -102,6 +107,14 @@ void conv3x3_wgrad_kernel(const WgradParams p)
 #pragma unroll
     for (int j = 0; j < 8; ++j) bsum[j] = 0.0f;
 
+    for (int bb = b0; bb < b1; ++bb) {
+    const int li = p.nlist ? bb / p.Bper : 0, b = p.nlist ? bb % p.Bper : bb;              // (wave-uniform)
+    const float* xb = p.nlist ? p.xl[li] : p.x;
+    const float* x2b = p.nlist ? p.x2l[li] : p.x2;
+    const float* dyb = p.nlist ? p.dyl[li] : p.dy;
+    const BufRsrc rx = make_rsrc(inA ? xb + ((size_t)b * p.CA + ci0) * HWX : x2b + ((size_t)b * (p.Cin - p.CA) + (ci0 - p.CA)) * HWX,
+                                 (uint32_t)((two ? 2 : 1) * HWX) * 4u);
+    const BufRsrc ry = make_rsrc(dyb + ((size_t)b * p.Cout + cog * 8) * HW, (uint32_t)(nco * HW) * 4u);
     // window rows: win[c][r][k] = X[ci0 + c][y - 1 + r][x - 1 + k]; rows outside the image are zeros.  Every load is UNCONDITIONAL
     // (a row outside the image / past the chunk reads through a descriptor with zero records: the range check returns 0) -- a load
     // under a branch makes the compiler wait with vmcnt(0) at the join, and the prefetch below would hide nothing (mfma_conv.h).
@@ -182,6 +195,7 @@ void conv3x3_wgrad_kernel(const WgradParams p)
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    }   // samples of this wave
     // reduce over the lanes four values at a time; lanes 15 / 31 / 47 / 63 publish values 4m + {0, 2, 1, 3}
     // value index: (c * 8 + j) * 9 + k for the weight gradients, 144 + j for the bias gradient
     auto value = [&](int i) -> float { return i < 144 ? acc[i / 72][(i % 72) / 9][i % 9] : bsum[i - 144]; };
@@ -206,25 +220,37 @@ void conv3x3_wgrad_kernel(const WgradParams p)
 
 }  // namespace smvs
 
+// list: nlist > 0 tensors of `B` samples each (x / x2 / dy ignored), else one tensor of B samples
 static int wgrad_launch(const float* x, const float* dy, float* dw, float* db, int B, int Cin, int Cout, int H, int W, int stride, void* stream,
-                        const float* x2 = nullptr, int CA = 0)
+                        const float* x2 = nullptr, int CA = 0, int nlist = 0, const float* const* xl = nullptr, const float* const* x2l = nullptr,
+                        const float* const* dyl = nullptr)
 {
     using namespace smvs;
-    if (!x || !dy || !dw) return fail(SMVS_ERR_ARG, "null pointer argument");
-    if (x2 && (CA < 2 || CA >= Cin || (CA & 1))) return fail(SMVS_ERR_ARG, "two-operand window: the first operand needs an even channel count in [2, Cin)");
-    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
+    if (!dw || (!nlist && (!x || !dy)) || (nlist && (!xl || !dyl))) return fail(SMVS_ERR_ARG, "null pointer argument");
+    const bool second = nlist ? x2l != nullptr : x2 != nullptr;
+    if (second && (CA < 2 || CA >= Cin || (CA & 1))) return fail(SMVS_ERR_ARG, "two-operand window: the first operand needs an even channel count in [2, Cin)");
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || nlist < 0 || nlist > WGRAD_LIST_MAX) return fail(SMVS_ERR_ARG, "non-positive dimension");
     if (stride != 1 && stride != 2) return fail(SMVS_ERR_ARG, "stride must be 1 or 2");
     if ((long long)2 * stride * stride * H * W * 4 >= (1ll << 31) || (long long)8 * H * W * 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "plane too large");
     WgradParams p{};
-    p.x = x; p.dy = dy; p.dw = dw; p.db = db; p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
-    p.x2 = x2; p.CA = x2 ? CA : Cin;
+    p.x = x; p.dy = dy; p.dw = dw; p.db = db; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
+    p.x2 = x2; p.CA = second ? CA : Cin;
+    p.nlist = nlist; p.Bper = B; p.B = nlist ? nlist * B : B;
+    for (int i = 0; i < nlist; ++i) {
+        if (!xl[i] || !dyl[i] || (second && !x2l[i])) return fail(SMVS_ERR_ARG, "null pointer in the tensor list");
+        p.xl[i] = xl[i]; p.x2l[i] = second ? x2l[i] : nullptr; p.dyl[i] = dyl[i];
+    }
     p.ncp = (Cin + 1) / 2; p.ncog = (Cout + 7) / 8; p.nxs = (W + 63) / 64;
-    // rows per wave: long enough to amortise the lane reduction (~3 rows of arithmetic), short enough for >= ~2048 waves
-    const long long base = (long long)p.ncp * p.ncog * p.nxs * B;
-    int rows = H;
-    while (rows > 16 && base * ((H + rows - 1) / rows) < 2048) rows = (rows + 1) / 2;
+    // Work per wave: whole samples while that leaves >= ~2048 waves (the window prologue and the lane reduction are paid once per wave),
+    // then single samples cut into row chunks: long enough to amortise the reduction (~3 rows of arithmetic), short enough for ~2048 waves.
+    const long long base = (long long)p.ncp * p.ncog * p.nxs;
+    int bchunk = p.B, rows = H;
+    while (bchunk > 1 && base * ((p.B + bchunk - 1) / bchunk) < 2048) bchunk = (bchunk + 1) / 2;
+    const int nbc = (p.B + bchunk - 1) / bchunk;
+    while (bchunk == 1 && rows > 16 && base * nbc * ((H + rows - 1) / rows) < 2048) rows = (rows + 1) / 2;
+    p.bchunk = bchunk; p.nbc = nbc;
     p.rows = rows; p.nrc = (H + rows - 1) / rows;
-    const long long units = base * p.nrc;
+    const long long units = base * p.nrc * p.nbc;
     if (units >= (1ll << 31)) return fail(SMVS_ERR_ARG, "too many work units");
     if (stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
     else             hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
@@ -250,4 +276,20 @@ extern "C" SMVS_EXPORT int smvs_conv3x3_wgrad_cat(const float* xA, int CA, const
 {
     if (CB > 0 && !xB) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
     return wgrad_launch(xA, dy, dw, db, B, CA + CB, Cout, H, W, 1, stream, CB > 0 ? xB : nullptr, CA);
+}
+
+// The same sums over a LIST of n tensors of Bper samples each (host arrays of device pointers; win2 null or n pointers): the planes of
+// a training step.  dw / dgrid_sum are ACCUMULATED into (zeroed by the caller), so lists longer than one launch's table just continue.
+extern "C" SMVS_EXPORT int smvs_conv3x3_wgrad_list(const float* const* win, const float* const* win2, const float* const* grid, int n,
+                                                   float* dw, float* dgrid_sum, int Bper, int CA, int CB, int Cgrid, int H, int W, int stride,
+                                                   void* stream)
+{
+    if (!win || !grid || n < 1) return smvs::fail(SMVS_ERR_ARG, "empty tensor list");
+    for (int i = 0; i < n; i += smvs::WGRAD_LIST_MAX) {
+        const int m = n - i < smvs::WGRAD_LIST_MAX ? n - i : smvs::WGRAD_LIST_MAX;
+        const int rc = wgrad_launch(nullptr, nullptr, dw, dgrid_sum, Bper, CA + CB, Cgrid, H, W, stride, stream, nullptr, CA, m, win + i,
+                                    (win2 && CB > 0) ? win2 + i : nullptr, grid + i);
+        if (rc) return rc;
+    }
+    return SMVS_OK;
 }

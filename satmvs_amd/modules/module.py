@@ -432,6 +432,102 @@ class _WgradArena:
         return False
 
 
+_ZERO_SCALAR = {}       # device -> 0-dim float32 zero: the storage every deferred-gradient placeholder expands
+
+
+def _placeholder(like):
+    """Stand-in for a weight gradient that _WgradSink will deliver later: a stride-0 expansion of one shared zero (no kernel, no memory)."""
+    z = _ZERO_SCALAR.get(like.device)
+    if z is None:
+        z = _ZERO_SCALAR[like.device] = torch.zeros((), dtype=torch.float32, device=like.device)
+    return z.expand(like.shape)
+
+
+def _is_placeholder(g):
+    z = _ZERO_SCALAR.get(g.device)
+    return z is not None and g.data_ptr() == z.data_ptr() and g.numel() > 1 and all(st == 0 for st in g.stride())
+
+
+class _WgradSink:
+    """Weight gradients of one training forward of a regulariser, DEFERRED: the plane loop calls every 3x3 layer once per plane, and a
+    weight-gradient launch per call is a 13 us latency floor on these shapes (~1 300 per training step of the 48/32/8 cascade, the
+    largest item of the step after the ConvGRU convolutions went native).  With the sink active a layer's backward only records
+    (window tensor(s), grid tensor) of its plane and returns a placeholder; when autograd reaches the parameter (_PlaneViewsFn: after
+    the last plane) ONE smvs_conv3x3_wgrad_list launch per layer sums over all planes."""
+    current = None
+
+    def __init__(self):
+        self.layers = {}        # weight address -> {"entries": [(win, win2, grid)], "meta": ..., "weight_shape": ...}
+        self.bias_of = {}       # bias address -> weight address (layers whose bias gradient is the grid tensor's sum)
+        self.results = {}       # weight address -> (dw, db or None)
+
+    def __enter__(self):
+        self.prev, _WgradSink.current = _WgradSink.current, self
+        return self
+
+    def __exit__(self, *exc):
+        _WgradSink.current = self.prev
+        return False
+
+    def add(self, weight, bias, win, win2, grid, stride):
+        key = weight.data_ptr()
+        self.results.pop(key, None)                              # (a second backward through the same graph starts over)
+        lay = self.layers.get(key)
+        if lay is None:
+            lay = self.layers[key] = {"entries": [], "shape": tuple(weight.shape), "stride": stride, "sums": bias is not None}
+            if bias is not None:
+                self.bias_of[bias.data_ptr()] = key
+        lay["entries"].append((win, win2, grid))
+
+    def result(self, key):
+        res = self.results.get(key)
+        if res is None:
+            lay = self.layers.pop(key)
+            ent = lay["entries"]
+            win0, win20, grid0 = ent[0]
+            dev = win0.device
+            nw = 1
+            for n in lay["shape"]:
+                nw *= n
+            Bper, CA = win0.shape[0], win0.shape[1]
+            CB = win20.shape[1] if win20 is not None else 0
+            Cg, H, W = grid0.shape[1], grid0.shape[2], grid0.shape[3]
+            buf = torch.zeros((nw + (Cg if lay["sums"] else 0),), dtype=torch.float32, device=dev)
+            dw = buf[:nw].view(lay["shape"])
+            with torch.cuda.device(dev):
+                _lib.call("smvs_conv3x3_wgrad_list", _lib.ptr_array([e[0] for e in ent]),
+                          _lib.ptr_array([e[1] for e in ent]) if win20 is not None else None, _lib.ptr_array([e[2] for e in ent]), len(ent),
+                          _lib.ptr(dw), _lib.ptr(buf[nw:]) if lay["sums"] else None, Bper, CA, CB, Cg, H, W, lay["stride"],
+                          _lib.current_stream(dev))
+            res = self.results[key] = (dw, buf[nw:] if lay["sums"] else None)
+        return res
+
+
+class _PlaneViewsFn(torch.autograd.Function):
+    """The D per-plane views of a parameter (RED_Regularization._per_plane_parameters) with the gradients summed here: whatever the
+    planes delivered as real tensors (one stack + one sum) plus what the layer's backward deferred to the sink."""
+
+    @staticmethod
+    def forward(ctx, p, d_num, sink):
+        ctx.sink, ctx.ptr = sink, p.data_ptr()
+        return p.unsqueeze(0).expand(d_num, *p.shape).unbind(0)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        real = [g for g in grads if g is not None and not _is_placeholder(g)]
+        total = None
+        sink = ctx.sink
+        if sink is not None:
+            if ctx.ptr in sink.layers or ctx.ptr in sink.results:
+                total = sink.result(ctx.ptr)[0]
+            elif ctx.ptr in sink.bias_of and (sink.bias_of[ctx.ptr] in sink.layers or sink.bias_of[ctx.ptr] in sink.results):
+                total = sink.result(sink.bias_of[ctx.ptr])[1]
+        if real:
+            s_ = real[0] if len(real) == 1 else torch.stack(real).sum(0)
+            total = s_ if total is None else total + s_
+        return total, None, None
+
+
 class _Conv3x3WgradFn(torch.autograd.Function):
     """A 3x3 / pad 1 nn.Conv2d (stride 1 or 2) or nn.ConvTranspose2d (stride 2 with output_padding 1, or stride 1) whose WEIGHT and BIAS
     gradients come from smvs_conv3x3_wgrad_strided (csrc/conv_wgrad.hip); the forward and the input gradient stay torch's (MIOpen's
@@ -443,7 +539,9 @@ class _Conv3x3WgradFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, transposed):
         ctx.save_for_backward(x, weight)
         ctx.meta = (bias is not None, int(stride), bool(transposed))
-        arena = _WgradArena.current
+        ctx.sink = _WgradSink.current
+        ctx.bias = bias if (ctx.sink is not None and bias is not None and not transposed) else None
+        arena = _WgradArena.current if ctx.sink is None else None
         ctx.zeroed = arena.take(weight.numel() + (weight.shape[0] if bias is not None and not transposed else 0)) if arena is not None else None
         if transposed:
             return F.conv_transpose2d(x, weight, bias, stride=stride, padding=1, output_padding=stride - 1)
@@ -465,6 +563,10 @@ class _Conv3x3WgradFn(torch.autograd.Function):
             Cw = window.shape[1]
             nw = weight.numel()
             sums = has_bias and not transposed                              # a convolution's bias gradient = the grid tensor's sums
+            if ctx.sink is not None:                                        # deferred: one launch per layer after the last plane
+                ctx.sink.add(weight, ctx.bias, window, None, grid, stride)
+                db = (_placeholder(ctx.bias) if sums else dy.sum((0, 2, 3))) if has_bias else None
+                return dx, _placeholder(weight), db, None, None
             buf, ctx.zeroed = ctx.zeroed, None                              # (a second backward through the same graph gets fresh memory)
             if buf is None or buf.device != xc.device:
                 buf = torch.zeros((nw + (Cg if sums else 0),), dtype=torch.float32, device=xc.device)    # one fill for both gradients
@@ -518,7 +620,9 @@ class _Conv3x3CatNativeFn(torch.autograd.Function):
                       _lib.ptr(bias) if bias is not None else None, _lib.ptr(out), B, Cout, H, W, _lib.current_stream(xa.device))
         ctx.save_for_backward(xa, xb, weight)
         ctx.has_bias = bias is not None
-        arena = _WgradArena.current
+        ctx.sink = _WgradSink.current
+        ctx.bias = bias if ctx.sink is not None else None
+        arena = _WgradArena.current if ctx.sink is None else None
         ctx.zeroed = arena.take(weight.numel() + (Cout if bias is not None else 0)) if arena is not None else None
         return out
 
@@ -538,7 +642,11 @@ class _Conv3x3CatNativeFn(torch.autograd.Function):
                           B, CA + CB, H, W, _lib.current_stream(dev))
                 dxa = dx[:, :CA] if ctx.needs_input_grad[0] else None
                 dxb = dx[:, CA:] if xb is not None and ctx.needs_input_grad[1] else None
-            if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            if (ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3])) and ctx.sink is not None:
+                ctx.sink.add(weight, ctx.bias, xa, xb, dy, 1)                # deferred: one launch per layer after the last plane
+                dw = _placeholder(weight)
+                db = _placeholder(ctx.bias) if ctx.has_bias else None
+            elif ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
                 nw = weight.numel()
                 buf, ctx.zeroed = ctx.zeroed, None
                 if buf is None or buf.device != dev:
@@ -791,6 +899,14 @@ class RED_Regularization(_REDCore):
             return torch.stack(outs, dim=1).squeeze(2)
         per_plane = sum(((m.weight.numel() + (m.weight.shape[0] if m.bias is not None else 0)) + 3) & ~3
                         for m in self.modules() if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and m.kernel_size == (3, 3))
+        sink = planes.pop("", None)
+        if sink is not None:                                     # weight gradients deferred to one launch per layer (_WgradSink)
+            with sink:
+                for d in range(d_num):
+                    with _reparametrize(self, {n: t[d] for n, t in planes.items()}):
+                        reg, *s = self.step(volume_variance[:, :, d], *s)
+                    outs.append(reg)
+            return torch.stack(outs, dim=1).squeeze(2)
         with _WgradArena(per_plane * d_num if volume_variance.is_cuda else 0, volume_variance.device):
             for d in range(d_num):
                 with _reparametrize(self, {n: t[d] for n, t in planes.items()}):
@@ -810,7 +926,12 @@ class RED_Regularization(_REDCore):
         named = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
         if not named:
             return None
-        return {n: torch.unbind(p.unsqueeze(0).expand(d_num, *p.shape), 0) for n, p in named}
+        if os.environ.get("SMVS_TRAIN_DEFER_WGRAD", "1") == "0" or not named[0][1].is_cuda or (_TRAIN_COMPOSITE_MASK & 8):
+            return {n: torch.unbind(p.unsqueeze(0).expand(d_num, *p.shape), 0) for n, p in named}
+        sink = _WgradSink()
+        views = {n: _PlaneViewsFn.apply(p, d_num, sink) for n, p in named}
+        views[""] = sink                                         # (popped by forward)
+        return views
 
 
 class slice_RED_Regularization(_REDCore):
