@@ -224,20 +224,24 @@ int smvs_conv3x3_wgrad_cat(const float* xA, int CA, const float* xB, int CB, con
 int smvs_conv3x3_wgrad_list(const float* const* win, const float* const* win2, const float* const* grid, int n,
                             float* dw, float* dgrid_sum, int Bper, int CA, int CB, int Cgrid, int H, int W, int stride, void* stream);
 
-/* A single 3x3 / stride 1 / pad 1 convolution over cat(xA, xB) on the kernels of the RED plane loop -- the ConvGRU convolutions of the
- * TRAINING forward (modules/module.py:34-57 under autograd) and their input gradients:
+/* A single 3x3 / pad 1 layer of the RED regulariser as a stand-alone call on the kernels of the plane loop -- the TRAINING forward of
+ * its convolutions (modules/module.py:34-57, :625-644 under autograd) and their input gradients:
  *   smvs_conv3x3_packed_floats(cin, cout)  floats of the packed weights
- *   smvs_conv3x3_pack(w, packed, cin, cout, adjoint)
- *       adjoint 0: w = nn.Conv2d weight (cout, cin, 3, 3);
- *       adjoint 1: w = the weight (cin, cout, 3, 3) of the convolution whose INPUT gradient is wanted: the packed correlation maps that
- *                  layer's output gradient (cin channels) to its input gradient (cout channels)
- *   smvs_conv3x3_fwd  out (B,Cout,H,W) = correlation of cat(xA (B,CA,H,W), xB (B,CB,H,W) or NULL) with the packed weights (+ bias (Cout) or NULL)
- * float32; accumulation in input-channel order (direct kernels) or as a k-ordered fmaf chain on v_mfma_f32_32x32x2_f32 (layers with
- * 32 / 64 / 128 output channels): same class of rounding as torch's direct convolution, 2e-5 relative in the tests. */
+ *   smvs_conv3x3_pack(w, packed, cin, cout, layout): the correlation from cin to cout channels whose weights are read from w as
+ *       layout 0: w[co][ci][ky][kx]      an nn.Conv2d weight (stride 1 / 2); the input gradient of an nn.ConvTranspose2d of weight (cout,cin,3,3)
+ *       layout 1: w[ci][co][ky][kx] kept as scatter taps for kind 2: an nn.ConvTranspose2d(stride 2) weight; the input gradient of a
+ *                                        stride-2 nn.Conv2d of weight (cin, cout, 3, 3)
+ *       layout 2: w[ci][co][2-ky][2-kx]  a stride-1 nn.ConvTranspose2d as a correlation; the input gradient of a stride-1 nn.Conv2d of
+ *                                        weight (cin, cout, 3, 3)
+ *   smvs_conv3x3_fwd(kind, ...)  out = [relu](layer(cat(xA (B,CA,H,W), xB (B,CB,H,W) or NULL)) + bias (Cout) or NULL)
+ *       kind 0: correlation, stride 1, out (B,Cout,H,W);   kind 1: correlation, stride 2 (H, W even), out (B,Cout,H/2,W/2);
+ *       kind 2: transposed convolution, stride 2, pad 1, output_padding 1 (layout-1 weights; one operand, no bias), out (B,Cout,2H,2W)
+ * float32; accumulation in input-channel order (direct kernels) or as a k-ordered fmaf chain on v_mfma_f32_32x32x2_f32 (correlations
+ * with 32 / 64 / 128 output channels): same class of rounding as torch's direct convolution, 2e-5 relative in the tests. */
 size_t smvs_conv3x3_packed_floats(int cin, int cout);
-int smvs_conv3x3_pack(const float* w, float* packed, int cin, int cout, int adjoint, void* stream);
-int smvs_conv3x3_fwd(const float* xA, int CA, const float* xB, int CB, const float* packed, const float* bias, float* out,
-                     int B, int Cout, int H, int W, void* stream);
+int smvs_conv3x3_pack(const float* w, float* packed, int cin, int cout, int layout, void* stream);
+int smvs_conv3x3_fwd(int kind, const float* xA, int CA, const float* xB, int CB, const float* packed, const float* bias, float* out,
+                     int B, int Cout, int H, int W, int relu, void* stream);
 
 /* Both gate norms of a ConvGRU cell in one call (modules/module.py:15-16, :37-40): x (B, 2C, HW) contiguous = the gate
  * convolution's output; channels [0, C) are normalised with (gamma, beta), channels [C, 2C) with (gamma2, beta2), each half

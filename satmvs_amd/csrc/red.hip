@@ -1634,15 +1634,22 @@ SMVS_EXPORT int smvs_red_pack_weights(const float* const* params, int C, float* 
     return SMVS_OK;
 }
 
-// ---- a single 3x3 / stride 1 / pad 1 convolution over cat(xA, xB) (training path of the regulariser) ---------------------------
-// The ConvGRU convolutions of the TRAINING forward and their input gradients (modules/module.py:_Conv3x3NativeFn) on the kernels of
-// the plane loop above -- MIOpen's Winograd kernels take ~19 us per call on these shapes (1 400 calls per training step of the
-// 48/32/8 cascade, profiles/r04_train_step.txt), and the concatenation of (x, h) is a launch of its own.
+// ---- a single 3x3 / pad 1 layer of the regulariser as a stand-alone call (training path) --------------------------------------
+// The TRAINING forward of the regulariser's layers and their input gradients (modules/module.py:_Conv3x3NativeFn) on the kernels of the
+// plane loop above -- MIOpen's kernels take ~19 us per call on these shapes (2 600 calls per training step of the 48/32/8 cascade,
+// profiles/r04_train_step.txt), the transposed ones go through im2col / GEMM / col2im, and the concatenation of (x, h) is a launch of
+// its own.
 //   smvs_conv3x3_packed_floats(cin, cout): floats of the packed weights (direct order + the MFMA order where the layer qualifies)
-//   smvs_conv3x3_pack(w, packed, cin, cout, adjoint): adjoint = 0: w = nn.Conv2d weight (cout, cin, 3, 3);
-//       adjoint = 1: w = the weight (cin, cout, 3, 3) of the convolution whose INPUT gradient is computed: the packed correlation maps
-//       its output gradient (cin channels) to its input gradient (cout channels) -- transposed, taps flipped
-//   smvs_conv3x3_fwd: out (B, Cout, H, W) = correlation of cat(xA (B,CA,H,W), xB (B,CB,H,W) or null) with the packed weights (+ bias)
+//   smvs_conv3x3_pack(w, packed, cin, cout, layout): the correlation from cin to cout channels whose weights are read from w as
+//       layout 0: w[co][ci][ky][kx]         -- an nn.Conv2d weight (stride 1 or 2); or, for the input gradient of an nn.ConvTranspose2d
+//                                              with weight (cout, cin, 3, 3): the same array
+//       layout 1: w[ci][co][ky][kx], taps kept as SCATTER taps of the stride-2 transposed kernel (kind 2 below) -- an nn.ConvTranspose2d
+//                                              weight; or the input gradient of a stride-2 nn.Conv2d with weight (cin, cout, 3, 3)
+//       layout 2: w[ci][co][2-ky][2-kx]     -- a stride-1 nn.ConvTranspose2d as a correlation; or the input gradient of a stride-1
+//                                              nn.Conv2d with weight (cin, cout, 3, 3)
+//   smvs_conv3x3_fwd(kind, ...): out = [relu](layer(cat(xA (B,CA,H,W), xB (B,CB,H,W) or null)) + bias)
+//       kind 0: correlation, stride 1, out (B,Cout,H,W);  kind 1: correlation, stride 2 (H, W even), out (B,Cout,H/2,W/2);
+//       kind 2: transposed convolution, stride 2, output_padding 1 (weights of layout 1; xB and bias unused), out (B,Cout,2H,2W)
 SMVS_EXPORT size_t smvs_conv3x3_packed_floats(int cin, int cout)
 {
     using namespace smvs;
@@ -1650,38 +1657,45 @@ SMVS_EXPORT size_t smvs_conv3x3_packed_floats(int cin, int cout)
     return packed_conv_floats(cin, cout) + (mfma_conv_ok(cin, 0, cout) ? mfma_packed_floats(cin, cout, 9) : 0);
 }
 
-SMVS_EXPORT int smvs_conv3x3_pack(const float* w, float* packed, int cin, int cout, int adjoint, void* stream)
+SMVS_EXPORT int smvs_conv3x3_pack(const float* w, float* packed, int cin, int cout, int layout, void* stream)
 {
     using namespace smvs;
     if (!w || !packed) return fail(SMVS_ERR_ARG, "null pointer argument");
-    if (cin < 1 || cout < 1) return fail(SMVS_ERR_ARG, "non-positive channel count");
+    if (cin < 1 || cout < 1 || layout < 0 || layout > 2) return fail(SMVS_ERR_ARG, "bad channel count or layout");
     hipStream_t st = (hipStream_t)stream;
     const int n = (int)packed_conv_floats(cin, cout);
-    hipLaunchKernelGGL(pack_conv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, packed, cin, cout, adjoint ? 2 : 0);
-    if (mfma_conv_ok(cin, 0, cout)) {
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, packed, cin, cout, layout);
+    if (layout != 1 && mfma_conv_ok(cin, 0, cout)) {
         const int nm = (int)mfma_packed_floats(cin, cout, 9);
-        hipLaunchKernelGGL(mfma_pack_kernel, dim3((nm + 255) / 256), dim3(256), 0, st, w, packed + n, cin, cout, 9, adjoint ? 1 : 0);
+        hipLaunchKernelGGL(mfma_pack_kernel, dim3((nm + 255) / 256), dim3(256), 0, st, w, packed + n, cin, cout, 9, layout == 2 ? 1 : 0);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "conv3x3_pack launch: %s", hipGetErrorString(e));
     return SMVS_OK;
 }
 
-SMVS_EXPORT int smvs_conv3x3_fwd(const float* xA, int CA, const float* xB, int CB, const float* packed, const float* bias, float* out,
-                                 int B, int Cout, int H, int W, void* stream)
+SMVS_EXPORT int smvs_conv3x3_fwd(int kind, const float* xA, int CA, const float* xB, int CB, const float* packed, const float* bias, float* out,
+                                 int B, int Cout, int H, int W, int relu, void* stream)
 {
     using namespace smvs;
     if (!xA || !packed || !out || (CB > 0 && !xB)) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (kind < 0 || kind > 2) return fail(SMVS_ERR_ARG, "kind must be 0, 1 or 2");
     if (B < 1 || CA < 1 || CB < 0 || Cout < 1 || H < 1 || W < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
-    if ((long long)(CA > CB ? CA : CB) * H * W * 4 >= (1ll << 31) || (long long)Cout * H * W * 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "plane too large");
+    if (kind == 1 && ((H | W) & 1)) return fail(SMVS_ERR_ARG, "stride 2: H and W must be even");
+    if (kind == 2 && (CB > 0 || bias)) return fail(SMVS_ERR_ARG, "transposed layer: one operand, no bias");
+    const int Ho = kind == 1 ? H / 2 : kind == 2 ? 2 * H : H, Wo = kind == 1 ? W / 2 : kind == 2 ? 2 * W : W;
+    if ((long long)(CA > CB ? CA : CB) * H * W * 4 >= (1ll << 31) || (long long)Cout * Ho * Wo * 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "plane too large");
     if ((long long)B * ((Cout + COT - 1) / COT) > 65535) return fail(SMVS_ERR_ARG, "batch too large");
     const int Cin = CA + CB;
     ConvArgs a{};
     a.inA = xA; a.CA = CA; a.scaleA = 1.0f; a.inB = CB > 0 ? xB : nullptr; a.CB = CB;
-    a.w = packed; a.bias = bias; a.out = out; a.Cout = Cout; a.Hi = a.Ho = H; a.Wi = a.Wo = W;
-    // the MFMA kernel reads its per-channel vectors as aligned float4 and pairs input channels: both operands even, bias 16-byte aligned
-    const bool mf = mfma_conv_ok(Cin, 0, Cout) && CA % 2 == 0 && (!bias || ((uintptr_t)bias & 15) == 0);
-    launch_conv(1, a, B, (hipStream_t)stream, mf ? packed + packed_conv_floats(Cin, Cout) : nullptr);
+    a.w = packed; a.bias = bias; a.out = out; a.Cout = Cout; a.Hi = H; a.Wi = W; a.Ho = Ho; a.Wo = Wo; a.relu = relu ? 1 : 0;
+    if (kind == 2) launch_convT(a, B, (hipStream_t)stream);
+    else {
+        // the MFMA kernel reads its per-channel vectors as aligned float4 and pairs input channels: both operands even, bias 16-byte aligned
+        const bool mf = mfma_conv_ok(Cin, 0, Cout) && CA % 2 == 0 && (!bias || ((uintptr_t)bias & 15) == 0);
+        launch_conv(kind == 1 ? 2 : 1, a, B, (hipStream_t)stream, mf ? packed + packed_conv_floats(Cin, Cout) : nullptr);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "conv3x3_fwd launch: %s", hipGetErrorString(e));
     return SMVS_OK;

@@ -185,7 +185,7 @@ class ConvReLU(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
 
     def forward(self, x):
-        return F.relu(_conv3x3(self.conv, x), inplace=True)
+        return _conv3x3_cat(self.conv, x, None, True)
 
 
 class ConvTransReLU(nn.Module):
@@ -195,7 +195,7 @@ class ConvTransReLU(nn.Module):
                                        output_padding=output_pad, bias=False)
 
     def forward(self, x):
-        return F.relu(_conv3x3(self.conv, x), inplace=True)
+        return _conv3x3_cat(self.conv, x, None, True)
 
 
 # ---- recurrent regulariser (RED) ------------------------------------------------------------------------
@@ -579,99 +579,137 @@ class _Conv3x3WgradFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
-_CONV_PACK = {}         # (weight address, adjoint) -> (version, epoch, storage weak reference, packed tensor): one entry per layer and direction
+_CONV_PACK = {}         # (weight address, layout, cin) -> (version, epoch, storage weak reference, packed tensor): one entry per layer and direction
 
 
-def _conv_packed(weight, adjoint):
-    """Kernel-layout copy of a (Cout, Cin, 3, 3) weight for smvs_conv3x3_fwd (adjoint: for the input gradient), packed once per
-    parameter version -- every plane of a training step uses a view of the same parameter."""
+def _conv_packed(weight, layout, cin, cout):
+    """Kernel-layout copy of a 3x3 weight for smvs_conv3x3_fwd (layouts: include/satmvs.h), packed once per parameter version --
+    every plane of a training step uses a view of the same parameter."""
     from torch.multiprocessing.reductions import StorageWeakRef
-    key = (weight.data_ptr(), bool(adjoint), weight.device.index)
+    key = (weight.data_ptr(), layout, cin, weight.device.index)
     hit = _CONV_PACK.get(key)
-    if hit is not None and hit[0] == weight._version and hit[1] == _PARAM_EPOCH[0] and not hit[2].expired() and hit[3].shape[0] > 0:
+    if hit is not None and hit[0] == weight._version and hit[1] == _PARAM_EPOCH[0] and not hit[2].expired():
         return hit[3]
-    cout, cin = weight.shape[0], weight.shape[1]
-    ci, co = (cout, cin) if adjoint else (cin, cout)
-    packed = torch.empty((_lib.load().smvs_conv3x3_packed_floats(ci, co),), dtype=torch.float32, device=weight.device)
+    packed = torch.empty((_lib.load().smvs_conv3x3_packed_floats(cin, cout),), dtype=torch.float32, device=weight.device)
     with torch.cuda.device(weight.device):
-        _lib.call("smvs_conv3x3_pack", _lib.ptr(weight), _lib.ptr(packed), ci, co, 1 if adjoint else 0, _lib.current_stream(weight.device))
+        _lib.call("smvs_conv3x3_pack", _lib.ptr(weight), _lib.ptr(packed), cin, cout, layout, _lib.current_stream(weight.device))
     if len(_CONV_PACK) > 256:
         _CONV_PACK.clear()
     _CONV_PACK[key] = (weight._version, _PARAM_EPOCH[0], StorageWeakRef(weight.untyped_storage()), packed)
     return packed
 
 
-class _Conv3x3CatNativeFn(torch.autograd.Function):
-    """conv2d(cat(xa, xb), weight, bias), 3x3 / stride 1 / pad 1, on the kernels of the RED plane loop (smvs_conv3x3_fwd: direct or
-    MFMA by channel count) -- forward, input gradient (the same kernels on the transposed, tap-flipped weights) and weight / bias
-    gradient (smvs_conv3x3_wgrad_cat), without the concatenated tensor.  xb may be None."""
+# layer kinds of _Conv3x3NativeFn: (forward kernel kind, forward weight layout, input-gradient kernel kind, its weight layout, window stride)
+_NATIVE_KINDS = {"c1": (0, 0, 0, 2, 1),      # nn.Conv2d stride 1:           correlation / correlation with the transposed, flipped weights
+                 "c2": (1, 0, 2, 1, 2),      # nn.Conv2d stride 2:           strided correlation / stride-2 transposed convolution
+                 "t2": (2, 1, 1, 0, 2),      # nn.ConvTranspose2d stride 2:  transposed convolution / strided correlation
+                 "t1": (0, 2, 0, 0, 1)}      # nn.ConvTranspose2d stride 1:  correlation with flipped taps / correlation
+
+
+class _Conv3x3NativeFn(torch.autograd.Function):
+    """[relu](layer(cat(xa, xb))) for the regulariser's 3x3 / pad 1 layers on the kernels of the RED plane loop (smvs_conv3x3_fwd: direct
+    or MFMA by channel count): forward, input gradient (the adjoint layer on the same kernels) and weight / bias gradient
+    (smvs_conv3x3_wgrad_list through _WgradSink, or smvs_conv3x3_wgrad_cat / _strided per call), without the concatenated tensor.
+    xb may be None; kind: _NATIVE_KINDS."""
 
     @staticmethod
-    def forward(ctx, xa, xb, weight, bias):
+    def forward(ctx, xa, xb, weight, bias, kind, relu):
+        fk, flay, _, _, _ = _NATIVE_KINDS[kind]
         xa = _f32c_fast(xa)
         xb = _f32c_fast(xb) if xb is not None else None
         B, CA, H, W = xa.shape
         CB = xb.shape[1] if xb is not None else 0
-        Cout = weight.shape[0]
-        out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=xa.device)
-        packed = _conv_packed(weight, False)
+        transposed = kind[0] == "t"
+        Cout = weight.shape[1] if transposed else weight.shape[0]
+        Ho, Wo = (H // 2, W // 2) if kind == "c2" else (2 * H, 2 * W) if kind == "t2" else (H, W)
+        out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=xa.device)
+        packed = _conv_packed(weight, flay, CA + CB, Cout)
+        fused_bias = bias if kind != "t2" else None              # (the stride-2 transposed layers of the regulariser have no bias)
         with torch.cuda.device(xa.device):
-            _lib.call("smvs_conv3x3_fwd", _lib.ptr(xa), CA, _lib.ptr(xb) if xb is not None else None, CB, _lib.ptr(packed),
-                      _lib.ptr(bias) if bias is not None else None, _lib.ptr(out), B, Cout, H, W, _lib.current_stream(xa.device))
-        ctx.save_for_backward(xa, xb, weight)
-        ctx.has_bias = bias is not None
+            _lib.call("smvs_conv3x3_fwd", fk, _lib.ptr(xa), CA, _lib.ptr(xb) if xb is not None else None, CB, _lib.ptr(packed),
+                      _lib.ptr(fused_bias) if fused_bias is not None else None, _lib.ptr(out), B, Cout, H, W, 1 if relu else 0,
+                      _lib.current_stream(xa.device))
+        ctx.save_for_backward(xa, xb, weight, out if relu else None)
+        ctx.kind, ctx.relu, ctx.has_bias = kind, bool(relu), bias is not None
         ctx.sink = _WgradSink.current
-        ctx.bias = bias if ctx.sink is not None else None
+        sums = bias is not None and not transposed               # a convolution's bias gradient = the sums of its output gradient
+        ctx.bias = bias if (ctx.sink is not None and sums) else None
         arena = _WgradArena.current if ctx.sink is None else None
-        ctx.zeroed = arena.take(weight.numel() + (Cout if bias is not None else 0)) if arena is not None else None
+        ctx.zeroed = arena.take(weight.numel() + (Cout if sums else 0)) if arena is not None else None
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        xa, xb, weight = ctx.saved_tensors
+        xa, xb, weight, out = ctx.saved_tensors
+        kind = ctx.kind
+        _, _, bk, blay, stride = _NATIVE_KINDS[kind]
         dy = _f32c_fast(dy)
+        if ctx.relu:
+            dy = torch.ops.aten.threshold_backward(dy, out, 0.0)
         B, CA, H, W = xa.shape
         CB = xb.shape[1] if xb is not None else 0
-        Cout = weight.shape[0]
+        transposed = kind[0] == "t"
+        Cout = dy.shape[1]
         dev = xa.device
         dxa = dxb = dw = db = None
         with torch.cuda.device(dev):
             if ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1]):
                 dx = torch.empty((B, CA + CB, H, W), dtype=torch.float32, device=dev)
-                _lib.call("smvs_conv3x3_fwd", _lib.ptr(dy), Cout, None, 0, _lib.ptr(_conv_packed(weight, True)), None, _lib.ptr(dx),
-                          B, CA + CB, H, W, _lib.current_stream(dev))
+                _lib.call("smvs_conv3x3_fwd", bk, _lib.ptr(dy), Cout, None, 0, _lib.ptr(_conv_packed(weight, blay, Cout, CA + CB)), None,
+                          _lib.ptr(dx), B, CA + CB, dy.shape[2], dy.shape[3], 0, _lib.current_stream(dev))
                 dxa = dx[:, :CA] if ctx.needs_input_grad[0] else None
                 dxb = dx[:, CA:] if xb is not None and ctx.needs_input_grad[1] else None
-            if (ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3])) and ctx.sink is not None:
-                ctx.sink.add(weight, ctx.bias, xa, xb, dy, 1)                # deferred: one launch per layer after the last plane
-                dw = _placeholder(weight)
-                db = _placeholder(ctx.bias) if ctx.has_bias else None
-            elif ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
-                nw = weight.numel()
-                buf, ctx.zeroed = ctx.zeroed, None
-                if buf is None or buf.device != dev:
-                    buf = torch.zeros((nw + (Cout if ctx.has_bias else 0),), dtype=torch.float32, device=dev)
-                dw = buf[:nw].view(weight.shape)
-                _lib.call("smvs_conv3x3_wgrad_cat", _lib.ptr(xa), CA, _lib.ptr(xb) if xb is not None else None, CB, _lib.ptr(dy), _lib.ptr(dw),
-                          _lib.ptr(buf[nw:]) if ctx.has_bias else None, B, Cout, H, W, _lib.current_stream(dev))
-                db = buf[nw:] if ctx.has_bias else None
-        return dxa, dxb, dw, db
+            if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+                sums = ctx.has_bias and not transposed
+                # the tensor read through the taps / the one on the output grid (they swap for the transposed layers)
+                window, win2, grid = (dy, None, xa) if transposed else (xa, xb, dy)
+                if ctx.sink is not None:                         # deferred: one launch per layer after the last plane
+                    ctx.sink.add(weight, ctx.bias, window, win2, grid, stride)
+                    dw = _placeholder(weight)
+                    db = (_placeholder(ctx.bias) if sums else dy.sum((0, 2, 3))) if ctx.has_bias else None
+                else:
+                    nw = weight.numel()
+                    buf, ctx.zeroed = ctx.zeroed, None           # (a second backward through the same graph gets fresh memory)
+                    if buf is None or buf.device != dev:
+                        buf = torch.zeros((nw + (Cout if sums else 0),), dtype=torch.float32, device=dev)
+                    dw = buf[:nw].view(weight.shape)
+                    _lib.call("smvs_conv3x3_wgrad_list", _lib.ptr_array([window]), _lib.ptr_array([win2]) if win2 is not None else None,
+                              _lib.ptr_array([grid]), 1, _lib.ptr(dw), _lib.ptr(buf[nw:]) if sums else None, B, window.shape[1],
+                              win2.shape[1] if win2 is not None else 0, grid.shape[1], grid.shape[2], grid.shape[3], stride,
+                              _lib.current_stream(dev))
+                    if ctx.has_bias:
+                        db = buf[nw:] if sums else dy.sum((0, 2, 3))
+        return dxa, dxb, dw, db, None, None
 
 
-def _conv3x3_cat(conv, xa, xb=None):
-    """conv(cat(xa, xb)) for the ConvGRU cells' 3x3 convolutions: fully native under autograd on the GPU (SMVS_TRAIN_COMPOSITE_MASK
+def _native_kind(conv):
+    """_NATIVE_KINDS key of a 3x3 / pad 1 layer, or None."""
+    if conv.kernel_size != (3, 3) or conv.padding != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1 or conv.stride not in ((1, 1), (2, 2)):
+        return None
+    s = conv.stride[0]
+    if isinstance(conv, nn.ConvTranspose2d):
+        return ("t%d" % s) if conv.output_padding == (s - 1, s - 1) and (s == 1 or conv.bias is None) else None
+    return ("c%d" % s) if isinstance(conv, nn.Conv2d) else None
+
+
+def _conv3x3_cat(conv, xa, xb=None, relu=False):
+    """[relu](conv(cat(xa, xb))) for the regulariser's 3x3 layers: fully native under autograd on the GPU (SMVS_TRAIN_COMPOSITE_MASK
     bit 16 keeps torch's convolution with the native weight gradient, bit 8 torch's convolution alone)."""
     x_all = (xa,) if xb is None else (xa, xb)
-    if (xa.is_cuda and all(t.dtype is torch.float32 for t in x_all) and torch.is_grad_enabled() and conv.weight.requires_grad
-            and conv.weight.dtype is torch.float32 and conv.weight.is_contiguous() and isinstance(conv, nn.Conv2d)
-            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
-            and not (_TRAIN_COMPOSITE_MASK & 24) and (xb is None or xa.shape[1] % 2 == 0)
-            and max(t.shape[1] for t in x_all) * xa.shape[2] * xa.shape[3] * 4 < 2 ** 31 and conv.weight.shape[0] * xa.shape[2] * xa.shape[3] * 4 < 2 ** 31
-            and sum(t.shape[1] for t in x_all) * xa.shape[2] * xa.shape[3] * 4 < 2 ** 31
-            and xa.shape[0] * ((max(conv.weight.shape[0], conv.weight.shape[1]) + 7) // 8) <= 65535
+    kind = _native_kind(conv)
+    h, w = xa.shape[2], xa.shape[3]
+    cin = sum(t.shape[1] for t in x_all)
+    cout = conv.weight.shape[1] if isinstance(conv, nn.ConvTranspose2d) else conv.weight.shape[0]
+    if (kind is not None and xa.is_cuda and all(t.dtype is torch.float32 for t in x_all) and torch.is_grad_enabled() and conv.weight.requires_grad
+            and conv.weight.dtype is torch.float32 and conv.weight.is_contiguous()
+            and not (_TRAIN_COMPOSITE_MASK & 24) and (xb is None or (xa.shape[1] % 2 == 0 and kind == "c1"))
+            and (kind != "c2" or (h % 2 == 0 and w % 2 == 0))
+            and max(cin, cout) * h * w * 4 * (4 if kind == "t2" else 1) < 2 ** 31
+            and xa.shape[0] * ((max(cin, cout) + 7) // 8) <= 65535
             and (conv.bias is None or conv.bias.data_ptr() % 16 == 0)):
-        return _Conv3x3CatNativeFn.apply(xa, xb, conv.weight, conv.bias)
-    return _conv3x3(conv, xa if xb is None else torch.cat((xa, xb), dim=1))
+        return _Conv3x3NativeFn.apply(xa, xb, conv.weight, conv.bias, kind, relu)
+    y = _conv3x3(conv, xa if xb is None else torch.cat((xa, xb), dim=1))
+    return F.relu(y, inplace=True) if relu else y
 
 
 def _conv3x3(conv, x):
@@ -881,7 +919,7 @@ class _REDCore(nn.Module):
         r2, s2 = self.conv_gru2(e1, s2)
         u1 = self.upconv1(u2 + r2)
         r1, s1 = self.conv_gru1(neg, s1)
-        return _conv3x3(self.upconv2d, u1 + r1), s1, s2, s3, s4
+        return _conv3x3_cat(self.upconv2d, u1 + r1), s1, s2, s3, s4
 
 
 class RED_Regularization(_REDCore):

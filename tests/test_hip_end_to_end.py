@@ -731,7 +731,7 @@ def test_conv3x3_cat_native_matches_torch(dev, B, ca, cb, cout, H, W):
         t.grad = None
     y1 = M._conv3x3_cat(conv, xa, xb)
     native = ca % 2 == 0 or cb == 0
-    assert ("Conv3x3CatNative" in type(y1.grad_fn).__name__) == native
+    assert ("Conv3x3Native" in type(y1.grad_fn).__name__) == native
     assert float((y1 - y0).abs().max()) <= 2e-5 * float(y0.abs().max())
     y1.backward(gy)
     got = [conv.weight.grad, conv.bias.grad] + [t.grad for t in x_all]
@@ -744,6 +744,44 @@ def test_conv3x3_cat_native_matches_torch(dev, B, ca, cb, cout, H, W):
         conv.weight.mul_(0.5)
     y2 = M._conv3x3_cat(conv, xa, xb)
     assert float((y2 - conv(torch.cat(x_all, 1))).abs().max()) <= 2e-5 * float(y0.abs().max())
+
+
+@pytest.mark.parametrize("kind,B,cin,cout,H,W,bias", [
+    ("conv_s2", 1, 32, 16, 96, 192, False), ("conv_s2", 2, 16, 32, 24, 48, False), ("conv_s2", 1, 32, 64, 24, 48, False), ("conv_s2", 1, 8, 16, 384, 768, False),
+    ("convT_s2", 1, 16, 8, 48, 96, False), ("convT_s2", 2, 64, 32, 12, 24, False), ("convT_s2", 1, 32, 16, 96, 192, False),
+    ("convT_s1", 1, 8, 1, 96, 192, True), ("convT_s1", 2, 8, 1, 16, 72, True), ("conv_s1", 1, 24, 8, 40, 64, True)])
+def test_regulariser_layer_native_matches_torch(dev, kind, B, cin, cout, H, W, bias):
+    """modules.module._conv3x3_cat(conv, x, None, relu) for the regulariser's encoder / decoder layers: smvs_conv3x3_fwd kinds 1 (stride-2
+    correlation) and 2 (stride-2 transposed convolution) and the flipped-tap correlation of the transposed output layer, each with its
+    adjoint as the input gradient, the fused ReLU and its mask in the backward, and the weight / bias gradient -- against torch autograd of
+    relu(layer(x)).  2e-5 of each tensor's scale."""
+    from satmvs_amd.modules import module as M
+    torch.manual_seed(B * 1000 + cin * 10 + cout)
+    if kind == "conv_s2":
+        conv = torch.nn.Conv2d(cin, cout, 3, stride=2, padding=1, bias=bias).to(dev)
+    elif kind == "conv_s1":
+        conv = torch.nn.Conv2d(cin, cout, 3, stride=1, padding=1, bias=bias).to(dev)
+    elif kind == "convT_s2":
+        conv = torch.nn.ConvTranspose2d(cin, cout, 3, stride=2, padding=1, output_padding=1, bias=bias).to(dev)
+    else:
+        conv = torch.nn.ConvTranspose2d(cin, cout, 3, stride=1, padding=1, output_padding=0, bias=bias).to(dev)
+    relu = kind != "convT_s1"
+    x = torch.randn(B, cin, H, W, device=dev, requires_grad=True)
+    y0 = conv(x)
+    y0 = torch.relu(y0) if relu else y0
+    gy = torch.randn_like(y0)
+    y0.backward(gy)
+    want = [conv.weight.grad.clone(), x.grad.clone()] + ([conv.bias.grad.clone()] if bias else [])
+    conv.zero_grad(); x.grad = None
+    y1 = M._conv3x3_cat(conv, x, None, relu)
+    assert "Conv3x3Native" in type(y1.grad_fn).__name__
+    assert y1.shape == y0.shape and float((y1 - y0).abs().max()) <= 2e-5 * float(y0.abs().max())
+    y1.backward(gy)
+    got = [conv.weight.grad, x.grad] + ([conv.bias.grad] if bias else [])
+    for g, r, name in zip(got, want, ("weight", "x", "bias")):
+        scale = float(r.abs().max())
+        assert g.shape == r.shape
+        assert float((g - r).abs().max()) <= (2e-4 if name != "x" else 2e-5) * scale, (kind, name, float((g - r).abs().max()), scale)
 
 
 @pytest.mark.parametrize("kind,B,cin,cout,H,W,bias", [
