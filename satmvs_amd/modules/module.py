@@ -404,13 +404,14 @@ class GroupNorm1(nn.GroupNorm):
         return torch.sigmoid(y) if act == "sigmoid" else torch.tanh(y) if act == "tanh" else y
 
 
+_TLS = threading.local()     # the active _WgradArena / _WgradSink of THIS thread (nn.DataParallel runs its replicas on one thread per device)
+
+
 class _WgradArena:
     """Zero-initialised gradient buffers for one training forward of a regulariser: ONE fill per forward instead of one per
     convolution and plane (the native weight-gradient kernel accumulates with atomics into zeroed memory; ~800 fills per training
     step of the 48/32/8 cascade).  A fresh tensor per forward: nothing aliases across steps; each convolution call takes its slice at
     forward time and its backward writes there once."""
-    current = None
-
     def __init__(self, floats, device):
         self.buf = torch.zeros((floats,), dtype=torch.float32, device=device)
         self.off = 0
@@ -424,11 +425,11 @@ class _WgradArena:
         return v
 
     def __enter__(self):
-        self.prev, _WgradArena.current = _WgradArena.current, self
+        self.prev, _TLS.arena = getattr(_TLS, "arena", None), self
         return self
 
     def __exit__(self, *exc):
-        _WgradArena.current = self.prev
+        _TLS.arena = self.prev
         return False
 
 
@@ -454,19 +455,17 @@ class _WgradSink:
     largest item of the step after the ConvGRU convolutions went native).  With the sink active a layer's backward only records
     (window tensor(s), grid tensor) of its plane and returns a placeholder; when autograd reaches the parameter (_PlaneViewsFn: after
     the last plane) ONE smvs_conv3x3_wgrad_list launch per layer sums over all planes."""
-    current = None
-
     def __init__(self):
         self.layers = {}        # weight address -> {"entries": [(win, win2, grid)], "meta": ..., "weight_shape": ...}
         self.bias_of = {}       # bias address -> weight address (layers whose bias gradient is the grid tensor's sum)
         self.results = {}       # weight address -> (dw, db or None)
 
     def __enter__(self):
-        self.prev, _WgradSink.current = _WgradSink.current, self
+        self.prev, _TLS.sink = getattr(_TLS, "sink", None), self
         return self
 
     def __exit__(self, *exc):
-        _WgradSink.current = self.prev
+        _TLS.sink = self.prev
         return False
 
     def add(self, weight, bias, win, win2, grid, stride):
@@ -539,9 +538,9 @@ class _Conv3x3WgradFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, transposed):
         ctx.save_for_backward(x, weight)
         ctx.meta = (bias is not None, int(stride), bool(transposed))
-        ctx.sink = _WgradSink.current
+        ctx.sink = getattr(_TLS, "sink", None)
         ctx.bias = bias if (ctx.sink is not None and bias is not None and not transposed) else None
-        arena = _WgradArena.current if ctx.sink is None else None
+        arena = getattr(_TLS, "arena", None) if ctx.sink is None else None
         ctx.zeroed = arena.take(weight.numel() + (weight.shape[0] if bias is not None and not transposed else 0)) if arena is not None else None
         if transposed:
             return F.conv_transpose2d(x, weight, bias, stride=stride, padding=1, output_padding=stride - 1)
@@ -631,10 +630,10 @@ class _Conv3x3NativeFn(torch.autograd.Function):
                       _lib.current_stream(xa.device))
         ctx.save_for_backward(xa, xb, weight, out if relu else None)
         ctx.kind, ctx.relu, ctx.has_bias = kind, bool(relu), bias is not None
-        ctx.sink = _WgradSink.current
+        ctx.sink = getattr(_TLS, "sink", None)
         sums = bias is not None and not transposed               # a convolution's bias gradient = the sums of its output gradient
         ctx.bias = bias if (ctx.sink is not None and sums) else None
-        arena = _WgradArena.current if ctx.sink is None else None
+        arena = getattr(_TLS, "arena", None) if ctx.sink is None else None
         ctx.zeroed = arena.take(weight.numel() + (Cout if sums else 0)) if arena is not None else None
         return out
 
