@@ -240,8 +240,10 @@ int smvs_conv3x3_wgrad_list(const float* const* win, const float* const* win2, c
  * with 32 / 64 / 128 output channels): same class of rounding as torch's direct convolution, 2e-5 relative in the tests. */
 size_t smvs_conv3x3_packed_floats(int cin, int cout);
 int smvs_conv3x3_pack(const float* w, float* packed, int cin, int cout, int layout, void* stream);
-int smvs_conv3x3_fwd(int kind, const float* xA, int CA, const float* xB, int CB, const float* packed, const float* bias, float* out,
-                     int B, int Cout, int H, int W, int relu, void* stream);
+int smvs_conv3x3_fwd(int kind, const float* xA, int CA, const float* xB, int CB, const float* packed, const float* bias, const float* init,
+                     float* out, int B, int Cout, int H, int W, int relu, void* stream);
+/* init (kinds 0 / 1; same shape as out, or NULL; may be out itself): added to the sums before bias / ReLU -- an input gradient that continues
+ * the contributions already collected for that tensor (whole-cell ConvGRU backward). */
 
 /* Both gate norms of a ConvGRU cell in one call (modules/module.py:15-16, :37-40): x (B, 2C, HW) contiguous = the gate
  * convolution's output; channels [0, C) are normalised with (gamma, beta), channels [C, 2C) with (gamma2, beta2), each half
@@ -261,6 +263,8 @@ int smvs_groupnorm1_pair_bwd(const float* dy, const float* x, const float* y, co
  *                      backward: du = dy (h - y), dh = dy u, dcand = dy (1 - u). */
 int smvs_gru_mul_cat_fwd(const float* x, const float* r, const float* h, float* out, int B, int Cx, int Ch, int HW, void* stream);
 int smvs_gru_mul_cat_bwd(const float* dcat, const float* r, const float* h, float* dr, float* dh, int B, int Cx, int Ch, int HW, void* stream);
+/* the same with the state gradient accumulated and stored in place: dcat[:, Cx:] <- dcat[:, Cx:] * r + dh_acc; dr = dcat[:, Cx:] * h */
+int smvs_gru_mul_cat_bwd_acc(float* dcat, const float* r, const float* h, const float* dh_acc, float* dr, int B, int Cx, int Ch, int HW, void* stream);
 int smvs_gru_blend_fwd(const float* u, const float* h, const float* y, float* out, long long n, void* stream);
 int smvs_gru_blend_bwd(const float* dy, const float* u, const float* h, const float* y, float* du, float* dh, float* dcand, long long n, void* stream);
 

@@ -54,7 +54,8 @@ _SIGNATURES = {
     "smvs_conv3x3_wgrad_cat": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "smvs_conv3x3_wgrad_list": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "smvs_conv3x3_pack": [_vp, _vp, _i, _i, _i, _vp],
-    "smvs_conv3x3_fwd": [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "smvs_conv3x3_fwd": [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "smvs_gru_mul_cat_bwd_acc": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "smvs_red_pack_weights": [_vp, _i, _vp, _vp],
     "smvs_red_step_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 4 + [_vp],
     "smvs_red_pred_planes": [_i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 7 + [_vp],

@@ -381,7 +381,37 @@ void gru_mul_cat_bwd_kernel(const float* __restrict__ dcat, const float* __restr
     }
 }
 
+// the same with dh accumulated and stored IN PLACE over dcat's second half: dcat[:, Cx:] <- dcat[:, Cx:] * r + dh_acc  (the whole-cell
+// backward, modules/module.py:_ConvGRUCellFn: dcat then is [dx | dh] ready to seed the gate convolution's input gradient)
+__global__ __launch_bounds__(GE_THREADS)
+void gru_mul_cat_bwd_acc_kernel(float* __restrict__ dcat, const float* __restrict__ r, const float* __restrict__ h, const float* __restrict__ dh_acc,
+                                float* __restrict__ dr, long long nx, long long nh)
+{
+    const int b = blockIdx.y;
+    const long long i = (long long)blockIdx.x * GE_THREADS + threadIdx.x;
+    if (i < nh) {
+        const size_t k = (size_t)b * nh + i, c = (size_t)b * (nx + nh) + nx + i;
+        const float g = dcat[c];
+        dr[k] = g * h[k];
+        dcat[c] = fmaf(g, r[k], dh_acc[k]);
+    }
+}
+
 }  // namespace smvs
+
+extern "C" SMVS_EXPORT int smvs_gru_mul_cat_bwd_acc(float* dcat, const float* r, const float* h, const float* dh_acc, float* dr, int B, int Cx, int Ch,
+                                                    int HW, void* stream)
+{
+    using namespace smvs;
+    if (!dcat || !r || !h || !dr || !dh_acc) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (B < 1 || Cx < 0 || Ch < 1 || HW < 1 || B > 65535) return fail(SMVS_ERR_ARG, "bad dimension");
+    const long long nx = (long long)Cx * HW, nh = (long long)Ch * HW;
+    hipLaunchKernelGGL(gru_mul_cat_bwd_acc_kernel, dim3((unsigned)((nh + GE_THREADS - 1) / GE_THREADS), B), dim3(GE_THREADS), 0, (hipStream_t)stream,
+                       dcat, r, h, dh_acc, dr, nx, nh);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "gru_mul_cat_bwd_acc launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
+}
 
 extern "C" SMVS_EXPORT int smvs_gru_blend_fwd(const float* u, const float* h, const float* y, float* out, long long n, void* stream)
 {

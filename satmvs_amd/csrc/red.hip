@@ -1650,6 +1650,8 @@ SMVS_EXPORT int smvs_red_pack_weights(const float* const* params, int C, float* 
 //   smvs_conv3x3_fwd(kind, ...): out = [relu](layer(cat(xA (B,CA,H,W), xB (B,CB,H,W) or null)) + bias)
 //       kind 0: correlation, stride 1, out (B,Cout,H,W);  kind 1: correlation, stride 2 (H, W even), out (B,Cout,H/2,W/2);
 //       kind 2: transposed convolution, stride 2, output_padding 1 (weights of layout 1; xB and bias unused), out (B,Cout,2H,2W)
+//       init (kinds 0 / 1; same shape as out, or null; may be `out` itself): added to the sums -- an input gradient that continues the
+//       gradient contributions already collected for that tensor
 SMVS_EXPORT size_t smvs_conv3x3_packed_floats(int cin, int cout)
 {
     using namespace smvs;
@@ -1674,22 +1676,22 @@ SMVS_EXPORT int smvs_conv3x3_pack(const float* w, float* packed, int cin, int co
     return SMVS_OK;
 }
 
-SMVS_EXPORT int smvs_conv3x3_fwd(int kind, const float* xA, int CA, const float* xB, int CB, const float* packed, const float* bias, float* out,
-                                 int B, int Cout, int H, int W, int relu, void* stream)
+SMVS_EXPORT int smvs_conv3x3_fwd(int kind, const float* xA, int CA, const float* xB, int CB, const float* packed, const float* bias, const float* init,
+                                 float* out, int B, int Cout, int H, int W, int relu, void* stream)
 {
     using namespace smvs;
     if (!xA || !packed || !out || (CB > 0 && !xB)) return fail(SMVS_ERR_ARG, "null pointer argument");
     if (kind < 0 || kind > 2) return fail(SMVS_ERR_ARG, "kind must be 0, 1 or 2");
     if (B < 1 || CA < 1 || CB < 0 || Cout < 1 || H < 1 || W < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
     if (kind == 1 && ((H | W) & 1)) return fail(SMVS_ERR_ARG, "stride 2: H and W must be even");
-    if (kind == 2 && (CB > 0 || bias)) return fail(SMVS_ERR_ARG, "transposed layer: one operand, no bias");
+    if (kind == 2 && (CB > 0 || bias || init)) return fail(SMVS_ERR_ARG, "transposed layer: one operand, no bias, no initial sums");
     const int Ho = kind == 1 ? H / 2 : kind == 2 ? 2 * H : H, Wo = kind == 1 ? W / 2 : kind == 2 ? 2 * W : W;
     if ((long long)(CA > CB ? CA : CB) * H * W * 4 >= (1ll << 31) || (long long)Cout * Ho * Wo * 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "plane too large");
     if ((long long)B * ((Cout + COT - 1) / COT) > 65535) return fail(SMVS_ERR_ARG, "batch too large");
     const int Cin = CA + CB;
     ConvArgs a{};
     a.inA = xA; a.CA = CA; a.scaleA = 1.0f; a.inB = CB > 0 ? xB : nullptr; a.CB = CB;
-    a.w = packed; a.bias = bias; a.out = out; a.Cout = Cout; a.Hi = H; a.Wi = W; a.Ho = Ho; a.Wo = Wo; a.relu = relu ? 1 : 0;
+    a.w = packed; a.bias = bias; a.init = init; a.out = out; a.Cout = Cout; a.Hi = H; a.Wi = W; a.Ho = Ho; a.Wo = Wo; a.relu = relu ? 1 : 0;
     if (kind == 2) launch_convT(a, B, (hipStream_t)stream);
     else {
         // the MFMA kernel reads its per-channel vectors as aligned float4 and pairs input channels: both operands even, bias 16-byte aligned

@@ -202,7 +202,7 @@ class ConvTransReLU(nn.Module):
 # debugging switch: SMVS_TRAIN_COMPOSITE=1 keeps the ConvGRU cells' GroupNorm / element-wise steps on torch's own
 # operators (A/B against the native ones; the cost-volume operators are native either way)
 _TRAIN_COMPOSITE_ONLY = os.environ.get("SMVS_TRAIN_COMPOSITE", "0") == "1"
-_TRAIN_COMPOSITE_MASK = 31 if _TRAIN_COMPOSITE_ONLY else int(os.environ.get("SMVS_TRAIN_COMPOSITE_MASK", "0"))   # bisecting: 1 GroupNorm, 2 cat(x, r*h), 4 u-blend, 8 conv weight gradient, 16 ConvGRU convolutions (forward + input gradient)
+_TRAIN_COMPOSITE_MASK = 63 if _TRAIN_COMPOSITE_ONLY else int(os.environ.get("SMVS_TRAIN_COMPOSITE_MASK", "0"))   # bisecting: 1 GroupNorm, 2 cat(x, r*h), 4 u-blend, 8 conv weight gradient, 16 ConvGRU convolutions (forward + input gradient), 32 the cell as one autograd node
 
 
 _FIND_WARNED = False
@@ -626,7 +626,7 @@ class _Conv3x3NativeFn(torch.autograd.Function):
         fused_bias = bias if kind != "t2" else None              # (the stride-2 transposed layers of the regulariser have no bias)
         with torch.cuda.device(xa.device):
             _lib.call("smvs_conv3x3_fwd", fk, _lib.ptr(xa), CA, _lib.ptr(xb) if xb is not None else None, CB, _lib.ptr(packed),
-                      _lib.ptr(fused_bias) if fused_bias is not None else None, _lib.ptr(out), B, Cout, H, W, 1 if relu else 0,
+                      _lib.ptr(fused_bias) if fused_bias is not None else None, None, _lib.ptr(out), B, Cout, H, W, 1 if relu else 0,
                       _lib.current_stream(xa.device))
         ctx.save_for_backward(xa, xb, weight, out if relu else None)
         ctx.kind, ctx.relu, ctx.has_bias = kind, bool(relu), bias is not None
@@ -654,7 +654,7 @@ class _Conv3x3NativeFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             if ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1]):
                 dx = torch.empty((B, CA + CB, H, W), dtype=torch.float32, device=dev)
-                _lib.call("smvs_conv3x3_fwd", bk, _lib.ptr(dy), Cout, None, 0, _lib.ptr(_conv_packed(weight, blay, Cout, CA + CB)), None,
+                _lib.call("smvs_conv3x3_fwd", bk, _lib.ptr(dy), Cout, None, 0, _lib.ptr(_conv_packed(weight, blay, Cout, CA + CB)), None, None,
                           _lib.ptr(dx), B, CA + CB, dy.shape[2], dy.shape[3], 0, _lib.current_stream(dev))
                 dxa = dx[:, :CA] if ctx.needs_input_grad[0] else None
                 dxb = dx[:, CA:] if xb is not None and ctx.needs_input_grad[1] else None
@@ -724,6 +724,92 @@ def _conv3x3(conv, x):
     return conv(x)
 
 
+def _wgrad_now_or_later(sink, weight, bias, window, win2, grid, stride):
+    """(dw, db) of a 3x3 convolution (bias gradient = the grid tensor's sums): placeholders when a _WgradSink collects the planes,
+    else one smvs_conv3x3_wgrad_list launch now."""
+    if sink is not None:
+        sink.add(weight, bias, window, win2, grid, stride)
+        return _placeholder(weight), (_placeholder(bias) if bias is not None else None)
+    dev = window.device
+    nw = weight.numel()
+    Cg = grid.shape[1]
+    buf = torch.zeros((nw + (Cg if bias is not None else 0),), dtype=torch.float32, device=dev)
+    dw = buf[:nw].view(weight.shape)
+    _lib.call("smvs_conv3x3_wgrad_list", _lib.ptr_array([window]), _lib.ptr_array([win2]) if win2 is not None else None, _lib.ptr_array([grid]), 1,
+              _lib.ptr(dw), _lib.ptr(buf[nw:]) if bias is not None else None, window.shape[0], window.shape[1],
+              win2.shape[1] if win2 is not None else 0, Cg, grid.shape[2], grid.shape[3], stride, _lib.current_stream(dev))
+    return dw, (buf[nw:] if bias is not None else None)
+
+
+class _ConvGRUCellFn(torch.autograd.Function):
+    """A whole ConvGRUCell2 step (reference: module.py:24-57) as ONE autograd node, batch 1: gate convolution over (x, h), both gate norms
+    + sigmoids, cat(x, r*h), candidate convolution, output norm + tanh, blend -- the same six native calls as the piecewise path, and a
+    hand-chained backward in which the three gradient contributions to h and the two to x meet inside the kernels instead of in
+    autograd's accumulation adds: the blend's state gradient rides into smvs_gru_mul_cat_bwd_acc, which leaves [dx | dh] in place of the
+    candidate convolution's input gradient, and that buffer seeds the gate convolution's input gradient (smvs_conv3x3_fwd's `init`).
+    Per cell and plane 3 adds + 1 cat (the gradient of torch.split) fewer: ~1 400 launches per training step of the 48/32/8 cascade."""
+
+    @staticmethod
+    def forward(ctx, x, h, gw, gb, rw, rb, uw, ub, ow, ob, nw_, nb_, eps):
+        dev = _lib.require_device(x, h, gw)
+        x, h = _f32c_fast(x), _f32c_fast(h)
+        B, Cx, H, W = x.shape
+        C = h.shape[1]
+        HW = H * W
+        st = _lib.current_stream(dev)
+        rw, rb, uw, ub, nw_, nb_ = [_f32c_fast(t.detach()) for t in (rw, rb, uw, ub, nw_, nb_)]
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        gates, ru, xc, craw, cand, out = e(B, 2 * C, H, W), e(B, 2 * C, H, W), e(B, Cx + C, H, W), e(B, C, H, W), e(B, C, H, W), e(B, C, H, W)
+        stats_g, stats_o = e(2 * B, 2), e(B, 2)
+        nblk = (C * HW + 4095) // 4096
+        with torch.cuda.device(dev):
+            _lib.call("smvs_conv3x3_fwd", 0, _lib.ptr(x), Cx, _lib.ptr(h), C, _lib.ptr(_conv_packed(gw, 0, Cx + C, 2 * C)), _lib.ptr(gb), None,
+                      _lib.ptr(gates), B, 2 * C, H, W, 0, st)
+            _lib.call("smvs_groupnorm1_pair_fwd", _lib.ptr(gates), _lib.ptr(rw), _lib.ptr(rb), _lib.ptr(uw), _lib.ptr(ub), float(eps), 1, _lib.ptr(ru),
+                      _lib.ptr(stats_g), _lib.ptr(_gn_scratch(dev, 4 * B * nblk)), B, C, HW, st)
+            r, u = ru[:, :C], ru[:, C:]
+            _lib.call("smvs_gru_mul_cat_fwd", _lib.ptr(x), _lib.ptr(r), _lib.ptr(h), _lib.ptr(xc), B, Cx, C, HW, st)
+            _lib.call("smvs_conv3x3_fwd", 0, _lib.ptr(xc), Cx + C, None, 0, _lib.ptr(_conv_packed(ow, 0, Cx + C, C)), _lib.ptr(ob), None,
+                      _lib.ptr(craw), B, C, H, W, 0, st)
+            _lib.call("smvs_groupnorm1_fwd", _lib.ptr(craw), C * HW, _lib.ptr(nw_), _lib.ptr(nb_), float(eps), 2, _lib.ptr(cand), _lib.ptr(stats_o),
+                      _lib.ptr(_gn_scratch(dev, 2 * B * nblk)), B, C, HW, st)
+            _lib.call("smvs_gru_blend_fwd", _lib.ptr(u), _lib.ptr(h), _lib.ptr(cand), _lib.ptr(out), h.numel(), st)
+        ctx.save_for_backward(x, h, gw, gb, ow, ob, rw, uw, nw_, gates, ru, xc, craw, cand, stats_g, stats_o)
+        ctx.sink = getattr(_TLS, "sink", None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dnew):
+        x, h, gw, gb, ow, ob, rw, uw, nw_, gates, ru, xc, craw, cand, stats_g, stats_o = ctx.saved_tensors
+        dev = x.device
+        B, Cx, H, W = x.shape
+        C = h.shape[1]
+        HW = H * W
+        st = _lib.current_stream(dev)
+        dnew = _f32c_fast(dnew)
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        dru, dh_b, dcand, dcraw, dxc, dgates = e(B, 2 * C, H, W), e(B, C, H, W), e(B, C, H, W), e(B, C, H, W), e(B, Cx + C, H, W), e(B, 2 * C, H, W)
+        g4, dn = e(4, C), e(2, C)
+        r, u = ru[:, :C], ru[:, C:]
+        nseg = (HW + 4095) // 4096
+        with torch.cuda.device(dev):
+            _lib.call("smvs_gru_blend_bwd", _lib.ptr(dnew), _lib.ptr(u), _lib.ptr(h), _lib.ptr(cand), _lib.ptr(dru[:, C:]), _lib.ptr(dh_b), _lib.ptr(dcand),
+                      h.numel(), st)
+            _lib.call("smvs_groupnorm1_bwd", _lib.ptr(dcand), _lib.ptr(craw), C * HW, _lib.ptr(cand), _lib.ptr(nw_), _lib.ptr(stats_o), 2, _lib.ptr(dcraw),
+                      C * HW, _lib.ptr(dn[0]), _lib.ptr(dn[1]), _lib.ptr(_gn_scratch(dev, 2 * B * C * nseg)), B, C, HW, st)
+            _lib.call("smvs_conv3x3_fwd", 0, _lib.ptr(dcraw), C, None, 0, _lib.ptr(_conv_packed(ow, 2, C, Cx + C)), None, None, _lib.ptr(dxc),
+                      B, Cx + C, H, W, 0, st)
+            dow, dob = _wgrad_now_or_later(ctx.sink, ow, ob, xc, None, dcraw, 1)
+            _lib.call("smvs_gru_mul_cat_bwd_acc", _lib.ptr(dxc), _lib.ptr(r), _lib.ptr(h), _lib.ptr(dh_b), _lib.ptr(dru), B, Cx, C, HW, st)
+            _lib.call("smvs_groupnorm1_pair_bwd", _lib.ptr(dru), _lib.ptr(gates), _lib.ptr(ru), _lib.ptr(rw), _lib.ptr(uw), _lib.ptr(stats_g), 1,
+                      _lib.ptr(dgates), _lib.ptr(g4[0]), _lib.ptr(g4[1]), _lib.ptr(g4[2]), _lib.ptr(g4[3]), _lib.ptr(_gn_scratch(dev, 4 * B * C * nseg)),
+                      B, C, HW, st)
+            _lib.call("smvs_conv3x3_fwd", 0, _lib.ptr(dgates), 2 * C, None, 0, _lib.ptr(_conv_packed(gw, 2, 2 * C, Cx + C)), None, _lib.ptr(dxc),
+                      _lib.ptr(dxc), B, Cx + C, H, W, 0, st)
+            dgw, dgb = _wgrad_now_or_later(ctx.sink, gw, gb, x, h, dgates, 1)
+        return dxc[:, :Cx], dxc[:, Cx:], dgw, dgb, g4[0], g4[1], g4[2], g4[3], dow, dob, dn[0], dn[1], None
+
+
 class ConvGRUCell2(nn.Module):
     """3x3 convolutional GRU with GroupNorm(1, C) on every gate.  reference: module.py:6-58."""
 
@@ -741,6 +827,15 @@ class ConvGRUCell2(nn.Module):
     def forward(self, x, h=None):
         if h is None:
             h = torch.zeros((x.shape[0], self.output_channel, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device)
+        gc, oc, rn, un, on = self.gate_conv, self.output_conv, self.reset_gate_norm, self.update_gate_norm, self.output_norm
+        C = self.output_channel
+        if (x.is_cuda and x.shape[0] == 1 and x.dtype is torch.float32 and h.dtype is torch.float32 and torch.is_grad_enabled() and not _TRAIN_COMPOSITE_MASK
+                and _native_kind(gc) == "c1" and _native_kind(oc) == "c1" and gc.bias is not None and oc.bias is not None
+                and all(p.dtype is torch.float32 and p.is_contiguous() for p in (gc.weight, oc.weight))
+                and x.shape[1] % 2 == 0 and (C * x.shape[2] * x.shape[3]) % 4 == 0 and gc.bias.data_ptr() % 16 == 0 and oc.bias.data_ptr() % 16 == 0
+                and (x.shape[1] + 2 * C) * x.shape[2] * x.shape[3] * 4 < 2 ** 31 and rn.affine and un.affine and on.affine and rn.eps == un.eps == on.eps):
+            new_h = _ConvGRUCellFn.apply(x, h, gc.weight, gc.bias, rn.weight, rn.bias, un.weight, un.bias, oc.weight, oc.bias, on.weight, on.bias, rn.eps)
+            return new_h, new_h
         gates = _conv3x3_cat(self.gate_conv, x, h)
         # the native element-wise paths are float32 kernels with 16-byte vector accesses and 16-bit grid limits: anything else
         # (a .double() model, exotic channel counts that leave a gate half unaligned, B*C > 65535) takes torch's operators
