@@ -205,6 +205,19 @@ _TRAIN_COMPOSITE_ONLY = os.environ.get("SMVS_TRAIN_COMPOSITE", "0") == "1"
 _TRAIN_COMPOSITE_MASK = 63 if _TRAIN_COMPOSITE_ONLY else int(os.environ.get("SMVS_TRAIN_COMPOSITE_MASK", "0"))   # bisecting: 1 GroupNorm, 2 cat(x, r*h), 4 u-blend, 8 conv weight gradient, 16 ConvGRU convolutions (forward + input gradient), 32 the cell as one autograd node
 
 
+_TRAIN_STREAMS = os.environ.get("SMVS_TRAIN_STREAMS", "1") != "0"      # training: ConvGRU levels 1-3 of a plane on side streams (A/B switch)
+_TRAIN_LOOP_PIPELINE = os.environ.get("SMVS_TRAIN_LOOP_PIPELINE", "1") != "0"   # ... and the plane loop software-pipelined (cells d | encoder d+1 | decoder d-1)
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device, n):
+    key = (device.index, threading.get_ident())
+    ss = _SIDE_STREAMS.get(key)
+    if ss is None or len(ss) < n:
+        ss = _SIDE_STREAMS[key] = [torch.cuda.Stream(device) for _ in range(n)]
+    return ss
+
+
 _FIND_WARNED = False
 _FIND_SWITCHED_OFF = False
 
@@ -477,6 +490,10 @@ class _WgradSink:
             if bias is not None:
                 self.bias_of[bias.data_ptr()] = key
         lay["entries"].append((win, win2, grid))
+        st = torch.cuda.current_stream(win.device)                # the backward of a side-stream cell runs on that stream
+        ev = torch.cuda.Event()
+        ev.record(st)
+        lay.setdefault("events", {})[st.cuda_stream] = ev
 
     def result(self, key):
         res = self.results.get(key)
@@ -493,6 +510,14 @@ class _WgradSink:
             Cg, H, W = grid0.shape[1], grid0.shape[2], grid0.shape[3]
             buf = torch.zeros((nw + (Cg if lay["sums"] else 0),), dtype=torch.float32, device=dev)
             dw = buf[:nw].view(lay["shape"])
+            here = torch.cuda.current_stream(dev)
+            for sid, ev in lay.get("events", {}).items():           # the planes' tensors come from the streams their cells ran on
+                if sid != here.cuda_stream:
+                    here.wait_event(ev)
+                    for e_ in ent:
+                        for t in e_:
+                            if t is not None:
+                                t.record_stream(here)
             with torch.cuda.device(dev):
                 _lib.call("smvs_conv3x3_wgrad_list", _lib.ptr_array([e[0] for e in ent]),
                           _lib.ptr_array([e[1] for e in ent]) if win20 is not None else None, _lib.ptr_array([e[2] for e in ent]), len(ent),
@@ -1003,6 +1028,8 @@ class _REDCore(nn.Module):
         if self._use_native(cost):
             return self.native_step(cost, s1, s2, s3, s4)
         neg = -cost
+        if cost.is_cuda and torch.is_grad_enabled() and _TRAIN_STREAMS:
+            return self._step_level_parallel(neg, s1, s2, s3, s4)
         e1 = self.conv1(neg)
         e2 = self.conv2(e1)
         e3 = self.conv3(e2)
@@ -1013,6 +1040,41 @@ class _REDCore(nn.Module):
         r2, s2 = self.conv_gru2(e1, s2)
         u1 = self.upconv1(u2 + r2)
         r1, s1 = self.conv_gru1(neg, s1)
+        return _conv3x3_cat(self.upconv2d, u1 + r1), s1, s2, s3, s4
+
+    def _step_level_parallel(self, neg, s1, s2, s3, s4):
+        """The training step of a plane with the ConvGRU cells of levels 1-3 on side streams: the four cells of a plane do not depend
+        on each other (a cell needs its encoder level and its own previous state), and each is a chain of ~10 latency-bound launches
+        each way.  Autograd runs a node's backward on the stream of its forward and orders the streams along the graph's edges, so the
+        backward overlaps the same way; inside a captured training step (train_graph) the forks and joins become graph branches.
+        Tensors that cross streams are registered with the caching allocator (record_stream).  (Streams that PERSIST over the plane loop
+        -- encoder running ahead, one recurrent chain per level, decoder on the caller's stream: the inference pipeline's data flow --
+        give identical results in eager mode, but hipStreamEndCapture of this image faults on that capture; fork / join per plane it is.)"""
+        dev = neg.device
+        main = torch.cuda.current_stream(dev)
+        side = _side_streams(dev, 3)
+
+        def cell_on(stream, cell, x, state):
+            stream.wait_stream(main)                             # x (and the first plane's state) were produced on the main stream
+            with torch.cuda.stream(stream):
+                r, st = cell(x, state)
+            x.record_stream(stream)
+            state.record_stream(stream)
+            return r, st
+
+        r1, s1 = cell_on(side[0], self.conv_gru1, neg, s1)
+        e1 = self.conv1(neg)
+        r2, s2 = cell_on(side[1], self.conv_gru2, e1, s2)
+        e2 = self.conv2(e1)
+        r3, s3 = cell_on(side[2], self.conv_gru3, e2, s3)
+        e3 = self.conv3(e2)
+        r4, s4 = self.conv_gru4(e3, s4)
+        u3 = self.upconv3(r4)
+        main.wait_stream(side[2]); r3.record_stream(main)
+        u2 = self.upconv2(u3 + r3)
+        main.wait_stream(side[1]); r2.record_stream(main)
+        u1 = self.upconv1(u2 + r2)
+        main.wait_stream(side[0]); r1.record_stream(main)
         return _conv3x3_cat(self.upconv2d, u1 + r1), s1, s2, s3, s4
 
 
@@ -1034,10 +1096,13 @@ class RED_Regularization(_REDCore):
         sink = planes.pop("", None)
         if sink is not None:                                     # weight gradients deferred to one launch per layer (_WgradSink)
             with sink:
-                for d in range(d_num):
-                    with _reparametrize(self, {n: t[d] for n, t in planes.items()}):
-                        reg, *s = self.step(volume_variance[:, :, d], *s)
-                    outs.append(reg)
+                if _TRAIN_STREAMS and _TRAIN_LOOP_PIPELINE and volume_variance.is_cuda:
+                    outs = self._planes_software_pipelined(volume_variance, s, planes, d_num)
+                else:
+                    for d in range(d_num):
+                        with _reparametrize(self, {n: t[d] for n, t in planes.items()}):
+                            reg, *s = self.step(volume_variance[:, :, d], *s)
+                        outs.append(reg)
             return torch.stack(outs, dim=1).squeeze(2)
         with _WgradArena(per_plane * d_num if volume_variance.is_cuda else 0, volume_variance.device):
             for d in range(d_num):
@@ -1045,6 +1110,70 @@ class RED_Regularization(_REDCore):
                     reg, *s = self.step(volume_variance[:, :, d], *s)
                 outs.append(reg)
         return torch.stack(outs, dim=1).squeeze(2)
+
+    def _planes_software_pipelined(self, volume, s, planes, d_num):
+        """The training loop software-pipelined over the planes: in iteration d the ConvGRU cells of plane d (one side stream per level),
+        the encoder of plane d+1 (a fifth side stream) and the decoder of plane d-1 (the caller's stream) run side by side; every side
+        stream is forked from the caller's stream and joined back inside the iteration (streams that persist over the loop fault in
+        hipStreamEndCapture on this image).  Same autograd graph as the plain loop -- the nodes only run on other streams, and
+        autograd's backward, which runs a node on the stream of its forward, overlaps the same way.  The chain of an iteration is
+        max(cells, decoder, encoder) = ~10 dependent launches instead of ~20."""
+        dev = volume.device
+        main = torch.cuda.current_stream(dev)
+        side = _side_streams(dev, 5)
+        enc_stream, cell_streams = side[0], side[1:5]
+        cells = (self.conv_gru1, self.conv_gru2, self.conv_gru3, self.conv_gru4)
+        s = list(s)
+
+        def params(d):
+            return _reparametrize(self, {n: t[d] for n, t in planes.items()})
+
+        def encoder(cost):
+            neg = -cost
+            e1 = self.conv1(neg)
+            e2 = self.conv2(e1)
+            return neg, e1, e2, self.conv3(e2)
+
+        def decoder(r1, r2, r3, r4):
+            u3 = self.upconv3(r4)
+            u2 = self.upconv2(u3 + r3)
+            u1 = self.upconv1(u2 + r2)
+            return _conv3x3_cat(self.upconv2d, u1 + r1)
+
+        outs, pending = [], None
+        with params(0):
+            xs = encoder(volume[:, :, 0])
+        for d in range(d_num):
+            rs = []
+            with params(d):
+                for k in range(4):
+                    cell_streams[k].wait_stream(main)
+                    with torch.cuda.stream(cell_streams[k]):
+                        r, s[k] = cells[k](xs[k], s[k])
+                    xs[k].record_stream(cell_streams[k])
+                    if d == 0:
+                        s[k].record_stream(main)                 # (the final states go back to the caller)
+                    rs.append(r)
+            nxt = None
+            if d + 1 < d_num:
+                enc_stream.wait_stream(main)
+                with torch.cuda.stream(enc_stream), params(d + 1):
+                    nxt = encoder(volume[:, :, d + 1])
+                volume.record_stream(enc_stream)
+            if pending is not None:
+                with params(d - 1):
+                    outs.append(decoder(*pending))
+            for k in range(4):
+                main.wait_stream(cell_streams[k])
+                rs[k].record_stream(main)
+            if nxt is not None:
+                main.wait_stream(enc_stream)
+                for t in nxt:
+                    t.record_stream(main)
+            pending, xs = rs, nxt
+        with params(d_num - 1):
+            outs.append(decoder(*pending))
+        return outs
 
     def _per_plane_parameters(self, d_num):
         """Training: every plane of the loop uses its own VIEW of each parameter (`p.expand(D, ...)` unbound along D: same
