@@ -403,6 +403,23 @@ def side_workloads(dev, stream):
         extra["cfg3_casred_cascade_48_32_8_768x384"] = rec
     except Exception as e:                                  # a side figure must never take the headline down
         extra["cfg3_casred_cascade_48_32_8_768x384"] = {"error": repr(e)[:200]}
+    # the training step of the same network (row f-2), captured in one HIP graph: in a process of its own -- a graph capture holds a
+    # private memory pool, and whatever happens there must not reach the headline
+    try:
+        import re
+        import subprocess
+        tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "bench_train_graph.py")
+        r = subprocess.run([sys.executable, tool, "9"], capture_output=True, text=True, timeout=240)
+        m = re.search(r"median ([0-9.]+) ms \(min ([0-9.]+), max ([0-9.]+)\), loss ([0-9.eE+-]+)", r.stdout)
+        if m:
+            extra["cfg3_casred_training_step_48_32_8_768x384"] = {
+                "ms_per_step": float(m.group(1)), "ms_min": float(m.group(2)), "ms_max": float(m.group(3)),
+                "note": "CascadeREDNet.train(): forward + smooth-L1 cascade loss + backward + RMSprop, B=1, random weights, one HIP graph "
+                        "(satmvs_amd.train_graph); tools/bench_train_graph.py in a subprocess, median of 9 replays; round 3: 126.0 ms"}
+        else:
+            extra["cfg3_casred_training_step_48_32_8_768x384"] = {"error": (r.stderr or r.stdout)[-200:]}
+    except Exception as e:
+        extra["cfg3_casred_training_step_48_32_8_768x384"] = {"error": repr(e)[:200]}
     return extra
 
 
