@@ -586,6 +586,29 @@ def test_graphed_training_step_matches_eager(dev, golden):
         assert torch.equal(p, before[k]), "a step at lr = 0 moved %s: the old rate was replayed" % k
     step(imgs, proj, dv, gts2)
     assert step.captures == n + 1                               # unchanged hyper-parameters: plain replay
+    # a replay steps the parameters on the device without touching autograd's version counters: the kernel-layout copies of the
+    # inference path must not outlive them (modules.module.bump_param_epoch) -- eval through the native kernels == eval through the
+    # PyTorch composite on the CURRENT parameters, before and after another (lr > 0) replay
+    for grp in opt_g.param_groups:
+        grp["lr"] = 5e-2
+    step(imgs, proj, dv, gts2)                                   # (re-captured for the new rate: everything below is plain replay)
+    n = step.captures
+    heights = []
+    for rep in range(2):
+        net_g.eval()
+        with torch.no_grad():
+            nat = net_g(imgs, proj, dv)["stage3"]["depth"].clone()
+            os.environ["SMVS_RED_TORCH"] = "1"
+            try:
+                comp = net_g(imgs, proj, dv)["stage3"]["depth"].clone()
+            finally:
+                del os.environ["SMVS_RED_TORCH"]
+        assert float((nat - comp).abs().max()) <= 2e-3, (rep, float((nat - comp).abs().max()))
+        heights.append(nat)
+        net_g.train()
+        step(imgs, proj, dv, gts2)
+    assert float((heights[0] - heights[1]).abs().max()) > 2e-2   # the step in between did move the network
+    assert step.captures == n
 
 
 def test_native_modules_match_composites_at_ragged_shapes(dev):
