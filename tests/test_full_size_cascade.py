@@ -191,3 +191,49 @@ def test_cascade_native_matches_composites_at_full_size(dev, tag, geo, arith):
             np.testing.assert_allclose(a[s]["photometric_confidence"].cpu().numpy(), b[s]["photometric_confidence"].cpu().numpy(), rtol=2e-3, atol=2e-5)
     assert a["stage3"]["depth"].shape == (1, H, W)
     assert float(a["stage3"]["depth"].std()) > 0.05           # not a constant map
+
+
+def test_training_step_full_size_native_vs_composite(dev):
+    """CascadeREDNet.train() at the real tile (3-view 768x384, planes 48/32/8): loss and every parameter gradient of the shipped training
+    path -- native layers under autograd, one-node ConvGRU cells, weight gradients deferred to one launch per layer, ConvGRU levels on
+    side streams with the plane loop software-pipelined -- against the SAME step with all of that switched off (the module's
+    SMVS_TRAIN_COMPOSITE_MASK / SMVS_TRAIN_STREAMS globals: torch's convolutions, GroupNorm and element-wise operators, one stream, the
+    plain plane loop; that path is pinned against the reference's own step at 64x128, tests/golden/train_step.npz).  Loss to 1e-5;
+    a parameter's gradient differs by float32 summation order only (atomics, split-K, another association over the planes), carried
+    through up to 48 recurrent planes: 1e-2 of its largest entry at worst (measured 8e-3: the stride-2 encoder
+    convolution of stage 2; FeatureNet, downstream of everything, 4e-3), 1e-3 for the median parameter."""
+    import torch.nn.functional as F
+    from satmvs_amd.modules import module as M
+    imgs, pm, dv = cascade_inputs("rpc", dev)
+    gts = {s: torch.full((1, H // k, W // k), 210.0, device=dev) for s, k in (("stage1", 4), ("stage2", 2), ("stage3", 1))}
+
+    def run():
+        torch.manual_seed(3)
+        net = build_net("red", "rpc").to(dev).train()
+        out = net(imgs, pm, dv)
+        loss = sum(w * F.smooth_l1_loss(out[s]["depth"], gts[s], reduction="mean") for s, w in (("stage1", 0.5), ("stage2", 1.0), ("stage3", 2.0)))
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    saved = (M._TRAIN_COMPOSITE_MASK, M._TRAIN_STREAMS)
+    try:
+        loss_n, g_n = run()
+        M._TRAIN_COMPOSITE_MASK, M._TRAIN_STREAMS = 63, False
+        loss_c, g_c = run()
+    finally:
+        M._TRAIN_COMPOSITE_MASK, M._TRAIN_STREAMS = saved
+    assert abs(loss_n - loss_c) <= 1e-5 * abs(loss_c), (loss_n, loss_c)
+    assert set(g_n) == set(g_c) and len(g_n) > 150
+    rel = {}
+    biggest = max(float(g.abs().max()) for g in g_c.values())
+    for k in g_c:
+        scale = float(g_c[k].abs().max())
+        if scale < 1e-6 * biggest:            # e.g. the output layer's bias: softmax over the planes is shift-invariant, its gradient is round-off in both runs
+            assert float(g_n[k].abs().max()) < 1e-5 * biggest, k
+            continue
+        rel[k] = float((g_n[k] - g_c[k]).abs().max()) / scale
+    top = sorted(rel.items(), key=lambda kv: -kv[1])[:5]
+    print("largest relative gradient differences:", ", ".join("%s %.2g" % kv for kv in top))
+    assert top[0][1] <= 1e-2, top
+    assert sorted(rel.values())[len(rel) // 2] <= 1e-3                # the median parameter
