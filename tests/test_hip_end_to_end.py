@@ -839,3 +839,34 @@ def test_conv3x3_native_weight_gradient_strided_and_transposed(dev, kind, B, cin
         assert got.shape == ref.shape
         assert float((got - ref).abs().max()) <= 2e-4 * scale, (kind, name, float((got - ref).abs().max()), scale)
     assert torch.allclose(x.grad, want[2], rtol=1e-4, atol=1e-4 * float(want[2].abs().max()))
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_red_training_loop_streams_equal_single_stream(dev, B):
+    """RED_Regularization's training loop with the ConvGRU levels on side streams and the planes software-pipelined
+    (modules.module._planes_software_pipelined) against the same loop on one stream: the same kernels in the same per-tensor order, so
+    the regularised volume is bit-identical and the gradients agree to the float atomics of the weight-gradient kernel (1e-5 of their
+    scale).  Batch 1 runs the one-node ConvGRU cells, batch 2 the piecewise path."""
+    from satmvs_amd.modules import module as M
+    torch.manual_seed(21)
+    red = M.RED_Regularization(16).to(dev).train()
+    vol0 = torch.randn(B, 16, 10, 48, 96, device=dev)
+    weight = torch.linspace(0, 1, B * 10 * 48 * 96, device=dev).view(B, 10, 48, 96)
+    res = []
+    saved = M._TRAIN_STREAMS
+    try:
+        for streams in (True, False):
+            M._TRAIN_STREAMS = streams
+            vol = vol0.clone().requires_grad_(True)
+            red.zero_grad()
+            out = red(vol)
+            (out * weight).sum().backward()
+            torch.cuda.synchronize()
+            res.append((out.detach().clone(), vol.grad.clone(), [p.grad.clone() for p in red.parameters()]))
+    finally:
+        M._TRAIN_STREAMS = saved
+    (o1, g1, p1), (o0, g0, p0) = res
+    assert torch.equal(o1, o0)
+    assert float((g1 - g0).abs().max()) <= 1e-5 * float(g0.abs().max())
+    for a, b in zip(p1, p0):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
