@@ -27,6 +27,7 @@ struct CostVolParams {
     int depth_is_4d;                // HEIGHT_PLANES | HEIGHT_TENSOR | HEIGHT_GENERATED
     HeightGen hg;                   // HEIGHT_GENERATED: hypotheses computed per pixel from the previous stage's map
     int xt, yt, dct, dch;           // tiles in x, y; plane chunks; planes per chunk
+    int chunk_major;                // staged kernel: order of the workgroups inside a band of rows, see launch_order()
     float rV, r_half_wm1, r_half_hm1;   // RN(1/V), RN(1/((W-1)/2)), RN(1/((H-1)/2)) in float32, divided once on the host
     float kw;                       // fused arithmetic (AR = 1): factor on the tap weights and the ref feature, see smvs_device.h
 };
@@ -235,6 +236,12 @@ __device__ __forceinline__ int wave_max(int v)
 #ifndef SMVS_BOX_W
 #define SMVS_BOX_W 44                 // staged box width: 11 chunks of 4 columns (a 40-column box from any 4-aligned origin)
 #endif
+#ifndef SMVS_ONE_BASE
+#define SMVS_ONE_BASE (-1)            // A/B switch of profiling builds
+#endif
+#ifndef SMVS_BOX_W8
+#define SMVS_BOX_W8 52                // ... of a box shared by 8 planes (3+ sources)
+#endif
 #ifndef SMVS_WAVES_PER_SIMD
 #define SMVS_WAVES_PER_SIMD 3
 #endif
@@ -245,7 +252,7 @@ constexpr int DM_BW = SMVS_BOX_W;      // staged box width (columns)
 constexpr int DM_R = SMVS_BOX_R;        // staged box rows: 2 pixel rows + south tap + parallax/rotation slack
 constexpr int DM_NBUF = 2;
 #ifndef SMVS_ABLATE
-#define SMVS_ABLATE 0                 // profiling builds only (tools/ab_build.sh x -DSMVS_ABLATE=n): 1 stores dropped, 2 no staging DMA, 4 no float64 chain, 8 no LDS tap reads, 32 no packed arithmetic -- results are WRONG
+#define SMVS_ABLATE 0                 // profiling builds only (tools/ab_build.sh x -DSMVS_ABLATE=n): 1 stores dropped, 2 no staging DMA, 4 no float64 chain, 8 no LDS tap reads, 32 no packed arithmetic, 64 staging DMA issued with every lane out of range (no memory traffic), 128 staging DMA from the first 64 KB of a channel (cache hits), 256 a step does not wait for its DMA to land -- results are WRONG
 #endif
 #ifndef SMVS_O2P_PLANES
 #define SMVS_O2P_PLANES 4          // planes per evaluation pass of a source view's cubics
@@ -258,6 +265,9 @@ constexpr int DM_NBUF = 2;
 #endif
 #ifndef SMVS_WPS_NSRC34_DP2
 #define SMVS_WPS_NSRC34_DP2 2         // 3-4 sources, 1-2 planes per wave (166 VGPRs at 4 sources): waves per SIMD compiled for
+#endif
+#ifndef SMVS_WPS_NSRC34_DP4
+#define SMVS_WPS_NSRC34_DP4 2         // 3-4 sources, 4 planes per wave: waves per SIMD compiled for
 #endif
 #ifndef SMVS_NSRC34_DP
 #define SMVS_NSRC34_DP 4              // planes per wave of a 3-4 source sweep (A/B switch of profiling builds)
@@ -303,22 +313,41 @@ __device__ __forceinline__ void wait_vmcnt_upto8(int n)
 // register pairs so that v_pk_* can broadcast either half through op_sel (no v_mov to build {w,w}).
 struct TapD { uint32_t base[DM_NBUF]; f32x2 wn, ws; };       // base[parity] = LDS address of the NW corner; wn = {nw, ne}, ws = {sw, se}
 
-template <int GEO, int NSRC, int CT, int DP, int AR>
-__global__ __launch_bounds__(64 * WV_WAVES, (NSRC <= 2 && DP <= 4 ? SMVS_WAVES_PER_SIMD : NSRC <= 2 ? (AR == AR_FUSED ? SMVS_WPS_DP8_FUSED : SMVS_WPS_DP8) : (NSRC <= 4 && DP <= 2 ? SMVS_WPS_NSRC34_DP2 : 2)))
+// NWY > 0 selects the WORKGROUP-SHARED form (round 5): the workgroup's NWY x NWP waves -- NWY stacked in y (2 pixel rows each),
+// NWP along the plane axis (DP planes each) -- stage ONE box per source, of 2 NWY + 3 rows, and share it: the DMA instructions
+// of a step are dealt out over the waves and one s_barrier per step orders "my part has landed" / "everybody is done with the
+// other buffer".  Fewer staged rows per voxel (7 rows per 4 pixel rows instead of 2 x 5; one box for NWP x DP planes), and a
+// wave's register and LDS footprint is that of DP planes while the box and the ref view's per-pixel work are amortised
+// over NWP x DP.  NWY = 0: every wave stages its own box and never meets a barrier (WV_WAVES waves stacked in y).
+template <int GEO, int NSRC, int CT, int DP, int AR, int NWY = 0, int NWP = 1, int WPS = 0>
+__global__ __launch_bounds__(NWY > 0 ? 64 * NWY * NWP : 64 * WV_WAVES,
+                             NWY > 0 ? WPS : (NSRC <= 2 && DP <= 4 ? SMVS_WAVES_PER_SIMD : NSRC <= 2 ? (AR == AR_FUSED ? SMVS_WPS_DP8_FUSED : SMVS_WPS_DP8) : (NSRC <= 4 && DP <= 2 ? SMVS_WPS_NSRC34_DP2 : NSRC <= 4 ? SMVS_WPS_NSRC34_DP4 : 2)))
 void costvol_dma_kernel(const CostVolParams p)
 {
     // Staging layout of one source box and channel pair: [row][channel of the pair][column] dwords, row pitch 2*BW; filled
     // by 16-byte LDS-DMA chunks (4 columns of one channel row), chunk k of the box at byte 16 k.
-    constexpr int BW = DM_BW, R = DM_R, C4 = BW / 4;
+    constexpr bool SHARED = NWY > 0;
+    constexpr int NW = SHARED ? NWY * NWP : WV_WAVES;        // waves per workgroup
+    constexpr int NY = SHARED ? NWY : WV_WAVES;              // of which stacked in y
+    // box width: 44 columns hold 4-5 planes of a 5-view 1536-wide tile (1.7 columns of parallax per plane at the steepest view);
+    // a box shared by 8 planes takes 52
+    constexpr int BW = SHARED && DP * NWP >= 8 && NSRC > 2 ? SMVS_BOX_W8 : DM_BW, R = SHARED ? 2 * NWY + 3 : DM_R, C4 = BW / 4;
     constexpr int SLOTS = R * 2 * C4;                        // 16-byte chunks per source box and channel pair
     constexpr int NI = (SLOTS + 63) / 64;                    // DMA instructions per source box and channel pair
     constexpr int SRC_DW = NI * 256;                         // dwords per source box, padded to whole DMA instructions
     constexpr int BUF_DW = NSRC * SRC_DW;
     constexpr int ZPAD_DW = 3 * BW + 4;                      // always-zero dwords a dropped tap reads (offsets 0 .. 3*BW+1)
-    constexpr int TILE_DW = DM_NBUF * BUF_DW + ZPAD_DW;
+    // ONE_BASE: a tap keeps one LDS address (buffer 0) and the odd steps add the buffer pitch -- one VALU add per tap and odd
+    // step for NSRC * DP fewer registers; every buffer is then followed by its own zero cells, so that a dropped tap's address
+    // moves with the others.  Taken where registers decide the occupancy (the shared form, 3+ sources).
+    constexpr bool ONE_BASE = SMVS_ONE_BASE >= 0 ? (SHARED && SMVS_ONE_BASE) : (SHARED && WPS >= 3 && NSRC > 2);
+    constexpr int BUFP_DW = ONE_BASE ? BUF_DW + ZPAD_DW : BUF_DW;       // buffer pitch
+    constexpr int TILE_DW = ONE_BASE ? DM_NBUF * BUFP_DW : DM_NBUF * BUF_DW + ZPAD_DW;
     constexpr int NSTEP = CT / 2;
     static_assert(BW % 4 == 0 && CT % 2 == 0 && 2 * DP + 2 <= 63 && DP * NSRC <= 32, "chunks / steps / vmcnt bookkeeping / tap mask");
-    __shared__ __attribute__((aligned(16))) uint32_t tile_all[WV_WAVES][(TILE_DW + 3) & ~3];
+    __shared__ __attribute__((aligned(16))) uint32_t tile_all[SHARED ? 1 : WV_WAVES][(TILE_DW + 3) & ~3];
+    __shared__ __attribute__((aligned(16))) int xch[SHARED ? NW : 1][NSRC][4];   // shared form: every wave's tap extents
+    __shared__ double scr_all[SHARED ? NW : 1][32];                             // shared form: a wave's scratch (reciprocal scales)
 #ifdef SMVS_LDS_PAD
     __shared__ float lds_pad[SMVS_LDS_PAD / 4];            // profiling builds only: caps the workgroups per CU
     if (p.B < 0) lds_pad[threadIdx.x] = 0.0f;
@@ -326,8 +355,9 @@ void costvol_dma_kernel(const CostVolParams p)
     // one wave = one 32 x 2 pixel patch x ONE group of DP planes (p.dch == DP): no loop over groups, so
     // nothing of the geometry phase stays live across the channel-pair loop
     uint32_t L = xcd_remap(blockIdx.x, gridDim.x);
-    const int xtile = L % p.xt; L /= p.xt;
-    const int dchunk = L % p.dct; L /= p.dct;
+    int xtile, dchunk;
+    if (p.chunk_major) { dchunk = L % p.dct; L /= p.dct; xtile = L % p.xt; L /= p.xt; }     // see launch_order()
+    else               { xtile = L % p.xt; L /= p.xt; dchunk = L % p.dct; L /= p.dct; }
     const int ytile = L % p.yt;
     const int b = L / p.yt;
 
@@ -335,20 +365,28 @@ void costvol_dma_kernel(const CostVolParams p)
     const int HW = H * W;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t* tile = tile_all[wave];
+    const int wy = SHARED ? wave % NY : wave;               // position in the workgroup's stack of row pairs
+    const int wp = SHARED ? wave / NY : 0;                  // ... and along the plane axis
+    uint32_t* tile = tile_all[SHARED ? 0 : wave];
     const uint32_t tile_lds = __builtin_amdgcn_readfirstlane(lds_addr(tile));
     const int x = xtile * WV_TX + (lane & (WV_TX - 1));
-    const int y = (ytile * WV_WAVES + wave) * WV_TY + (lane >> 5);
+    const int y = (ytile * NY + wy) * WV_TY + (lane >> 5);
     const bool active = (x < W) && (y < H);
     const int pix = min(y, H - 1) * W + min(x, W - 1);
-    const int dg = p.d_begin + dchunk * DP;
-    const int np = min(DP, p.d_end - dg);
+    const int dg = p.d_begin + (dchunk * NWP + wp) * DP;
+    const int np = min(DP, p.d_end - dg);                    // may be <= 0 in the shared form (a wave past the last plane: it only stages)
 
-    if ((ytile * WV_WAVES + wave) * WV_TY >= H) return;      // whole wave below the image (no barriers used)
+    if constexpr (!SHARED) {
+        if ((ytile * WV_WAVES + wave) * WV_TY >= H) return;  // whole wave below the image (no barriers used)
+    }
 
     // zero cells behind each buffer: a tap whose footprint misses the image reads these, so it
     // contributes 0 * weight exactly like four masked gathers (0, or NaN for a NaN coordinate)
-    for (int i = lane; i < ZPAD_DW; i += 64) tile[DM_NBUF * BUF_DW + i] = 0u;
+    if constexpr (ONE_BASE) {
+        for (int i = lane; i < ZPAD_DW; i += 64) tile[BUF_DW + i] = tile[BUFP_DW + BUF_DW + i] = 0u;     // (every wave writes the same zeros)
+    } else {
+        for (int i = lane; i < ZPAD_DW; i += 64) tile[DM_NBUF * BUF_DW + i] = 0u;
+    }
 
     const float fV = (float)p.V;
     const float rV = p.rV;
@@ -400,7 +438,7 @@ void costvol_dma_kernel(const CostVolParams p)
             const int v = lane / 3, k = lane - 3 * v;
             const int idx = (v == 0) ? (k == 0 ? I_SAMP_SCALE : k == 1 ? I_LINE_SCALE : I_H_SCALE)
                                      : (k == 0 ? I_LAT_SCALE : k == 1 ? I_LON_SCALE : I_H_SCALE);
-            double* slot = reinterpret_cast<double*>(tile);
+            double* slot = SHARED ? scr_all[SHARED ? wave : 0] : reinterpret_cast<double*>(tile);
             if (lane < 3 * (NSRC + 1)) slot[lane] = 1.0 / p.geo[((size_t)b * p.V + v) * RPC_LEN + idx];
             ref_n.a = slot[0]; ref_n.b = slot[1]; ref_n.h = slot[2];
 #pragma unroll
@@ -501,6 +539,29 @@ void costvol_dma_kernel(const CostVolParams p)
     for (int s = 0; s < NSRC; ++s) {
         int a0 = lo_x[s], a1 = hi_x[s], b0 = lo_y[s], b1 = hi_y[s];
         wave_minmax4(a0, a1, b0, b1);
+        if constexpr (SHARED) {
+            if (lane == 0) { xch[wave][s][0] = a0; xch[wave][s][1] = a1; xch[wave][s][2] = b0; xch[wave][s][3] = b1; }
+        }
+        lo_x[s] = a0; hi_x[s] = a1; lo_y[s] = b0; hi_y[s] = b1;
+    }
+    if constexpr (SHARED) {
+        // the workgroup's box = the union of its waves' extents (wave-uniform values, read back as broadcasts)
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) {
+            int a0 = INT_MAX, a1 = INT_MIN, b0 = INT_MAX, b1 = INT_MIN;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                a0 = min(a0, xch[w][s][0]); a1 = max(a1, xch[w][s][1]);
+                b0 = min(b0, xch[w][s][2]); b1 = max(b1, xch[w][s][3]);
+            }
+            lo_x[s] = __builtin_amdgcn_readfirstlane(a0); hi_x[s] = __builtin_amdgcn_readfirstlane(a1);
+            lo_y[s] = __builtin_amdgcn_readfirstlane(b0); hi_y[s] = __builtin_amdgcn_readfirstlane(b1);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s) {
+        const int a0 = lo_x[s], a1 = hi_x[s], b0 = lo_y[s], b1 = hi_y[s];
         const bool empty = a1 < a0;
         const int al = (a1 + 4 >= W) ? (W & 3) : 0;
         const int ax = a0 - ((a0 - al) & 3);
@@ -521,7 +582,38 @@ void costvol_dma_kernel(const CostVolParams p)
         // DMA lane map.  Chunk k of a source box = 4 columns of (row, channel) with k = (row * 2 + channel) * C4 + column / 4;
         // lane l of DMA instruction j carries chunk 64 j + l to LDS byte 16 (64 j + l) of the box.  Chunks outside the box
         // rows, the image, or right of the last column any tap reads get an out-of-range offset = zeros.
-        uint32_t vo[NSRC][NI];
+        // Shared form: the NSRC * NI instructions of a step are dealt out over the workgroup's waves, instruction i = s * NI + j
+        // to wave i % NW; a wave keeps the offsets, destination and descriptor of its own KD instructions only.
+        constexpr int NDMA = NSRC * NI;
+        constexpr int KD = SHARED ? (NDMA + NW - 1) / NW : 1;
+        uint32_t vo[SHARED ? 1 : NSRC][SHARED ? 1 : NI];
+        uint32_t vk[KD], dstk[KD];
+        bool usek[KD];
+        BufRsrc rsk[KD];
+        if constexpr (SHARED) {
+#pragma unroll
+            for (int k = 0; k < KD; ++k) {
+                const int i = k * NW + wave;                        // wave-uniform
+                const int sk = min(i / NI, NSRC - 1), j = i - (i / NI) * NI;
+                int bxs = bx0[0], bys = by0[0], bws = bw[0], bhs = bh[0];
+                const float* sp = p.src[0];
+#pragma unroll
+                for (int t = 1; t < NSRC; ++t)
+                    if (sk == t) { bxs = bx0[t]; bys = by0[t]; bws = bw[t]; bhs = bh[t]; sp = p.src[t]; }
+                const int slot = 64 * j + lane;
+                const int row = slot / (2 * C4), rem = slot - row * (2 * C4);
+                const int ch = rem >= C4 ? 1 : 0, col = (rem - ch * C4) * 4;
+                const int rel = (row * W + col) * 4 + ch * HW * 4;
+                const int gx = bxs + col, gy = bys + row;
+                const bool valid = (row < bhs) && (col < bws) && ((uint32_t)gy < (uint32_t)H) && (gx >= 0) && (gx + 4 <= W);
+                vk[k] = valid ? (uint32_t)(rel + (bys * W + bxs) * 4) : SMVS_OOB;
+                if (SMVS_ABLATE & 64) vk[k] = SMVS_OOB;
+                if (SMVS_ABLATE & 128) vk[k] = valid ? (vk[k] & 0xfff0u) : SMVS_OOB;
+                usek[k] = (i < NDMA) && (64 * j < bhs * 2 * C4);
+                dstk[k] = (uint32_t)(sk * SRC_DW * 4 + j * 1024);
+                rsk[k] = make_rsrc(sp + (size_t)b * CT * HW, (uint32_t)CT * (uint32_t)HW * 4u);
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int slot = 64 * j + lane;
@@ -533,7 +625,10 @@ void costvol_dma_kernel(const CostVolParams p)
                 const int gx = bx0[s] + col, gy = by0[s] + row;
                 const bool valid = (row < bh[s]) && (col < bw[s]) && ((uint32_t)gy < (uint32_t)H) && (gx >= 0) && (gx + 4 <= W);
                 vo[s][j] = valid ? (uint32_t)(rel + (by0[s] * W + bx0[s]) * 4) : SMVS_OOB;
+                if (SMVS_ABLATE & 64) vo[s][j] = SMVS_OOB;
+                if (SMVS_ABLATE & 128) vo[s][j] = valid ? (vo[s][j] & 0xfff0u) : SMVS_OOB;
             }
+        }
         }
 #pragma unroll
         for (int pl = 0; pl < DP; ++pl)
@@ -542,9 +637,9 @@ void costvol_dma_kernel(const CostVolParams p)
                 const bool ok = (okmask >> (pl * NSRC + s)) & 1u;
                 const int box0 = s * SRC_DW - ((by0[s] + 1) * (2 * BW) + bx0[s] + 1);      // wave-uniform
                 const uint32_t a = tile_lds + 4u * (uint32_t)((int)txy[pl][s] + box0);
-                const uint32_t z = tile_lds + 4u * (uint32_t)(DM_NBUF * BUF_DW);
+                const uint32_t z = tile_lds + 4u * (uint32_t)(ONE_BASE ? BUF_DW : DM_NBUF * BUF_DW);
                 tap[pl][s].base[0] = ok ? a : z;
-                tap[pl][s].base[1] = ok ? a + 4u * (uint32_t)BUF_DW : z;
+                tap[pl][s].base[1] = ONE_BASE ? 0u : ok ? a + 4u * (uint32_t)BUF_DW : z;
             }
         uint32_t ovo[DP];                                 // per-plane byte offset of this pixel inside one channel volume
 #pragma unroll
@@ -574,14 +669,20 @@ void costvol_dma_kernel(const CostVolParams p)
         for (int s = 0; s < NSRC; ++s) ni[s] = (bh[s] * 2 * C4 + 63) >> 6;
         auto issue_dma = [&](int st) {
             if (SMVS_ABLATE & 2) return;
-            const uint32_t buf = tile_lds + (uint32_t)((st & 1) * BUF_DW * 4);
+            const uint32_t buf = tile_lds + (uint32_t)((st & 1) * BUFP_DW * 4);
             const int choff = 2 * st * HW * 4;
+            if constexpr (SHARED) {
 #pragma unroll
-            for (int s = 0; s < NSRC; ++s) {
+                for (int k = 0; k < KD; ++k)
+                    if (usek[k]) dma_x4_to_lds(rsk[k], buf + dstk[k], vk[k], choff);      // wave-uniform
+            } else {
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    // destination = buf + a compile-time offset, formed inside the asm by one s_add into M0
-                    if (j < ni[s]) dma_at(s, j, buf, vo[s][j], choff);        // wave-uniform
+                for (int s = 0; s < NSRC; ++s) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        // destination = buf + a compile-time offset, formed inside the asm by one s_add into M0
+                        if (j < ni[s]) dma_at(s, j, buf, vo[s][j], choff);        // wave-uniform
+                    }
                 }
             }
         };
@@ -606,9 +707,14 @@ void costvol_dma_kernel(const CostVolParams p)
             // operations are outstanding.
             const f32x2 refc = ref0;
             SMVS_T(const unsigned long long tw0 = now();)
-            if (st == 0) wait_vmcnt<0>();
+            if (SMVS_ABLATE & 256) { if (st == 0) wait_vmcnt<0>(); }      // profiling: the landing of DMA(st) is not waited for
+            else if (st == 0) wait_vmcnt<0>();
             else if (st + 1 < NSTEP) wait_vmcnt<2 * DP + 2>();
             else wait_vmcnt<2 * DP>();
+            // shared form: my part of DMA(st) has landed -> so has everybody's, and everybody has finished step st-1, whose
+            // buffer DMA(st+1) is about to overwrite.  (A wave's LDS reads of step st-1 have all returned: its last unit
+            // waited for lgkmcnt(0).)
+            if constexpr (SHARED) asm volatile("s_barrier" ::: "memory");
             SMVS_T(const unsigned long long tw1 = now(); t_vm += tw1 - tw0;)
             ref0 = ref1;
             if (st + 1 < NSTEP) {
@@ -643,7 +749,8 @@ void costvol_dma_kernel(const CostVolParams p)
                 }
 #pragma unroll
                 for (int k = 0; k < US; ++k)
-                    lds_read_tap_planar<BW>(tap[pl][s0 + k].base[PAR], cv[u & 1][k][0], cv[u & 1][k][1], cv[u & 1][k][2], cv[u & 1][k][3]);
+                    lds_read_tap_planar<BW>(ONE_BASE ? tap[pl][s0 + k].base[0] + (uint32_t)(PAR * BUFP_DW * 4) : tap[pl][s0 + k].base[PAR],
+                                            cv[u & 1][k][0], cv[u & 1][k][1], cv[u & 1][k][2], cv[u & 1][k][3]);
             };
             auto store_plane = [&](int pl, f32x2 var) {
                 SMVS_T(const unsigned long long ts0 = now();)
@@ -769,6 +876,7 @@ void costvol_dma_kernel(const CostVolParams p)
         // ---- fallback: direct gathers for this plane group (box larger than the staged tile).
         //      Rare and wave-uniform; the source taps are rebuilt plane by plane from the ground point
         //      of phase A in a rolled loop (same float64 values as the staged path would have used).
+        SMVS_T(if (lane == 0) atomicAdd(&smvs_timing[6], 1ull);)      // waves that took the fallback
         const float* refp = p.ref + (size_t)b * CT * HW + pix;
         float* outp = p.out + (size_t)b * CT * p.D_out * HW + pix;
 #pragma unroll 1
@@ -836,6 +944,21 @@ static int kernel_choice()
     return tune_int("SMVS_COSTVOL_DIRECT", 0) == 1 ? K_DIRECT : K_DMA;      // A/B switch (tuning builds only)
 }
 
+// Order of the workgroups of one band of rows (an XCD sweeps a run of consecutive workgroups, xcd_remap): x tile fastest, then
+// plane chunk -- every plane chunk walks the band's source rows once more and finds them in that XCD's L2 (4 MiB) as long as the
+// band's staged rows fit: rows x sources x channels x W x 4 B = 1 MB at the metric shape (traffic 1.007 x algorithmic).  At
+// 5 views x 1536 columns the band is 3.9 MB: every chunk missed and the features came from HBM once per plane chunk (FETCH_SIZE
+// 1.58 GB against 0.755 GB for the 8-plane shard, 12 GB for the 64-plane sweep; profiles/r04_cfg4_summary.txt).  Above 1.5 MB
+// the plane chunk runs fastest instead: all plane chunks of an x tile are in flight together and share ~0.1 MB.
+#ifndef SMVS_CHUNK_MAJOR
+#define SMVS_CHUNK_MAJOR (-1)         // A/B switch of profiling builds: 0 / 1 force an order
+#endif
+static int launch_order(const CostVolParams& p, int rows, int nsrc)
+{
+    if (SMVS_CHUNK_MAJOR >= 0) return SMVS_CHUNK_MAJOR;
+    return (long long)rows * nsrc * p.C * p.W * 4 > 1536 * 1024 ? 1 : 0;
+}
+
 template <int GEO, int NSRC, int DP, int AR>
 static hipError_t launch_staged(CostVolParams p, hipStream_t st)
 {
@@ -844,6 +967,7 @@ static hipError_t launch_staged(CostVolParams p, hipStream_t st)
     p.yt = (p.H + WV_TY * WV_WAVES - 1) / (WV_TY * WV_WAVES);
     p.dch = DP;
     p.dct = (nd + DP - 1) / DP;
+    p.chunk_major = launch_order(p, WV_TY * WV_WAVES + 3, NSRC);
     const long long nb = (long long)p.xt * p.yt * p.dct * p.B;
     if (nb >= (1ll << 31)) return hipErrorInvalidValue;
     dim3 blk(64 * WV_WAVES), grd((unsigned)nb);
@@ -860,6 +984,65 @@ static hipError_t launch_staged(CostVolParams p, hipStream_t st)
     return hipGetLastError();
 #endif
 }
+
+// Shared-box form: a workgroup = NWY x NWP waves = 32 x 2 NWY pixels x DP NWP planes
+template <int GEO, int NSRC, int DP, int AR, int NWY, int NWP, int WPS>
+static hipError_t launch_shared(CostVolParams p, hipStream_t st)
+{
+    const int nd = p.d_end - p.d_begin;
+    p.xt = (p.W + WV_TX - 1) / WV_TX;
+    p.yt = (p.H + WV_TY * NWY - 1) / (WV_TY * NWY);
+    p.dch = DP;
+    p.dct = (nd + DP * NWP - 1) / (DP * NWP);
+    p.chunk_major = launch_order(p, WV_TY * NWY + 3, NSRC);
+    const long long nb = (long long)p.xt * p.yt * p.dct * p.B;
+    if (nb >= (1ll << 31)) return hipErrorInvalidValue;
+    dim3 blk(64 * NWY * NWP), grd((unsigned)nb);
+#ifdef SMVS_ONLY_BENCH
+    if (p.C == 32) hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 32, DP, AR, NWY, NWP, WPS>), grd, blk, 0, st, p);
+    return hipGetLastError();
+#else
+    switch (p.C) {
+    case 8:  hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 8, DP, AR, NWY, NWP, WPS>), grd, blk, 0, st, p); break;
+    case 16: hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 16, DP, AR, NWY, NWP, WPS>), grd, blk, 0, st, p); break;
+    default: hipLaunchKernelGGL((costvol_dma_kernel<GEO, NSRC, 32, DP, AR, NWY, NWP, WPS>), grd, blk, 0, st, p); break;
+    }
+    return hipGetLastError();
+#endif
+}
+
+// shared-box configuration of the 3-4 source sweeps (4+ planes): planes per wave, waves in y, waves along planes, waves per SIMD
+#ifndef SMVS_N34_SHARED
+#define SMVS_N34_SHARED 1
+#endif
+#ifndef SMVS_N34_DP
+#define SMVS_N34_DP 4
+#endif
+#ifndef SMVS_N34_NWY
+#define SMVS_N34_NWY 2
+#endif
+#ifndef SMVS_N34_NWP
+#define SMVS_N34_NWP 2
+#endif
+#ifndef SMVS_N34_WPS
+#define SMVS_N34_WPS 2
+#endif
+// ... and of the 1-2 source sweeps that divide into eights at C = 32 (A/B switch; 0 = every wave its own box)
+#ifndef SMVS_N2_SHARED
+#define SMVS_N2_SHARED 0
+#endif
+#ifndef SMVS_N2_DP
+#define SMVS_N2_DP 8
+#endif
+#ifndef SMVS_N2_NWY
+#define SMVS_N2_NWY 2
+#endif
+#ifndef SMVS_N2_NWP
+#define SMVS_N2_NWP 1
+#endif
+#ifndef SMVS_N2_WPS
+#define SMVS_N2_WPS 2
+#endif
 
 template <int GEO, int NSRC, int AR>
 static hipError_t launch_ct(CostVolParams p, hipStream_t st)
@@ -879,6 +1062,12 @@ static hipError_t launch_ct(CostVolParams p, hipStream_t st)
             // voxel and the ref view's plane-invariant part amortised over twice the planes outweigh the drop to two
             // waves per SIMD (219 VGPRs) -- measured 0.699 vs 0.717 ms at the metric shape; at C = 8 (float64-bound) 4 planes per
             // wave stay faster (0.053 vs 0.061 ms)
+#if SMVS_N2_SHARED
+            if constexpr (NSRC <= 2 && GEO == 0) { if (nd % 8 == 0 && p.C == 32) return launch_shared<GEO, NSRC, SMVS_N2_DP, AR, SMVS_N2_NWY, SMVS_N2_NWP, SMVS_N2_WPS>(p, st); }
+#endif
+#if SMVS_N34_SHARED
+            if constexpr (NSRC > 2 && NSRC <= 4) { if (nd % (SMVS_N34_DP * SMVS_N34_NWP) == 0) return launch_shared<GEO, NSRC, SMVS_N34_DP, AR, SMVS_N34_NWY, SMVS_N34_NWP, SMVS_N34_WPS>(p, st); }
+#endif
 #if SMVS_DP8
             if constexpr (NSRC <= 2 && (GEO == 0 || SMVS_DP8_HOMO)) { if (nd % 8 == 0 && p.C >= SMVS_DP8_MINC) return launch_staged<GEO, NSRC, 8, AR>(p, st); }
 #endif

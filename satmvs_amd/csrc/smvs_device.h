@@ -521,6 +521,14 @@ __device__ __forceinline__ void dma_x4_to_lds_at(const BufRsrc& rs, uint32_t lds
                  :: "s"(lds_base), "v"(voffset), "s"(rs.v), "s"(soffset), "n"(OFF) : "memory", "m0", "scc");
 }
 
+// Same, destination in an SGPR (the shared-box form: a wave issues the instructions dealt to it, their places in the
+// box set are wave-uniform run-time values -- a handful per wave, so they stay in SGPRs)
+__device__ __forceinline__ void dma_x4_to_lds(const BufRsrc& rs, uint32_t lds_byte_addr, uint32_t voffset, int soffset)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_byte_addr), "v"(voffset), "s"(rs.v), "s"(soffset) : "memory", "m0");
+}
+
 #pragma clang diagnostic pop
 
 // The four corners of one tap for a channel pair out of the PLANAR staging layout [row][channel of the pair][column]

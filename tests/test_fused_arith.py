@@ -86,6 +86,8 @@ def test_set_arith_round_trip(dev):
     dict(B=1, V=4, C=32, D=8, H=40, W=72, jitter=True),        # 3 sources (odd: compiler-scheduled units)
     dict(B=1, V=6, C=16, D=5, H=40, W=72, jitter=True),        # 5 sources
     dict(B=2, V=7, C=32, D=4, H=24, W=66, jitter=False),       # 6 sources: three units per plane (middle-unit tail)
+    dict(B=2, V=5, C=16, D=8, H=38, W=70, jitter=True),        # shared-box form: 4 sources, 8 planes, ragged tile, batch 2
+    dict(B=1, V=4, C=8, D=16, H=24, W=100, jitter=False),      # shared-box form: 3 sources (one source per unit), (B,D) heights
 ])
 def test_fused_costvol_vs_oracle_and_float64(dev, oracle, fused, cfg):
     from satmvs_amd import _lib

@@ -158,6 +158,9 @@ def test_costvol_golden(dev, golden):
     dict(B=1, V=6, C=16, D=5, H=40, W=72, jitter=True),        # staged kernel, 5 sources (2 planes per wave, odd plane count)
     dict(B=2, V=7, C=32, D=4, H=24, W=66, jitter=False),       # staged kernel, 6 sources, batch 2, (B,D) heights, ragged width
     dict(B=1, V=8, C=8, D=1, H=16, W=96, jitter=True),         # staged kernel, 7 sources, single plane
+    dict(B=2, V=5, C=16, D=8, H=38, W=70, jitter=True),        # shared-box form (4 sources, 8 planes): ragged tile whose last workgroup has a row pair below the image, batch 2
+    dict(B=1, V=4, C=8, D=16, H=24, W=100, jitter=False),      # shared-box form, 3 sources, (B,D) heights, two plane chunks
+    dict(B=1, V=5, C=32, D=8, H=6, W=20, jitter=True),         # shared-box form, smaller than one workgroup patch
 ])
 def test_costvol_vs_oracle(dev, oracle, cfg):
     from satmvs_amd.modules import warping
@@ -193,6 +196,34 @@ def test_costvol_pinhole_vs_oracle(dev, oracle):
     want = oracle.costvol_variance(feats, proj, depth, "pinhole")
     got = warping.variance_cost_volume([_t(f, dev) for f in feats], _t(proj, dev), _t(depth, dev), "pinhole")
     _close_f32(got, want)
+
+
+def test_costvol_shared_box_paths_agree(dev, oracle, arith):
+    """3-4 sources, sweeps that divide into eights: a workgroup of 2 x 2 waves stages ONE box per source for 4 rows x 8 planes
+    (csrc/costvol_kernels.h, shared form).  Plane windows take the shared form (8 planes), the per-wave form (4 / 2 / 1 planes)
+    or, with planes too far apart for the box, the direct gathers inside it: identical bits in both arithmetic modes, so
+    a sharded build equals the unsharded one; the exact mode also equals the oracle."""
+    from satmvs_amd.modules import warping
+    feats, rpc, depth = _inputs(1, 5, 16, 24, 42, 72, seed=8)
+    depth[0, 5, 7, 9] = np.nan
+    depth[0, 17, :4] = 9000.0                                       # off the source images
+    f = [_t(x, dev) for x in feats]
+    r, d = _t(rpc, dev), _t(depth, dev)
+    full = warping.variance_cost_volume(f, r, d, "rpc")
+    for lo, hi in ((0, 8), (8, 24), (3, 11), (16, 24), (5, 6), (0, 4), (10, 12), (1, 24)):
+        part = warping.variance_cost_volume(f, r, d, "rpc", d_begin=lo, d_end=hi)
+        assert torch.equal(torch.nan_to_num(part, nan=-7.0), torch.nan_to_num(full[:, :, lo:hi], nan=-7.0)), (lo, hi)
+    if arith == "exact":
+        want = oracle.costvol_variance(feats, rpc, depth, "rpc")
+        got = full.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        _close_f32(got[~np.isnan(want)], want[~np.isnan(want)])
+    # planes 57 m apart: the workgroup's boxes do not fit -> every wave takes the direct gathers for its planes
+    wide = np.broadcast_to(np.linspace(0.0, 3000.0, 8, dtype=np.float32).reshape(1, 8, 1, 1), (1, 8, 42, 72)).copy()
+    w = _t(wide, dev)
+    whole = warping.variance_cost_volume(f, r, w, "rpc")
+    for pl in range(8):
+        assert torch.equal(warping.variance_cost_volume(f, r, w, "rpc", d_begin=pl, d_end=pl + 1), whole[:, :, pl:pl + 1]), pl
 
 
 @pytest.mark.parametrize("C", [8, 16])                          # direct kernel / staged kernel

@@ -2,7 +2,7 @@
 # On the GPU box: sustained run of each gpurun_ab build with power / sclk samples.  tools/power_sweep.sh base x4 ...
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 for v in "$@"; do
-  SMVS_LIB_PATH=$REPO/gpurun_ab/$v.so python $REPO/bench.py --no-cpu-baseline --no-extra --steps ${PS_STEPS:-6000} --warmup 10 > /tmp/ps_$v.out 2>&1 &
+  SMVS_LIB_PATH=$REPO/gpurun_ab/$v.so python $REPO/bench.py --no-cpu-baseline --no-extra ${PS_WORKLOAD:+--workload $PS_WORKLOAD} --steps ${PS_STEPS:-6000} --warmup 10 > /tmp/ps_$v.out 2>&1 &
   pid=$!
   sleep ${PS_DELAY:-5}
   p=""; c=""

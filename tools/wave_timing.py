@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-wave phase times of the staged cost-volume kernel (library built with -DSMVS_TIMING):
-    SMVS_LIB_PATH=gpurun_ab/timing.so python tools/wave_timing.py"""
+    SMVS_LIB_PATH=gpurun_ab/timing.so [SMVS_WORKLOAD=cfg4_rpc_5view_1536x768x8_c32] python tools/wave_timing.py"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,8 +9,13 @@ import bench
 _lib.load()
 lib = ctypes.CDLL(os.environ["SMVS_LIB_PATH"])
 dev = torch.device("cuda:0")
-V, C, D, H, W = bench.WORKLOADS["cfg2_rpc_3view_768x384x64_c32"]
+wl = os.environ.get("SMVS_WORKLOAD", "cfg2_rpc_3view_768x384x64_c32")
+V, C, D, H, W = bench.WORKLOADS[wl]
 feats, rpc, depth = bench.make_inputs(V, C, D, D, 0, H, W, dev)
+if wl in bench.SIDE_HEIGHTS:
+    lo, hi = bench.SIDE_HEIGHTS[wl]
+    depth = torch.linspace(lo, hi, D, dtype=torch.float32).view(1, D, 1, 1).expand(1, D, H, W).contiguous().to(dev)
+_lib.set_arith("exact")          # the stamps live in costvol.hip's copy of the kernels (the exact instances)
 out = torch.empty((1, C, D, H, W), dtype=torch.float32, device=dev)
 srcs = _lib.ptr_array(feats[1:])
 st = _lib.current_stream(dev)
@@ -24,6 +29,6 @@ for _ in range(n): step()
 lib.smvs_debug_timing(buf, 1)
 w = buf[7]
 names = ["geometry", "box+setup", "pair loop", " vmcnt waits", " store issue", " dma issue"]
-print("waves %d (%d launches)" % (w, n))
+print("waves %d staged + %d fallback (%d launches)" % (w, buf[6], n))
 for i in (0, 1, 2, 3, 4, 5):
     print("%-14s %9.0f clocks per wave" % (names[i], buf[i] / w))
