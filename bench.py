@@ -168,12 +168,42 @@ def time_steps(step, steps, barrier=lambda: None):
     return elapsed, float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
 
+def rank_identities(dist, dev, world, rank, one_device):
+    """Evidence that the collective really spanned `world` devices: every rank's (rank, device index, PCI bus id, device name,
+    host pid) all-gathered through the process group itself, the backend's name and -- for "nccl" (= RCCL on ROCm) -- the
+    library version.  Asserts the bus ids are distinct unless this is the one-GPU rehearsal (SMVS_BENCH_ONE_DEVICE=1)."""
+    props = torch.cuda.get_device_properties(dev)
+    try:
+        bus = torch.cuda.get_device_properties(dev).pci_bus_id
+        bus = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), bus, getattr(props, "pci_device_id", 0))
+    except AttributeError:
+        bus = "unknown"
+    uuid = str(getattr(props, "uuid", ""))
+    mine = {"rank": rank, "device_index": dev.index, "pci_bus_id": bus, "uuid": uuid, "name": props.name, "pid": os.getpid()}
+    if dist is None:
+        return {"backend": None, "ranks": [mine]}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    backend = dist.get_backend()
+    info = {"backend": backend, "ranks": everyone, "distinct_devices": len({(r["pci_bus_id"], r["uuid"]) for r in everyone})}
+    if backend == "nccl":
+        try:
+            info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:                                  # noqa: BLE001 -- reported, never fatal
+            info["rccl_version"] = "unavailable (%s)" % type(e).__name__
+    if not one_device and info["distinct_devices"] != world:
+        raise SystemExit("bench.py --gpus %d: the ranks report only %d distinct devices: %r" % (world, info["distinct_devices"], everyone))
+    return info
+
+
 def kernel_name(V, C, planes=4):
     direct = C not in (8, 16, 32)                           # dispatch rule of costvol.hip (launch_ct)
     if direct:
         return "costvol_fwd_kernel<rpc,%d,%d>" % (V - 1, C)
     dp = 1 if planes == 1 else 2 if (planes == 2 or V - 1 > 4) else 8 if (planes % 8 == 0 and V - 1 <= 2 and C == 32) else 4
     from satmvs_amd import _lib
+    if 3 <= V - 1 <= 4 and planes % 8 == 0:                 # shared-box form: 2 x 2 waves, one box per source for 4 rows x 8 planes
+        return "costvol_dma_kernel<rpc,%d,%d,4,%s,shared 2x2>" % (V - 1, C, _lib.get_arith())
     return "costvol_dma_kernel<rpc,%d,%d,%d,%s>" % (V - 1, C, dp, _lib.get_arith())
 
 
@@ -452,7 +482,7 @@ def cfg4_strong(dev, stream, rank, world, dist, barrier):
         step()
     steps = 10
     elapsed, _ = time_steps(step, steps, barrier)
-    serial_ms = None
+    serial_ms = exch = None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -463,9 +493,13 @@ def cfg4_strong(dev, stream, rank, world, dist, barrier):
         t = torch.tensor([se], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         serial_ms = float(t.item()) / steps * 1e3
+        _, ex_ms = time_steps(lambda: shard.allreduce_regression_state(state), 10, barrier)
+        slab = int(state.numel() * 8)
+        exch = {"bytes": slab, "bytes_sent_per_rank": int(2 * (world - 1) * slab // world), "ms": round(ex_ms, 4),
+                "GB/s_per_rank_and_direction": round(2 * (world - 1) * slab / world / (ex_ms * 1e-3) / 1e9, 2)}
     ms = elapsed / steps * 1e3
     bpv = algorithmic_bytes_per_voxel(V, C, D)
-    return {"workload": "cfg4_rpc_5view_1536x768x64_c32", "planes_per_gpu": nd, "ms_per_step": round(ms, 4),
+    return {"workload": "cfg4_rpc_5view_1536x768x64_c32", "planes_per_gpu": nd, "ms_per_step": round(ms, 4), "exchange": exch,
             "Mvox/s": round(D * H * W / ms / 1e3, 1), "scaling": "strong",
             "roofline_frac_aggregate": round(bpv * D * H * W / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
             "exchange_overlapped": world > 1, "ms_per_step_not_overlapped": None if serial_ms is None else round(serial_ms, 4),
@@ -566,12 +600,15 @@ def main():
         t = torch.tensor([serial_elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         serial_ms = float(t.item()) / min(args.steps, 50) * 1e3
+        slab = int(state.numel() * 8)
         exchange = {"op": "reduce-scatter (all_to_all of pixel chunks + rank-ordered local sum,sum,max) + all_gather of the (3,1,%d,%d) f64 regression partials, inside the timed step" % (H, W),
-                    "bytes": int(state.numel() * 8), "ms": round(ex_ms, 4),
+                    "bytes": slab, "bytes_sent_per_rank": int(2 * (world - 1) * slab // world), "ms": round(ex_ms, 4),
+                    "GB/s_per_rank_and_direction": round(2 * (world - 1) * slab / world / (ex_ms * 1e-3) / 1e9, 2),
                     "overlap": "issued behind the step's kernel on its own stream; the next step's kernel does not wait for it (a stream of tiles)",
                     "ms_per_step_not_overlapped": round(serial_ms, 4),
                     "device_work": "all_to_all_single out of the slab + smvs_regress_fold (one kernel) + in-place all_gather_into_tensor"}
 
+    ids = rank_identities(dist, dev, world, rank, one_device)   # collective: every rank takes part
     cfg4 = None
     if not args.no_extra:
         del out
@@ -601,6 +638,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload) if world == 1 else None,
                          "bytes_per_voxel": bpv, "kernel_ms": round(kern_ms, 4)},
         }
+        line["devices"] = ids
         if exchange is not None:
             line["exchange"] = exchange
             line["exchange_overlapped"] = True              # `value` is tile-stream throughput; exchange.ms_per_step_not_overlapped is the single-tile latency

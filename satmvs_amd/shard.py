@@ -30,7 +30,7 @@ def plane_range(num_planes, rank, world):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def allreduce_regression_state(state, group=None):
+def allreduce_regression_state(state, group=None, force=False):
     """In-place reduction of the (3,B,H,W) float64 accumulators over the ranks: rows 0,1 summed, row 2 maxed.
 
     A reduce-scatter + all-gather that carries all three rows at once, with no layout copies: the flattened slab is cut into
@@ -40,8 +40,9 @@ def allreduce_regression_state(state, group=None):
     on every rank and run, so the result is deterministic) straight into its chunk of the slab, and the chunks are
     all-gathered IN PLACE (input = this rank's chunk of the output).  Per exchange on the device: 2 collectives + 1 kernel
     (round 3: 2 collectives + 6 torch kernels).  A slab whose length the rank count does not divide is padded (one copy in,
-    one out); CPU tensors and the host-staged gloo rehearsal fold with torch operators."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    one out); CPU tensors and the host-staged gloo rehearsal fold with torch operators.  `force` runs the collectives for a
+    group of one rank as well (the result is the input): the smoke test of the RCCL entry points on a one-GPU box."""
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return state
     if state.shape[0] != 3:
         raise ValueError("state must be (3,B,H,W): [exp_sum, depth_img, max_prob]")

@@ -159,6 +159,56 @@ def test_bench_two_rank_rehearsal_on_one_device(tmp_path):
     assert line["exchange"]["bytes"] == 3 * 384 * 768 * 8 and line["exchange"]["ms"] > 0
     assert line["extra"]["cfg4_strong_scaling"]["planes_per_gpu"] == 32
     assert line["value"] > 0 and "cpu_baseline" not in line
+    # the fields that let a real SCALE run be checked: backend, every rank's device, bytes on the wire
+    assert line["devices"]["backend"] == "gloo" and [r["rank"] for r in line["devices"]["ranks"]] == [0, 1]
+    assert all(r["pci_bus_id"] and r["pid"] > 0 for r in line["devices"]["ranks"])
+    assert line["exchange"]["bytes_sent_per_rank"] == 3 * 384 * 768 * 8 and line["exchange"]["ms_per_step_not_overlapped"] > 0
+    c4 = line["extra"]["cfg4_strong_scaling"]
+    assert c4["exchange"]["bytes"] == 3 * 768 * 1536 * 8 and c4["exchange"]["ms"] > 0 and c4["ms_per_step_not_overlapped"] > 0
+
+
+def _nccl_smoke(port, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1)           # "nccl" is RCCL on ROCm
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    from satmvs_amd import shard
+    g = torch.Generator(device="cpu").manual_seed(3)
+    state = torch.randn((3, 2, 24, 40), generator=g, dtype=torch.float64).to(dev)
+    want = state.clone()
+    shard.allreduce_regression_state(state, force=True)             # all_to_all_single + smvs_regress_fold + in-place all_gather_into_tensor
+    ragged = torch.randn((3, 1, 5, 7), generator=g, dtype=torch.float64).to(dev)
+    want2 = ragged.clone()
+    shard.allreduce_regression_state(ragged, force=True)
+    b = torch.arange(16, dtype=torch.float32, device=dev)
+    dist.broadcast(b, src=0)                                        # the last shard's broadcast of the finished sums
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(state, want) and torch.equal(ragged, want2) and b.sum().item() == 120.0)
+    with open(out_path, "w") as f:
+        f.write("%s %s %s" % (ok, dist.get_backend(), ".".join(str(x) for x in torch.cuda.nccl.version())))
+    dist.destroy_process_group()
+
+
+def test_rccl_entry_points_smoke_world_size_one(tmp_path):
+    """The exchange of shard.allreduce_regression_state through backend "nccl" (RCCL) with a group of ONE rank: every RCCL
+    entry point the N > 1 path uses (all_to_all_single out of the slab, in-place all_gather_into_tensor, broadcast) is
+    called once on the real backend with device buffers and the fold kernel between them; the slab must come back
+    unchanged.  The multi-rank numerics are covered by the gloo tests above; this one only proves the calls are legal
+    for RCCL (a one-GPU box has no second device to talk to)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    out = str(tmp_path / "smoke.txt")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_nccl_smoke, args=(_free_port(), out))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    ok, backend, version = open(out).read().split()
+    assert ok == "True" and backend == "nccl" and version[0].isdigit()
 
 
 @pytest.mark.parametrize("world,B,H,W", [(8, 1, 384, 768), (2, 2, 24, 40), (4, 1, 8, 24)])
