@@ -57,6 +57,40 @@ def load_rpc_as_array(filepath):
     return data, data[4] + data[9], data[4] - data[9]
 
 
+# The 20 RPC monomials in the order of tools/RPCCore.py:8-28 as index triples over (1, L, P, H): coefficient n multiplies
+# v[i] * v[j] * v[k].  The quaternary-cubic ("QC") form spreads it evenly over the permutations of its triple in a symmetric
+# (4,4,4) tensor, so that  poly = sum_ijk T[i,j,k] v_i v_j v_k  (data_io.py:95-120).
+_QC_TRIPLES = [(0, 0, 0), (0, 0, 1), (0, 0, 2), (0, 0, 3), (0, 1, 2), (0, 1, 3), (0, 2, 3), (0, 1, 1), (0, 2, 2), (0, 3, 3),
+               (1, 2, 3), (1, 1, 1), (1, 2, 2), (1, 3, 3), (1, 1, 2), (2, 2, 2), (2, 3, 3), (1, 1, 3), (2, 2, 3), (3, 3, 3)]
+_QC_SCALARS = ["line_off", "samp_off", "lat_off", "lon_off", "height_off", "line_scale", "samp_scale", "lat_scale", "lon_scale",
+               "height_scale"]
+_QC_TENSORS = ["line_num", "line_den", "samp_num", "samp_den", "lat_num", "lat_den", "lon_num", "lon_den"]
+
+
+def to_tensor(data):
+    """20 cubic coefficients -> the symmetric (4,4,4) float64 tensor of the `use_qc` operators: every permutation of a monomial's
+    index triple holds coefficient / (number of distinct permutations) -- 1, 3 or 6 (data_io.py:95-120)."""
+    import itertools
+    data = np.asarray(data, np.float64)
+    assert data.shape == (20,)
+    out = np.zeros((4, 4, 4), np.float64)
+    for c, t in zip(data, _QC_TRIPLES):
+        perms = set(itertools.permutations(t))
+        for q in perms:
+            out[q] = c / float(len(perms))
+    return out
+
+
+def load_rpc_as_qc_tensor(filepath):
+    """`.rpc` text -> the dict the `use_qc=True` networks consume (data_io.py:123-150): ten float64 scalars `line_off` ...
+    `height_scale` and eight `<line|samp|lat|lon>_<num|den>_tensor` (4,4,4) arrays."""
+    data = load_rpc_as_array(filepath)[0]
+    rpc = {k: data[i] for i, k in enumerate(_QC_SCALARS)}
+    for n, k in enumerate(_QC_TENSORS):
+        rpc[k + "_tensor"] = to_tensor(data[10 + 20 * n: 30 + 20 * n])
+    return rpc
+
+
 _RPC_NAMES = (["LINE_OFF", "SAMP_OFF", "LAT_OFF", "LONG_OFF", "HEIGHT_OFF", "LINE_SCALE", "SAMP_SCALE", "LAT_SCALE",
                "LONG_SCALE", "HEIGHT_SCALE"]
               + ["%s_%d" % (n, i + 1) for n in ("LINE_NUM_COEFF", "LINE_DEN_COEFF", "SAMP_NUM_COEFF", "SAMP_DEN_COEFF",

@@ -7,8 +7,8 @@ A scene folder holds  image/<view>/<tile>.png,  rpc/<view>/<tile>.rpc,  height/<
 A sample is what networks/casred.py consumes: "imgs" (V,3,H,W) float32, each view normalised to zero mean / unit variance per
 channel; "cam_para" {"stage1": rpc at 1/4 resolution, "stage2": 1/2, "stage3": full} (V,170) float64; "depth_values"
 [h_min, h_max] of the ref view; and, outside "pred" mode, the ground-truth height map and its validity mask at the three
-scales (nearest-neighbour decimation).  `use_qc` (the quaternary-cubic tensor form of the RPCs) is served by
-satmvs_amd.modules.warping.qc_dict_to_rpc on the operator side; the assembler here hands out the 170-vectors.
+scales (nearest-neighbour decimation).  With `use_qc=True` "cam_para" holds, per stage, a list of V dictionaries in the
+quaternary-cubic tensor form of the RPCs (satmvsdataset.py:166-296, data_io.py:123-150) -- what the `use_qc=True` networks index.
 """
 from __future__ import annotations
 
@@ -16,7 +16,9 @@ import os
 
 import numpy as np
 
-from .data_io import load_pfm, load_rpc_as_array
+import copy
+
+from .data_io import load_pfm, load_rpc_as_array, load_rpc_as_qc_tensor
 
 # offsets of the image-side normalisation inside the 170-vector (tools/RPCCore.py:8-28): LINE_OFF, SAMP_OFF, LINE_SCALE, SAMP_SCALE
 _IMAGE_SIDE = (0, 1, 5, 6)
@@ -86,14 +88,40 @@ def gen_all_mvs_list_rpc(data_folder, view_num):
     return out
 
 
+def random_color(image, rng=np.random):
+    """The reference's training-time augmentation (preprocess.py:163-178): colour, brightness, contrast and sharpness of a PIL image
+    enhanced by factors drawn as randint / 100 from [0.01, 3], [0.1, 2], [0.1, 2], [0, 3], in that order."""
+    from PIL import ImageEnhance
+    image = ImageEnhance.Color(image).enhance(rng.randint(1, 301) / 100.)
+    image = ImageEnhance.Brightness(image).enhance(rng.randint(10, 201) / 100.)
+    image = ImageEnhance.Contrast(image).enhance(rng.randint(10, 201) / 100.)
+    return ImageEnhance.Sharpness(image).enhance(rng.randint(0, 301) / 100.)
+
+
+image_augment = random_color           # preprocess.py:156-160
+
+_QC_IMAGE_SIDE = ("line_off", "samp_off", "line_scale", "samp_scale")
+
+
+def scale_rpc_qc(rpcs, factor):
+    """scale_rpc for a list of QC dictionaries (satmvsdataset.py:212-224)."""
+    out = copy.deepcopy(rpcs)
+    for r in out:
+        for k in _QC_IMAGE_SIDE:
+            r[k] = r[k] / factor
+    return out
+
+
 class MVSDataset:
     """Drop-in for dataset.satmvsdataset.MVSDataset (a torch Dataset: __len__ / __getitem__); modes "train", "val", "test",
-    "pred".  Image augmentation of the train mode (random colour / brightness / contrast / sharpness, preprocess.py:163-178) is
-    the reference's training-time noise source and is not reproduced: pass `augment` (a PIL image -> PIL image callable)."""
+    "pred"; `use_qc` selects the QC-dictionary samples (get_sample_qc / get_pred_sample_qc).  The "train" mode augments every view
+    with the reference's random_color unless another `augment` (a PIL image -> PIL image callable) is given; augment=False
+    switches it off."""
 
     def __init__(self, data_folder, mode, view_num, ref_view=2, use_qc=False, augment=None):
         assert mode in ["train", "val", "test", "pred"]
-        self.data_folder, self.mode, self.view_num, self.ref_view, self.use_qc, self.augment = data_folder, mode, view_num, ref_view, use_qc, augment
+        self.data_folder, self.mode, self.view_num, self.ref_view, self.use_qc = data_folder, mode, view_num, ref_view, use_qc
+        self.augment = image_augment if augment is None else (augment or None)
         if mode == "pred" or ref_view < 0:
             self.sample_list = gen_all_mvs_list_rpc(data_folder, view_num)
         else:
@@ -103,29 +131,32 @@ class MVSDataset:
     def __len__(self):
         return len(self.sample_list)
 
-    def _views(self, data, augment):
+    def _views(self, data, augment, qc=False):
         imgs, rpcs = [], []
         for view in range(self.view_num):
             image = read_img(data[2 * view])
             if augment is not None:
                 image = augment(image)
             imgs.append(center_image(np.asarray(image)))
-            rpcs.append(load_rpc_as_array(data[2 * view + 1])[0])
-        rpcs = np.stack(rpcs)
-        cams = {"stage1": scale_rpc(rpcs, 4), "stage2": scale_rpc(rpcs, 2), "stage3": rpcs}
+            rpcs.append(load_rpc_as_qc_tensor(data[2 * view + 1]) if qc else load_rpc_as_array(data[2 * view + 1])[0])
+        if qc:
+            cams = {"stage1": scale_rpc_qc(rpcs, 4), "stage2": scale_rpc_qc(rpcs, 2), "stage3": rpcs}
+        else:
+            rpcs = np.stack(rpcs)
+            cams = {"stage1": scale_rpc(rpcs, 4), "stage2": scale_rpc(rpcs, 2), "stage3": rpcs}
         return np.stack(imgs).transpose([0, 3, 1, 2]), cams
 
     @staticmethod
     def _names(data):
         return data[0].split("/")[-2], os.path.splitext(data[0].split("/")[-1])[0]
 
-    def get_sample(self, idx):
+    def get_sample(self, idx, qc=False):
         data = self.sample_list[idx]
-        # (the reference indexes the height range by 2 * ref_view + 1 into the sample's path list, satmvsdataset.py:44 -- for
+        # (the reference indexes the height range by 2 * ref_view + 1 into the sample's path list, satmvsdataset.py:44 / :175 -- for
         #  the default ref_view = 2 of a 3-view sample that is the LAST source's rpc file, not the ref view's; reproduced)
         _, depth_max, depth_min = load_rpc_as_array(data[2 * self.ref_view + 1])
         depth_image = load_pfm(data[2 * self.view_num]).astype(np.float32)
-        imgs, cams = self._views(data, self.augment if self.mode == "train" else None)
+        imgs, cams = self._views(data, self.augment if self.mode == "train" else None, qc)
         depth_values = np.array([depth_min, depth_max], dtype=np.float32)
         mask = np.float32((depth_image >= depth_min) * 1.0) * np.float32((depth_image <= depth_max) * 1.0)
         out_view, out_name = self._names(data)
@@ -134,13 +165,21 @@ class MVSDataset:
                 "mask": {"stage1": decimate_nearest(mask, 4), "stage2": decimate_nearest(mask, 2), "stage3": mask},
                 "depth_values": depth_values, "out_view": out_view, "out_name": out_name}
 
-    def get_pred_sample(self, idx):
+    def get_pred_sample(self, idx, qc=False):
         data = self.sample_list[idx]
-        _, depth_max, depth_min = load_rpc_as_array(data[1])
-        imgs, cams = self._views(data, None)
+        # (the pred samples take the height range of path 1 = the ref view's rpc in the 170-vector form, satmvsdataset.py:123, and
+        #  of path 2 * ref_view + 1 in the QC form, :262; reproduced)
+        _, depth_max, depth_min = load_rpc_as_array(data[2 * self.ref_view + 1 if qc else 1])
+        imgs, cams = self._views(data, None, qc)
         out_view, out_name = self._names(data)
         return {"imgs": imgs, "cam_para": cams, "depth_values": np.array([depth_min, depth_max], dtype=np.float32),
                 "out_view": out_view, "out_name": out_name}
 
+    def get_sample_qc(self, idx):
+        return self.get_sample(idx, qc=True)
+
+    def get_pred_sample_qc(self, idx):
+        return self.get_pred_sample(idx, qc=True)
+
     def __getitem__(self, idx):
-        return self.get_pred_sample(idx) if self.mode == "pred" else self.get_sample(idx)
+        return self.get_pred_sample(idx, self.use_qc) if self.mode == "pred" else self.get_sample(idx, self.use_qc)

@@ -715,16 +715,9 @@ def gen_filter():
     save("filter", **out)
 
 
-def gen_dataset():
-    """dataset/satmvsdataset.py:36-160 (MVSDataset.get_sample / get_pred_sample) + dataset/gen_list.py + read_img / center_image,
-    run AS IS on a small scene folder written by OUR writers (tests/golden/scene/: 3 views x 2 tiles of 32x64 PNG -- one tile
-    single-band --, .rpc, .pfm).  Modules the image lacks are stood in for at import time, nothing of the reference is edited or
-    stored: osgeo.gdal / matplotlib.pyplot (imported, never called on this path) by empty modules, cv2 by a module whose
-    resize(..., INTER_NEAREST) is OpenCV's nearest rule src = floor(dst * scale) in numpy -- so everything the assembler does is
-    pinned by this fixture EXCEPT cv2.resize itself."""
+def _import_ref_dataset():
+    """The reference's MVSDataset class, imported unmodified behind the import-time stand-ins described in gen_dataset."""
     import types
-    from PIL import Image
-    from satmvs_amd import data_io
     cv2 = types.ModuleType("cv2")
     cv2.INTER_NEAREST = 0
 
@@ -750,6 +743,19 @@ def gen_dataset():
         mpl.pyplot = types.ModuleType("matplotlib.pyplot")
         sys.modules["matplotlib"], sys.modules["matplotlib.pyplot"] = mpl, mpl.pyplot
     from dataset.satmvsdataset import MVSDataset as RefDataset
+    return RefDataset
+
+
+def gen_dataset():
+    """dataset/satmvsdataset.py:36-160 (MVSDataset.get_sample / get_pred_sample) + dataset/gen_list.py + read_img / center_image,
+    run AS IS on a small scene folder written by OUR writers (tests/golden/scene/: 3 views x 2 tiles of 32x64 PNG -- one tile
+    single-band --, .rpc, .pfm).  Modules the image lacks are stood in for at import time, nothing of the reference is edited or
+    stored: osgeo.gdal / matplotlib.pyplot (imported, never called on this path) by empty modules, cv2 by a module whose
+    resize(..., INTER_NEAREST) is OpenCV's nearest rule src = floor(dst * scale) in numpy -- so everything the assembler does is
+    pinned by this fixture EXCEPT cv2.resize itself."""
+    from PIL import Image
+    from satmvs_amd import data_io
+    RefDataset = _import_ref_dataset()
 
     scene = os.path.join(HERE, "scene")
     V, H, W = 3, 32, 64
@@ -785,10 +791,40 @@ def gen_dataset():
     save("dataset", **out)
 
 
+_QC_SCALARS = ["line_off", "samp_off", "lat_off", "lon_off", "height_off", "line_scale", "samp_scale", "lat_scale", "lon_scale", "height_scale"]
+_QC_TENSORS = ["line_num", "line_den", "samp_num", "samp_den", "lat_num", "lat_den", "lon_num", "lon_den"]
+
+
+def gen_dataset_qc():
+    """dataset/satmvsdataset.py:166-296 (MVSDataset(use_qc=True): get_sample_qc / get_pred_sample_qc over
+    dataset/data_io.py:95-150 load_rpc_as_qc_tensor / to_tensor) run AS IS on the scene folder gen_dataset wrote: per stage and view the
+    ten scalars and the eight (4,4,4) tensors of the QC dictionaries, images, height range, height maps and masks."""
+    RefDataset = _import_ref_dataset()
+    scene = os.path.join(HERE, "scene")
+    out = {}
+    for mode, ref_view in (("test", 2), ("test", 0), ("pred", 2)):
+        ds = RefDataset(scene, mode, 3, ref_view=ref_view, use_qc=True)
+        out["%s%d.len" % (mode, ref_view)] = np.int64(len(ds))
+        for i in range(len(ds)):
+            smp = ds[i]
+            key = "%s%d.%s.%s" % (mode, ref_view, smp["out_view"], smp["out_name"])
+            out[key + ".imgs"] = smp["imgs"]
+            out[key + ".depth_values"] = smp["depth_values"]
+            for st in ("stage1", "stage2", "stage3"):
+                cams = smp["cam_para"][st]
+                assert isinstance(cams, list) and len(cams) == 3
+                out[key + ".cam." + st + ".scalars"] = np.array([[c[k] for k in _QC_SCALARS] for c in cams], np.float64)
+                out[key + ".cam." + st + ".tensors"] = np.stack([np.stack([c[k + "_tensor"] for k in _QC_TENSORS]) for c in cams])
+                if mode != "pred":
+                    out[key + ".depth." + st] = smp["depth"][st]
+                    out[key + ".mask." + st] = smp["mask"][st]
+    save("dataset_qc", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (gen_iccv, gen_project, gen_grid_sample, gen_rpc_warp, gen_qc, gen_homo, gen_costvol, gen_pred,
-               gen_regress, gen_depth_range, gen_ucs_samples, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad, gen_io, gen_filter, gen_train, gen_dataset):
+               gen_regress, gen_depth_range, gen_ucs_samples, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad, gen_io, gen_filter, gen_train, gen_dataset, gen_dataset_qc):
         if only and fn.__name__[4:] not in only:
             continue
         fn()

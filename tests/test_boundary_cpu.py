@@ -345,3 +345,65 @@ def test_dataset_assembler_matches_reference(golden):
     # a sample feeds the networks as it is: (V,3,H,W) images, per-stage (V,170) RPCs
     smp = MVSDataset(scene, "pred", 3)[0]
     assert abs(float(smp["imgs"][0, 0].mean())) < 1e-5 and abs(float(smp["imgs"][0, 0].std()) - 1.0) < 1e-3
+
+
+def test_dataset_qc_samples_match_reference(golden):
+    """MVSDataset(use_qc=True) -- get_sample_qc / get_pred_sample_qc over data_io.load_rpc_as_qc_tensor / to_tensor -- against the
+    reference's own MVSDataset(use_qc=True) on the same scene folder (tests/golden/dataset_qc.npz, gen_golden.py::gen_dataset_qc):
+    per stage a LIST of V dictionaries (ten float64 scalars, eight symmetric (4,4,4) tensors), identical values; the QC tensors fold
+    back to the 170-vector the non-QC sample carries (modules.warping.qc_dict_to_rpc), so both forms drive the same kernels."""
+    import torch
+    from satmvs_amd.dataset import MVSDataset
+    from satmvs_amd import data_io
+    from satmvs_amd.modules.warping import qc_dict_to_rpc
+    g = golden("dataset_qc")
+    scene = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene")
+    scal, tens = data_io._QC_SCALARS, data_io._QC_TENSORS
+    for mode, ref_view in (("test", 2), ("test", 0), ("pred", 2)):
+        ds = MVSDataset(scene, mode, 3, ref_view=ref_view, use_qc=True)
+        plain = MVSDataset(scene, mode, 3, ref_view=ref_view)
+        assert len(ds) == int(g["%s%d.len" % (mode, ref_view)])
+        for i in range(len(ds)):
+            smp = ds[i]
+            key = "%s%d.%s.%s" % (mode, ref_view, smp["out_view"], smp["out_name"])
+            assert np.array_equal(smp["imgs"], g[key + ".imgs"]) and smp["imgs"].dtype == np.float32
+            assert smp["depth_values"].dtype == np.float32 and np.array_equal(smp["depth_values"], g[key + ".depth_values"]), key
+            for st in ("stage1", "stage2", "stage3"):
+                cams = smp["cam_para"][st]
+                assert isinstance(cams, list) and len(cams) == 3 and all(isinstance(c, dict) for c in cams)
+                got_s = np.array([[c[k] for k in scal] for c in cams], np.float64)
+                got_t = np.stack([np.stack([c[k + "_tensor"] for k in tens]) for c in cams])
+                assert np.array_equal(got_s, g[key + ".cam." + st + ".scalars"]), (key, st)
+                assert got_t.dtype == np.float64 and np.array_equal(got_t, g[key + ".cam." + st + ".tensors"]), (key, st)
+                if mode != "pred":
+                    assert np.array_equal(smp["depth"][st], g[key + ".depth." + st]) and np.array_equal(smp["mask"][st], g[key + ".mask." + st])
+                # the dictionaries, batched as a DataLoader would, fold back to the 170-vectors of the plain sample
+                for v, c in enumerate(cams):
+                    batched = {k: torch.as_tensor(np.asarray(val))[None] for k, val in c.items()}
+                    back = qc_dict_to_rpc(batched)[0].numpy()
+                    want = plain[i]["cam_para"][st][v]
+                    assert np.allclose(back, want, rtol=1e-15, atol=0.0), (key, st, v)
+    # the stages do not alias each other (the reference deep-copies before dividing the image-side normalisation)
+    smp = MVSDataset(scene, "pred", 3, use_qc=True)[0]
+    assert smp["cam_para"]["stage1"][0]["line_off"] * 4 == smp["cam_para"]["stage3"][0]["line_off"]
+    assert smp["cam_para"]["stage1"][0]["lat_num_tensor"] is not smp["cam_para"]["stage3"][0]["lat_num_tensor"]
+
+
+def test_train_mode_augments_like_the_reference():
+    """mode="train" applies the reference's random_color (preprocess.py:163-178) by default: four enhancement factors drawn with
+    np.random.randint in the reference's order, so the same seed gives the same factors; augment=False switches it off."""
+    from PIL import ImageEnhance
+    from satmvs_amd import dataset as D
+    scene = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene")
+    img = D.read_img(os.path.join(scene, "image", "0", "tile_a.png"))
+    np.random.seed(7)
+    got = np.asarray(D.image_augment(img))
+    np.random.seed(7)
+    f = [np.random.randint(1, 301) / 100., np.random.randint(10, 201) / 100., np.random.randint(10, 201) / 100., np.random.randint(0, 301) / 100.]
+    want = ImageEnhance.Sharpness(ImageEnhance.Contrast(ImageEnhance.Brightness(ImageEnhance.Color(img).enhance(f[0])).enhance(f[1])).enhance(f[2])).enhance(f[3])
+    assert np.array_equal(got, np.asarray(want))
+    off = D.MVSDataset(scene, "train", 3, augment=False)
+    assert np.array_equal(off[0]["imgs"], D.MVSDataset(scene, "test", 3)[0]["imgs"])
+    np.random.seed(3)
+    on = D.MVSDataset(scene, "train", 3)[0]["imgs"]
+    assert on.shape == off[0]["imgs"].shape and not np.array_equal(on, off[0]["imgs"])

@@ -723,7 +723,12 @@ def test_conv3x3_native_weight_gradient_matches_torch(dev, B, cin, cout, H, W):
     conv.zero_grad(); x.grad = None
     y1 = M._conv3x3(conv, x)
     assert y1.grad_fn is not None and "Conv3x3Wgrad" in type(y1.grad_fn).__name__
-    assert torch.equal(y1, y0)
+    # the forward is torch's own convolution: the same bits -- unless MIOpen itself answers two identical calls with different solvers
+    # (seen on one box for the 128 -> 64 channel 12x24 level: a first call and a later call of the SAME nn.Conv2d differed in the last bits)
+    if not torch.equal(y1, y0):
+        with torch.no_grad():
+            again = conv(x)
+        assert torch.equal(y1, again) or float((y1 - y0).abs().max()) <= 1e-5 * float(y0.abs().max())
     y1.backward(gy)
     for got, ref, name in ((conv.weight.grad, want[0], "weight"), (conv.bias.grad, want[1], "bias")):
         scale = float(ref.abs().max())
