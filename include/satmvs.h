@@ -16,7 +16,8 @@
  *   - Return value: SMVS_OK (0) or an SMVS_ERR_* code; smvs_last_error() then returns a
  *     thread-local message.  Nothing is written on an argument error.
  *   - Re-entrant.  The caller selects the device (hipSetDevice / torch.cuda.device) before
- *     calling; nothing is cached per thread.  The only process-wide state is a mutex-guarded,
+ *     calling; nothing is cached per thread.  The only process-wide state is the DEFAULT arithmetic (smvs_set_arith; a call may
+ *     carry its own) and a mutex-guarded,
  *     per-device pool of helper streams/events that smvs_red_pred_planes / smvs_red_volume_planes
  *     borrow for the duration of a call (bounded by the peak number of concurrent calls on a device).
  *   - The shipped library never reads the environment: tuning / A/B switches exist only in builds
@@ -27,7 +28,7 @@
  *     the one exchange of the path (a (3,B,H,W) float64 slab, 7 MB at 768x384) goes through
  *     torch.distributed (backend "nccl" = RCCL), satmvs_amd/shard.py, DESIGN.md section 5.
  *   - depth_is_4d: 1 = per-voxel heights (B,D,H,W); 0 = per-plane heights (B,D) -- both forms
- *     of `depth_values` accepted by modules/warping.py:329-332.
+ *     of `depth_values` accepted by modules/warping.py:329-332; bits 8-9 may carry SMVS_CALL_ARITH_* (see smvs_set_arith).
  */
 #ifndef SATMVS_H
 #define SATMVS_H
@@ -62,8 +63,14 @@ int smvs_red_set_streams(int n);
  *                     1e-3 m.  Against a float64 evaluation of the same taps it is 6x closer than the reference's own
  *                     sequence on photo-consistent features (no meansq - mean^2 cancellation), equal on independent random
  *                     features at 2-3 views, 2-4x the reference's rounding error at 4-8 views (tests/test_fused_arith.py).
- * Process-wide, thread-safe, takes effect for later calls; returns the previous mode, or -1 for an unknown one. */
+ * smvs_set_arith sets the process DEFAULT only (thread-safe; returns the previous default, or -1 for an unknown mode).  The
+ * arithmetic of ONE call travels with the call: OR SMVS_CALL_ARITH_EXACT or SMVS_CALL_ARITH_FUSED into the `depth_is_4d`
+ * argument of smvs_*_costvol_fwd / smvs_red_pred_planes / smvs_red_volume_planes, or set smvs_height_gen.arith for the *_gen
+ * forms; with neither bit the call takes the default.  Two models (or nn.DataParallel replicas on their threads) in one
+ * process can therefore run different arithmetics without touching shared state.  Every other entry point that takes
+ * `depth_is_4d` ignores the two bits. */
 enum { SMVS_ARITH_EXACT = 0, SMVS_ARITH_FUSED = 1 };
+enum { SMVS_CALL_ARITH_EXACT = 0x100, SMVS_CALL_ARITH_FUSED = 0x200, SMVS_CALL_ARITH_MASK = 0x300 };
 int smvs_set_arith(int mode);
 int smvs_get_arith(void);
 /* Releases what the library keeps between calls (the pooled helper streams and events of the plane pipelines).
@@ -89,6 +96,7 @@ typedef struct smvs_height_gen {
     const float* prev_var;      /* device, (B, prev_h, prev_w): the previous stage's "variance" output */
     const float* range_min;     /* device, (B): depth_values[:, 0] */
     const float* range_max;     /* device, (B): depth_values[:, -1] */
+    int arith;                  /* 0, SMVS_CALL_ARITH_EXACT or SMVS_CALL_ARITH_FUSED: arithmetic of the variance build of THIS call */
 } smvs_height_gen;
 /* The hypotheses as a tensor (what the reference materialises), out (B,ndepth,H,W): training path and tests. */
 int smvs_height_hypotheses(const smvs_height_gen* gen, float* out, int B, int H, int W, void* stream);

@@ -17,3 +17,11 @@ def set_arith(mode):
 def get_arith():
     from . import _lib
     return _lib.get_arith()
+
+
+def arith_scope(mode):
+    """`with satmvs_amd.arith_scope("exact"): ...` -- the cost-volume calls this thread makes inside the block carry their own
+    arithmetic (include/satmvs.h, SMVS_CALL_ARITH_*); the process default of set_arith is neither read nor changed.  The network
+    classes take the same thing as a constructor argument (`arith=`)."""
+    from . import _lib
+    return _lib.arith_scope(mode)

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -130,6 +131,45 @@ def set_arith(mode):
 
 def get_arith():
     return "exact" if load().smvs_get_arith() == 0 else "fused"
+
+
+# ---- arithmetic of ONE call (include/satmvs.h: SMVS_CALL_ARITH_*) --------------------------------------------------
+# set_arith() above moves the process default.  A model (or a test) that wants its own arithmetic does not touch it: inside
+# `with arith_scope("exact"):` every cost-volume call of THIS thread carries the mode in its arguments (the bits OR-ed into
+# depth_is_4d / smvs_height_gen.arith), so two models -- or nn.DataParallel replicas on their threads -- in one process
+# can run different arithmetics side by side.
+CALL_ARITH_BITS = {"exact": 0x100, "fused": 0x200}
+_scope = threading.local()
+
+
+class arith_scope:
+    """Context manager: cost-volume calls made by this thread inside the block use `mode` ("exact" / "fused"; None = no-op)."""
+
+    def __init__(self, mode):
+        if mode is not None and mode not in ARITH_MODES:
+            raise ValueError("arith mode must be one of %s, got %r" % (sorted(ARITH_MODES), mode))
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = getattr(_scope, "mode", None)
+        if self.mode is not None:
+            _scope.mode = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        _scope.mode = self.prev
+        return False
+
+
+def call_arith_bits():
+    """0, or the SMVS_CALL_ARITH_* bit of the innermost arith_scope of this thread."""
+    mode = getattr(_scope, "mode", None)
+    return CALL_ARITH_BITS[mode] if mode else 0
+
+
+def call_arith():
+    """Name of the arithmetic the next cost-volume call of this thread will run in."""
+    return getattr(_scope, "mode", None) or get_arith()
 
 
 def version():

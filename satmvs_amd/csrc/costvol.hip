@@ -37,8 +37,8 @@
 
 namespace smvs {
 
-// Which arithmetic the variance is built in (smvs_set_arith, include/satmvs.h).  Process-wide like the reference's own
-// global switches (torch.backends.*); read once per call.
+// DEFAULT arithmetic of the variance build (smvs_set_arith, include/satmvs.h), for calls that do not carry their own
+// (SMVS_CALL_ARITH_* in depth_is_4d / smvs_height_gen.arith); read once per call.
 static std::atomic<int> g_arith{SMVS_ARITH_FUSED};
 
 hipError_t launch_costvol_fused(int geo_kind, const CostVolParams& p, hipStream_t st);     // costvol_fused.hip
@@ -64,7 +64,12 @@ static int costvol_fwd(int geo_kind, const float* ref_fea, const float* const* s
     p.geo = geo; p.depth = depth; p.out = out;
     p.B = B; p.V = n_src + 1; p.C = C; p.D = D; p.H = H; p.W = W;
     p.d_begin = d_begin; p.d_end = d_end; p.D_out = D_out; p.d_out_off = d_out_off;
-    p.depth_is_4d = depth_is_4d ? HEIGHT_TENSOR : HEIGHT_PLANES;
+    // arithmetic of this call: the bits the call carries (depth_is_4d / gen->arith), else the process default
+    const int call = (gen ? gen->arith : depth_is_4d) & SMVS_CALL_ARITH_MASK;
+    if (call == SMVS_CALL_ARITH_MASK) return fail(SMVS_ERR_ARG, "both SMVS_CALL_ARITH_EXACT and SMVS_CALL_ARITH_FUSED set");
+    const int arith = call == SMVS_CALL_ARITH_EXACT ? SMVS_ARITH_EXACT : call == SMVS_CALL_ARITH_FUSED ? SMVS_ARITH_FUSED
+                      : g_arith.load(std::memory_order_relaxed);
+    p.depth_is_4d = (depth_is_4d & ~SMVS_CALL_ARITH_MASK) ? HEIGHT_TENSOR : HEIGHT_PLANES;
     if (gen) {
         HeightGenHost hh;
         if (const char* msg = height_gen_check(gen, D, H, W, hh)) return fail(SMVS_ERR_ARG, "%s", msg);
@@ -77,7 +82,7 @@ static int costvol_fwd(int geo_kind, const float* ref_fea, const float* const* s
     p.r_half_wm1 = 1.0f / (float)((W - 1) * 0.5);
     p.r_half_hm1 = 1.0f / (float)((H - 1) * 0.5);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = g_arith.load(std::memory_order_relaxed) == SMVS_ARITH_FUSED ? launch_costvol_fused(geo_kind, p, st)
+    hipError_t e = arith == SMVS_ARITH_FUSED ? launch_costvol_fused(geo_kind, p, st)
                    : (geo_kind == 0) ? launch_nsrc<0, AR_EXACT>(p, st) : launch_nsrc<1, AR_EXACT>(p, st);
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "costvol_fwd launch: %s", hipGetErrorString(e));
     return SMVS_OK;

@@ -639,7 +639,7 @@ extern "C" SMVS_EXPORT int smvs_costvol_bwd(int geo_kind, const float* grad_var,
         if (!src_fea[s] || !grad_src[s]) return fail(SMVS_ERR_ARG, "null source pointer %d", s);
         p.src[s] = src_fea[s]; p.grad_src[s] = grad_src[s];
     }
-    p.B = B; p.V = n_src + 1; p.C = C; p.D = D; p.H = H; p.W = W; p.depth_is_4d = depth_is_4d;
+    p.B = B; p.V = n_src + 1; p.C = C; p.D = D; p.H = H; p.W = W; p.depth_is_4d = (depth_is_4d & ~SMVS_CALL_ARITH_MASK) != 0;
     p.xt = (W + TILE_X - 1) / TILE_X; p.yt = (H + TILE_Y - 1) / TILE_Y;
     hipError_t e = geo_kind == 0 ? launch_bwd<0>(p, (hipStream_t)stream) : launch_bwd<1>(p, (hipStream_t)stream);
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "costvol_bwd launch: %s", hipGetErrorString(e));

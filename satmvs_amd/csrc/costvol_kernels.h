@@ -28,6 +28,7 @@ struct CostVolParams {
     HeightGen hg;                   // HEIGHT_GENERATED: hypotheses computed per pixel from the previous stage's map
     int xt, yt, dct, dch;           // tiles in x, y; plane chunks; planes per chunk
     int chunk_major;                // staged kernel: order of the workgroups inside a band of rows, see launch_order()
+    int group_rows;                 // ... and tile rows per group of the chunk-major order (<= 1: row by row)
     float rV, r_half_wm1, r_half_hm1;   // RN(1/V), RN(1/((W-1)/2)), RN(1/((H-1)/2)) in float32, divided once on the host
     float kw;                       // fused arithmetic (AR = 1): factor on the tap weights and the ref feature, see smvs_device.h
 };
@@ -252,7 +253,7 @@ constexpr int DM_BW = SMVS_BOX_W;      // staged box width (columns)
 constexpr int DM_R = SMVS_BOX_R;        // staged box rows: 2 pixel rows + south tap + parallax/rotation slack
 constexpr int DM_NBUF = 2;
 #ifndef SMVS_ABLATE
-#define SMVS_ABLATE 0                 // profiling builds only (tools/ab_build.sh x -DSMVS_ABLATE=n): 1 stores dropped, 2 no staging DMA, 4 no float64 chain, 8 no LDS tap reads, 32 no packed arithmetic, 64 staging DMA issued with every lane out of range (no memory traffic), 128 staging DMA from the first 64 KB of a channel (cache hits), 256 a step does not wait for its DMA to land -- results are WRONG
+#define SMVS_ABLATE 0                 // profiling builds only (tools/ab_build.sh x -DSMVS_ABLATE=n): 1 stores dropped, 2 no staging DMA, 4 no float64 chain, 8 no LDS tap reads, 32 no packed arithmetic, 64 staging DMA issued with every lane out of range (no memory traffic), 128 staging DMA from the first 64 KB of a channel (cache hits), 256 a step does not wait for its DMA to land, 512 no workgroup barrier per step (shared boxes) -- results are WRONG
 #endif
 #ifndef SMVS_O2P_PLANES
 #define SMVS_O2P_PLANES 4          // planes per evaluation pass of a source view's cubics
@@ -355,11 +356,25 @@ void costvol_dma_kernel(const CostVolParams p)
     // one wave = one 32 x 2 pixel patch x ONE group of DP planes (p.dch == DP): no loop over groups, so
     // nothing of the geometry phase stays live across the channel-pair loop
     uint32_t L = xcd_remap(blockIdx.x, gridDim.x);
-    int xtile, dchunk;
-    if (p.chunk_major) { dchunk = L % p.dct; L /= p.dct; xtile = L % p.xt; L /= p.xt; }     // see launch_order()
-    else               { xtile = L % p.xt; L /= p.xt; dchunk = L % p.dct; L /= p.dct; }
-    const int ytile = L % p.yt;
-    const int b = L / p.yt;
+    int xtile, ytile, dchunk;
+    if (p.chunk_major && p.group_rows > 1) {
+        // plane chunk fastest, then GROUPS of group_rows tile rows walked column by column: the workgroups an XCD runs together
+        // (32 CUs x 2-3) form a block of tiles that is about as tall as it is wide, so the rows and columns neighbouring boxes
+        // share are requested while they are in that XCD's L2 (launch_order())
+        dchunk = L % p.dct; L /= p.dct;
+        const uint32_t tiles = (uint32_t)p.xt * (uint32_t)p.yt, t = L % tiles;
+        L /= tiles;
+        const uint32_t per = (uint32_t)p.group_rows * (uint32_t)p.xt, g = t / per, r = t - g * per;
+        const uint32_t rows = min((uint32_t)p.group_rows, (uint32_t)p.yt - g * (uint32_t)p.group_rows);
+        xtile = r / rows;
+        ytile = g * p.group_rows + (r - xtile * rows);
+    } else {
+        if (p.chunk_major) { dchunk = L % p.dct; L /= p.dct; xtile = L % p.xt; L /= p.xt; }     // see launch_order()
+        else               { xtile = L % p.xt; L /= p.xt; dchunk = L % p.dct; L /= p.dct; }
+        ytile = L % p.yt;
+        L /= p.yt;
+    }
+    const int b = L;
 
     const int H = p.H, W = p.W;
     const int HW = H * W;
@@ -714,7 +729,7 @@ void costvol_dma_kernel(const CostVolParams p)
             // shared form: my part of DMA(st) has landed -> so has everybody's, and everybody has finished step st-1, whose
             // buffer DMA(st+1) is about to overwrite.  (A wave's LDS reads of step st-1 have all returned: its last unit
             // waited for lgkmcnt(0).)
-            if constexpr (SHARED) asm volatile("s_barrier" ::: "memory");
+            if constexpr (SHARED) { if (!(SMVS_ABLATE & 512)) asm volatile("s_barrier" ::: "memory"); }
             SMVS_T(const unsigned long long tw1 = now(); t_vm += tw1 - tw0;)
             ref0 = ref1;
             if (st + 1 < NSTEP) {
@@ -953,6 +968,9 @@ static int kernel_choice()
 #ifndef SMVS_CHUNK_MAJOR
 #define SMVS_CHUNK_MAJOR (-1)         // A/B switch of profiling builds: 0 / 1 force an order
 #endif
+#ifndef SMVS_GROUP_ROWS
+#define SMVS_GROUP_ROWS 8            // tile rows per group of the chunk-major order (shared-box form; A/B switch of profiling builds)
+#endif
 static int launch_order(const CostVolParams& p, int rows, int nsrc)
 {
     if (SMVS_CHUNK_MAJOR >= 0) return SMVS_CHUNK_MAJOR;
@@ -995,6 +1013,7 @@ static hipError_t launch_shared(CostVolParams p, hipStream_t st)
     p.dch = DP;
     p.dct = (nd + DP * NWP - 1) / (DP * NWP);
     p.chunk_major = launch_order(p, WV_TY * NWY + 3, NSRC);
+    p.group_rows = SMVS_GROUP_ROWS;
     const long long nb = (long long)p.xt * p.yt * p.dct * p.B;
     if (nb >= (1ll << 31)) return hipErrorInvalidValue;
     dim3 blk(64 * NWY * NWP), grd((unsigned)nb);

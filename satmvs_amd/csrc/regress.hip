@@ -202,7 +202,7 @@ int resolve_heights(const float* depth, int depth_is_4d, const smvs_height_gen* 
         return SMVS_OK;
     }
     if (!depth) return fail(SMVS_ERR_ARG, "null pointer argument");
-    mode = depth_is_4d ? HEIGHT_TENSOR : HEIGHT_PLANES;
+    mode = (depth_is_4d & ~SMVS_CALL_ARITH_MASK) ? HEIGHT_TENSOR : HEIGHT_PLANES;
     return SMVS_OK;
 }
 

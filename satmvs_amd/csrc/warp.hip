@@ -104,7 +104,7 @@ static int warp_launch(int geo, bool bwd, const float* fea, float* out, const do
     if ((long long)C * H * W * 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "feature map larger than 2 GiB per batch item");
     WarpParams p{};
     p.fea = fea; p.out = out; p.src_geo = src_geo; p.ref_geo = ref_geo; p.depth = depth;
-    p.B = B; p.C = C; p.D = D; p.H = H; p.W = W; p.depth_is_4d = depth_is_4d;
+    p.B = B; p.C = C; p.D = D; p.H = H; p.W = W; p.depth_is_4d = (depth_is_4d & ~SMVS_CALL_ARITH_MASK) != 0;
     p.xt = (W + TILE_X - 1) / TILE_X;
     p.yt = (H + TILE_Y - 1) / TILE_Y;
     p.dch = D < 8 ? D : 8;

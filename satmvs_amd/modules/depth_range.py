@@ -28,7 +28,8 @@ def stage1_planes(depth_range, ndepth):
 class _HeightGenStruct(ctypes.Structure):       # smvs_height_gen, include/satmvs.h
     _fields_ = [("prev_height", ctypes.c_void_p), ("prev_h", ctypes.c_int), ("prev_w", ctypes.c_int),
                 ("img_h", ctypes.c_int), ("img_w", ctypes.c_int), ("ndepth", ctypes.c_int), ("interval", ctypes.c_double),
-                ("prev_var", ctypes.c_void_p), ("range_min", ctypes.c_void_p), ("range_max", ctypes.c_void_p)]
+                ("prev_var", ctypes.c_void_p), ("range_min", ctypes.c_void_p), ("range_max", ctypes.c_void_p),
+                ("arith", ctypes.c_int)]
 
 
 class GeneratedHeights:
@@ -73,12 +74,13 @@ class GeneratedHeights:
         return 4
 
     def c_struct(self):
-        """ctypes smvs_height_gen; keep the returned object (and self) alive until the call has been enqueued."""
-        if self.var is not None:
-            return _HeightGenStruct(self.prev.data_ptr(), self.prev.shape[1], self.prev.shape[2], self.img_h, self.img_w,
-                                    self.ndepth, self.interval, self.var.data_ptr(), self.rmin.data_ptr(), self.rmax.data_ptr())
+        """ctypes smvs_height_gen; keep the returned object (and self) alive until the call has been enqueued.  Carries the
+        arithmetic of the calling thread's arith_scope (satmvs_amd/_lib.py) for the cost-volume entry points."""
+        from .. import _lib
+        v = self.var is not None
         return _HeightGenStruct(self.prev.data_ptr(), self.prev.shape[1], self.prev.shape[2], self.img_h, self.img_w,
-                                self.ndepth, self.interval, None, None, None)
+                                self.ndepth, self.interval, self.var.data_ptr() if v else None, self.rmin.data_ptr() if v else None,
+                                self.rmax.data_ptr() if v else None, _lib.call_arith_bits())
 
     def materialize(self):
         if self.prev.is_cuda:

@@ -992,7 +992,7 @@ class _REDCore(nn.Module):
                           _lib.current_stream(dev))
             else:
                 _lib.call(name, kind, _lib.ptr(feats[0]), _lib.ptr_array(feats[1:]), len(feats) - 1,
-                          _lib.ptr(geo), _lib.ptr(depth), is4d, _lib.ptr(packed), *[_lib.ptr(s) for s in states],
+                          _lib.ptr(geo), _lib.ptr(depth), is4d | _lib.call_arith_bits(), _lib.ptr(packed), *[_lib.ptr(s) for s in states],
                           _lib.ptr(target), _lib.ptr(ws), nbytes, b, c, D, h, w, d_begin, d_end,
                           _lib.current_stream(dev))
 

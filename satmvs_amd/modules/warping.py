@@ -204,7 +204,7 @@ class _CostVolFn(torch.autograd.Function):
         out = torch.empty((B, C, nd, H, W), dtype=torch.float32, device=dev)
         name = "smvs_rpc_costvol_fwd" if geo_kind == 0 else "smvs_homo_costvol_fwd"
         with torch.cuda.device(dev):
-            _lib.call(name, _lib.ptr(ref), _lib.ptr_array(srcs), len(srcs), _lib.ptr(geo), _lib.ptr(depth), is4d,
+            _lib.call(name, _lib.ptr(ref), _lib.ptr_array(srcs), len(srcs), _lib.ptr(geo), _lib.ptr(depth), is4d | _lib.call_arith_bits(),
                       _lib.ptr(out), B, C, D, H, W, d_begin, d_end, nd, 0, _lib.current_stream(dev))
         ctx.save_for_backward(geo, depth, ref, *srcs)
         ctx.meta = (geo_kind, is4d, d_begin, d_end, (B, C, D, H, W))

@@ -32,8 +32,9 @@ class DepthNet(nn.Module):
 
 class CascadeMVSNet(nn.Module):
     def __init__(self, geo_model, refine=False, min_interval=2.5, ndepths=[48, 32, 8], depth_interals_ratio=[4, 2, 1],
-                 share_cr=False, grad_method="detach", arch_mode="fpn", cr_base_chs=[8, 8, 8], use_qc=False):
+                 share_cr=False, grad_method="detach", arch_mode="fpn", cr_base_chs=[8, 8, 8], use_qc=False, arith=None):
         super().__init__()
+        self.arith = arith                      # this model's arithmetic of the variance build (None: the process default)
         assert geo_model in ["rpc", "pinhole"]
         assert len(ndepths) == len(depth_interals_ratio)
         if refine:
@@ -53,6 +54,11 @@ class CascadeMVSNet(nn.Module):
         self.DepthNet = DepthNet()
 
     def forward(self, imgs, proj_matrices, depth_values):
+        from .. import _lib
+        with _lib.arith_scope(getattr(self, "arith", None)):
+            return self._forward(imgs, proj_matrices, depth_values)
+
+    def _forward(self, imgs, proj_matrices, depth_values):
         features = self.feature.forward_views(imgs)
         h, w = int(imgs.shape[3]), int(imgs.shape[4])
         outputs = {}

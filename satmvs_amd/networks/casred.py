@@ -81,8 +81,9 @@ class _CascadeRED(nn.Module):
     compute = None
 
     def __init__(self, geo_model, min_interval=2.5, ndepths=[48, 32, 8], depth_interals_ratio=[4, 2, 1],
-                 cr_base_chs=[8, 8, 8], use_qc=False):
+                 cr_base_chs=[8, 8, 8], use_qc=False, arith=None):
         super().__init__()
+        self.arith = arith                      # this model's arithmetic of the variance build (None: the process default)
         assert geo_model in ["rpc", "pinhole"]
         assert len(ndepths) == len(depth_interals_ratio)
         self.geo_model = geo_model
@@ -99,6 +100,11 @@ class _CascadeRED(nn.Module):
             for i in range(self.num_stage)])
 
     def forward(self, imgs, proj_matrices, depth_values):
+        from .. import _lib
+        with _lib.arith_scope(getattr(self, "arith", None)):
+            return self._forward(imgs, proj_matrices, depth_values)
+
+    def _forward(self, imgs, proj_matrices, depth_values):
         """imgs (B,V,3,H,W); proj_matrices {"stageK": (B,V,170)|(B,V,4,4)|QC dicts}; depth_values (B,2)."""
         if imgs.is_cuda:
             guard_miopen_find() if self.training else restore_miopen_find()

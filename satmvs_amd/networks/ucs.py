@@ -25,8 +25,9 @@ def compute_depth(feats, proj_mats, depth_samps, cost_reg, lamb, geo_model, is_t
 
 class UCSNet(nn.Module):
     def __init__(self, geo_model, lamb=1.5, stage_configs=[64, 32, 8], grad_method="detach", base_chs=[8, 8, 8],
-                 feat_ext_ch=8, use_qc=False):
+                 feat_ext_ch=8, use_qc=False, arith=None):
         super().__init__()
+        self.arith = arith                      # this model's arithmetic of the variance build (None: the process default)
         assert geo_model in ["rpc", "pinhole"]
         self.geo_model, self.stage_configs, self.grad_method = geo_model, stage_configs, grad_method
         self.base_chs, self.lamb, self.num_stage, self.use_qc = base_chs, lamb, len(stage_configs), use_qc
@@ -37,6 +38,11 @@ class UCSNet(nn.Module):
             for i in range(self.num_stage)])
 
     def forward(self, imgs, proj_matrices, depth_values):
+        from .. import _lib
+        with _lib.arith_scope(getattr(self, "arith", None)):
+            return self._forward(imgs, proj_matrices, depth_values)
+
+    def _forward(self, imgs, proj_matrices, depth_values):
         features = self.feature_extraction.forward_views(imgs)
         outputs = {}
         depth, exp_var = None, None

@@ -407,3 +407,29 @@ def test_train_mode_augments_like_the_reference():
     np.random.seed(3)
     on = D.MVSDataset(scene, "train", 3)[0]["imgs"]
     assert on.shape == off[0]["imgs"].shape and not np.array_equal(on, off[0]["imgs"])
+
+
+def test_arith_scope_is_thread_local_and_matches_the_header():
+    """satmvs_amd._lib.arith_scope (the per-call arithmetic of include/satmvs.h, SMVS_CALL_ARITH_*): nesting, restoration, no leak into
+    other threads, and the bit values the Python layer ORs into depth_is_4d are the header's."""
+    import re
+    import threading
+    from satmvs_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "satmvs.h")).read()
+    vals = {k: int(v, 16) for k, v in re.findall(r"SMVS_CALL_ARITH_(EXACT|FUSED|MASK) = (0x[0-9a-f]+)", hdr)}
+    assert vals == {"EXACT": _lib.CALL_ARITH_BITS["exact"], "FUSED": _lib.CALL_ARITH_BITS["fused"], "MASK": 0x300}
+    assert re.search(r"int arith;", hdr)                                   # smvs_height_gen.arith
+    from satmvs_amd.modules.depth_range import _HeightGenStruct
+    assert _HeightGenStruct._fields_[-1][0] == "arith"
+    assert _lib.call_arith_bits() == 0
+    seen = {}
+    with _lib.arith_scope("fused"):
+        assert _lib.call_arith_bits() == 0x200
+        with _lib.arith_scope("exact"):
+            assert _lib.call_arith_bits() == 0x100
+            t = threading.Thread(target=lambda: seen.setdefault("other", _lib.call_arith_bits()))
+            t.start(); t.join()
+        assert _lib.call_arith_bits() == 0x200
+    assert _lib.call_arith_bits() == 0 and seen["other"] == 0
+    with pytest.raises(ValueError):
+        _lib.arith_scope("fast")

@@ -1,0 +1,166 @@
+"""A WELL-CONDITIONED whole-cascade parity case for the RED networks at the size bench.py times (3-view 768x384, planes 48/32/8).
+
+tests/test_full_size_cascade.py compares the native plane pipeline with the torch / MIOpen composites on smooth random images and
+random weights; there the softmax of a random regulariser is nearly flat over the whole height span, 32-48 recurrent planes turn ANY
+float32 round-off into centimetres (stage 2: 5-6 cm float32-against-float32) and the test can only ask "as close to float64 as
+MIOpen is, within 1.5x".  This file builds the case the contract is stated on instead:
+
+  * three PHOTO-CONSISTENT views -- one textured surface rendered through the three RPCs (the recipe of tests/golden/gen_golden.py::
+    gen_photo at the real tile), so that the variance volume has a valley along the surface;
+  * regulariser weights that behave like TRAINED ones, without a checkpoint: the seeded random initialisation (scaled by 1/4, so that
+    every layer still carries generic values) plus a deterministic photo-consistency path -- the candidate convolution of the
+    full-resolution ConvGRU cell sums the negated variance channels at its centre tap, its update gate is biased towards "take the
+    candidate", and the output layer (upconv2d, /root/reference/modules/module.py:612, :693) sums the cell's state -- and the output
+    layer of every stage scaled by the smallest power-of-two gain that makes the stage's softmax peaky (mean photometric confidence
+    >= 0.5; found once per network by running the native forward).  Random weights ALONE cannot serve: a gain only sharpens the
+    multi-modal logits of a random regulariser into an arg max over unrelated planes, and a tie between two of them flips on the last
+    bit of any float32 implementation (measured with gain 8: MIOpen's own composite 318-359 m from the float64 evaluation at stage 1);
+  * per stage and arithmetic mode: native pipeline, all-composite pipeline and a float64 evaluation of the stage on the same inputs.
+
+Heights within 1e-3 m (north_star) at EVERY stage, native against float64 AND native against the composite, free-running through
+the cascade as well -- no allowance.  Reference: /root/reference/networks/casred.py:285-333 (cascade), :161-238 (plane loop),
+/root/reference/modules/module.py:653-693 (slice_RED_Regularization), :595-649 (RED_Regularization)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_full_size_cascade import H, W, H_TOL, build_net, native_vs_composite, randomise_batchnorm, red_stages_against_float64
+
+pytestmark = pytest.mark.gpu
+MIN_CONFIDENCE = 0.5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    torch.backends.cudnn.benchmark = False
+    return torch.device("cuda:0")
+
+
+_RENDERED = {}
+
+
+def photo_consistent_inputs(dev, seed=41):
+    """(imgs (1,3,3,H,W), {stage: rpc}, height range, truth (H,W)): a smooth surface around 200 m carrying a band-limited texture,
+    seen by three TLC-shaped RPC views (nadir / forward / backward tilt).  Every view's image is the texture at the ground point its
+    pixel's ray meets the surface in (fixed-point iteration on the inverse RPC), normalised per view and channel like center_image."""
+    from satmvs_amd import rpc_synth
+    if seed not in _RENDERED:
+        _RENDERED[seed] = _render(seed)
+    imgs, rpc, truth = _RENDERED[seed]
+    pm = {"stage1": torch.from_numpy(rpc_synth.rescale_rpc(rpc[None], 4)).to(dev), "stage2": torch.from_numpy(rpc_synth.rescale_rpc(rpc[None], 2)).to(dev),
+          "stage3": torch.from_numpy(rpc[None].copy()).to(dev)}
+    return torch.from_numpy(imgs).to(dev), pm, torch.tensor([[0.0, 400.0]], device=dev), truth
+
+
+def _render(seed):
+    from satmvs_amd import rpc_synth
+    rpc = rpc_synth.make_view_rpcs(3, H, W, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    lat0, lon0, ls, os_ = rpc[0, 2], rpc[0, 3], rpc[0, 7], rpc[0, 8]
+
+    def surface(lat, lon):
+        u, v = (lat - lat0) / ls, (lon - lon0) / os_
+        return 200.0 + 22.0 * np.sin(2.1 * u + 0.4) * np.cos(1.7 * v - 0.3) + 9.0 * np.sin(4.3 * v + 1.0)
+
+    # texture frequencies scaled with the tile (gen_photo's 20-220 rad per half tile at 64x128): wavelengths of ~6-60 pixels here
+    waves = [(rng.uniform(40, 500) * rng.choice([-1, 1]), rng.uniform(40, 500), rng.uniform(0, 6.28), rng.uniform(0.3, 1.0)) for _ in range(3 * 20)]
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    imgs = np.zeros((1, 3, 3, H, W), np.float32)
+    truth = None
+    for v in range(3):
+        h = np.full(H * W, 200.0)
+        for _ in range(12):
+            lat, lon = rpc_synth.photo2obj(rpc[v], xx.ravel(), yy.ravel(), h)
+            h = surface(lat, lon)
+        lat, lon = rpc_synth.photo2obj(rpc[v], xx.ravel(), yy.ravel(), h)
+        u, w_ = (lat - lat0) / ls, (lon - lon0) / os_
+        for ch in range(3):
+            t = sum(a * np.sin(fu * u + fv * w_ + ph) for fu, fv, ph, a in waves[20 * ch:20 * ch + 20]).reshape(H, W)
+            imgs[0, v, ch] = (t - t.mean()) / (t.std() + 1e-8)
+        if v == 0:
+            truth = h.reshape(H, W).astype(np.float32)
+    return imgs, rpc, truth
+
+
+def trained_like(net, shrink=0.25, gamma=1.0, update_bias=-3.0, seed=45):
+    """See the module docstring: seeded weights * shrink + a photo-consistency path through conv_gru1 -> upconv2d (in place)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    with torch.no_grad():
+        for reg in net.cost_regularization:
+            for m in reg.modules():
+                if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                    m.weight.mul_(shrink)
+                    if m.bias is not None:
+                        m.bias.mul_(shrink)
+                elif isinstance(m, torch.nn.GroupNorm):                      # generic affine parameters instead of (1, 0)
+                    m.weight.copy_((0.8 + 0.4 * torch.rand(m.weight.shape, generator=g)).to(m.weight.device))
+                    m.bias.copy_((0.1 * torch.randn(m.bias.shape, generator=g)).to(m.bias.device))
+            cell = reg.conv_gru1
+            C = cell.output_conv.weight.shape[1] - cell.output_channel      # channels of the variance plane
+            cell.output_conv.weight[:, :C, 1, 1] += 1.0 / C                   # candidate_j = sum_c (-var_c) / C + (small random part)
+            cell.output_norm.weight.fill_(gamma)
+            cell.output_norm.bias.zero_()
+            cell.update_gate_norm.bias.fill_(update_bias)                    # u = sigmoid(~update_bias): the state follows the candidate
+            reg.upconv2d.weight[:, 0, 1, 1] += 1.0                           # logit = sum_j state_j + (small random part)
+
+
+def make_peaky(net, imgs, pm, dv, min_conf=MIN_CONFIDENCE, max_log2=16):
+    """Scales the output layer of every stage's regulariser, stage by stage (a stage's hypotheses follow the previous stage's heights),
+    by the smallest power of two that lifts the stage's mean photometric confidence to `min_conf`.  Returns ({stage: gain},
+    {stage: mean confidence})."""
+    gains, confs = {}, {}
+    with torch.no_grad():
+        for k in range(3):
+            key = "stage%d" % (k + 1)
+            out_layer = net.cost_regularization[k].upconv2d
+            g = 1.0
+            for _ in range(max_log2 + 1):
+                conf = float(net(imgs, pm, dv)[key]["photometric_confidence"].mean())
+                if conf >= min_conf:
+                    break
+                out_layer.weight.mul_(2.0)
+                if out_layer.bias is not None:
+                    out_layer.bias.mul_(2.0)
+                g *= 2.0
+            gains[key], confs[key] = g, conf
+    return gains, confs
+
+
+def conditioned_case(tag, dev):
+    torch.manual_seed(43)
+    net = build_net(tag, "rpc").to(dev).eval()
+    randomise_batchnorm(net, 44)
+    trained_like(net)
+    imgs, pm, dv, truth = photo_consistent_inputs(dev)
+    gains, confs = make_peaky(net, imgs, pm, dv)
+    return net, imgs, pm, dv, truth, gains, confs
+
+
+@pytest.mark.parametrize("tag", ["redinf", "red"])
+def test_red_cascade_well_conditioned_full_size(dev, tag, arith):
+    net, imgs, pm, dv, truth, gains, confs = conditioned_case(tag, dev)
+    for s, c in confs.items():
+        assert c >= MIN_CONFIDENCE, "stage %s not peaky: mean confidence %.3f at gain %g" % (s, c, gains[s])
+    err, a, b = native_vs_composite(net, imgs, pm, dv)
+    f64 = red_stages_against_float64(net, imgs, pm, dv, "rpc")
+    msg = "%s (%s arithmetic) gains %s confidence %s | free-running native vs composite %s | (native-f64, composite-f64, native-composite) %s" % (
+        tag, arith, gains, {s: "%.3f" % c for s, c in confs.items()}, {s: "%.3g" % e for s, e in err.items()},
+        {s: tuple("%.3g" % x for x in v) for s, v in f64.items()})
+    print(msg)
+    log = os.environ.get("SMVS_CONDITIONED_LOG")
+    if log:
+        with open(log, "a") as f:
+            f.write(msg + "\n")
+    for s in ("stage1", "stage2", "stage3"):
+        e_nat, e_comp, e_nc = f64[s]
+        assert e_nat <= H_TOL, "%s %s: native %.3g m from the float64 evaluation (composite %.3g m)" % (tag, s, e_nat, e_comp)
+        assert e_nc <= H_TOL, "%s %s: native %.3g m from the composite on the same stage inputs" % (tag, s, e_nc)
+        assert err[s] <= H_TOL, "%s %s: free-running native vs composite %.3g m" % (tag, s, err[s])
+    # the photo-consistency path makes the cascade follow the rendered surface (away from the tile border)
+    herr = np.abs(a["stage3"]["depth"][0].cpu().numpy() - truth)[32:-32, 32:-32]
+    print("stage 3 |height - rendered surface|: median %.2f m, 90 %% %.2f m" % (float(np.median(herr)), float(np.percentile(herr, 90))))
+    assert float(np.median(herr)) < 5.0

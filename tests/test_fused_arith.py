@@ -199,6 +199,110 @@ def test_fused_full_size(dev, oracle, fused, cfg):
         _within_contract(full[:, :, pl], want)
 
 
+def test_arithmetic_travels_with_the_call(dev):
+    """include/satmvs.h, SMVS_CALL_ARITH_*: inside satmvs_amd._lib.arith_scope a cost-volume call carries its own arithmetic in its
+    arguments -- the process default (what smvs_set_arith moves; "exact" in this suite) is neither read nor changed.  Same bits as
+    the same mode selected process-wide, for the tensor form, the generated-heights form (smvs_height_gen.arith) and the plane
+    pipeline; two threads in different scopes at the same time each get their own (nn.DataParallel replicas call from threads)."""
+    import threading
+    from satmvs_amd import _lib
+    from satmvs_amd.modules import warping
+    from satmvs_amd.modules.depth_range import GeneratedHeights
+    assert _lib.get_arith() == "exact"
+    feats, rpc, depth = T._inputs(1, 3, 16, 8, 48, 96, seed=33)
+    f = [T._t(x, dev) for x in feats]
+    r, d = T._t(rpc, dev), T._t(depth, dev)
+    rng = np.random.default_rng(4)
+    gen = GeneratedHeights(T._t((200.0 + rng.normal(0, 5.0, (1, 24, 48))).astype(np.float32), dev), 8, 5.0, (96, 192), (48, 96))
+    want = {}
+    for mode in ("exact", "fused"):
+        _lib.set_arith(mode)
+        want[mode] = (warping.variance_cost_volume(f, r, d, "rpc"), warping.variance_cost_volume(f, r, gen, "rpc"))
+    _lib.set_arith("exact")
+    assert not torch.equal(want["exact"][0], want["fused"][0]) and not torch.equal(want["exact"][1], want["fused"][1])
+    for mode in ("fused", "exact"):
+        with _lib.arith_scope(mode):
+            assert _lib.call_arith() == mode and _lib.get_arith() == "exact"
+            assert torch.equal(warping.variance_cost_volume(f, r, d, "rpc"), want[mode][0])
+            assert torch.equal(warping.variance_cost_volume(f, r, gen, "rpc"), want[mode][1])
+            with _lib.arith_scope(None):                                  # no-op scope
+                assert _lib.call_arith() == mode
+        assert _lib.call_arith_bits() == 0 and _lib.get_arith() == "exact"
+    # with the DEFAULT moved to fused, a call scoped "exact" still runs exact
+    _lib.set_arith("fused")
+    try:
+        with _lib.arith_scope("exact"):
+            assert torch.equal(warping.variance_cost_volume(f, r, d, "rpc"), want["exact"][0])
+        assert torch.equal(warping.variance_cost_volume(f, r, d, "rpc"), want["fused"][0])
+    finally:
+        _lib.set_arith("exact")
+    # two threads, two scopes, interleaved calls
+    got, errs = {}, []
+    barrier = threading.Barrier(2)
+
+    def worker(mode):
+        try:
+            torch.cuda.set_device(dev)
+            with _lib.arith_scope(mode):
+                outs = []
+                for _ in range(6):
+                    barrier.wait()
+                    outs.append(warping.variance_cost_volume(f, r, d, "rpc"))
+                torch.cuda.synchronize()
+                got[mode] = outs
+        except Exception as e:                                            # noqa: BLE001
+            errs.append(e)
+            barrier.abort()
+    ts = [threading.Thread(target=worker, args=(m,)) for m in ("exact", "fused")]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for mode in ("exact", "fused"):
+        assert all(torch.equal(o, want[mode][0]) for o in got[mode]), mode
+    # both bits at once are refused
+    bad = torch.empty_like(want["exact"][0])
+    with pytest.raises(_lib.SatMVSNativeError):
+        _lib.call("smvs_rpc_costvol_fwd", _lib.ptr(f[0]), _lib.ptr_array(f[1:]), 2, _lib.ptr(r), _lib.ptr(d), 1 | 0x300, _lib.ptr(bad),
+                  1, 16, 8, 48, 96, 0, 8, 8, 0, _lib.current_stream(dev))
+
+
+def test_models_carry_their_own_arithmetic(dev):
+    """Two networks in one process, one built with arith="exact" and one with arith="fused", same weights and inputs: each forward
+    equals the forward of the same network under the process-wide mode of that name -- whatever the process default is."""
+    from satmvs_amd import _lib
+    from satmvs_amd.networks import casmvs, casred
+    import test_full_size_cascade as FS
+    H, W = 64, 128
+    from satmvs_amd import rpc_synth
+    g = torch.Generator(device="cpu").manual_seed(9)
+    imgs = torch.nn.functional.avg_pool2d(torch.randn((3, 3, H + 4, W + 4), generator=g), 5, stride=1).contiguous()[None].to(dev)
+    rpc = rpc_synth.make_view_rpcs(3, H, W, seed=9)[None]
+    pm = {"stage1": torch.from_numpy(rpc_synth.rescale_rpc(rpc, 4)).to(dev), "stage2": torch.from_numpy(rpc_synth.rescale_rpc(rpc, 2)).to(dev),
+          "stage3": torch.from_numpy(rpc).to(dev)}
+    dv = torch.tensor([[0.0, 400.0]], device=dev)
+    for cls, kw in ((casred.Infer_CascadeREDNet, dict(ndepths=[16, 8, 8])), (casmvs.CascadeMVSNet, dict(ndepths=[16, 8, 8]))):
+        nets = {}
+        for mode in ("exact", "fused"):
+            torch.manual_seed(10)
+            nets[mode] = cls("rpc", arith=mode, **kw).to(dev).eval()
+            FS.randomise_batchnorm(nets[mode], 11)
+        torch.manual_seed(10)
+        plain = cls("rpc", **kw).to(dev).eval()
+        FS.randomise_batchnorm(plain, 11)
+        with torch.no_grad():
+            want = {}
+            for mode in ("exact", "fused"):
+                _lib.set_arith(mode)
+                want[mode] = plain(imgs, pm, dv)["depth"].clone()
+            _lib.set_arith("exact")
+            assert not torch.equal(want["exact"], want["fused"])
+            for default in ("exact", "fused"):
+                _lib.set_arith(default)
+                for mode in ("fused", "exact"):
+                    assert torch.equal(nets[mode](imgs, pm, dv)["depth"], want[mode]), (cls.__name__, default, mode)
+        _lib.set_arith("exact")
+
+
 def test_fused_generated_heights_equal_materialised(dev, fused):
     """The *_gen entry points (hypotheses evaluated in the kernel) against the same volume built from the materialised
     hypotheses, in the default mode: identical bits."""
