@@ -109,7 +109,7 @@ def native_vs_composite(net, imgs, pm, dv):
     return _stage_errors(a, b), a, b
 
 
-def red_stages_against_float64(net, imgs, pm, dv, geo):
+def red_stages_against_float64(net, imgs, pm, dv, geo, detail=None):
     """Stage by stage for the RED cascades, every stage on the SAME inputs (the composite run's features and incoming height map):
          native    the stage's native pipeline (hypotheses generated in the kernels -> variance planes -> RED kernels -> regression)
          composite the same stage on torch / MIOpen float32 operators
@@ -150,12 +150,22 @@ def red_stages_against_float64(net, imgs, pm, dv, geo):
                 for d in range(nd):
                     r, *st = reg64.step(var[:, :, d].double(), *st)
                     logits.append(r)
-                p64 = torch.softmax(torch.stack(logits, 1).squeeze(2), 1)
                 hv = dvt.double() if dvt.dim() == 4 else dvt.double().view(1, nd, 1, 1)
-                h64 = (p64 * hv).sum(1)
+                if type(net).__name__ == "Infer_CascadeREDNet":
+                    # the pred loop's own regression (casred.py:218-236): exp(double(logit)) WITHOUT a maximum subtracted, sums + 1e-10 --
+                    # not the same function as a softmax where every plane's exp underflows (strongly negative logits give height 0)
+                    p64 = torch.exp(torch.stack(logits, 1).squeeze(2))
+                    es = p64.sum(1)
+                    h64 = (p64 * hv).sum(1) / (es + 1e-10)
+                    p64 = p64 / (es + 1e-10).unsqueeze(1)
+                else:
+                    p64 = torch.softmax(torch.stack(logits, 1).squeeze(2), 1)
+                    h64 = (p64 * hv).sum(1)
             finally:
                 del os.environ["SMVS_RED_TORCH"]
             out[key] = (float((nat.double() - h64).abs().max()), float((comp.double() - h64).abs().max()), float((nat - comp).abs().max()))
+            if detail is not None:
+                detail[key] = {"native": nat, "composite": comp, "float64": h64, "p64": p64.max(1)[0], "hyp": dvt}
             prev = comp
             del var, logits, p64, reg64
     return out
@@ -197,7 +207,7 @@ def test_training_step_full_size_native_vs_composite(dev):
     """CascadeREDNet.train() at the real tile (3-view 768x384, planes 48/32/8): loss and every parameter gradient of the shipped training
     path -- native layers under autograd, one-node ConvGRU cells, weight gradients deferred to one launch per layer, ConvGRU levels on
     side streams with the plane loop software-pipelined -- against the SAME step with all of that switched off (the module's
-    SMVS_TRAIN_COMPOSITE_MASK / SMVS_TRAIN_STREAMS globals: torch's convolutions, GroupNorm and element-wise operators, one stream, the
+    switches (satmvs_amd/modules/switches.py: SW.train_composite_mask / SW.train_streams): torch's convolutions, GroupNorm and element-wise operators, one stream, the
     plain plane loop; that path is pinned against the reference's own step at 64x128, tests/golden/train_step.npz).  Loss to 1e-5;
     a parameter's gradient differs by float32 summation order only (atomics, split-K, another association over the planes), carried
     through up to 48 recurrent planes: 1e-2 of its largest entry at worst (measured 8e-3: the stride-2 encoder
@@ -216,13 +226,13 @@ def test_training_step_full_size_native_vs_composite(dev):
         torch.cuda.synchronize()
         return float(loss.detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
 
-    saved = (M._TRAIN_COMPOSITE_MASK, M._TRAIN_STREAMS)
+    saved = (M.SW.train_composite_mask, M.SW.train_streams)
     try:
         loss_n, g_n = run()
-        M._TRAIN_COMPOSITE_MASK, M._TRAIN_STREAMS = 63, False
+        M.SW.train_composite_mask, M.SW.train_streams = 63, False
         loss_c, g_c = run()
     finally:
-        M._TRAIN_COMPOSITE_MASK, M._TRAIN_STREAMS = saved
+        M.SW.train_composite_mask, M.SW.train_streams = saved
     assert abs(loss_n - loss_c) <= 1e-5 * abs(loss_c), (loss_n, loss_c)
     assert set(g_n) == set(g_c) and len(g_n) > 150
     rel = {}

@@ -443,7 +443,7 @@ def test_training_forward_switches_miopen_find_off(dev, golden):
         with torch.no_grad():
             net.eval()(imgs, proj, dv)
         assert torch.backends.cudnn.benchmark is True
-        module._FIND_WARNED = False
+        module.SW.find_warned = False
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")
             out = net.train()(imgs, proj, dv)
@@ -454,7 +454,7 @@ def test_training_forward_switches_miopen_find_off(dev, golden):
             net.eval()(imgs, proj, dv)
         assert torch.backends.cudnn.benchmark is True
     finally:
-        module._FIND_SWITCHED_OFF = False
+        module.SW.find_switched_off = False
         torch.backends.cudnn.benchmark = saved
 
 
@@ -858,10 +858,10 @@ def test_red_training_loop_streams_equal_single_stream(dev, B):
     vol0 = torch.randn(B, 16, 10, 48, 96, device=dev)
     weight = torch.linspace(0, 1, B * 10 * 48 * 96, device=dev).view(B, 10, 48, 96)
     res = []
-    saved = M._TRAIN_STREAMS
+    saved = M.SW.train_streams
     try:
         for streams in (True, False):
-            M._TRAIN_STREAMS = streams
+            M.SW.train_streams = streams
             vol = vol0.clone().requires_grad_(True)
             red.zero_grad()
             out = red(vol)
@@ -869,7 +869,7 @@ def test_red_training_loop_streams_equal_single_stream(dev, B):
             torch.cuda.synchronize()
             res.append((out.detach().clone(), vol.grad.clone(), [p.grad.clone() for p in red.parameters()]))
     finally:
-        M._TRAIN_STREAMS = saved
+        M.SW.train_streams = saved
     (o1, g1, p1), (o0, g0, p0) = res
     assert torch.equal(o1, o0)
     assert float((g1 - g0).abs().max()) <= 1e-5 * float(g0.abs().max())
