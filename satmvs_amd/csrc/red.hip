@@ -736,7 +736,14 @@ __device__ __forceinline__ void gn_coeffs2(const double* st0, const double* st1,
     m0 = lds2[0][0]; r0 = lds2[0][1]; m1 = lds2[1][0]; r1 = lds2[1][1];
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return fuse_sigmoid(x); }     // the same functions as the fused launches (mfma_conv.h)
+// Gate activations of the shipped element-wise kernels: expf / tanhf and a true division (the fast forms of the fused
+// tuning-build launches, mfma_conv.h -- rcp + __expf, tanh as 1 - 2 / (1 + e^2x) -- lose bits in every one of up to 384 recurrent steps
+// and bought nothing on these memory-bound kernels).  SMVS_RED_FAST_ACT=1 (profiling builds) keeps the fast forms.
+#ifndef SMVS_RED_FAST_ACT
+#define SMVS_RED_FAST_ACT 0
+#endif
+__device__ __forceinline__ float sigmoidf_(float x) { return SMVS_RED_FAST_ACT ? fuse_sigmoid(x) : 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return SMVS_RED_FAST_ACT ? fuse_tanh(x) : tanhf(x); }
 
 // ---- level-batched launches ------------------------------------------------------------------------------------------
 // The four ConvGRU levels of a plane do not depend on each other (only the decoder crosses levels), and each of
@@ -890,7 +897,7 @@ __device__ __forceinline__ void gru_combine_body(const GruJob& g, int bx, int b,
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const float u = sigmoidf_(fmaf((vu.v[e] - mu) * su, wu, bu));
-        const float y = fuse_tanh(fmaf((vc.v[e] - m) * s, wo, bo));
+        const float y = tanhf_(fmaf((vc.v[e] - m) * s, wo, bo));
         o.v[e] = u * vh.v[e] + (1.0f - u) * y;
     }
     *reinterpret_cast<fvec<E>*>(g.h_out + i) = o;

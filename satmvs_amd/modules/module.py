@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 from .. import _lib
 from .switches import SW, guard_miopen_find, restore_miopen_find          # noqa: F401  (re-exported: the networks import them from here)
-from .train_fns import (_reparametrize, GroupNorm1, _ConvGRUCellFn, _GroupNormPairFn, _GruBlendFn, _GruMulCatFn, _PlaneViewsFn, _WgradArena, _WgradSink, _conv3x3_cat, _conv3x3, _native_kind, _side_streams, _PARAM_EPOCH, bump_param_epoch, _GroupNorm1Fn, _Conv3x3NativeFn, _Conv3x3WgradFn, _conv_packed, _gn_scratch, _f32c_fast, _TLS, _placeholder, _is_placeholder, _wgrad_now_or_later)          # noqa: F401
+from .train_fns import (_reparametrize, _NATIVE_KINDS, GroupNorm1, _ConvGRUCellFn, _GroupNormPairFn, _GruBlendFn, _GruMulCatFn, _PlaneViewsFn, _WgradArena, _WgradSink, _conv3x3_cat, _conv3x3, _native_kind, _side_streams, _PARAM_EPOCH, bump_param_epoch, _GroupNorm1Fn, _Conv3x3NativeFn, _Conv3x3WgradFn, _conv_packed, _gn_scratch, _f32c_fast, _TLS, _placeholder, _is_placeholder, _wgrad_now_or_later)          # noqa: F401
 
 
 # ---- native-path plumbing shared by the three modules with HIP kernels ---------------------------------
@@ -445,6 +445,8 @@ class RED_Regularization(_REDCore):
         s = self.initial_states(b, h, w, volume_variance.device)
         outs = []
         planes = self._per_plane_parameters(d_num) if torch.is_grad_enabled() else None
+        if planes is not None and volume_variance.is_cuda and SW.train_streams:
+            self._prepack_on_callers_stream()
         if planes is None:
             for d in range(d_num):
                 reg, *s = self.step(volume_variance[:, :, d], *s)
@@ -469,6 +471,21 @@ class RED_Regularization(_REDCore):
                     reg, *s = self.step(volume_variance[:, :, d], *s)
                 outs.append(reg)
         return torch.stack(outs, dim=1).squeeze(2)
+
+    def _prepack_on_callers_stream(self):
+        """Kernel-layout copies of every 3x3 weight the native training path will ask for (forward AND input-gradient layouts), packed on
+        the caller's stream BEFORE the plane loop forks its side streams: the pack kernels then precede every consumer on every stream
+        -- and, inside a captured training step, every branch of the graph -- through the fork itself, whichever stream asks
+        train_fns._conv_packed first (the cache has no stream bookkeeping of its own).  A hit costs a dictionary lookup."""
+        for m in self.modules():
+            kind = _native_kind(m) if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) else None
+            w = getattr(m, "weight", None)
+            if kind is None or w is None or not w.is_cuda or w.dtype is not torch.float32 or not w.is_contiguous() or not w.requires_grad:
+                continue
+            _, flay, _, blay, _ = _NATIVE_KINDS[kind]
+            cin, cout = (w.shape[0], w.shape[1]) if kind[0] == "t" else (w.shape[1], w.shape[0])
+            _conv_packed(w, flay, cin, cout)
+            _conv_packed(w, blay, cout, cin)
 
     def _planes_software_pipelined(self, volume, s, planes, d_num):
         """The training loop software-pipelined over the planes: in iteration d the ConvGRU cells of plane d (one side stream per level),

@@ -109,12 +109,13 @@ def native_vs_composite(net, imgs, pm, dv):
     return _stage_errors(a, b), a, b
 
 
-def red_stages_against_float64(net, imgs, pm, dv, geo, detail=None):
+def red_stages_against_float64(net, imgs, pm, dv, geo, detail=None, var_mode="exact"):
     """Stage by stage for the RED cascades, every stage on the SAME inputs (the composite run's features and incoming height map):
          native    the stage's native pipeline (hypotheses generated in the kernels -> variance planes -> RED kernels -> regression)
          composite the same stage on torch / MIOpen float32 operators
          float64   the stage's regulariser and regression evaluated in float64 (torch operators on a .double() copy of the
-                   module) on the float32 variance volume of the exact build (bit-identical to the reference's)
+                   module) on the float32 variance volume of the exact build (bit-identical to the reference's); var_mode="current":
+                   on the variance volume of the arithmetic in force, i.e. what the two float32 pipelines consumed
     Returns {stage: (max |native - float64|, max |composite - float64|, max |native - composite|)} in metres."""
     import copy
     from satmvs_amd import _lib
@@ -141,9 +142,8 @@ def red_stages_against_float64(net, imgs, pm, dv, geo, detail=None):
             try:
                 comp = type(net).compute(feats, pm[key], depth_values=dvg, num_depth=nd, cost_regularization=reg, geo_model=geo, use_qc=False)["depth"]
                 dvt = dvg.materialize() if isinstance(dvg, GeneratedHeights) else dvg
-                mode = _lib.set_arith("exact")
-                var = variance_cost_volume(feats, pm[key], dvt, geo)
-                _lib.set_arith(mode)
+                with _lib.arith_scope(None if var_mode == "current" else var_mode):      # "current": the variance the stage itself consumed
+                    var = variance_cost_volume(feats, pm[key], dvt, geo)
                 reg64 = copy.deepcopy(reg).double()
                 st = reg64.initial_states(1, H // scale, W // scale, imgs.device, torch.float64)
                 logits = []

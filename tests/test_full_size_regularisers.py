@@ -68,7 +68,7 @@ def _weights(module):
 
 
 @pytest.mark.parametrize("name,C,H,W,D,per_pixel", STAGES)
-def test_red_volume_pipeline_full_size(dev, oracle, name, C, H, W, D, per_pixel):
+def test_red_volume_pipeline_full_size(dev, oracle, arith, name, C, H, W, D, per_pixel):
     from satmvs_amd.modules.module import RED_Regularization
     from satmvs_amd.modules.warping import variance_cost_volume
     torch.manual_seed(11)
@@ -77,7 +77,7 @@ def test_red_volume_pipeline_full_size(dev, oracle, name, C, H, W, D, per_pixel)
     with torch.no_grad():
         assert reg._use_native(feats[0])
         got = reg.native_volume(feats, rpc, dv, "rpc", False)                       # smvs_red_volume_planes
-        var = variance_cost_volume(feats, rpc, dv, "rpc", False)                     # bit-identical to the oracle's (test_hip_parity)
+        var = variance_cost_volume(feats, rpc, dv, "rpc", False)                     # bit-identical to the oracle's in the exact mode (test_hip_parity); both modes: `arith`
         ref = _composite("SMVS_RED_TORCH", lambda: reg(var))                         # PyTorch / MIOpen composite, every plane
     assert got.shape == ref.shape == (1, D, H, W)
     scale = max(1.0, float(ref.abs().max()))
@@ -96,7 +96,7 @@ def test_red_volume_pipeline_full_size(dev, oracle, name, C, H, W, D, per_pixel)
 
 
 @pytest.mark.parametrize("name,C,H,W,D,per_pixel", STAGES)
-def test_red_pred_pipeline_full_size(dev, name, C, H, W, D, per_pixel):
+def test_red_pred_pipeline_full_size(dev, arith, name, C, H, W, D, per_pixel):
     from satmvs_amd.modules.module import slice_RED_Regularization
     from satmvs_amd.networks.casred import compute_depth_when_pred
     torch.manual_seed(12)

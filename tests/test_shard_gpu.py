@@ -61,10 +61,18 @@ def _worker(rank, world, port, out_dir, recurrent):
     dist.destroy_process_group()
 
 
-def test_sharded_red_pred_two_ranks_bit_identical(tmp_path):
+@pytest.mark.parametrize("mode", ["exact", "fused"])
+def test_sharded_red_pred_two_ranks_bit_identical(tmp_path, mode):
+    """... in the suite's arithmetic ("exact") and in the library's default ("fused": the ranks inherit SMVS_ARITH): plane windows of the
+    fused instance are bit-identical to the whole sweep too, so the sharded result equals the single-GPU one in either mode."""
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
+    saved = os.environ.get("SMVS_ARITH")
+    os.environ["SMVS_ARITH"] = mode
+    try:
+        mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
+    finally:
+        os.environ["SMVS_ARITH"] = saved if saved is not None else "exact"
     r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(2)]
     assert tuple(r[0]["planes"]) != tuple(r[1]["planes"]) and r[0]["planes"][1] == r[1]["planes"][0]   # a real split
     for k in range(2):
