@@ -365,26 +365,45 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
                     if (v[i] != 0.0f && !((SMVS_BWD_ABLATE & 1) && v[i] != 1234.5f)) unsafeAtomicAdd(q + i * W, v[i]);
             }
         };
+        // Round 5: the gradient planes run TWO channels ahead.  They are the kernel's only stream that always misses the caches (2.4 GB
+        // read once), and with one channel of arithmetic (~3 us) between request and use the waves still waited for them (SQ_WAIT_ANY
+        // 37 % of the wave cycles).  Two register sets take turns (the channel loop is unrolled by two so that no set is copied while
+        // its loads are in flight); every iteration issues, in this order, the atomics of the previous channel, the boxes and the
+        // reference value of the next one and LAST the gradient planes of the one after it -- so that the counted wait at the top of
+        // an iteration (at most DCH operations in flight = those newest loads) covers everything this channel needs.
+        // (1-2 source views; with more the second register set costs the kernel its occupancy: one channel ahead as before)
+        constexpr int AHEAD = NSRC <= 2 ? 2 : 1;
+        float g_far[AHEAD == 2 ? DCH : 1];
+        if constexpr (AHEAD == 2) {
+#pragma unroll
+            for (int k = 0; k < DCH; ++k) g_far[k] = gp[((size_t)min(1, C - 1) * D + min(k, d1 - d0 - 1)) * HW];
+        }
+        float gref_prev = 0.0f;
         stage(0, 0);
-        for (int c = 0; c < C; ++c) {
+        auto channel = [&](const int c, float (&gcur)[DCH]) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < DCH; ++k)
 #pragma unroll
                 for (int s = 0; s < NSRC; ++s) asm volatile("" : "+v"(tt[k][s]));       // see the other loop
-            // everything requested one iteration ago has had this channel's arithmetic to arrive: this channel's boxes, r and g
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // this channel's boxes, r (requested one iteration ago) and g (two iterations ago) have arrived once only the newest DCH
+            // operations -- the gradient planes of channel c + 1 -- are still in flight
+            if (c == 0 || AHEAD == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the prologue issued the boxes last)
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DCH) : "memory");
             const float r = r_next;
             float gq[DCH];
 #pragma unroll
-            for (int k = 0; k < DCH; ++k) gq[k] = g_next[k];
+            for (int k = 0; k < DCH; ++k) gq[k] = gcur[k];
+            if (c > 0) {                                    // the previous channel's sums leave while this one is worked on
+                flush_boxes(c - 1);
+                if (active && !((SMVS_BWD_ABLATE & 4) && gref_prev != 1234.5f)) unsafeAtomicAdd(grefp + (size_t)(c - 1) * HW, gref_prev);
+            }
             {
-                const int cn = min(c + 1, C - 1);
+                const int cn = min(c + 1, C - 1), cf = min(c + AHEAD, C - 1);
                 stage(cn, (c + 1) & 1);
                 r_next = refp[(size_t)cn * HW];
 #pragma unroll
-                for (int k = 0; k < DCH; ++k) g_next[k] = gp[((size_t)cn * D + min(k, d1 - d0 - 1)) * HW];
+                for (int k = 0; k < DCH; ++k) gcur[k] = gp[((size_t)cf * D + min(k, d1 - d0 - 1)) * HW];
             }
-            if (c > 0) flush_boxes(c - 1);                  // the previous channel's sums leave while this one is worked on
             const int choff = c * HW * 4;
             const uint32_t fpar = wave_lds + (uint32_t)((c & 1) * NSRC * FBOX_BYTES);
             float gref = 0.0f;
@@ -490,9 +509,18 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
                     }
                 }
             }
-            if (active && !((SMVS_BWD_ABLATE & 4) && gref != 1234.5f)) unsafeAtomicAdd(grefp + (size_t)c * HW, gref);
+            gref_prev = gref;
+        };
+        if constexpr (AHEAD == 2) {
+            for (int c = 0; c < C; c += 2) {
+                channel(c, g_next);
+                if (c + 1 < C) channel(c + 1, g_far);
+            }
+        } else {
+            for (int c = 0; c < C; ++c) channel(c, g_next);
         }
         flush_boxes(C - 1);
+        if (active && !((SMVS_BWD_ABLATE & 4) && gref_prev != 1234.5f)) unsafeAtomicAdd(grefp + (size_t)(C - 1) * HW, gref_prev);
         return;
     }
 

@@ -8,7 +8,7 @@ captured into one HIP graph with torch operators only (no satmvs library in the 
   capturing stream "decoder": waits for every st[l][d], accumulates
 
 Variants (argv[1]): persist (the shape described above), perplane (fork / join inside every iteration: what ships), nograph (eager);
-persist_bwd / perplane_bwd: the weights require gradients and loss.backward() is captured too (autograd runs a node's backward on the
+persist_bwd / perplane_bwd / nostream_bwd (everything on the capturing stream): the weights require gradients and loss.backward() is captured too (autograd runs a node's backward on the
 stream of its forward: the round-4 observation was made on the captured TRAINING step).
 Prints the result checksum of 3 replays and "OK", or dies where the runtime does."""
 import sys
@@ -28,7 +28,7 @@ conv = torch.nn.functional.conv2d
 
 
 def loop(main):
-    side = [torch.cuda.Stream(dev) for _ in range(1 + LEVELS)]
+    side = [main] * (1 + LEVELS) if mode == "nostream" else [torch.cuda.Stream(dev) for _ in range(1 + LEVELS)]
     states = [torch.zeros(1, 16, 96, 192, device=dev) for _ in range(LEVELS)]
     acc = torch.zeros(1, 16, 96, 192, device=dev)
     if mode != "perplane":
