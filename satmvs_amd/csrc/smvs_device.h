@@ -523,9 +523,21 @@ __device__ __forceinline__ void dma_x4_to_lds_at(const BufRsrc& rs, uint32_t lds
 
 // Same, destination in an SGPR (the shared-box form: a wave issues the instructions dealt to it, their places in the
 // box set are wave-uniform run-time values -- a handful per wave, so they stay in SGPRs)
+#ifndef SMVS_DMA_SHARED_POLICY_ID
+#define SMVS_DMA_SHARED_POLICY_ID 0        // cache policy of the shared-box staging loads (A/B switch of profiling builds): 0 default, 1 nt, 2 sc1, 3 sc0 sc1
+#endif
+#if SMVS_DMA_SHARED_POLICY_ID == 1
+#define SMVS_DMA_SHARED_POLICY " nt"
+#elif SMVS_DMA_SHARED_POLICY_ID == 2
+#define SMVS_DMA_SHARED_POLICY " sc1"
+#elif SMVS_DMA_SHARED_POLICY_ID == 3
+#define SMVS_DMA_SHARED_POLICY " sc0 sc1"
+#else
+#define SMVS_DMA_SHARED_POLICY ""
+#endif
 __device__ __forceinline__ void dma_x4_to_lds(const BufRsrc& rs, uint32_t lds_byte_addr, uint32_t voffset, int soffset)
 {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" SMVS_DMA_SHARED_POLICY " lds"
                  :: "s"(lds_byte_addr), "v"(voffset), "s"(rs.v), "s"(soffset) : "memory", "m0");
 }
 

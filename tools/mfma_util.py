@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """MFMA utilisation of the convolution kernels from a tools/profile_r03.sh summary (kernel trace + counter passes of
-tools/run_native_models.py):   python tools/mfma_util.py gpurun_out/prof_r03/summary.txt
+tools/run_native_models.py):   python tools/mfma_util.py gpurun_out/prof_r03/summary.txt [trace block] [pmc block]
 
   flops      = SQ_INSTS_VALU_MFMA_MOPS_F32 * 512      (one v_mfma_f32_32x32x2_f32 = 4096 flop = 8 MOPS; the counter pair
                                                         MFMA_BUSY_CYCLES / MOPS = 8.0 cycles confirms the unit: 64 cycles per instruction)
@@ -11,17 +11,19 @@ tools/run_native_models.py):   python tools/mfma_util.py gpurun_out/prof_r03/sum
 import re, sys
 
 txt = open(sys.argv[1]).read()
+TRACE = sys.argv[2] if len(sys.argv) > 2 else "trace_models"          # block names of tools/rocpd_summary.py: kernel trace ...
+PMC = sys.argv[3] if len(sys.argv) > 3 else "pmcm_SQ_INSTS_VALU_MFMA"    # ... and the MFMA counter pass
 blocks = re.split(r"^== ", txt, flags=re.M)
 dur = {}
 cnt = {}
 for b in blocks:
     head = b.split("\n", 1)[0]
-    if head.startswith("kernel trace: trace_models"):
+    if head.startswith("kernel trace: " + TRACE):
         for l in b.splitlines()[2:]:
             m = re.match(r"(.{72}) +(\d+) +([\d.]+) +([\d.]+)", l)
             if m:
                 dur[m.group(1).strip()[:60]] = (int(m.group(2)), float(m.group(4)))
-    if head.startswith("pmc pass: pmcm_SQ_INSTS_VALU_MFMA"):
+    if head.startswith("pmc pass: " + PMC):
         for l in b.splitlines()[1:]:
             m = re.match(r" +(.{60}) (\S+) +n=(\d+) +mean=(\S+)", l)
             if m:
