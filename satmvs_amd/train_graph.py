@@ -75,6 +75,8 @@ class GraphedTrainStep:
         self._graph = None
         self._hyper_captured = None
         self.captures = 0                                     # how many times a graph was captured (shape / hyper-parameter changes)
+        self._hyper_recaptures = 0                            # ... of which in a row because only a float hyper-parameter moved
+        self._warned = False
 
     def _eager(self, args):
         self.optimizer.zero_grad(set_to_none=True)
@@ -84,7 +86,17 @@ class GraphedTrainStep:
         self.optimizer.step()
         return loss.detach(), _map(out, lambda t: t.detach())
 
-    def _capture(self, args):
+    def _release(self):
+        """Drop the captured graph and what was allocated from its private pool on its behalf: the packed-weight copies the native
+        layers cached during the capture (modules/train_fns.py, modules/module.py) would otherwise pin that pool."""
+        self._graph = None
+        from .modules import module as _m
+        from .modules import train_fns as _t
+        _t._CONV_PACK.clear()
+        with _m._PACK_CACHE_LOCK:
+            _m._PACK_CACHE.clear()
+
+    def _capture(self, args, warmup=None):
         dev = args[0].device
         self._static = _map(args, lambda t: t.detach().clone())
         # the warm-up steps (allocator, MIOpen's find, lazily created optimizer state) must not train: parameters, buffers and
@@ -96,7 +108,7 @@ class GraphedTrainStep:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(self.warmup):
+            for _ in range(self.warmup if warmup is None else warmup):
                 self._eager(self._static)
         torch.cuda.current_stream(dev).wait_stream(side)
         with torch.no_grad():
@@ -121,15 +133,28 @@ class GraphedTrainStep:
     def recapture(self):
         """Forget the captured graph: the next call captures again (after a change of learning rate, loss weights, ...)."""
         self._sig = None
-        self._graph = None
+        self._release()
 
     def __call__(self, *args):
         sig = _signature(args)
+        hyper_only = sig == self._sig and self._graph is not None
         if sig != self._sig or _hyper(self.optimizer) != self._hyper_captured:
-            self._graph = None                                # release the old graph (and its private pool) before capturing again
-            self._capture(args)
+            self._release()                                   # the old graph (and its private pool) goes before capturing again
+            # same shapes, only a float hyper-parameter moved (a per-iteration scheduler): allocator, MIOpen's choices and the optimizer
+            # state are warm already -- one warm-up step re-creates the autograd graph's buffers, no more
+            self._capture(args, warmup=1 if hyper_only else None)
             self._sig = sig
+            self._hyper_recaptures = self._hyper_recaptures + 1 if hyper_only else 0
+            if self._hyper_recaptures >= 3 and not self._warned:
+                self._warned = True
+                import warnings
+                warnings.warn("GraphedTrainStep: re-captured %d times in a row because a float hyper-parameter of the optimizer changed "
+                              "(a per-iteration learning-rate schedule?) -- every re-capture costs a warm-up step, a state restore and a "
+                              "synchronize, far more than an eager step.  Give the optimizer a TENSOR lr (capturable: the graph reads it "
+                              "from device memory, `optimizer.param_groups[i]['lr'].fill_(x)` needs no re-capture) or step the schedule "
+                              "per epoch." % self._hyper_recaptures)
         else:
+            self._hyper_recaptures = 0
             _zip_copy(self._static, args)
         self._graph.replay()
         bump_param_epoch()                                    # the replay stepped the parameters without touching autograd's version counters

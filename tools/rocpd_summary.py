@@ -42,7 +42,7 @@ def main(root):
     for db in tr:
         print("== kernel trace: %s" % os.path.relpath(db, root))
         kernel_stats(db)
-    for db in sorted(glob.glob(os.path.join(root, "pmc_*", "*.db")) + glob.glob(os.path.join(root, "pmcm_*", "*.db"))):
+    for db in sorted(glob.glob(os.path.join(root, "pmc*", "*.db"))):
         print("== pmc pass: %s" % os.path.basename(os.path.dirname(db)))
         pmc_stats(db)
 
