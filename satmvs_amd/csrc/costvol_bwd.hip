@@ -58,7 +58,7 @@ struct CostVolBwdParams {
 #define SMVS_BWD_OCC 2                 // waves per SIMD the kernel is compiled for
 #endif
 #ifndef SMVS_BWD_ABLATE
-#define SMVS_BWD_ABLATE 0              // timing experiments only (wrong results): 1 no flush atomics, 2 no box adds, 4 no reference atomic, 16 geometry only
+#define SMVS_BWD_ABLATE 0              // timing experiments only (wrong results): 1 no flush atomics, 2 no box adds, 4 no reference atomic, 16 geometry only, 32 box adds as ds_add_u32
 #endif
 #ifndef SMVS_BWD_DCH8_SRC
 #define SMVS_BWD_DCH8_SRC 4           // up to this many source views a lane keeps 8 planes of taps (2 beyond: the register scheme only); measured 3 / 4 views: 4.01 -> 3.66, 6.78 -> 5.88 ms against 4-plane chunks
@@ -105,6 +105,15 @@ __device__ __forceinline__ void fbox_wait_n(f32x2& north, f32x2& south)
 // the four corners of a full tap into the gradient box (LDS byte address of the north-west cell); no return value, in order per wave
 __device__ __forceinline__ void gbox_add4(uint32_t addr, float c0, float c1, float c2, float c3)
 {
+#if SMVS_BWD_ABLATE & 32            // timing experiment (wrong results): 32-bit integer adds into the same cells
+    const int i0 = (int)c0, i1 = (int)c1, i2 = (int)c2, i3 = (int)c3;
+    asm volatile("ds_add_u32 %0, %1\n\t"
+                 "ds_add_u32 %0, %2 offset:8\n\t"
+                 "ds_add_u32 %0, %3 offset:%5\n\t"
+                 "ds_add_u32 %0, %4 offset:%6"
+                 :: "v"(addr), "v"(i0), "v"(i1), "v"(i2), "v"(i3), "n"(BOX_W * 8), "n"(BOX_W * 8 + 8) : "memory");
+    return;
+#endif
     const double d0 = (double)c0, d1 = (double)c1, d2 = (double)c2, d3 = (double)c3;
     asm volatile("ds_add_f64 %0, %1\n\t"
                  "ds_add_f64 %0, %2 offset:8\n\t"

@@ -662,7 +662,7 @@ def test_native_modules_match_composites_at_ragged_shapes(dev):
                     assert float((p_ - q_).abs().max()) <= 2e-5, (c, bsz, h, w)
 
 
-def test_native_paths_run_on_dataparallel_replicas(dev, golden):
+def test_native_paths_run_on_dataparallel_replicas(dev, golden, arith):
     """torch.nn.parallel.replicate (what nn.DataParallel does for every forward with >= 2 devices; here both
     replicas on cuda:0) leaves modules whose named_parameters() is empty: the native RED / CostRegNet / FeatureNet
     paths must still find their weights and reproduce the parent's outputs bit for bit."""
@@ -682,6 +682,28 @@ def test_native_paths_run_on_dataparallel_replicas(dev, golden):
         for s in ("stage1", "stage2", "stage3"):
             assert torch.equal(got[s]["depth"], want[s]["depth"]), s
             assert torch.equal(got[s]["photometric_confidence"], want[s]["photometric_confidence"]), s
+        # a model that carries its OWN arithmetic (arith=, round 5) keeps it on a replica that runs on another thread -- what
+        # nn.DataParallel does -- whatever the process default (the `arith` fixture) is
+        import threading
+        other = "fused" if arith == "exact" else "exact"
+        net.arith = other
+        box = {}
+        with torch.no_grad():
+            want_o = net(imgs, proj, dv)
+            reps = torch.nn.parallel.replicate(net, [0, 0], detach=True)
+
+            def run():
+                torch.cuda.set_device(dev)
+                with torch.no_grad():
+                    box["out"] = reps[1](imgs, proj, dv)
+                torch.cuda.synchronize()
+            t = threading.Thread(target=run)
+            t.start(); t.join()
+        assert reps[1].arith == other
+        for s in ("stage1", "stage2", "stage3"):
+            assert torch.equal(box["out"][s]["depth"], want_o[s]["depth"]), s
+        assert not torch.equal(want_o["stage3"]["depth"], want["stage3"]["depth"])
+        net.arith = None
 
 
 def test_scene_folder_to_height_map(dev):
