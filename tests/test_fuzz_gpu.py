@@ -12,11 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(tool, *args):
+def _run(tool, *args, arith=None):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     cmd = [sys.executable, os.path.join(ROOT, "tests", "fuzz", tool)] + [str(a) for a in args]
-    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    env = dict(os.environ, SMVS_ARITH=arith) if arith else None          # the fuzzers inherit the suite's arithmetic ("exact") unless told otherwise
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, "%s\n%s" % (" ".join(cmd), p.stderr[-2000:])
     assert "MISMATCH" not in p.stdout, "%s\n%s" % (" ".join(cmd), p.stdout[-3000:])
     return p.stdout.strip().splitlines()[-1]
@@ -27,8 +28,10 @@ def test_fuzz_cost_volume_forward_vs_oracle():
     assert last.startswith("60 cases: 0 differing voxels"), last
 
 
-def test_fuzz_cost_volume_backward_vs_warp_autograd():
-    last = _run("fuzz_costvol_bwd.py", 60, 12)
+@pytest.mark.parametrize("mode", ["exact", "fused"])
+def test_fuzz_cost_volume_backward_vs_warp_autograd(mode):
+    """(both arithmetics of the forward: the gradient kernel is the same, the library default must run it too)"""
+    last = _run("fuzz_costvol_bwd.py", 60, 12, arith=mode)
     assert last.startswith("60 cases, worst relative error"), last
     assert float(last.split()[-1]) <= 1e-4, last
 

@@ -609,6 +609,18 @@ def test_graphed_training_step_matches_eager(dev, golden):
         step(imgs, proj, dv, gts2)
     assert float((heights[0] - heights[1]).abs().max()) > 2e-2   # the step in between did move the network
     assert step.captures == n
+    # a per-iteration schedule of a python-float rate re-captures on every call: after three in a row the step says so (once) and
+    # points at a tensor lr; the re-captures themselves keep training correctly (one warm-up step each, state restored)
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for i in range(4):
+            for grp in opt_g.param_groups:
+                grp["lr"] = 1e-3 * (1.0 + 0.1 * i)
+            loss_i, _ = step(imgs, proj, dv, gts2)
+            assert np.isfinite(float(loss_i))
+    assert step.captures == n + 4
+    assert sum("re-captured" in str(x.message) for x in w) == 1
 
 
 def test_native_modules_match_composites_at_ragged_shapes(dev):
