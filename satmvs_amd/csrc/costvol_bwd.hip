@@ -63,6 +63,9 @@ struct CostVolBwdParams {
 #ifndef SMVS_BWD_DCH8_SRC
 #define SMVS_BWD_DCH8_SRC 4           // up to this many source views a lane keeps 8 planes of taps (2 beyond: the register scheme only); measured 3 / 4 views: 4.01 -> 3.66, 6.78 -> 5.88 ms against 4-plane chunks
 #endif
+#ifndef SMVS_BWD_BOX_AHEAD
+#define SMVS_BWD_BOX_AHEAD 0           // 1: feature boxes two channels ahead on three LDS buffers (1-2 source views).  Measured in round 5: 3.91-3.96 against 3.89-3.92 ms (profiles/r05_bwd_prefetch2.txt) -- the boxes' latency is not what the waves wait for; off
+#endif
 #ifndef SMVS_BWD_LDS
 #define SMVS_BWD_LDS 1                 // 0: never take the boxed path (A/B)
 #endif
@@ -149,7 +152,11 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
 {
     static_assert(DCH * NSRC <= 32, "tap flag masks");
     constexpr bool BOX = SMVS_BWD_LDS && NSRC <= BOX_MAX_SRC;
-    constexpr int WAVE_LDS = NSRC * (2 * FBOX_BYTES + GBOX_BYTES);          // [2 buffers][view] feature boxes, then [view] gradient boxes
+    // feature boxes: two buffers (the next channel's boxes land while this one's are read) -- three with 1-2 source views, where the
+    // boxes are requested TWO channels ahead like the gradient planes (round 5: the first of the eight plane chunks of a tile that asks
+    // for a channel's rows takes an HBM miss, ~2-4 us, more than a channel of arithmetic)
+    constexpr int NFB = (SMVS_BWD_BOX_AHEAD && NSRC <= 2) ? 3 : 2;
+    constexpr int WAVE_LDS = NSRC * (NFB * FBOX_BYTES + GBOX_BYTES);        // [NFB buffers][view] feature boxes, then [view] gradient boxes
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[BOX ? BWD_WAVES * WAVE_LDS : 16];
     uint32_t L = xcd_remap(blockIdx.x, gridDim.x);
     const int xtile = L % p.xt; L /= p.xt;
@@ -180,9 +187,9 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
 
     // the wave's gradient boxes start out clear; every flush leaves them clear again
     const uint32_t wave_lds = BOX ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr(lds_all) + (uint32_t)(wv_ * WAVE_LDS))) : 0u;
-    const uint32_t gbox_lds = wave_lds + (uint32_t)(NSRC * 2 * FBOX_BYTES);
+    const uint32_t gbox_lds = wave_lds + (uint32_t)(NSRC * NFB * FBOX_BYTES);
     if (BOX) {
-        double* mine = (double*)(lds_all + wv_ * WAVE_LDS + NSRC * 2 * FBOX_BYTES);
+        double* mine = (double*)(lds_all + wv_ * WAVE_LDS + NSRC * NFB * FBOX_BYTES);
         for (int i = lane; i < NSRC * BOX_CELLS; i += 64) mine[i] = 0.0;
     }
 
@@ -389,6 +396,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
         }
         float gref_prev = 0.0f;
         stage(0, 0);
+        if constexpr (NFB == 3) stage(min(1, C - 1), 1);
         auto channel = [&](const int c, float (&gcur)[DCH]) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < DCH; ++k)
@@ -396,7 +404,11 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
                 for (int s = 0; s < NSRC; ++s) asm volatile("" : "+v"(tt[k][s]));       // see the other loop
             // this channel's boxes, r (requested one iteration ago) and g (two iterations ago) have arrived once only the newest DCH
             // operations -- the gradient planes of channel c + 1 -- are still in flight
-            if (c == 0 || AHEAD == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the prologue issued the boxes last)
+            // (three box buffers: the boxes of channel c + 1 -- 2 NSRC instructions, issued in front of those planes -- may be in flight too)
+            if constexpr (NFB == 3) {
+                if (c == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NSRC) : "memory");     // (the prologue issued the boxes of channel 1 last)
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NSRC + DCH) : "memory");
+            } else if (c == 0 || AHEAD == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the prologue issued the boxes last)
             else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DCH) : "memory");
             const float r = r_next;
             float gq[DCH];
@@ -408,13 +420,14 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
             }
             {
                 const int cn = min(c + 1, C - 1), cf = min(c + AHEAD, C - 1);
-                stage(cn, (c + 1) & 1);
-                r_next = refp[(size_t)cn * HW];
+                r_next = refp[(size_t)cn * HW];                 // (ahead of the boxes: it must have arrived by the next channel)
+                if constexpr (NFB == 3) stage(cf, (c + 2) % 3);
+                else stage(cn, (c + 1) & 1);
 #pragma unroll
                 for (int k = 0; k < DCH; ++k) gcur[k] = gp[((size_t)cf * D + min(k, d1 - d0 - 1)) * HW];
             }
             const int choff = c * HW * 4;
-            const uint32_t fpar = wave_lds + (uint32_t)((c & 1) * NSRC * FBOX_BYTES);
+            const uint32_t fpar = wave_lds + (uint32_t)((NFB == 3 ? c % 3 : (c & 1)) * NSRC * FBOX_BYTES);
             float gref = 0.0f;
             if (any_hole == 0) {
                 // Interior of the image (every tap of the chunk is a full tap, every lane and plane is live): straight-line code,
