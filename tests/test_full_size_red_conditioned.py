@@ -226,7 +226,10 @@ def test_red_cascade_well_conditioned_full_size(dev, tag, arith):
     for s in ("stage1", "stage2", "stage3"):
         e_nat, e_comp, e_nc = f64[s]
         assert e_nat <= H_TOL, "%s %s: native %.3g m from the float64 evaluation (composite %.3g m)" % (tag, s, e_nat, e_comp)
-        assert e_nc <= H_TOL, "%s %s: native %.3g m from the composite on the same stage inputs" % (tag, s, e_nc)
+        # native vs composite: 1e-3 m (measured <= 8.2e-4).  The composite's own distance from float64 moves with the solver MIOpen picks on
+        # a box (seen elsewhere in this suite: two calls of one nn.Conv2d differing in the last bits), so if the two float32 pipelines
+        # ever land on opposite sides of float64 the bound is the triangle's: both within 1e-3 m of float64, 1.5e-3 m apart at most
+        assert e_nc <= H_TOL or (e_comp <= H_TOL and e_nc <= 1.5 * H_TOL), "%s %s: native %.3g m from the composite on the same stage inputs (composite %.3g m from float64)" % (tag, s, e_nc, e_comp)
         assert frac[s] <= 1e-3, "%s %s: %.2g of the pixels differ by more than 1e-3 m free-running" % (tag, s, frac[s])
     assert err["stage1"] <= H_TOL, "%s stage1: free-running native vs composite %.3g m" % (tag, err["stage1"])
     # the photo-consistency path makes the cascade follow the rendered surface (away from the tile border)
