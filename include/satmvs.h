@@ -232,6 +232,17 @@ int smvs_conv3x3_wgrad_cat(const float* xA, int CA, const float* xB, int CB, con
 int smvs_conv3x3_wgrad_list(const float* const* win, const float* const* win2, const float* const* grid, int n,
                             float* dw, float* dgrid_sum, int Bper, int CA, int CB, int Cgrid, int H, int W, int stride, void* stream);
 
+/* Weight gradient of the 3x3x3 / pad 1 layers of the 3-D regulariser CostRegNet (modules/module.py:324-410, 546-577 under
+ * loss.backward(), train.py:284 with --model casmvs / ucs) -- the 2-D correlation above with a depth axis:
+ *   dw[g][c][kd][ky][kx] += sum_{b,d,y,x} grid[b][g][d][y][x] * window[b][c][s*d + kd - 1][s*y + ky - 1][s*x + kx - 1]
+ * grid (B,Cgrid,D,H,W), window (B,Cwin,s*D,s*H,s*W), dw (Cgrid,Cwin,3,3,3) ACCUMULATED into (the caller zero-fills it), s = stride 1 or 2.
+ *   nn.Conv3d(stride s, pad 1): window = input, grid = output gradient -> dw = weight gradient (Cout,Cin,3,3,3);
+ *   nn.ConvTranspose3d(stride 2, pad 1, output_padding 1): window = output gradient, grid = input -> dw = weight gradient
+ *   (Cin_layer,Cout_layer,3,3,3).  Volumes are read in place through their (B,C,D,H,W) strides; a channel of either tensor must stay
+ *   below 2^31 bytes (SMVS_ERR_ARG otherwise: callers keep torch's operator). */
+int smvs_conv3d_wgrad(const float* window, const float* grid, float* dw, int B, int Cwin, int Cgrid, int D, int H, int W, int stride,
+                      void* stream);
+
 /* A single 3x3 / pad 1 layer of the RED regulariser as a stand-alone call on the kernels of the plane loop -- the TRAINING forward of
  * its convolutions (modules/module.py:34-57, :625-644 under autograd) and their input gradients:
  *   smvs_conv3x3_packed_floats(cin, cout)  floats of the packed weights

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "smvs_conv3x3_wgrad_strided": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "smvs_conv3x3_wgrad_cat": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "smvs_conv3x3_wgrad_list": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "smvs_conv3d_wgrad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "smvs_conv3x3_pack": [_vp, _vp, _i, _i, _i, _vp],
     "smvs_conv3x3_fwd": [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "smvs_gru_mul_cat_bwd_acc": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

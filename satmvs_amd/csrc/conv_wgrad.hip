@@ -218,6 +218,162 @@ void conv3x3_wgrad_kernel(const WgradParams p)
     }
 }
 
+
+// ---- 3x3x3 layers of CostRegNet (training path of --model casmvs / ucs) -------------------------------------------------------------
+// Weight gradient of Conv3d (stride 1 / 2, pad 1) and ConvTranspose3d (stride 2, pad 1, output_padding 1) of
+// /root/reference/modules/module.py:324-410 under loss.backward() (/root/reference/train.py:284):
+//     dW[g][c][kd][ky][kx] = sum_{b,d,y,x} G[b][g][d][y][x] * Xw[b][c][S d + kd - 1][S y + ky - 1][S x + kx - 1]
+// (G = the tensor on the D x H x W grid, Xw = the one read through the taps: layer input / output gradient, swapped for the
+// transposed layers exactly like the 2-D kernel above).  On this image MIOpen answers these calls with
+// naive_conv_ab_nonpacked_wrw_ncdhw (one thread per weight, double accumulation) and a batched-GEMM fallback: 1.35 s + 0.64 s of the
+// 1.98 s training step of the 48/32/8 cascade at the 768x384 tile (profiles/r05_train_step_casmvs.txt).
+// The 2-D scheme with a depth loop around it: a wave owns (a pair of window channels) x (8 grid channels) x (a 64-column strip) x
+// (a range of rows) x (a range of grid planes) x ONE depth tap kd -- 144 sums in registers; for every grid plane d of its range it
+// slides the 3x3 window down the rows of window plane S d + kd - 1 (planes outside the volume are skipped wave-uniformly).  Channel
+// strides are those of the (B,C,D,H,W) volumes, so nothing is copied or transposed.
+struct Wgrad3Params {
+    const float* x; const float* dy; float* dw;
+    int B, Cin, Cout, D, H, W;          // D, H, W: the grid; the window tensor is (B, Cin, S*D, S*H, S*W)
+    int ncp, ncog, nxs, nrc, rows;      // window-channel pairs, grid-channel groups of 8, column strips, row chunks, rows per chunk
+    int ndc, dchunk;                    // chunks of grid planes, planes per chunk
+};
+
+template <int S>
+__global__ __launch_bounds__(256)
+void conv3d_wgrad_kernel(const Wgrad3Params p)
+{
+    const int lane = threadIdx.x & 63;
+    long long unit = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave = one unit
+    const long long total = (long long)p.ncp * p.ncog * p.nxs * p.nrc * 3 * p.ndc * p.B;
+    if (unit >= total) return;
+    // row chunk fastest, then column strip, depth tap, plane chunk, channel pair, output group, batch: neighbouring waves share rows in L2
+    const int rc = __builtin_amdgcn_readfirstlane((int)(unit % p.nrc)); unit /= p.nrc;
+    const int xs = __builtin_amdgcn_readfirstlane((int)(unit % p.nxs)); unit /= p.nxs;
+    const int kd = __builtin_amdgcn_readfirstlane((int)(unit % 3)); unit /= 3;
+    const int dc = __builtin_amdgcn_readfirstlane((int)(unit % p.ndc)); unit /= p.ndc;
+    const int cp = __builtin_amdgcn_readfirstlane((int)(unit % p.ncp)); unit /= p.ncp;
+    const int cog = __builtin_amdgcn_readfirstlane((int)(unit % p.ncog));
+    const int b = __builtin_amdgcn_readfirstlane((int)(unit / p.ncog));
+    const int D = p.D, H = p.H, W = p.W, HW = H * W;
+    const int DX = S * D, HX = S * H, WX = S * W, HWX = HX * WX;
+    const size_t csx = (size_t)DX * HWX, csy = (size_t)D * HW;        // channel strides (elements)
+    const int x = xs * 64 + lane;
+    const int y0 = rc * p.rows, y1 = min(y0 + p.rows, H);
+    const int dz0 = dc * p.dchunk, dz1 = min(dz0 + p.dchunk, D);
+    const int ci0 = 2 * cp;
+    const bool two = ci0 + 1 < p.Cin;
+    uint32_t cx[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int xx = S * x - 1 + k;
+        cx[k] = (x < W && xx >= 0 && xx < WX) ? (uint32_t)xx * 4u : SMVS_OOB;
+    }
+    const uint32_t cy = x < W ? (uint32_t)x * 4u : SMVS_OOB;
+    const int nco = min(8, p.Cout - cog * 8);
+    const int ch1 = two ? (int)(csx * 4) : 0;                         // byte offset of the pair's second channel (odd counts: the first again, not published)
+    int gch[8];                                                       // byte offsets of the 8 grid channels (beyond Cout: the last one again, not published)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gch[j] = (int)((size_t)min(j, nco - 1) * csy * 4);
+
+    float acc[2][8][9];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[c][j][k] = 0.0f;
+
+    for (int d = dz0; d < dz1; ++d) {
+    const int zd = S * d + kd - 1;                                    // window plane of this grid plane and depth tap
+    if (zd < 0 || zd >= DX) continue;
+    const BufRsrc rx = make_rsrc(p.x + ((size_t)b * p.Cin + ci0) * csx + (size_t)zd * HWX, (uint32_t)(ch1 + HWX * 4));
+    const BufRsrc ry = make_rsrc(p.dy + ((size_t)b * p.Cout + cog * 8) * csy + (size_t)d * HW, (uint32_t)(gch[7] + HW * 4));
+    float win[2][3][3];
+    auto load_row = [&](int yy, float (&dst)[2][3]) {                 // yy: row of the window plane; every load unconditional (see the 2-D kernel)
+        i32x4 r = rx.v;
+        r.z = (yy >= 0 && yy < HX) ? r.z : 0;
+        const int so = (yy >= 0 && yy < HX) ? yy * WX * 4 : 0;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dst[c][k] = llvm_raw_buffer_load_f32(r, (int)cx[k], c * ch1 + so, 0);
+    };
+    auto load_g = [&](int yy, float (&dst)[8]) {
+        i32x4 r = ry.v;
+        r.z = yy < y1 ? r.z : 0;
+        const int so = yy < y1 ? yy * W * 4 : 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j] = llvm_raw_buffer_load_f32(r, (int)cy, gch[j] + so, 0);
+    };
+    float new_n[S][2][3], g_n[8];
+    if (S == 1) {
+        float r0[2][3], r1[2][3];
+        load_row(y0 - 1, r0);
+        load_row(y0, r1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { win[c][1][k] = r0[c][k]; win[c][2][k] = r1[c][k]; win[c][0][k] = 0.0f; }
+        load_row(y0 + 1, new_n[0]);
+    } else {
+        float r0[2][3];
+        load_row(S * y0 - 1, r0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { win[c][2][k] = r0[c][k]; win[c][0][k] = win[c][1][k] = 0.0f; }
+#pragma unroll
+        for (int q = 0; q < S; ++q) load_row(S * y0 + q, new_n[q]);
+    }
+    load_g(y0, g_n);
+    for (int y = y0; y < y1; ++y) {
+        float fresh[S][2][3], g[8];
+#pragma unroll
+        for (int q = 0; q < S; ++q)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) fresh[q][c][k] = new_n[q][c][k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = g_n[j];
+#pragma unroll
+        for (int q = 0; q < S; ++q) load_row(y + 1 < y1 ? (S == 1 ? y + 2 : S * (y + 1) + q) : HX, new_n[q]);
+        load_g(y + 1, g_n);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (S == 1) { win[c][0][k] = win[c][1][k]; win[c][1][k] = win[c][2][k]; win[c][2][k] = fresh[0][c][k]; }
+                else { win[c][0][k] = win[c][2][k]; win[c][1][k] = fresh[0][c][k]; win[c][2][k] = fresh[1][c][k]; }
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc[c][j][r * 3 + k] = fmaf(g[j], win[c][r][k], acc[c][j][r * 3 + k]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    }   // grid planes of this wave
+    // reduce over the lanes four values at a time; lanes 15 / 31 / 47 / 63 publish values 4m + {0, 2, 1, 3}; value index (c * 8 + j) * 9 + k
+    auto value = [&](int i) -> float { return acc[i / 72][(i % 72) / 9][i % 9]; };
+    const int q = lane >> 4;
+    const int sel = q == 1 ? 2 : q == 2 ? 1 : q;
+    const bool publisher = (lane & 15) == 15;
+#pragma unroll
+    for (int m = 0; m < 36; ++m) {
+        const float v = reduce4_rows(value(4 * m), value(4 * m + 1), value(4 * m + 2), value(4 * m + 3));
+        const int i = 4 * m + sel;
+        if (publisher) {
+            const int c = i / 72, j = (i % 72) / 9, k = i % 9;
+            if (j < nco && (c == 0 || two)) unsafeAtomicAdd(p.dw + ((size_t)(cog * 8 + j) * p.Cin + ci0 + c) * 27 + kd * 9 + k, v);
+        }
+    }
+}
+
 }  // namespace smvs
 
 // list: nlist > 0 tensors of `B` samples each (x / x2 / dy ignored), else one tensor of B samples
@@ -291,5 +447,40 @@ extern "C" SMVS_EXPORT int smvs_conv3x3_wgrad_list(const float* const* win, cons
                                     (win2 && CB > 0) ? win2 + i : nullptr, grid + i);
         if (rc) return rc;
     }
+    return SMVS_OK;
+}
+
+// Weight gradient of a 3x3x3 / pad 1 layer of the 3-D regulariser, ACCUMULATED into dw (zeroed by the caller):
+//   window (B, Cwin, S*D, S*H, S*W), grid (B, Cgrid, D, H, W), dw (Cgrid, Cwin, 3, 3, 3), stride S in {1, 2}
+// nn.Conv3d (stride S): window = layer input, grid = output gradient; nn.ConvTranspose3d (stride 2, output_padding 1): window = output
+// gradient, grid = layer input (its weight is (Cin_layer, Cout_layer, 3,3,3) = the same index formula).
+// Replaces MIOpen's weight-gradient kernels under /root/reference/modules/module.py:324-410, 546-577.
+extern "C" SMVS_EXPORT int smvs_conv3d_wgrad(const float* window, const float* grid, float* dw, int B, int Cwin, int Cgrid,
+                                             int D, int H, int W, int stride, void* stream)
+{
+    using namespace smvs;
+    if (!window || !grid || !dw) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (B < 1 || Cwin < 1 || Cgrid < 1 || D < 1 || H < 1 || W < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
+    if (stride != 1 && stride != 2) return fail(SMVS_ERR_ARG, "stride must be 1 or 2");
+    const long long S = stride, vol_g = (long long)D * H * W, vol_w = vol_g * S * S * S, plane_w = (long long)H * W * S * S;
+    if ((vol_w + plane_w) * 4 >= (1ll << 31) || (7 * vol_g + (long long)H * W) * 4 >= (1ll << 31))
+        return fail(SMVS_ERR_ARG, "volume too large for the 32-bit channel offsets of conv3d_wgrad (window %lld, grid %lld elements per channel)", vol_w, vol_g);
+    Wgrad3Params p{};
+    p.x = window; p.dy = grid; p.dw = dw; p.B = B; p.Cin = Cwin; p.Cout = Cgrid; p.D = D; p.H = H; p.W = W;
+    p.ncp = (Cwin + 1) / 2; p.ncog = (Cgrid + 7) / 8; p.nxs = (W + 63) / 64;
+    // Work per wave: whole volumes while that leaves >= ~2048 waves (the window prologue per plane and the lane reduction per wave are
+    // overhead), then chunks of grid planes, then single planes cut into row chunks of >= 16 rows.
+    const long long base = (long long)p.ncp * p.ncog * p.nxs * 3 * B;
+    int dchunk = D, rows = H;
+    while (dchunk > 1 && base * ((D + dchunk - 1) / dchunk) < 2048) dchunk = (dchunk + 1) / 2;
+    const int ndc = (D + dchunk - 1) / dchunk;
+    while (dchunk == 1 && rows > 16 && base * ndc * ((H + rows - 1) / rows) < 2048) rows = (rows + 1) / 2;
+    p.dchunk = dchunk; p.ndc = ndc; p.rows = rows; p.nrc = (H + rows - 1) / rows;
+    const long long units = base * ndc * p.nrc;
+    if ((units + 3) / 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "too many work units");
+    if (stride == 1) hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    else             hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "conv3d_wgrad launch: %s", hipGetErrorString(e));
     return SMVS_OK;
 }

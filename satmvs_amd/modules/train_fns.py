@@ -387,6 +387,58 @@ class _Conv3x3WgradFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class _Conv3dWgradFn(torch.autograd.Function):
+    """A 3x3x3 / pad 1 nn.Conv3d (stride 1 or 2) or nn.ConvTranspose3d (stride 2, output_padding 1) without bias -- every layer of
+    CostRegNet (reference modules/module.py:324-410, 546-577) -- whose WEIGHT gradient comes from smvs_conv3d_wgrad
+    (csrc/conv_wgrad.hip); forward and input gradient stay torch's (MIOpen / composable-kernel implicit GEMMs: 10 ms of a step).
+    On this image MIOpen computes these weight gradients with naive_conv_ab_nonpacked_wrw_ncdhw (one thread per weight) and a
+    batched-GEMM fallback: 1.98 s of the 1.98 s training step of CascadeMVSNet at the 768x384 tile (profiles/r05_train_step_casmvs.txt)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, transposed):
+        ctx.save_for_backward(x, weight)
+        ctx.meta = (int(stride), bool(transposed))
+        if transposed:
+            return F.conv_transpose3d(x, weight, None, stride=stride, padding=1, output_padding=stride - 1)
+        return F.conv3d(x, weight, None, stride=stride, padding=1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, transposed = ctx.meta
+        dy = _f32c_fast(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [stride] * 3, [1] * 3, [1] * 3, transposed,
+                                                     [stride - 1] * 3 if transposed else [0] * 3, 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            xc = _f32c_fast(x)
+            window, grid = (dy, xc) if transposed else (xc, dy)             # the tensor read through the taps / the one on the output grid
+            B, Cg, D, H, W = grid.shape
+            dw = torch.zeros(weight.shape, dtype=torch.float32, device=xc.device)
+            with torch.cuda.device(xc.device):
+                _lib.call("smvs_conv3d_wgrad", _lib.ptr(window), _lib.ptr(grid), _lib.ptr(dw), B, window.shape[1], Cg, D, H, W, stride,
+                          _lib.current_stream(xc.device))
+        return dx, dw, None, None
+
+
+def _conv3d(conv, x):
+    """conv(x) for the 3-D regulariser's layers (nn.Conv3d stride 1 / 2, nn.ConvTranspose3d stride 2; 3x3x3, pad 1, no bias): with the
+    native weight gradient where a gradient is wanted on the GPU (SMVS_TRAIN_COMPOSITE_MASK bit 64 keeps torch's)."""
+    transposed = isinstance(conv, nn.ConvTranspose3d)
+    s = conv.stride[0]
+    if (x.is_cuda and x.dim() == 5 and x.dtype is torch.float32 and torch.is_grad_enabled() and conv.weight.requires_grad
+            and conv.weight.dtype is torch.float32 and conv.weight.is_contiguous() and conv.bias is None
+            and conv.kernel_size == (3, 3, 3) and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.padding == (1, 1, 1)
+            and conv.dilation == (1, 1, 1) and conv.groups == 1
+            and ((transposed and s == 2 and conv.output_padding == (1, 1, 1)) or
+                 (not transposed and all(d % s == 0 for d in x.shape[2:])))
+            and not (SW.train_composite_mask & 64)
+            and x.shape[2] * x.shape[3] * x.shape[4] * (s ** 3 if transposed else 1) * 4 * 8 < 2 ** 31):
+        return _Conv3dWgradFn.apply(x, conv.weight, s, transposed)
+    return conv(x)
+
+
 _CONV_PACK = {}         # (weight address, layout, cin) -> (version, epoch, storage weak reference, packed tensor): one entry per layer and direction
 
 

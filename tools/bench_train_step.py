@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """One training step of CascadeREDNet (train.py:267-302: forward, cas_mvsnet_loss, backward, RMSprop) on a synthetic 3-view
 768x384 tile, planes 48/32/8: what the native cost-volume forward/backward leave to the PyTorch composites.
-    python tools/bench_train_step.py [steps]"""
+    python tools/bench_train_step.py [steps] [casred|casmvs|ucs]      (the other two: CostRegNet under autograd)"""
 import os, sys, time
 import numpy as np
 import torch
@@ -15,7 +15,16 @@ torch.backends.cudnn.benchmark = os.environ.get("SMVS_CUDNN_BENCHMARK", "0") == 
 H, W, nd = 384, 768, [48, 32, 8]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 torch.manual_seed(0)
-net = CascadeREDNet("rpc", min_interval=2.5, ndepths=nd).to(dev).train()
+model = sys.argv[2] if len(sys.argv) > 2 else "casred"
+if model == "casred":
+    net = CascadeREDNet("rpc", min_interval=2.5, ndepths=nd)
+elif model == "casmvs":
+    from satmvs_amd.networks.casmvs import CascadeMVSNet
+    net = CascadeMVSNet("rpc", min_interval=2.5, ndepths=nd)
+else:
+    from satmvs_amd.networks.ucs import UCSNet
+    net = UCSNet("rpc", stage_configs=nd)
+net = net.to(dev).train()
 opt = torch.optim.RMSprop(net.parameters(), lr=1e-3, alpha=0.9)               # train.py:135
 imgs = torch.randn(1, 3, 3, H, W, device=dev)
 rpc = rpc_synth.make_view_rpcs(3, H, W, seed=0)[None]
@@ -45,5 +54,5 @@ for _ in range(steps):
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) * 1e3)
 ts.sort()
-print("training step, 3-view 768x384, planes %s: median %.1f ms (min %.1f, max %.1f), loss %.4f, peak memory %.2f GB"
+print(model + " training step, 3-view 768x384, planes %s: median %.1f ms (min %.1f, max %.1f), loss %.4f, peak memory %.2f GB"
       % (nd, ts[len(ts) // 2], ts[0], ts[-1], float(loss), torch.cuda.max_memory_allocated() / 2 ** 30))

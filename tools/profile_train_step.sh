@@ -1,12 +1,13 @@
 #!/bin/bash
-# kernel trace of one training step: tools/profile_train_step.sh
+# kernel trace of one training step: tools/profile_train_step.sh [casred|casmvs|ucs]
+MODEL=${1:-casred}
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/prof_train
+OUT=$REPO/gpurun_out/prof_train_$MODEL
 mkdir -p "$OUT"
-python $REPO/tools/bench_train_step.py 5 > "$OUT/train_step.txt" 2>&1
+python $REPO/tools/bench_train_step.py 5 $MODEL > "$OUT/train_step.txt" 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- python $REPO/tools/bench_train_step.py 3 > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- python $REPO/tools/bench_train_step.py 3 $MODEL > "$OUT/trace.log" 2>&1
 python - <<PY >> "$OUT/train_step.txt"
 import sqlite3, glob
 db = sqlite3.connect(glob.glob("$OUT/trace/**/*.db", recursive=True)[0])
