@@ -243,6 +243,35 @@ int smvs_conv3x3_wgrad_list(const float* const* win, const float* const* win2, c
 int smvs_conv3d_wgrad(const float* window, const float* grid, float* dw, int B, int Cwin, int Cgrid, int D, int H, int W, int stride,
                       void* stream);
 
+/* A single 3x3x3 / pad 1 layer of CostRegNet as a stand-alone call on the kernels of smvs_costreg_fwd (direct or MFMA by channel
+ * count) WITHOUT the folded BatchNorm -- the TRAINING forward of its convolutions (modules/module.py:324-410 under autograd, batch
+ * statistics follow as a separate operator) and their input gradients, which are the adjoint layers on the same kernels:
+ *   smvs_conv3d_packed_floats(cin, cout)  floats of the packed weights of a layer from cin to cout channels
+ *   smvs_conv3d_pack(w, packed, cin, cout, layout): weights read from w as
+ *       layout 0: w[co][ci][27]       an nn.Conv3d weight (kinds 0 / 1); the input gradient of an nn.ConvTranspose3d of weight (cout,cin,27)
+ *       layout 1: w[ci][co][27]       scatter taps for kind 2: an nn.ConvTranspose3d(stride 2) weight; the input gradient of a stride-2
+ *                                     nn.Conv3d of weight (cin, cout, 27)
+ *       layout 2: w[ci][co][26 - k]   the input gradient of a stride-1 nn.Conv3d of weight (cin, cout, 27) as a correlation (kind 0)
+ *   smvs_conv3d_fwd(kind, ...)  out = [relu](layer(in (B,Cin,Di,Hi,Wi))) [+ skip]
+ *       kind 0: correlation, stride 1, out (B,Cout,Di,Hi,Wi);   kind 1: correlation, stride 2 (even dims), out (B,Cout,Di/2,Hi/2,Wi/2);
+ *       kind 2: transposed convolution, stride 2, output_padding 1, out (B,Cout,2Di,2Hi,2Wi).   skip: NULL or a tensor of out's shape. */
+size_t smvs_conv3d_packed_floats(int cin, int cout);
+int smvs_conv3d_pack(const float* w, float* packed, int cin, int cout, int layout, void* stream);
+int smvs_conv3d_fwd(int kind, const float* in, const float* packed, const float* skip, float* out, int B, int Cin, int Cout,
+                    int Di, int Hi, int Wi, int relu, void* stream);
+
+/* nn.BatchNorm3d in TRAINING form (batch statistics over (B, N = D*H*W) per channel) with the block's ReLU -- the normalisation of every
+ * Conv3d / Deconv3d block of CostRegNet under autograd (modules/module.py:324-410):
+ *   fwd: y = [relu]((x - mean) * rstd * gamma + beta);  saved_mean_rstd (C,2) for the backward;  running_mean / running_var (or NULL, NULL)
+ *        updated like torch.nn.functional.batch_norm(training=True): (1 - momentum) * running + momentum * batch (unbiased variance)
+ *   bwd: dx, dgamma (C), dbeta (C) from dy, the layer's INPUT x and saved_mean_rstd; with relu != 0 the gradient passes where the forward's
+ *        output was positive (recomputed from x: neither a mask nor the output is kept)
+ * x, y, dy, dx: (B,C,N) contiguous float32; workspace: 2*C doubles of scratch (cleared by the call). */
+int smvs_batchnorm_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                             float eps, int relu, float* y, float* saved_mean_rstd, double* workspace, int B, int C, long long N, void* stream);
+int smvs_batchnorm_train_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* saved_mean_rstd, int relu,
+                             float* dx, float* dgamma, float* dbeta, double* workspace, int B, int C, long long N, void* stream);
+
 /* A single 3x3 / pad 1 layer of the RED regulariser as a stand-alone call on the kernels of the plane loop -- the TRAINING forward of
  * its convolutions (modules/module.py:34-57, :625-644 under autograd) and their input gradients:
  *   smvs_conv3x3_packed_floats(cin, cout)  floats of the packed weights

@@ -55,6 +55,10 @@ _SIGNATURES = {
     "smvs_conv3x3_wgrad_cat": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "smvs_conv3x3_wgrad_list": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "smvs_conv3d_wgrad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "smvs_conv3d_pack": [_vp, _vp, _i, _i, _i, _vp],
+    "smvs_batchnorm_train_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _i, _i, C.c_longlong, _vp],
+    "smvs_batchnorm_train_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, C.c_longlong, _vp],
+    "smvs_conv3d_fwd": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "smvs_conv3x3_pack": [_vp, _vp, _i, _i, _i, _vp],
     "smvs_conv3x3_fwd": [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "smvs_gru_mul_cat_bwd_acc": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -70,7 +74,8 @@ _SIGNATURES = {
 _SIZE_FUNCS = {"smvs_red_packed_floats": [_i], "smvs_red_workspace_bytes": [_i] * 4,
                "smvs_red_pred_workspace_bytes": [_i] * 4, "smvs_costreg_packed_floats": [_i],
                "smvs_costreg_workspace_bytes": [_i] * 5, "smvs_featnet_packed_floats": [_i] * 2,
-               "smvs_featnet_workspace_bytes": [_i] * 5, "smvs_conv3x3_packed_floats": [_i] * 2}
+               "smvs_featnet_workspace_bytes": [_i] * 5, "smvs_conv3x3_packed_floats": [_i] * 2,
+               "smvs_conv3d_packed_floats": [_i] * 2}
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SIZE_FUNCS) + ["smvs_version", "smvs_last_error", "smvs_red_set_streams", "smvs_shutdown",
                                                                     "smvs_set_arith", "smvs_get_arith"])
 ARITH_MODES = {"exact": 0, "fused": 1}      # SMVS_ARITH_EXACT / SMVS_ARITH_FUSED of include/satmvs.h

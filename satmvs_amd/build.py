@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libsatmvs_hip.so")
-SOURCES = ["costvol.hip", "costvol_fused.hip", "costvol_bwd.hip", "warp.hip", "regress.hip", "red.hip", "costreg.hip", "featnet.hip", "filter.hip", "groupnorm.hip", "conv_wgrad.hip"]
+SOURCES = ["costvol.hip", "costvol_fused.hip", "costvol_bwd.hip", "warp.hip", "regress.hip", "red.hip", "costreg.hip", "featnet.hip", "filter.hip", "groupnorm.hip", "conv_wgrad.hip", "batchnorm.hip"]
 HEADERS = ["smvs_device.h", "smvs_host.h", "mfma_conv.h", "costvol_kernels.h", os.path.join("..", "..", "include", "satmvs.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fvisibility=hidden", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]

@@ -63,7 +63,9 @@ static CrLayout cr_layout(int C)
     return o;
 }
 
-__global__ void cr_pack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int cin, int cout, int transposed)
+// transposed: src is (cin, cout, 27) instead of (cout, cin, 27); flip (with transposed): taps mirrored in all three dimensions -- the
+// ADJOINT of a stride-1 correlation of weight (cin, cout, 27) as a correlation from cin to cout channels (smvs_conv3d_pack layout 2)
+__global__ void cr_pack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int cin, int cout, int transposed, int flip)
 {
     const int ncog = (cout + CR_COT - 1) / CR_COT;
     const int n = ncog * cin * 27 * CR_COT;
@@ -71,7 +73,7 @@ __global__ void cr_pack_conv_kernel(const float* __restrict__ src, float* __rest
         const int j = i % CR_COT, k = (i / CR_COT) % 27, ci = (i / (CR_COT * 27)) % cin, cog = i / (CR_COT * 27 * cin);
         const int co = cog * CR_COT + j;
         float v = 0.0f;
-        if (co < cout) v = transposed ? src[((size_t)ci * cout + co) * 27 + k] : src[((size_t)co * cin + ci) * 27 + k];
+        if (co < cout) v = transposed ? src[((size_t)ci * cout + co) * 27 + (flip ? 26 - k : k)] : src[((size_t)co * cin + ci) * 27 + k];
         dst[i] = v;
     }
 }
@@ -435,6 +437,41 @@ void convT3d_split_kernel(const Conv3Args a)
     }
 }
 
+// One layer on the kernels above: wm = MFMA-order weights (null: direct kernels)
+static void cr_launch_layer(const CrLayer& l, const float* in, const float* w, const float* scale, const float* shift, const float* wm,
+                            const float* skip, float* out, int B, const int (&di)[3], const int (&dout)[3], bool direct_only, hipStream_t st)
+{
+    Conv3Args a{};
+    a.in = in; a.w = w; a.scale = scale; a.shift = shift;
+    a.skip = skip; a.out = out; a.Cin = l.cin; a.Cout = l.cout; a.relu = l.relu;
+    a.Di = di[0]; a.Hi = di[1]; a.Wi = di[2];
+    a.Do = dout[0]; a.Ho = dout[1]; a.Wo = dout[2];
+    const int ncog = (l.cout + CR_COT - 1) / CR_COT;
+    if (wm) {
+        MfmaConvArgs m{};
+        m.inA = in; m.CA = l.cin; m.scaleA = 1.0f; m.w = wm;
+        m.scale = a.scale; m.shift = a.shift; m.skip = skip; m.out = out;
+        m.Cout = l.cout; m.relu = l.relu; m.stride = l.stride;
+        m.Di = a.Di; m.Hi = a.Hi; m.Wi = a.Wi; m.Do = a.Do; m.Ho = a.Ho; m.Wo = a.Wo;
+        mfma_conv_launch<27>(m, B, st);
+    } else if (l.transposed) {
+        dim3 grd((a.Wi + 63) / 64, (a.Hi * a.Di + 3) / 4, B * ncog);
+        static const int split_below = tune_int("SMVS_CONV_SPLIT_BELOW", 1024);
+        if ((long long)((a.Di * a.Hi * a.Wi + 63) / 64) * B * ncog < split_below / 2 && !direct_only)
+            hipLaunchKernelGGL(convT3d_split_kernel, dim3((a.Di * a.Hi * a.Wi + 63) / 64, 1, B * ncog), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL(convT3d_kernel, grd, dim3(256), 0, st, a);
+    } else {
+        dim3 grd((a.Wo + 63) / 64, (a.Ho * a.Do + 3) / 4, B * ncog);
+        const dim3 grd1((a.Wo + CR_S1_TILE - 1) / CR_S1_TILE, (a.Ho * a.Do + 3) / 4, B * ncog);
+        static const bool gather = tune_int("SMVS_CONV3D_GATHER", 0) == 1;
+        if (l.stride == 1 && !gather && l.cout <= 2) hipLaunchKernelGGL(conv3d_s1_kernel<2>, grd1, dim3(256), 0, st, a);
+        else if (l.stride == 1 && !gather) hipLaunchKernelGGL(conv3d_s1_kernel<CR_COT>, grd1, dim3(256), 0, st, a);
+        else if (l.stride == 1)       hipLaunchKernelGGL(conv3d_kernel<1>, grd, dim3(256), 0, st, a);
+        else               hipLaunchKernelGGL(conv3d_kernel<2>, grd, dim3(256), 0, st, a);
+    }
+}
+
 struct CrWorkspace { size_t c0, t1, c2, t3, c4, t5, t6, x7, x9, x11, total; };
 
 static CrWorkspace cr_workspace(int B, int D, int H, int W)
@@ -480,7 +517,7 @@ SMVS_EXPORT int smvs_costreg_pack_weights(const float* const* params, int C, flo
         const float* const* q = params + (i < 10 ? i * 5 : 50);
         const int n = (int)cr_packed_conv(L[i].cin, L[i].cout);
         hipLaunchKernelGGL(cr_pack_conv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, q[0], packed + lay.w[i],
-                           L[i].cin, L[i].cout, L[i].transposed);
+                           L[i].cin, L[i].cout, L[i].transposed, 0);
         if (cr_use_mfma(L[i])) {
             const int nm = (int)mfma_packed_floats(L[i].cin, L[i].cout, 27);
             hipLaunchKernelGGL(mfma_pack_kernel, dim3((nm + 255) / 256), dim3(256), 0, st, q[0], packed + lay.wm[i],
@@ -527,38 +564,67 @@ SMVS_EXPORT int smvs_costreg_fwd(const float* packed, const float* vol, float* o
         const CrLayer& l = L[s.layer];
         if ((long long)l.cin * dims[s.lin][0] * dims[s.lin][1] * dims[s.lin][2] * 4 >= (1ll << 32))
             return fail(SMVS_ERR_ARG, "layer %d input larger than 4 GiB per batch item", i);
-        Conv3Args a{};
-        a.in = s.in; a.w = packed + lay.w[s.layer]; a.scale = packed + lay.scale[s.layer]; a.shift = packed + lay.shift[s.layer];
-        a.skip = s.skip; a.out = s.out; a.Cin = l.cin; a.Cout = l.cout; a.relu = l.relu;
-        a.Di = dims[s.lin][0]; a.Hi = dims[s.lin][1]; a.Wi = dims[s.lin][2];
-        a.Do = dims[s.lout][0]; a.Ho = dims[s.lout][1]; a.Wo = dims[s.lout][2];
-        const int ncog = (l.cout + CR_COT - 1) / CR_COT;
-        if (cr_use_mfma(l) && !direct_only) {
-            MfmaConvArgs m{};
-            m.inA = s.in; m.CA = l.cin; m.scaleA = 1.0f; m.w = packed + lay.wm[s.layer];
-            m.scale = a.scale; m.shift = a.shift; m.skip = s.skip; m.out = s.out;
-            m.Cout = l.cout; m.relu = l.relu; m.stride = l.stride;
-            m.Di = a.Di; m.Hi = a.Hi; m.Wi = a.Wi; m.Do = a.Do; m.Ho = a.Ho; m.Wo = a.Wo;
-            mfma_conv_launch<27>(m, B, st);
-        } else if (l.transposed) {
-            dim3 grd((a.Wi + 63) / 64, (a.Hi * a.Di + 3) / 4, B * ncog);
-            static const int split_below = tune_int("SMVS_CONV_SPLIT_BELOW", 1024);
-            if ((long long)((a.Di * a.Hi * a.Wi + 63) / 64) * B * ncog < split_below / 2 && !direct_only)
-                hipLaunchKernelGGL(convT3d_split_kernel, dim3((a.Di * a.Hi * a.Wi + 63) / 64, 1, B * ncog), dim3(256), 0, st, a);
-            else
-                hipLaunchKernelGGL(convT3d_kernel, grd, dim3(256), 0, st, a);
-        } else {
-            dim3 grd((a.Wo + 63) / 64, (a.Ho * a.Do + 3) / 4, B * ncog);
-            const dim3 grd1((a.Wo + CR_S1_TILE - 1) / CR_S1_TILE, (a.Ho * a.Do + 3) / 4, B * ncog);
-            static const bool gather = tune_int("SMVS_CONV3D_GATHER", 0) == 1;
-            if (l.stride == 1 && !gather && l.cout <= 2) hipLaunchKernelGGL(conv3d_s1_kernel<2>, grd1, dim3(256), 0, st, a);
-            else if (l.stride == 1 && !gather) hipLaunchKernelGGL(conv3d_s1_kernel<CR_COT>, grd1, dim3(256), 0, st, a);
-            else if (l.stride == 1)       hipLaunchKernelGGL(conv3d_kernel<1>, grd, dim3(256), 0, st, a);
-            else               hipLaunchKernelGGL(conv3d_kernel<2>, grd, dim3(256), 0, st, a);
-        }
+        cr_launch_layer(l, s.in, packed + lay.w[s.layer], packed + lay.scale[s.layer], packed + lay.shift[s.layer],
+                        cr_use_mfma(l) && !direct_only ? packed + lay.wm[s.layer] : nullptr, s.skip, s.out, B, dims[s.lin], dims[s.lout],
+                        direct_only, st);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "costreg_fwd launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
+}
+
+// ---- single layers: the TRAINING forward of CostRegNet's convolutions and their input gradients (include/satmvs.h) ----------------------
+// packed buffer of one layer: [direct-order weights][ones (cout padded to 8)][zeros][MFMA-order weights where that kernel takes the layer]
+SMVS_EXPORT size_t smvs_conv3d_packed_floats(int cin, int cout)
+{
+    if (cin < 1 || cout < 1) return 0;
+    const size_t cp = (size_t)((cout + smvs::CR_COT - 1) / smvs::CR_COT) * smvs::CR_COT;
+    return smvs::cr_packed_conv(cin, cout) + 2 * cp + (smvs::mfma_conv_ok(cin, 0, cout) ? smvs::mfma_packed_floats(cin, cout, 27) : 0);
+}
+
+SMVS_EXPORT int smvs_conv3d_pack(const float* w, float* packed, int cin, int cout, int layout, void* stream)
+{
+    using namespace smvs;
+    if (!w || !packed) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (cin < 1 || cout < 1) return fail(SMVS_ERR_ARG, "non-positive channel count");
+    if (layout < 0 || layout > 2) return fail(SMVS_ERR_ARG, "layout must be 0, 1 or 2");
+    hipStream_t st = (hipStream_t)stream;
+    const int n = (int)cr_packed_conv(cin, cout);
+    const int cp = ((cout + CR_COT - 1) / CR_COT) * CR_COT;
+    hipLaunchKernelGGL(cr_pack_conv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, packed, cin, cout, layout != 0, layout == 2);
+    hipLaunchKernelGGL(cr_pack_bn_kernel, dim3((cp + 63) / 64), dim3(64), 0, st, w, w, w, w, packed + n, packed + n + cp, cout, cp, 0);
+    if (mfma_conv_ok(cin, 0, cout) && layout != 1) {
+        const int nm = (int)mfma_packed_floats(cin, cout, 27);
+        hipLaunchKernelGGL(mfma_pack_kernel, dim3((nm + 255) / 256), dim3(256), 0, st, w, packed + n + 2 * cp, cin, cout, 27, layout == 2);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "conv3d_pack launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
+}
+
+SMVS_EXPORT int smvs_conv3d_fwd(int kind, const float* in, const float* packed, const float* skip, float* out, int B, int Cin, int Cout,
+                                int Di, int Hi, int Wi, int relu, void* stream)
+{
+    using namespace smvs;
+    if (!in || !packed || !out) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (kind < 0 || kind > 2) return fail(SMVS_ERR_ARG, "kind must be 0 (stride 1), 1 (stride 2) or 2 (transposed, stride 2)");
+    if (B < 1 || Cin < 1 || Cout < 1 || Di < 1 || Hi < 1 || Wi < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
+    if (kind == 1 && ((Di | Hi | Wi) & 1)) return fail(SMVS_ERR_ARG, "stride-2 layer needs even D, H, W (got %dx%dx%d)", Di, Hi, Wi);
+    const int di[3] = {Di, Hi, Wi};
+    const int dout[3] = {kind == 1 ? Di / 2 : kind == 2 ? Di * 2 : Di, kind == 1 ? Hi / 2 : kind == 2 ? Hi * 2 : Hi,
+                         kind == 1 ? Wi / 2 : kind == 2 ? Wi * 2 : Wi};
+    const long long vi = (long long)Di * Hi * Wi, vo = (long long)dout[0] * dout[1] * dout[2];
+    if (Cin * vi * 4 >= (1ll << 32) || Cout * vo * 4 >= (1ll << 32)) return fail(SMVS_ERR_ARG, "layer input or output larger than 4 GiB per batch item");
+    const int ncog = (Cout + CR_COT - 1) / CR_COT;
+    const long long rows = kind == 2 ? (long long)Di * Hi : (long long)dout[0] * dout[1];
+    if ((rows + 3) / 4 > 65535 || (long long)B * ncog > 65535 || vo / 32 * B >= (1ll << 31)) return fail(SMVS_ERR_ARG, "volume too large for one launch grid");
+    const CrLayer l{Cin, Cout, kind == 0 ? 1 : 2, kind == 2, 0, relu ? 1 : 0};
+    const size_t n = cr_packed_conv(Cin, Cout);
+    const int cp = ncog * CR_COT;
+    const bool mf = kind != 2 && mfma_conv_ok(Cin, 0, Cout);
+    cr_launch_layer(l, in, packed, packed + n, packed + n + cp, mf ? packed + n + 2 * cp : nullptr, skip, out, B, di, dout, false, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "conv3d_fwd launch: %s", hipGetErrorString(e));
     return SMVS_OK;
 }
 

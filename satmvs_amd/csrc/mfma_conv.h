@@ -175,7 +175,7 @@ constexpr int MFMA_FUSE_TW = 34, MFMA_FUSE_TH = 3;           // LDS tile of one 
 
 // W pack kernel: src (Cout, Cin, TAPS) [conv] -> dst [cip][p][nt][h][32]
 // step p of channel pair cip covers kk = 2p + h in the 2*TAPS-long (ci0 taps..., ci1 taps...) list.
-// adjoint = 1 (9 taps): src is an nn.Conv2d weight (cin, cout, 3, 3) -- of the layer whose ADJOINT (gradient with respect to its input:
+// adjoint = 1: src is an nn.Conv2d / nn.Conv3d weight (cin, cout, 3, 3[, 3]) -- of the layer whose ADJOINT (gradient with respect to its input:
 // the correlation of the output gradient with the transposed, tap-flipped weights) is packed: W'[co][ci][t] = src[ci][co][8 - t].
 static __global__ void mfma_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int cin, int cout, int taps, int adjoint)
 {
@@ -196,7 +196,7 @@ static __global__ void mfma_pack_kernel(const float* __restrict__ src, float* __
         const int kk = 2 * p + h;
         const int ci = 2 * cip + (kk >= taps ? 1 : 0), tap = kk >= taps ? kk - taps : kk;
         const int co = t * 32 + j;
-        dst[i] = co < cout ? src[((size_t)co * cin + ci) * taps + tap] : 0.0f;
+        dst[i] = co < cout ? (adjoint ? src[((size_t)ci * cout + co) * taps + (taps - 1 - tap)] : src[((size_t)co * cin + ci) * taps + tap]) : 0.0f;
     }
 }
 

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 from .. import _lib
 from .switches import SW, guard_miopen_find, restore_miopen_find          # noqa: F401  (re-exported: the networks import them from here)
-from .train_fns import (_reparametrize, _NATIVE_KINDS, GroupNorm1, _ConvGRUCellFn, _GroupNormPairFn, _GruBlendFn, _GruMulCatFn, _PlaneViewsFn, _WgradArena, _WgradSink, _conv3x3_cat, _conv3x3, _native_kind, _side_streams, _PARAM_EPOCH, bump_param_epoch, _GroupNorm1Fn, _Conv3x3NativeFn, _Conv3x3WgradFn, _conv_packed, _gn_scratch, _f32c_fast, _TLS, _placeholder, _is_placeholder, _wgrad_now_or_later, _conv3d, _Conv3dWgradFn)          # noqa: F401
+from .train_fns import (_reparametrize, _NATIVE_KINDS, GroupNorm1, _ConvGRUCellFn, _GroupNormPairFn, _GruBlendFn, _GruMulCatFn, _PlaneViewsFn, _WgradArena, _WgradSink, _conv3x3_cat, _conv3x3, _native_kind, _side_streams, _PARAM_EPOCH, bump_param_epoch, _GroupNorm1Fn, _Conv3x3NativeFn, _Conv3x3WgradFn, _conv_packed, _gn_scratch, _f32c_fast, _TLS, _placeholder, _is_placeholder, _wgrad_now_or_later, _conv3d, _Conv3dWgradFn, _Conv3dNativeFn, _bn3d_relu, _BatchNormReluFn)          # noqa: F401
 
 
 # ---- native-path plumbing shared by the three modules with HIP kernels ---------------------------------
@@ -151,8 +151,11 @@ class Conv3d(nn.Module):
         self.relu = relu
 
     def forward(self, x):
-        x = _conv3d(self.conv, x)             # torch's operator with the native weight gradient where one is wanted (train_fns._conv3d)
+        x = _conv3d(self.conv, x)             # native under autograd where a gradient is wanted on the GPU (train_fns._conv3d)
         if self.bn is not None:
+            y = _bn3d_relu(self.bn, x, self.relu)     # training form + ReLU as one native operator (train_fns._bn3d_relu), or None
+            if y is not None:
+                return y
             x = self.bn(x)
         return F.relu(x, inplace=True) if self.relu else x
 
@@ -170,6 +173,9 @@ class Deconv3d(nn.Module):
     def forward(self, x):
         x = _conv3d(self.conv, x)
         if self.bn is not None:
+            y = _bn3d_relu(self.bn, x, self.relu)
+            if y is not None:
+                return y
             x = self.bn(x)
         return F.relu(x, inplace=True) if self.relu else x
 

@@ -23,8 +23,8 @@ class _Switches:
         e = (os.environ if env is None else env).get
         # SMVS_TRAIN_COMPOSITE=1 keeps the training path on torch's own operators (A/B against the native ones; the cost-volume
         # operators are native either way); SMVS_TRAIN_COMPOSITE_MASK bisects: 1 GroupNorm, 2 cat(x, r*h), 4 u-blend, 8 conv weight
-        # gradient, 16 ConvGRU convolutions (forward + input gradient), 32 the cell as one autograd node, 64 CostRegNet's 3-D weight gradient
-        self.train_composite_mask = 127 if e("SMVS_TRAIN_COMPOSITE", "0") == "1" else int(e("SMVS_TRAIN_COMPOSITE_MASK", "0"))
+        # gradient, 16 ConvGRU convolutions (forward + input gradient), 32 the cell as one autograd node, 64 CostRegNet's 3-D weight gradient, 128 its forward + input gradient, 256 its BatchNorm3d + ReLU
+        self.train_composite_mask = 511 if e("SMVS_TRAIN_COMPOSITE", "0") == "1" else int(e("SMVS_TRAIN_COMPOSITE_MASK", "0"))
         self.train_streams = e("SMVS_TRAIN_STREAMS", "1") != "0"              # ConvGRU levels 1-3 of a plane on side streams
         self.train_loop_pipeline = e("SMVS_TRAIN_LOOP_PIPELINE", "1") != "0"  # ... and the plane loop software-pipelined (cells d | encoder d+1 | decoder d-1)
         self.train_plane_views = e("SMVS_TRAIN_PLANE_VIEWS", "1") != "0"      # per-plane parameter views (one gradient sum per parameter)

@@ -422,9 +422,91 @@ class _Conv3dWgradFn(torch.autograd.Function):
         return dx, dw, None, None
 
 
+def _conv3d_packed(weight, layout, cin, cout):
+    """Kernel-layout copy of a 3x3x3 weight for smvs_conv3d_fwd (layouts: include/satmvs.h), packed once per parameter version (the cache
+    of _conv_packed: keyed by address, layout and direction; a graph replay bumps the epoch)."""
+    from torch.multiprocessing.reductions import StorageWeakRef
+    key = (weight.data_ptr(), "3d%d" % layout, cin, weight.device.index)
+    hit = _CONV_PACK.get(key)
+    if hit is not None and hit[0] == weight._version and hit[1] == _PARAM_EPOCH[0] and not hit[2].expired():
+        return hit[3]
+    packed = torch.empty((_lib.load().smvs_conv3d_packed_floats(cin, cout),), dtype=torch.float32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        _lib.call("smvs_conv3d_pack", _lib.ptr(weight), _lib.ptr(packed), cin, cout, layout, _lib.current_stream(weight.device))
+    if len(_CONV_PACK) > 256:
+        _CONV_PACK.clear()
+    _CONV_PACK[key] = (weight._version, _PARAM_EPOCH[0], StorageWeakRef(weight.untyped_storage()), packed)
+    return packed
+
+
+# layer kinds of _Conv3dNativeFn: (forward kernel kind, forward weight layout, input-gradient kernel kind, its weight layout, window stride)
+_NATIVE3D_KINDS = {"c1": (0, 0, 0, 2, 1),    # nn.Conv3d stride 1:           correlation / correlation with the transposed, flipped weights
+                   "c2": (1, 0, 2, 1, 2),    # nn.Conv3d stride 2:           strided correlation / stride-2 transposed convolution
+                   "t2": (2, 1, 1, 0, 2)}    # nn.ConvTranspose3d stride 2:  transposed convolution / strided correlation
+
+
+def _conv3d_out_dims(kind, dims):
+    return tuple(d // 2 for d in dims) if kind == "c2" else tuple(2 * d for d in dims) if kind == "t2" else tuple(dims)
+
+
+def _conv3d_launchable(kind_id, B, cin, cout, dims):
+    """Limits of smvs_conv3d_fwd (one launch grid, 32-bit byte offsets per batch item): callers outside keep torch's operator."""
+    do = tuple(d // 2 for d in dims) if kind_id == 1 else tuple(2 * d for d in dims) if kind_id == 2 else tuple(dims)
+    vi, vo = dims[0] * dims[1] * dims[2], do[0] * do[1] * do[2]
+    rows = dims[0] * dims[1] if kind_id == 2 else do[0] * do[1]
+    return (cin * vi * 4 < 2 ** 32 and cout * vo * 4 < 2 ** 32 and (rows + 3) // 4 <= 65535 and B * ((cout + 7) // 8) <= 65535
+            and vo // 32 * B < 2 ** 31)
+
+
+class _Conv3dNativeFn(torch.autograd.Function):
+    """A 3x3x3 / pad 1 layer of CostRegNet (nn.Conv3d stride 1 / 2, nn.ConvTranspose3d stride 2 with output_padding 1, no bias) on the
+    kernels of the inference regulariser without the folded BatchNorm (smvs_conv3d_fwd: direct or MFMA by channel count): forward,
+    input gradient (the adjoint layer on the same kernels) and weight gradient (smvs_conv3d_wgrad).  Replaces, per layer and step, a
+    composable-kernel implicit GEMM (forward), an im2col / GEMM / col2im chain or a grouped backward-data GEMM with its layout
+    transposes (input gradient) and MIOpen's naive weight-gradient kernel.  kind: _NATIVE3D_KINDS."""
+
+    @staticmethod
+    def forward(ctx, x, weight, kind):
+        fk, flay, _, _, _ = _NATIVE3D_KINDS[kind]
+        x = _f32c_fast(x)
+        B, Cin = x.shape[0], x.shape[1]
+        dims = tuple(x.shape[2:])
+        Cout = weight.shape[1] if kind == "t2" else weight.shape[0]
+        out = torch.empty((B, Cout) + _conv3d_out_dims(kind, dims), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call("smvs_conv3d_fwd", fk, _lib.ptr(x), _lib.ptr(_conv3d_packed(weight, flay, Cin, Cout)), None, _lib.ptr(out), B, Cin, Cout,
+                      dims[0], dims[1], dims[2], 0, _lib.current_stream(x.device))
+        ctx.save_for_backward(x, weight)
+        ctx.kind = kind
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        kind = ctx.kind
+        _, _, bk, blay, stride = _NATIVE3D_KINDS[kind]
+        dy = _f32c_fast(dy)
+        B, Cin = x.shape[0], x.shape[1]
+        Cout = dy.shape[1]
+        dev = x.device
+        dx = dw = None
+        with torch.cuda.device(dev):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _lib.call("smvs_conv3d_fwd", bk, _lib.ptr(dy), _lib.ptr(_conv3d_packed(weight, blay, Cout, Cin)), None, _lib.ptr(dx), B, Cout, Cin,
+                          dy.shape[2], dy.shape[3], dy.shape[4], 0, _lib.current_stream(dev))
+            if ctx.needs_input_grad[1]:
+                window, grid = (dy, x) if kind == "t2" else (x, dy)         # the tensor read through the taps / the one on the output grid
+                dw = torch.zeros(weight.shape, dtype=torch.float32, device=dev)
+                _lib.call("smvs_conv3d_wgrad", _lib.ptr(window), _lib.ptr(grid), _lib.ptr(dw), B, window.shape[1], grid.shape[1],
+                          grid.shape[2], grid.shape[3], grid.shape[4], stride, _lib.current_stream(dev))
+        return dx, dw, None
+
+
 def _conv3d(conv, x):
-    """conv(x) for the 3-D regulariser's layers (nn.Conv3d stride 1 / 2, nn.ConvTranspose3d stride 2; 3x3x3, pad 1, no bias): with the
-    native weight gradient where a gradient is wanted on the GPU (SMVS_TRAIN_COMPOSITE_MASK bit 64 keeps torch's)."""
+    """conv(x) for the 3-D regulariser's layers (nn.Conv3d stride 1 / 2, nn.ConvTranspose3d stride 2; 3x3x3, pad 1, no bias) where a
+    gradient is wanted on the GPU: fully native (forward, input gradient, weight gradient); SMVS_TRAIN_COMPOSITE_MASK bit 128 keeps
+    torch's forward and input gradient with the native weight gradient, bit 64 torch's operator alone."""
     transposed = isinstance(conv, nn.ConvTranspose3d)
     s = conv.stride[0]
     if (x.is_cuda and x.dim() == 5 and x.dtype is torch.float32 and torch.is_grad_enabled() and conv.weight.requires_grad
@@ -435,8 +517,66 @@ def _conv3d(conv, x):
                  (not transposed and all(d % s == 0 for d in x.shape[2:])))
             and not (SW.train_composite_mask & 64)
             and x.shape[2] * x.shape[3] * x.shape[4] * (s ** 3 if transposed else 1) * 4 * 8 < 2 ** 31):
+        kind = "t2" if transposed else "c%d" % s
+        fk, _, bk, _, _ = _NATIVE3D_KINDS[kind]
+        B, cin = x.shape[0], x.shape[1]
+        cout = conv.weight.shape[1] if transposed else conv.weight.shape[0]
+        dims = tuple(x.shape[2:])
+        if (not (SW.train_composite_mask & 128) and _conv3d_launchable(fk, B, cin, cout, dims)
+                and _conv3d_launchable(bk, B, cout, cin, _conv3d_out_dims(kind, dims))):
+            return _Conv3dNativeFn.apply(x, conv.weight, kind)
         return _Conv3dWgradFn.apply(x, conv.weight, s, transposed)
     return conv(x)
+
+
+class _BatchNormReluFn(torch.autograd.Function):
+    """[relu](BatchNorm3d(x)) in training form (batch statistics, running statistics updated) on smvs_batchnorm_train_fwd / _bwd
+    (csrc/batchnorm.hip): the conv -> bn -> relu blocks of CostRegNet (reference modules/module.py:324-410).  Saves the block's input
+    and (mean, rstd) only: the ReLU mask is recomputed from x in the backward.  `bn` (the nn.BatchNorm3d) rides along as a non-tensor
+    argument: its running statistics are updated in place like F.batch_norm(training=True) does."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, relu):
+        x = _f32c_fast(x)
+        B, C = x.shape[0], x.shape[1]
+        N = x.numel() // (B * C)
+        y = torch.empty_like(x)
+        saved = torch.empty((C, 2), dtype=torch.float32, device=x.device)
+        ws = torch.empty((2 * C,), dtype=torch.float64, device=x.device)
+        track = bn.track_running_stats and bn.running_mean is not None
+        with torch.cuda.device(x.device):
+            _lib.call("smvs_batchnorm_train_fwd", _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bn.running_mean) if track else None,
+                      _lib.ptr(bn.running_var) if track else None, float(bn.momentum), float(bn.eps), 1 if relu else 0, _lib.ptr(y), _lib.ptr(saved),
+                      _lib.ptr(ws), B, C, N, _lib.current_stream(x.device))
+        ctx.save_for_backward(x, gamma, beta, saved)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, saved = ctx.saved_tensors
+        dy = _f32c_fast(dy)
+        B, C = x.shape[0], x.shape[1]
+        N = x.numel() // (B * C)
+        dx = torch.empty_like(x)
+        dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        ws = torch.empty((2 * C,), dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call("smvs_batchnorm_train_bwd", _lib.ptr(dy), _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(saved), 1 if ctx.relu else 0,
+                      _lib.ptr(dx), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(ws), B, C, N, _lib.current_stream(x.device))
+        return dx, dgb[0], dgb[1], None, None
+
+
+def _bn3d_relu(bn, x, relu):
+    """[relu](bn(x)) for a training nn.BatchNorm3d on the native kernels, or None where they do not apply (evaluation mode, CPU, no
+    affine parameters, cumulative-average momentum, SMVS_TRAIN_COMPOSITE_MASK bit 256): the caller keeps torch's operators."""
+    if not (bn.training and x.is_cuda and x.dim() == 5 and x.dtype is torch.float32 and torch.is_grad_enabled() and bn.affine
+            and bn.momentum is not None and bn.weight.dtype is torch.float32 and bn.weight.is_contiguous() and bn.bias.is_contiguous()
+            and x.shape[1] <= 65535 and not (SW.train_composite_mask & 256)):
+        return None
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BatchNormReluFn.apply(x, bn.weight, bn.bias, bn, relu)
 
 
 _CONV_PACK = {}         # (weight address, layout, cin) -> (version, epoch, storage weak reference, packed tensor): one entry per layer and direction

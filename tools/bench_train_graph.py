@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """The training step of tools/bench_train_step.py captured in one HIP graph (forward, loss, backward, RMSprop) and replayed:
 the eager step is bound by the host (32 k launches per step), the graph by the GPU.
-    python tools/bench_train_graph.py [steps]"""
+    python tools/bench_train_graph.py [steps] [casred|casmvs|ucs]"""
 import os, sys, time
 import torch
 import torch.nn.functional as F
@@ -14,7 +14,16 @@ torch.backends.cudnn.benchmark = os.environ.get("SMVS_CUDNN_BENCHMARK", "0") == 
 H, W, nd = 384, 768, [48, 32, 8]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 torch.manual_seed(0)
-net = CascadeREDNet("rpc", min_interval=2.5, ndepths=nd).to(dev).train()
+model = sys.argv[2] if len(sys.argv) > 2 else "casred"
+if model == "casred":
+    net = CascadeREDNet("rpc", min_interval=2.5, ndepths=nd)
+elif model == "casmvs":
+    from satmvs_amd.networks.casmvs import CascadeMVSNet
+    net = CascadeMVSNet("rpc", min_interval=2.5, ndepths=nd)
+else:
+    from satmvs_amd.networks.ucs import UCSNet
+    net = UCSNet("rpc", stage_configs=nd)
+net = net.to(dev).train()
 opt = torch.optim.RMSprop(net.parameters(), lr=1e-3, alpha=0.9, capturable=True)
 imgs = torch.randn(1, 3, 3, H, W, device=dev)
 rpc = rpc_synth.make_view_rpcs(3, H, W, seed=0)[None]
@@ -41,5 +50,5 @@ for _ in range(steps):
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) * 1e3)
 ts.sort()
-print("graphed training step (satmvs_amd.train_graph), 3-view 768x384, planes %s: median %.1f ms (min %.1f, max %.1f), loss %.4f"
+print(model + " graphed training step (satmvs_amd.train_graph), 3-view 768x384, planes %s: median %.1f ms (min %.1f, max %.1f), loss %.4f"
       % (nd, ts[len(ts) // 2], ts[0], ts[-1], float(loss)))
