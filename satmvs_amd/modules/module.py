@@ -104,6 +104,9 @@ class Conv2d(nn.Module):
     def forward(self, x):
         x = self.conv(x)
         if self.bn is not None:
+            y = _bn3d_relu(self.bn, x, self.relu)     # training form + ReLU as one native operator (train_fns._bn3d_relu), or None
+            if y is not None:
+                return y
             x = self.bn(x)
         return F.relu(x, inplace=True) if self.relu else x
 
@@ -124,6 +127,9 @@ class Deconv2d(nn.Module):
             h, w = x.shape[2], x.shape[3]
             y = y[:, :, :2 * h, :2 * w].contiguous()
         if self.bn is not None:
+            z = _bn3d_relu(self.bn, y, self.relu)
+            if z is not None:
+                return z
             y = self.bn(y)
         return F.relu(y, inplace=True) if self.relu else y
 

@@ -530,8 +530,9 @@ def _conv3d(conv, x):
 
 
 class _BatchNormReluFn(torch.autograd.Function):
-    """[relu](BatchNorm3d(x)) in training form (batch statistics, running statistics updated) on smvs_batchnorm_train_fwd / _bwd
-    (csrc/batchnorm.hip): the conv -> bn -> relu blocks of CostRegNet (reference modules/module.py:324-410).  Saves the block's input
+    """[relu](BatchNorm3d(x)) / [relu](BatchNorm2d(x)) in training form (batch statistics, running statistics updated) on
+    smvs_batchnorm_train_fwd / _bwd (csrc/batchnorm.hip): the conv -> bn -> relu blocks of CostRegNet (reference modules/module.py:324-410)
+    and of FeatureNet (:78-118).  Saves the block's input
     and (mean, rstd) only: the ReLU mask is recomputed from x in the backward.  `bn` (the nn.BatchNorm3d) rides along as a non-tensor
     argument: its running statistics are updated in place like F.batch_norm(training=True) does."""
 
@@ -568,9 +569,9 @@ class _BatchNormReluFn(torch.autograd.Function):
 
 
 def _bn3d_relu(bn, x, relu):
-    """[relu](bn(x)) for a training nn.BatchNorm3d on the native kernels, or None where they do not apply (evaluation mode, CPU, no
-    affine parameters, cumulative-average momentum, SMVS_TRAIN_COMPOSITE_MASK bit 256): the caller keeps torch's operators."""
-    if not (bn.training and x.is_cuda and x.dim() == 5 and x.dtype is torch.float32 and torch.is_grad_enabled() and bn.affine
+    """[relu](bn(x)) for a training nn.BatchNorm3d / nn.BatchNorm2d on the native kernels, or None where they do not apply (evaluation
+    mode, CPU, no affine parameters, cumulative-average momentum, SMVS_TRAIN_COMPOSITE_MASK bit 256): the caller keeps torch's operators."""
+    if not (bn.training and x.is_cuda and x.dim() in (4, 5) and x.dtype is torch.float32 and torch.is_grad_enabled() and bn.affine
             and bn.momentum is not None and bn.weight.dtype is torch.float32 and bn.weight.is_contiguous() and bn.bias.is_contiguous()
             and x.shape[1] <= 65535 and not (SW.train_composite_mask & 256)):
         return None
