@@ -434,10 +434,10 @@ def side_workloads(dev, stream):
         extra["cfg3_casred_cascade_48_32_8_768x384"] = {"error": repr(e)[:200]}
     # the training step of the same network (row f-2), captured in one HIP graph: in a process of its own -- a graph capture holds a
     # private memory pool, and whatever happens there must not reach the headline
+    import re
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "bench_train_graph.py")
     try:
-        import re
-        import subprocess
-        tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "bench_train_graph.py")
         r = subprocess.run([sys.executable, tool, "9"], capture_output=True, text=True, timeout=240)
         m = re.search(r"median ([0-9.]+) ms \(min ([0-9.]+), max ([0-9.]+)\), loss ([0-9.eE+-]+)", r.stdout)
         if m:
@@ -449,6 +449,20 @@ def side_workloads(dev, stream):
             extra["cfg3_casred_training_step_48_32_8_768x384"] = {"error": (r.stderr or r.stdout)[-200:]}
     except Exception as e:
         extra["cfg3_casred_training_step_48_32_8_768x384"] = {"error": repr(e)[:200]}
+    # ... and of the two cascades with the 3-D regulariser (CostRegNet: every 3x3x3 layer and BatchNorm3d + ReLU native under autograd)
+    for model, key in (("casmvs", "cfg3_casmvs_training_step_48_32_8_768x384"), ("ucs", "cfg3_ucs_training_step_48_32_8_768x384")):
+        try:
+            r = subprocess.run([sys.executable, tool, "9", model], capture_output=True, text=True, timeout=240)
+            m = re.search(r"median ([0-9.]+) ms \(min ([0-9.]+), max ([0-9.]+)\), loss ([0-9.eE+-]+)", r.stdout)
+            if m:
+                extra[key] = {"ms_per_step": float(m.group(1)), "ms_min": float(m.group(2)), "ms_max": float(m.group(3)),
+                              "note": "%s.train(): forward + smooth-L1 cascade loss + backward + RMSprop, B=1, random weights, one HIP graph; "
+                                      "with torch's own operators (MIOpen's naive 3-D weight gradient) the same step took 1984 ms on this "
+                                      "image (profiles/r05_train_step_casmvs_before.txt)" % ("CascadeMVSNet" if model == "casmvs" else "UCSNet")}
+            else:
+                extra[key] = {"error": (r.stderr or r.stdout)[-200:]}
+        except Exception as e:
+            extra[key] = {"error": repr(e)[:200]}
     return extra
 
 

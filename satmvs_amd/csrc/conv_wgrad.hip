@@ -305,7 +305,17 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
 #pragma unroll
         for (int j = 0; j < 8; ++j) dst[j] = llvm_raw_buffer_load_f32(r, (int)cy, gch[j] + so, 0);
     };
-    float new_n[S][2][3], g_n[8];
+    // Rows run TWO iterations ahead on two register sets (the row loop is unrolled by two so that no set is copied while its loads are
+    // in flight): with one row ahead -- the 2-D kernel's scheme -- a wave of the 3-D shapes still waited for its rows (a row of
+    // arithmetic is ~500 clocks, an L2 miss four times that, and the kernel runs at two waves per SIMD).
+    // The rows of iteration y: window row y + 1 (S = 1) / rows 2y, 2y + 1 (S = 2) and grid row y.
+    constexpr int AH = S == 1 ? 2 : 1;         // (stride 2 loads two window rows per iteration: a second set would cost the second wave per SIMD)
+    float set_w[AH][S][2][3], set_g[AH][8];
+    auto load_iter = [&](int yi, float (&w)[S][2][3], float (&g)[8]) {   // rows of iteration yi (past the chunk: rows outside the tensor = zeros)
+#pragma unroll
+        for (int q = 0; q < S; ++q) load_row(yi < y1 ? (S == 1 ? yi + 1 : S * yi + q) : HX, w[q]);
+        load_g(yi, g);
+    };
     if (S == 1) {
         float r0[2][3], r1[2][3];
         load_row(y0 - 1, r0);
@@ -314,7 +324,6 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int k = 0; k < 3; ++k) { win[c][1][k] = r0[c][k]; win[c][2][k] = r1[c][k]; win[c][0][k] = 0.0f; }
-        load_row(y0 + 1, new_n[0]);
     } else {
         float r0[2][3];
         load_row(S * y0 - 1, r0);
@@ -322,23 +331,20 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int k = 0; k < 3; ++k) { win[c][2][k] = r0[c][k]; win[c][0][k] = win[c][1][k] = 0.0f; }
-#pragma unroll
-        for (int q = 0; q < S; ++q) load_row(S * y0 + q, new_n[q]);
     }
-    load_g(y0, g_n);
-    for (int y = y0; y < y1; ++y) {
+    load_iter(y0, set_w[0], set_g[0]);
+    if constexpr (AH == 2) load_iter(y0 + 1, set_w[1], set_g[1]);
+    auto row_step = [&](const int y, float (&sw)[S][2][3], float (&sg)[8]) __attribute__((always_inline)) {
         float fresh[S][2][3], g[8];
 #pragma unroll
         for (int q = 0; q < S; ++q)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) fresh[q][c][k] = new_n[q][c][k];
+                for (int k = 0; k < 3; ++k) fresh[q][c][k] = sw[q][c][k];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = g_n[j];
-#pragma unroll
-        for (int q = 0; q < S; ++q) load_row(y + 1 < y1 ? (S == 1 ? y + 2 : S * (y + 1) + q) : HX, new_n[q]);
-        load_g(y + 1, g_n);
+        for (int j = 0; j < 8; ++j) g[j] = sg[j];
+        load_iter(y + AH, sw, sg);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -356,6 +362,14 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
 #pragma unroll
                     for (int k = 0; k < 3; ++k) acc[c][j][r * 3 + k] = fmaf(g[j], win[c][r][k], acc[c][j][r * 3 + k]);
         __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (AH == 2) {
+        for (int y = y0; y < y1; y += 2) {
+            row_step(y, set_w[0], set_g[0]);
+            if (y + 1 < y1) row_step(y + 1, set_w[1], set_g[1]);
+        }
+    } else {
+        for (int y = y0; y < y1; ++y) row_step(y, set_w[0], set_g[0]);
     }
     }   // grid planes of this wave
     // reduce over the lanes four values at a time; lanes 15 / 31 / 47 / 63 publish values 4m + {0, 2, 1, 3}; value index (c * 8 + j) * 9 + k

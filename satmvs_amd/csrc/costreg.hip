@@ -65,11 +65,13 @@ static CrLayout cr_layout(int C)
 
 // transposed: src is (cin, cout, 27) instead of (cout, cin, 27); flip (with transposed): taps mirrored in all three dimensions -- the
 // ADJOINT of a stride-1 correlation of weight (cin, cout, 27) as a correlation from cin to cout channels (smvs_conv3d_pack layout 2)
-__global__ void cr_pack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int cin, int cout, int transposed, int flip)
+// tail > 0 (single layers, smvs_conv3d_pack): `tail` ones and `tail` zeros follow the weights -- the identity scale / shift of the epilogue
+__global__ void cr_pack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int cin, int cout, int transposed, int flip, int tail)
 {
     const int ncog = (cout + CR_COT - 1) / CR_COT;
     const int n = ncog * cin * 27 * CR_COT;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + 2 * tail; i += gridDim.x * blockDim.x) {
+        if (i >= n) { dst[i] = i < n + tail ? 1.0f : 0.0f; continue; }
         const int j = i % CR_COT, k = (i / CR_COT) % 27, ci = (i / (CR_COT * 27)) % cin, cog = i / (CR_COT * 27 * cin);
         const int co = cog * CR_COT + j;
         float v = 0.0f;
@@ -517,7 +519,7 @@ SMVS_EXPORT int smvs_costreg_pack_weights(const float* const* params, int C, flo
         const float* const* q = params + (i < 10 ? i * 5 : 50);
         const int n = (int)cr_packed_conv(L[i].cin, L[i].cout);
         hipLaunchKernelGGL(cr_pack_conv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, q[0], packed + lay.w[i],
-                           L[i].cin, L[i].cout, L[i].transposed, 0);
+                           L[i].cin, L[i].cout, L[i].transposed, 0, 0);
         if (cr_use_mfma(L[i])) {
             const int nm = (int)mfma_packed_floats(L[i].cin, L[i].cout, 27);
             hipLaunchKernelGGL(mfma_pack_kernel, dim3((nm + 255) / 256), dim3(256), 0, st, q[0], packed + lay.wm[i],
@@ -591,8 +593,7 @@ SMVS_EXPORT int smvs_conv3d_pack(const float* w, float* packed, int cin, int cou
     hipStream_t st = (hipStream_t)stream;
     const int n = (int)cr_packed_conv(cin, cout);
     const int cp = ((cout + CR_COT - 1) / CR_COT) * CR_COT;
-    hipLaunchKernelGGL(cr_pack_conv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, packed, cin, cout, layout != 0, layout == 2);
-    hipLaunchKernelGGL(cr_pack_bn_kernel, dim3((cp + 63) / 64), dim3(64), 0, st, w, w, w, w, packed + n, packed + n + cp, cout, cp, 0);
+    hipLaunchKernelGGL(cr_pack_conv_kernel, dim3((n + 2 * cp + 255) / 256), dim3(256), 0, st, w, packed, cin, cout, layout != 0, layout == 2, cp);
     if (mfma_conv_ok(cin, 0, cout) && layout != 1) {
         const int nm = (int)mfma_packed_floats(cin, cout, 27);
         hipLaunchKernelGGL(mfma_pack_kernel, dim3((nm + 255) / 256), dim3(256), 0, st, w, packed + n + 2 * cp, cin, cout, 27, layout == 2);

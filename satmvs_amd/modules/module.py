@@ -102,7 +102,9 @@ class Conv2d(nn.Module):
         self.relu = relu
 
     def forward(self, x):
-        x = self.conv(x)
+        # 3x3 / pad 1 layers: native under autograd where a gradient is wanted on the GPU (forward, input and weight gradient on the RED
+        # regulariser's layer kernels, train_fns._conv3x3_cat); anything else (FeatureNet's 5x5 stride-2 layers, inference) is torch's
+        x = _conv3x3_cat(self.conv, x) if SW.train_featnet_native and self.conv.bias is None else self.conv(x)
         if self.bn is not None:
             y = _bn3d_relu(self.bn, x, self.relu)     # training form + ReLU as one native operator (train_fns._bn3d_relu), or None
             if y is not None:
@@ -122,7 +124,7 @@ class Deconv2d(nn.Module):
         self.relu = relu
 
     def forward(self, x):
-        y = self.conv(x)
+        y = _conv3x3_cat(self.conv, x) if SW.train_featnet_native and self.conv.bias is None else self.conv(x)
         if self.stride == 2:
             h, w = x.shape[2], x.shape[3]
             y = y[:, :, :2 * h, :2 * w].contiguous()

@@ -29,6 +29,7 @@ class _Switches:
         self.train_loop_pipeline = e("SMVS_TRAIN_LOOP_PIPELINE", "1") != "0"  # ... and the plane loop software-pipelined (cells d | encoder d+1 | decoder d-1)
         self.train_plane_views = e("SMVS_TRAIN_PLANE_VIEWS", "1") != "0"      # per-plane parameter views (one gradient sum per parameter)
         self.train_defer_wgrad = e("SMVS_TRAIN_DEFER_WGRAD", "1") != "0"      # weight gradients of a layer in one launch over all planes
+        self.train_featnet_native = e("SMVS_TRAIN_FEATNET_NATIVE", "1") != "0"  # FeatureNet's 3x3 layers on the native layer kernels under autograd
         self.allow_miopen_find = e("SMVS_ALLOW_MIOPEN_FIND", "0") == "1"      # leave torch.backends.cudnn.benchmark alone while training
 
     @staticmethod

@@ -652,6 +652,67 @@ def gen_train():
     save("train_step", **arrays)
 
 
+def gen_train3d():
+    """One training step of the reference's two cascades with the 3-D regulariser, train.py:267-302 without the optimiser:
+    CascadeMVSNet (networks/casmvs.py:79-140) and UCSNet (networks/ucs.py:79-150) in train() mode (BatchNorm2d / BatchNorm3d on batch
+    statistics, CostRegNet module.py:546-577 under autograd, differentiable warp) -> cas_mvsnet_loss (networks/loss.py:5-25, dlossw
+    0.5/1/2) -> loss.backward().  Inputs, seeds and weights are those of gen_cascade (casmvs: seed 18, ucs: seed 19).  Stored per net:
+    the loss, the per-stage heights, d loss / d parameter in full for stage 1's regulariser (cost_regularization.0.*, tensors of at
+    most 20 000 entries) and for
+    FeatureNet's first and last layers, a (sum, sum of squares) checksum of EVERY parameter gradient, and the BatchNorm running
+    statistics after the step as checksums."""
+    from networks.loss import cas_mvsnet_loss
+    B, V, H, W = 1, 3, 64, 128
+    nd = [16, 8, 8]
+    torch.manual_seed(16)
+    imgs = torch.randn(B, V, 3, H, W)
+    rpc_full = ref_rpcs(V, H, W, seed=51, batch=B)
+    proj = {"stage1": torch.from_numpy(rpc_synth.rescale_rpc(rpc_full, 4)),
+            "stage2": torch.from_numpy(rpc_synth.rescale_rpc(rpc_full, 2)),
+            "stage3": torch.from_numpy(rpc_full)}
+    dv = torch.tensor([[20.0, 380.0]])
+    gt, mask = {}, {}
+    for i, s in enumerate((4, 2, 1)):
+        h, w = H // s, W // s
+        yy, xx = torch.meshgrid(torch.linspace(0, 1, h), torch.linspace(0, 1, w), indexing="ij")
+        gt["stage%d" % (i + 1)] = (200.0 + 40.0 * torch.sin(3.0 * xx + 0.3) * torch.cos(2.0 * yy - 0.2)).unsqueeze(0)
+        m = torch.ones(1, h, w)
+        m[:, : h // 8, : w // 6] = 0.0
+        mask["stage%d" % (i + 1)] = m
+    arrays = {"ndepths": np.array(nd), "dlossw": np.array([0.5, 1.0, 2.0])}
+    for s in ("stage1", "stage2", "stage3"):
+        arrays["gt." + s], arrays["mask." + s] = gt[s].numpy(), mask[s].numpy()
+    for tag, seed, ctor in (("casmvs", 18, lambda: ref_casmvs.CascadeMVSNet("rpc", min_interval=2.5, ndepths=nd)),
+                            ("ucs", 19, lambda: ref_ucs.UCSNet("rpc", stage_configs=nd))):
+        torch.manual_seed(seed)
+        net = ctor().train()
+        out = net(imgs, proj, dv)
+        loss, depth_loss = cas_mvsnet_loss(out, gt, mask, dlossw=[0.5, 1.0, 2.0])
+        loss.backward()
+        arrays[tag + ".seed"] = np.int64(seed)
+        arrays[tag + ".loss"], arrays[tag + ".depth_loss"] = loss.detach().numpy(), depth_loss.detach().numpy()
+        for s in ("stage1", "stage2", "stage3"):
+            arrays["%s.depth.%s" % (tag, s)] = out[s]["depth"].detach().numpy()
+        names, sums = [], []
+        full = [k for k, _ in net.named_parameters()]
+        first_last = {full[0], full[1], full[2]} | set(k for k in full if ".out1." in k or ".out3." in k)
+        for k, p_ in net.named_parameters():
+            assert p_.grad is not None, k
+            g_ = p_.grad
+            names.append(k)
+            sums.append([float(g_.double().sum()), float((g_.double() ** 2).sum())])
+            if (k.startswith("cost_regularization.0.") and g_.numel() <= 20000) or k in first_last:      # (conv4..conv7: checksums only)
+                arrays["%s.grad.%s" % (tag, k)] = g_.numpy()
+        arrays[tag + ".grad_names"], arrays[tag + ".grad_sums"] = np.array(names), np.array(sums)
+        bnames, bsums = [], []
+        for k, b_ in net.named_buffers():
+            if "running_" in k:
+                bnames.append(k)
+                bsums.append([float(b_.double().sum()), float((b_.double() ** 2).sum())])
+        arrays[tag + ".buffer_names"], arrays[tag + ".buffer_sums"] = np.array(bnames), np.array(bsums)
+    save("train_step3d", **arrays)
+
+
 def filter_scene(H=64, W=96, V=3, seed=3):
     """V consistent height maps of one smooth surface (one per view, through OUR synthesiser: inputs only), an 8 m
     blunder patch in the last view and a confidence map with a low-confidence corner."""
@@ -824,7 +885,7 @@ def gen_dataset_qc():
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (gen_iccv, gen_project, gen_grid_sample, gen_rpc_warp, gen_qc, gen_homo, gen_costvol, gen_pred,
-               gen_regress, gen_depth_range, gen_ucs_samples, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad, gen_io, gen_filter, gen_train, gen_dataset, gen_dataset_qc):
+               gen_regress, gen_depth_range, gen_ucs_samples, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad, gen_io, gen_filter, gen_train, gen_train3d, gen_dataset, gen_dataset_qc):
         if only and fn.__name__[4:] not in only:
             continue
         fn()
