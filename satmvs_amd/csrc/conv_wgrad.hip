@@ -231,12 +231,59 @@ void conv3x3_wgrad_kernel(const WgradParams p)
 // (a range of rows) x (a range of grid planes) x ONE depth tap kd -- 144 sums in registers; for every grid plane d of its range it
 // slides the 3x3 window down the rows of window plane S d + kd - 1 (planes outside the volume are skipped wave-uniformly).  Channel
 // strides are those of the (B,C,D,H,W) volumes, so nothing is copied or transposed.
+// Explicitly counted row pipeline (round 5, SMVS_WGRAD3_COUNTED; measured: no gain, off).  With plain loads the compiler closes every
+// iteration of the row loop with s_waitcnt vmcnt(0) -- the prefetched row is a loop-carried value -- so a row of memory latency is covered
+// by ONE row of arithmetic (72 v_pk_fma_f32).  Loads issued through inline assembly are invisible to
+// the compiler's wait insertion; the kernel waits itself, counted: two register sets, each requested two iterations before its use.
+__device__ __forceinline__ void wg_load(float& dst, const i32x4& r, uint32_t voff, int soff)
+{
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=&v"(dst) : "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wg_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// the counted wait that releases a register set: the registers are operands of the wait itself, so that no read of them can be scheduled
+// above it (an empty pinning statement next to an operand-less wait is not enough: the copies were hoisted over the wait)
+template <int N>
+__device__ __forceinline__ void wg_wait_set(float (&w)[2][3], float (&g)[8])
+{
+    asm volatile("s_waitcnt vmcnt(%14)"
+                 : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[1][2]),
+                   "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]), "+v"(g[7])
+                 : "n"(N) : "memory");
+}
+// The counted wait AND the hand-over of a set's 14 registers in ONE statement: the set is read nowhere else, so its registers live from the
+// load statements to this one and nothing can be scheduled (or copied) in between that reads them before the wait.
+template <int N>
+__device__ __forceinline__ void wg_wait_take(const float (&w)[2][3], const float (&g)[8], float (&fw)[1][2][3], float (&fg)[8])
+{
+    asm volatile("s_waitcnt vmcnt(%28)\n\t"
+                 "v_mov_b32 %0, %14\n\tv_mov_b32 %1, %15\n\tv_mov_b32 %2, %16\n\tv_mov_b32 %3, %17\n\tv_mov_b32 %4, %18\n\tv_mov_b32 %5, %19\n\t"
+                 "v_mov_b32 %6, %20\n\tv_mov_b32 %7, %21\n\tv_mov_b32 %8, %22\n\tv_mov_b32 %9, %23\n\tv_mov_b32 %10, %24\n\tv_mov_b32 %11, %25\n\t"
+                 "v_mov_b32 %12, %26\n\tv_mov_b32 %13, %27"
+                 : "=&v"(fw[0][0][0]), "=&v"(fw[0][0][1]), "=&v"(fw[0][0][2]), "=&v"(fw[0][1][0]), "=&v"(fw[0][1][1]), "=&v"(fw[0][1][2]),
+                   "=&v"(fg[0]), "=&v"(fg[1]), "=&v"(fg[2]), "=&v"(fg[3]), "=&v"(fg[4]), "=&v"(fg[5]), "=&v"(fg[6]), "=&v"(fg[7])
+                 : "v"(w[0][0]), "v"(w[0][1]), "v"(w[0][2]), "v"(w[1][0]), "v"(w[1][1]), "v"(w[1][2]),
+                   "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]), "n"(N)
+                 : "memory");
+}
+__device__ __forceinline__ void wg_wait_rows(float (&a)[2][3], float (&b)[2][3])
+{
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]),
+                   "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2])
+                 :: "memory");
+}
+
 struct Wgrad3Params {
     const float* x; const float* dy; float* dw;
     int B, Cin, Cout, D, H, W;          // D, H, W: the grid; the window tensor is (B, Cin, S*D, S*H, S*W)
     int ncp, ncog, nxs, nrc, rows;      // window-channel pairs, grid-channel groups of 8, column strips, row chunks, rows per chunk
     int ndc, dchunk;                    // chunks of grid planes, planes per chunk
 };
+
+#ifndef SMVS_WGRAD3_COUNTED
+#define SMVS_WGRAD3_COUNTED 0           // 1: stride 1 on the explicitly counted two-set row pipeline below.  Built and measured in round 5 (tests green): 10.4 against 9.9 ms per 5 casmvs steps -- row latency is not what bounds the kernel (two-ahead through the compiler: 9.9 as well); off
+#endif
 
 template <int S>
 __global__ __launch_bounds__(256)
@@ -305,47 +352,8 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
 #pragma unroll
         for (int j = 0; j < 8; ++j) dst[j] = llvm_raw_buffer_load_f32(r, (int)cy, gch[j] + so, 0);
     };
-    // Rows run TWO iterations ahead on two register sets (the row loop is unrolled by two so that no set is copied while its loads are
-    // in flight): with one row ahead -- the 2-D kernel's scheme -- a wave of the 3-D shapes still waited for its rows (a row of
-    // arithmetic is ~500 clocks, an L2 miss four times that, and the kernel runs at two waves per SIMD).
     // The rows of iteration y: window row y + 1 (S = 1) / rows 2y, 2y + 1 (S = 2) and grid row y.
-    constexpr int AH = S == 1 ? 2 : 1;         // (stride 2 loads two window rows per iteration: a second set would cost the second wave per SIMD)
-    float set_w[AH][S][2][3], set_g[AH][8];
-    auto load_iter = [&](int yi, float (&w)[S][2][3], float (&g)[8]) {   // rows of iteration yi (past the chunk: rows outside the tensor = zeros)
-#pragma unroll
-        for (int q = 0; q < S; ++q) load_row(yi < y1 ? (S == 1 ? yi + 1 : S * yi + q) : HX, w[q]);
-        load_g(yi, g);
-    };
-    if (S == 1) {
-        float r0[2][3], r1[2][3];
-        load_row(y0 - 1, r0);
-        load_row(y0, r1);
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { win[c][1][k] = r0[c][k]; win[c][2][k] = r1[c][k]; win[c][0][k] = 0.0f; }
-    } else {
-        float r0[2][3];
-        load_row(S * y0 - 1, r0);
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { win[c][2][k] = r0[c][k]; win[c][0][k] = win[c][1][k] = 0.0f; }
-    }
-    load_iter(y0, set_w[0], set_g[0]);
-    if constexpr (AH == 2) load_iter(y0 + 1, set_w[1], set_g[1]);
-    auto row_step = [&](const int y, float (&sw)[S][2][3], float (&sg)[8]) __attribute__((always_inline)) {
-        float fresh[S][2][3], g[8];
-#pragma unroll
-        for (int q = 0; q < S; ++q)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) fresh[q][c][k] = sw[q][c][k];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = sg[j];
-        load_iter(y + AH, sw, sg);
-        __builtin_amdgcn_sched_barrier(0);
+    auto fma_row = [&](const float (&fresh)[S][2][3], const float (&g)[8]) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -361,15 +369,98 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
                     for (int k = 0; k < 3; ++k) acc[c][j][r * 3 + k] = fmaf(g[j], win[c][r][k], acc[c][j][r * 3 + k]);
-        __builtin_amdgcn_sched_barrier(0);
     };
-    if constexpr (AH == 2) {
-        for (int y = y0; y < y1; y += 2) {
-            row_step(y, set_w[0], set_g[0]);
-            if (y + 1 < y1) row_step(y + 1, set_w[1], set_g[1]);
+    if constexpr (!(S == 1 && SMVS_WGRAD3_COUNTED)) {
+        if (S == 1) {
+            float r0[2][3], r1[2][3];
+            load_row(y0 - 1, r0);
+            load_row(y0, r1);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { win[c][1][k] = r0[c][k]; win[c][2][k] = r1[c][k]; win[c][0][k] = 0.0f; }
+        } else {
+            float r0[2][3];
+            load_row(S * y0 - 1, r0);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { win[c][2][k] = r0[c][k]; win[c][0][k] = win[c][1][k] = 0.0f; }
         }
+    }
+    if constexpr (S == 1 && SMVS_WGRAD3_COUNTED) {
+        // (every load of this path goes through wg_load: one compiler-visible load whose value is first used inside the row loop would
+        //  put the compiler's own vmcnt(0) INTO the loop)
+        {
+            float r0[2][3], r1[2][3];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int yy = y0 - 1 + q;
+                i32x4 r = rx.v;
+                r.z = (yy >= 0 && yy < HX) ? r.z : 0;
+                const int so = (yy >= 0 && yy < HX) ? yy * WX * 4 : 0;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) wg_load(q ? r1[c][k] : r0[c][k], r, cx[k], c * ch1 + so);
+            }
+            wg_wait_rows(r0, r1);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { win[c][1][k] = r0[c][k]; win[c][2][k] = r1[c][k]; win[c][0][k] = 0.0f; }
+        }
+        // Two sets of 6 + 8 registers; set (y - y0) & 1 holds iteration y's rows.  A step hands its set over to the arithmetic's registers
+        // inside the counted wait (wg_wait_take) and requests the set again, for iteration y + 2, BEFORE its arithmetic: a request has two
+        // rows of arithmetic to land in.  In flight at a wait: the other set's 14 loads.
+        float sw[2][2][3], sg[2][8];
+        auto issue = [&](int yi, float (&w)[2][3], float (&g)[8]) __attribute__((always_inline)) {
+            i32x4 rw = rx.v, rg = ry.v;
+            const bool vw = yi < y1 && yi + 1 < HX, vg = yi < y1;     // (yi + 1 >= 0 always: yi >= y0 >= 0)
+            rw.z = vw ? rw.z : 0; rg.z = vg ? rg.z : 0;               // rows outside the plane / past the chunk: zero records = zeros
+            const int sow = vw ? (yi + 1) * WX * 4 : 0, sog = vg ? yi * W * 4 : 0;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) wg_load(w[c][k], rw, cx[k], c * ch1 + sow);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wg_load(g[j], rg, cy, gch[j] + sog);
+        };
+        auto step = [&](int y, float (&w)[2][3], float (&g)[8]) __attribute__((always_inline)) {
+            float fw[1][2][3], fg[8];
+            wg_wait_take<14>(w, g, fw, fg);
+            issue(y + 2, w, g);
+            if (y < y1) fma_row(fw, fg);                              // (wave-uniform: an odd chunk's last half-step multiplies nothing)
+        };
+        issue(y0, sw[0], sg[0]);
+        issue(y0 + 1, sw[1], sg[1]);
+        for (int y = y0; y < y1; y += 2) {
+            step(y, sw[0], sg[0]);
+            step(y + 1, sw[1], sg[1]);
+        }
+        wg_wait<0>();                                                 // nothing of ours in flight when the next plane starts
     } else {
-        for (int y = y0; y < y1; ++y) row_step(y, set_w[0], set_g[0]);
+        float new_n[S][2][3], g_n[8];
+#pragma unroll
+        for (int q = 0; q < S; ++q) load_row(S == 1 ? y0 + 1 : S * y0 + q, new_n[q]);
+        load_g(y0, g_n);
+        for (int y = y0; y < y1; ++y) {
+            float fresh[S][2][3], g[8];
+#pragma unroll
+            for (int q = 0; q < S; ++q)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) fresh[q][c][k] = new_n[q][c][k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = g_n[j];
+#pragma unroll
+            for (int q = 0; q < S; ++q) load_row(y + 1 < y1 ? (S == 1 ? y + 2 : S * (y + 1) + q) : HX, new_n[q]);
+            load_g(y + 1, g_n);
+            __builtin_amdgcn_sched_barrier(0);
+            fma_row(fresh, g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     }   // grid planes of this wave
     // reduce over the lanes four values at a time; lanes 15 / 31 / 47 / 63 publish values 4m + {0, 2, 1, 3}; value index (c * 8 + j) * 9 + k
@@ -484,11 +575,14 @@ extern "C" SMVS_EXPORT int smvs_conv3d_wgrad(const float* window, const float* g
     p.ncp = (Cwin + 1) / 2; p.ncog = (Cgrid + 7) / 8; p.nxs = (W + 63) / 64;
     // Work per wave: whole volumes while that leaves >= ~2048 waves (the window prologue per plane and the lane reduction per wave are
     // overhead), then chunks of grid planes, then single planes cut into row chunks of >= 16 rows.
+    // (round 5: 8192 waves of >= 32 rows -- four rounds of the chip's 2048 wave slots instead of one and a bit -- measured SLOWER, 9.9 ->
+    //  14.1 ms per 5 casmvs steps: the per-wave prologue and the 36-step lane reduction with its 144 atomics outweigh the emptier last round)
     const long long base = (long long)p.ncp * p.ncog * p.nxs * 3 * B;
+    const long long want = tune_int("SMVS_WGRAD3_WAVES", 2048);
     int dchunk = D, rows = H;
-    while (dchunk > 1 && base * ((D + dchunk - 1) / dchunk) < 2048) dchunk = (dchunk + 1) / 2;
+    while (dchunk > 1 && base * ((D + dchunk - 1) / dchunk) < want) dchunk = (dchunk + 1) / 2;
     const int ndc = (D + dchunk - 1) / dchunk;
-    while (dchunk == 1 && rows > 16 && base * ndc * ((H + rows - 1) / rows) < 2048) rows = (rows + 1) / 2;
+    while (dchunk == 1 && rows > 16 && base * ndc * ((H + rows - 1) / rows) < want) rows = (rows + 1) / 2;
     p.dchunk = dchunk; p.ndc = ndc; p.rows = rows; p.nrc = (H + rows - 1) / rows;
     const long long units = base * ndc * p.nrc;
     if ((units + 3) / 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "too many work units");

@@ -66,6 +66,9 @@ struct CostVolBwdParams {
 #ifndef SMVS_BWD_BOX_AHEAD
 #define SMVS_BWD_BOX_AHEAD 0           // 1: feature boxes two channels ahead on three LDS buffers (1-2 source views).  Measured in round 5: 3.91-3.96 against 3.89-3.92 ms (profiles/r05_bwd_prefetch2.txt) -- the boxes' latency is not what the waves wait for; off
 #endif
+#ifndef SMVS_BWD_FLUSH_TOGETHER
+#define SMVS_BWD_FLUSH_TOGETHER 0      // 1: (1-2 source views) the flush exchanges of every view in flight together, one wait.  Measured in round 5: 3.92 against 3.93 ms -- the two LDS round trips per channel are not what the waves wait for; off
+#endif
 #ifndef SMVS_BWD_LDS
 #define SMVS_BWD_LDS 1                 // 0: never take the boxed path (A/B)
 #endif
@@ -123,6 +126,32 @@ __device__ __forceinline__ void gbox_add4(uint32_t addr, float c0, float c1, flo
                  "ds_add_f64 %0, %3 offset:%5\n\t"
                  "ds_add_f64 %0, %4 offset:%6"
                  :: "v"(addr), "v"(d0), "v"(d1), "v"(d2), "v"(d3), "n"(BOX_W * 8), "n"(BOX_W * 8 + 8) : "memory");
+}
+// the same exchange without the wait and without the rounding: the caller issues every view's eight first and waits once (gbox_wait_all)
+__device__ __forceinline__ void gbox_take8_nowait(uint32_t addr, double (&d)[BOX_H])
+{
+    const double zero = 0.0;
+    asm volatile("ds_wrxchg_rtn_b64 %0, %8, %9\n\t"
+                 "ds_wrxchg_rtn_b64 %1, %8, %9 offset:%10\n\t"
+                 "ds_wrxchg_rtn_b64 %2, %8, %9 offset:%11\n\t"
+                 "ds_wrxchg_rtn_b64 %3, %8, %9 offset:%12\n\t"
+                 "ds_wrxchg_rtn_b64 %4, %8, %9 offset:%13\n\t"
+                 "ds_wrxchg_rtn_b64 %5, %8, %9 offset:%14\n\t"
+                 "ds_wrxchg_rtn_b64 %6, %8, %9 offset:%15\n\t"
+                 "ds_wrxchg_rtn_b64 %7, %8, %9 offset:%16"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+                 : "v"(addr), "v"(zero), "n"(BOX_W * 8), "n"(BOX_W * 16), "n"(BOX_W * 24), "n"(BOX_W * 32),
+                   "n"(BOX_W * 40), "n"(BOX_W * 48), "n"(BOX_W * 56)
+                 : "memory");
+}
+template <int NV>
+__device__ __forceinline__ void gbox_wait_all(double (&d)[NV][BOX_H])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int i = 0; i < BOX_H; ++i) asm volatile("" : "+v"(d[s][i]));
 }
 // read and clear the lane's cell of each of the 8 box rows
 __device__ __forceinline__ void gbox_take8(uint32_t addr, float (&v)[BOX_H])
@@ -371,6 +400,23 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
             }
         };
         auto flush_boxes = [&](int c) {                     // one atomic per touched cell: row i of the box, column = lane
+            if constexpr (SMVS_BWD_FLUSH_TOGETHER && NSRC <= 2) {
+                // every view's exchanges first, ONE wait (round 5: per view the wave sat through a full LDS round trip, twice per channel)
+                double d[NSRC][BOX_H];
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s) gbox_take8_nowait(gbox_lds + (uint32_t)(s * GBOX_BYTES) + (uint32_t)lane * 8u, d[s]);
+                gbox_wait_all<NSRC>(d);
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s) {
+                    float* q = p.grad_src[s] + ((size_t)b * C + c) * HW + box_g0[s] + lane;
+#pragma unroll
+                    for (int i = 0; i < BOX_H; ++i) {
+                        const float v = (float)d[s][i];
+                        if (v != 0.0f && !((SMVS_BWD_ABLATE & 1) && v != 1234.5f)) unsafeAtomicAdd(q + i * W, v);
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) {
                 float v[BOX_H];
