@@ -239,9 +239,13 @@ int smvs_conv3x3_wgrad_list(const float* const* win, const float* const* win2, c
  *   nn.Conv3d(stride s, pad 1): window = input, grid = output gradient -> dw = weight gradient (Cout,Cin,3,3,3);
  *   nn.ConvTranspose3d(stride 2, pad 1, output_padding 1): window = output gradient, grid = input -> dw = weight gradient
  *   (Cin_layer,Cout_layer,3,3,3).  Volumes are read in place through their (B,C,D,H,W) strides; a channel of either tensor must stay
- *   below 2^31 bytes (SMVS_ERR_ARG otherwise: callers keep torch's operator). */
-int smvs_conv3d_wgrad(const float* window, const float* grid, float* dw, int B, int Cwin, int Cgrid, int D, int H, int W, int stride,
-                      void* stream);
+ *   below 2^31 bytes (SMVS_ERR_ARG otherwise: callers keep torch's operator).
+ *   workspace: NULL -- the waves add their partial sums to dw with float atomics (order-dependent rounding; the ~100-400 waves that
+ *   share 144 weights serialise on five cache lines) -- or smvs_conv3d_wgrad_workspace_floats(...) floats of scratch: the waves store their
+ *   partial sums there and a second kernel adds them to dw in a fixed order (deterministic, and what the shipped training path uses). */
+size_t smvs_conv3d_wgrad_workspace_floats(int B, int Cwin, int Cgrid, int D, int H, int W);
+int smvs_conv3d_wgrad(const float* window, const float* grid, float* dw, float* workspace, size_t workspace_floats, int B, int Cwin,
+                      int Cgrid, int D, int H, int W, int stride, void* stream);
 
 /* A single 3x3x3 / pad 1 layer of CostRegNet as a stand-alone call on the kernels of smvs_costreg_fwd (direct or MFMA by channel
  * count) WITHOUT the folded BatchNorm -- the TRAINING forward of its convolutions (modules/module.py:324-410 under autograd, batch

@@ -54,7 +54,7 @@ _SIGNATURES = {
     "smvs_conv3x3_wgrad_strided": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "smvs_conv3x3_wgrad_cat": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "smvs_conv3x3_wgrad_list": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "smvs_conv3d_wgrad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "smvs_conv3d_wgrad": [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp],
     "smvs_conv3d_pack": [_vp, _vp, _i, _i, _i, _vp],
     "smvs_batchnorm_train_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _i, _i, C.c_longlong, _vp],
     "smvs_batchnorm_train_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, C.c_longlong, _vp],
@@ -75,7 +75,7 @@ _SIZE_FUNCS = {"smvs_red_packed_floats": [_i], "smvs_red_workspace_bytes": [_i] 
                "smvs_red_pred_workspace_bytes": [_i] * 4, "smvs_costreg_packed_floats": [_i],
                "smvs_costreg_workspace_bytes": [_i] * 5, "smvs_featnet_packed_floats": [_i] * 2,
                "smvs_featnet_workspace_bytes": [_i] * 5, "smvs_conv3x3_packed_floats": [_i] * 2,
-               "smvs_conv3d_packed_floats": [_i] * 2}
+               "smvs_conv3d_packed_floats": [_i] * 2, "smvs_conv3d_wgrad_workspace_floats": [_i] * 6}
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SIZE_FUNCS) + ["smvs_version", "smvs_last_error", "smvs_red_set_streams", "smvs_shutdown",
                                                                     "smvs_set_arith", "smvs_get_arith"])
 ARITH_MODES = {"exact": 0, "fused": 1}      # SMVS_ARITH_EXACT / SMVS_ARITH_FUSED of include/satmvs.h

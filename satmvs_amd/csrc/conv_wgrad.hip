@@ -279,6 +279,7 @@ struct Wgrad3Params {
     int B, Cin, Cout, D, H, W;          // D, H, W: the grid; the window tensor is (B, Cin, S*D, S*H, S*W)
     int ncp, ncog, nxs, nrc, rows;      // window-channel pairs, grid-channel groups of 8, column strips, row chunks, rows per chunk
     int ndc, dchunk;                    // chunks of grid planes, planes per chunk
+    float* part;                        // null: sums go to dw with float atomics; else (groups, waves per group, 144) partial sums for conv3d_wgrad_fold
 };
 
 #ifndef SMVS_WGRAD3_COUNTED
@@ -474,9 +475,37 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
         const int i = 4 * m + sel;
         if (publisher) {
             const int c = i / 72, j = (i % 72) / 9, k = i % 9;
-            if (j < nco && (c == 0 || two)) unsafeAtomicAdd(p.dw + ((size_t)(cog * 8 + j) * p.Cin + ci0 + c) * 27 + kd * 9 + k, v);
+            if (p.part) {
+                // group = (cog, cp, kd): the waves that sum into the same 144 weights; wave index inside it = (b, dc, xs, rc)
+                const size_t grp = ((size_t)cog * p.ncp + cp) * 3 + kd;
+                const size_t wv = (((size_t)b * p.ndc + dc) * p.nxs + xs) * p.nrc + rc;
+                p.part[(grp * ((size_t)p.B * p.ndc * p.nxs * p.nrc) + wv) * 144 + i] = v;
+            } else if (j < nco && (c == 0 || two)) {
+                unsafeAtomicAdd(p.dw + ((size_t)(cog * 8 + j) * p.Cin + ci0 + c) * 27 + kd * 9 + k, v);
+            }
         }
     }
+}
+
+// Second stage of the two-stage form: dw += the sum of a group's per-wave partial sums.  Round 5: with float atomics straight from the
+// waves, the ~100-400 waves of a group hammer the same five cache lines of dw (144 floats) -- the serialised L2 atomics bounded the
+// kernel (more, shorter waves made it SLOWER: 9.9 -> 14.1 ms per 5 steps at 4x the waves), and the sums depended on the arrival order.
+// One block per group, thread = one of the 144 weights, partial sums read coalesced and added in wave order: deterministic.
+__global__ __launch_bounds__(192)
+void conv3d_wgrad_fold_kernel(const Wgrad3Params p)
+{
+    const int grp = blockIdx.x, i = threadIdx.x;
+    if (i >= 144) return;
+    const int kd = grp % 3, cp = (grp / 3) % p.ncp, cog = grp / (3 * p.ncp);
+    const size_t nper = (size_t)p.B * p.ndc * p.nxs * p.nrc;
+    const float* q = p.part + (size_t)grp * nper * 144 + i;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    size_t w = 0;
+    for (; w + 4 <= nper; w += 4) { s0 += q[w * 144]; s1 += q[(w + 1) * 144]; s2 += q[(w + 2) * 144]; s3 += q[(w + 3) * 144]; }
+    for (; w < nper; ++w) s0 += q[w * 144];
+    const int c = i / 72, j = (i % 72) / 9, k = i % 9;
+    const int co = cog * 8 + j, ci = 2 * cp + c;
+    if (co < p.Cout && ci < p.Cin) p.dw[((size_t)co * p.Cin + ci) * 27 + kd * 9 + k] += (s0 + s1) + (s2 + s3);
 }
 
 }  // namespace smvs
@@ -560,8 +589,53 @@ extern "C" SMVS_EXPORT int smvs_conv3x3_wgrad_list(const float* const* win, cons
 // nn.Conv3d (stride S): window = layer input, grid = output gradient; nn.ConvTranspose3d (stride 2, output_padding 1): window = output
 // gradient, grid = layer input (its weight is (Cin_layer, Cout_layer, 3,3,3) = the same index formula).
 // Replaces MIOpen's weight-gradient kernels under /root/reference/modules/module.py:324-410, 546-577.
-extern "C" SMVS_EXPORT int smvs_conv3d_wgrad(const float* window, const float* grid, float* dw, int B, int Cwin, int Cgrid,
-                                             int D, int H, int W, int stride, void* stream)
+static void wgrad3_split(smvs::Wgrad3Params& p, bool two_stage)
+{
+    using namespace smvs;
+    // Work per wave.  The chip holds 2048 of these waves at a time (218 VGPRs: two per SIMD), a launch runs in ROUNDS of that many and a
+    // round lasts as long as one wave: pick the split into chunks of grid planes x row chunks that minimises
+    //     rounds x (rows a wave walks + ~6 rows of prologue per plane + ~12 rows of lane reduction per wave)
+    // Two-stage form only; with atomics straight from the waves (no workspace) the first form stays: halve until >= 2048 waves, because
+    // every further wave of a group lengthens the chain of serialised atomics on the group's five cache lines.
+    const int D = p.D, H = p.H;
+    const long long base = (long long)p.ncp * p.ncog * p.nxs * 3 * p.B;
+    int dchunk = D, rows = H;
+    if (two_stage) {
+        const long long slots = tune_int("SMVS_WGRAD3_SLOTS", 2048);
+        long long best = -1;
+        for (int dcs = 1; dcs <= D; ++dcs) {
+            const int nd = (D + dcs - 1) / dcs;
+            if ((D + nd - 1) / nd != dcs) continue;                        // (equivalent splits: keep the balanced one)
+            for (int nr = 1; nr <= (dcs == 1 ? (H + 15) / 16 : 1); ++nr) { // row chunks only below one plane per wave
+                const int rw = (H + nr - 1) / nr;
+                if ((H + rw - 1) / rw != nr) continue;
+                const long long units = base * nd * nr;
+                const long long cost = ((units + slots - 1) / slots) * ((long long)dcs * (rw + 6) + 12);
+                if (best < 0 || cost < best) { best = cost; dchunk = dcs; rows = rw; }
+            }
+        }
+    } else {
+        while (dchunk > 1 && base * ((D + dchunk - 1) / dchunk) < 2048) dchunk = (dchunk + 1) / 2;
+        const int nd = (D + dchunk - 1) / dchunk;
+        while (dchunk == 1 && rows > 16 && base * nd * ((H + rows - 1) / rows) < 2048) rows = (rows + 1) / 2;
+    }
+    p.dchunk = dchunk; p.ndc = (D + dchunk - 1) / dchunk; p.rows = rows; p.nrc = (H + rows - 1) / rows;
+}
+
+// floats of workspace the two-stage form of smvs_conv3d_wgrad wants for this shape (0: unsupported arguments)
+extern "C" SMVS_EXPORT size_t smvs_conv3d_wgrad_workspace_floats(int B, int Cwin, int Cgrid, int D, int H, int W)
+{
+    using namespace smvs;
+    if (B < 1 || Cwin < 1 || Cgrid < 1 || D < 1 || H < 1 || W < 1) return 0;
+    Wgrad3Params p{};
+    p.B = B; p.Cin = Cwin; p.Cout = Cgrid; p.D = D; p.H = H; p.W = W;
+    p.ncp = (Cwin + 1) / 2; p.ncog = (Cgrid + 7) / 8; p.nxs = (W + 63) / 64;
+    wgrad3_split(p, true);
+    return (size_t)p.ncp * p.ncog * 3 * ((size_t)B * p.ndc * p.nxs * p.nrc) * 144;
+}
+
+extern "C" SMVS_EXPORT int smvs_conv3d_wgrad(const float* window, const float* grid, float* dw, float* workspace, size_t workspace_floats,
+                                             int B, int Cwin, int Cgrid, int D, int H, int W, int stride, void* stream)
 {
     using namespace smvs;
     if (!window || !grid || !dw) return fail(SMVS_ERR_ARG, "null pointer argument");
@@ -573,21 +647,17 @@ extern "C" SMVS_EXPORT int smvs_conv3d_wgrad(const float* window, const float* g
     Wgrad3Params p{};
     p.x = window; p.dy = grid; p.dw = dw; p.B = B; p.Cin = Cwin; p.Cout = Cgrid; p.D = D; p.H = H; p.W = W;
     p.ncp = (Cwin + 1) / 2; p.ncog = (Cgrid + 7) / 8; p.nxs = (W + 63) / 64;
-    // Work per wave: whole volumes while that leaves >= ~2048 waves (the window prologue per plane and the lane reduction per wave are
-    // overhead), then chunks of grid planes, then single planes cut into row chunks of >= 16 rows.
-    // (round 5: 8192 waves of >= 32 rows -- four rounds of the chip's 2048 wave slots instead of one and a bit -- measured SLOWER, 9.9 ->
-    //  14.1 ms per 5 casmvs steps: the per-wave prologue and the 36-step lane reduction with its 144 atomics outweigh the emptier last round)
+    const size_t need = workspace ? smvs_conv3d_wgrad_workspace_floats(B, Cwin, Cgrid, D, H, W) : 0;
+    if (workspace && workspace_floats < need) return fail(SMVS_ERR_ARG, "workspace too small: %zu < %zu floats", workspace_floats, need);
+    wgrad3_split(p, workspace != nullptr);
+    p.part = workspace;
     const long long base = (long long)p.ncp * p.ncog * p.nxs * 3 * B;
-    const long long want = tune_int("SMVS_WGRAD3_WAVES", 2048);
-    int dchunk = D, rows = H;
-    while (dchunk > 1 && base * ((D + dchunk - 1) / dchunk) < want) dchunk = (dchunk + 1) / 2;
-    const int ndc = (D + dchunk - 1) / dchunk;
-    while (dchunk == 1 && rows > 16 && base * ndc * ((H + rows - 1) / rows) < want) rows = (rows + 1) / 2;
-    p.dchunk = dchunk; p.ndc = ndc; p.rows = rows; p.nrc = (H + rows - 1) / rows;
+    const int ndc = p.ndc;
     const long long units = base * ndc * p.nrc;
     if ((units + 3) / 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "too many work units");
     if (stride == 1) hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
     else             hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    if (workspace) hipLaunchKernelGGL(conv3d_wgrad_fold_kernel, dim3((unsigned)(p.ncp * p.ncog * 3)), dim3(192), 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "conv3d_wgrad launch: %s", hipGetErrorString(e));
     return SMVS_OK;

@@ -387,6 +387,21 @@ class _Conv3x3WgradFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+def _conv3d_wgrad(window, grid, weight_shape, stride):
+    """dw (zero-filled, then smvs_conv3d_wgrad in its two-stage, deterministic form: per-wave partial sums in a scratch buffer from torch's
+    allocator, folded by a second kernel)."""
+    dev = window.device
+    B, Cg, D, H, W = grid.shape
+    Cw = window.shape[1]
+    dw = torch.zeros(weight_shape, dtype=torch.float32, device=dev)
+    nws = _lib.load().smvs_conv3d_wgrad_workspace_floats(B, Cw, Cg, D, H, W)
+    ws = torch.empty((max(nws, 1),), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("smvs_conv3d_wgrad", _lib.ptr(window), _lib.ptr(grid), _lib.ptr(dw), _lib.ptr(ws), nws, B, Cw, Cg, D, H, W, stride,
+                  _lib.current_stream(dev))
+    return dw
+
+
 class _Conv3dWgradFn(torch.autograd.Function):
     """A 3x3x3 / pad 1 nn.Conv3d (stride 1 or 2) or nn.ConvTranspose3d (stride 2, output_padding 1) without bias -- every layer of
     CostRegNet (reference modules/module.py:324-410, 546-577) -- whose WEIGHT gradient comes from smvs_conv3d_wgrad
@@ -414,11 +429,7 @@ class _Conv3dWgradFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             xc = _f32c_fast(x)
             window, grid = (dy, xc) if transposed else (xc, dy)             # the tensor read through the taps / the one on the output grid
-            B, Cg, D, H, W = grid.shape
-            dw = torch.zeros(weight.shape, dtype=torch.float32, device=xc.device)
-            with torch.cuda.device(xc.device):
-                _lib.call("smvs_conv3d_wgrad", _lib.ptr(window), _lib.ptr(grid), _lib.ptr(dw), B, window.shape[1], Cg, D, H, W, stride,
-                          _lib.current_stream(xc.device))
+            dw = _conv3d_wgrad(window, grid, weight.shape, stride)
         return dx, dw, None, None
 
 
@@ -497,9 +508,7 @@ class _Conv3dNativeFn(torch.autograd.Function):
                           dy.shape[2], dy.shape[3], dy.shape[4], 0, _lib.current_stream(dev))
             if ctx.needs_input_grad[1]:
                 window, grid = (dy, x) if kind == "t2" else (x, dy)         # the tensor read through the taps / the one on the output grid
-                dw = torch.zeros(weight.shape, dtype=torch.float32, device=dev)
-                _lib.call("smvs_conv3d_wgrad", _lib.ptr(window), _lib.ptr(grid), _lib.ptr(dw), B, window.shape[1], grid.shape[1],
-                          grid.shape[2], grid.shape[3], grid.shape[4], stride, _lib.current_stream(dev))
+                dw = _conv3d_wgrad(window, grid, weight.shape, stride)
         return dx, dw, None
 
 

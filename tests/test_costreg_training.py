@@ -88,21 +88,32 @@ def test_conv3d_native_weight_gradient_alone(dev, kind, B, cin, cout, D, H, W):
 
 
 def test_conv3d_wgrad_accumulates_and_rejects_bad_arguments(dev):
-    """The C entry point accumulates into dw (two calls = twice the gradient) and answers bad arguments with SMVS_ERR_ARG."""
+    """The C entry point accumulates into dw (two calls = twice the gradient) in both its forms -- float atomics, and the two-stage form
+    with a workspace, which is deterministic -- and answers bad arguments with SMVS_ERR_ARG."""
     from satmvs_amd import _lib
     torch.manual_seed(3)
     x = torch.randn(1, 4, 4, 8, 16, device=dev)
     gy = torch.randn(1, 6, 4, 8, 16, device=dev)
     dw = torch.zeros(6, 4, 3, 3, 3, device=dev)
-    for _ in range(2):
-        _lib.call("smvs_conv3d_wgrad", _lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), 1, 4, 6, 4, 8, 16, 1, _lib.current_stream(dev))
+    nws = _lib.load().smvs_conv3d_wgrad_workspace_floats(1, 4, 6, 4, 8, 16)
+    assert nws > 0 and nws % 144 == 0
+    ws = torch.empty(nws, device=dev)
+    _lib.call("smvs_conv3d_wgrad", _lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), None, 0, 1, 4, 6, 4, 8, 16, 1, _lib.current_stream(dev))        # atomics
+    _lib.call("smvs_conv3d_wgrad", _lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), _lib.ptr(ws), nws, 1, 4, 6, 4, 8, 16, 1, _lib.current_stream(dev))  # two-stage
     w = torch.zeros(6, 4, 3, 3, 3, dtype=torch.float64, requires_grad=True)
     torch.nn.functional.conv3d(x.double().cpu(), w, padding=1).backward(gy.double().cpu())
     assert float((dw.double().cpu() - 2 * w.grad).abs().max()) <= 4e-5 * float(w.grad.abs().max())
+    # the two-stage form is deterministic: two calls give the same bits
+    a, b = torch.zeros_like(dw), torch.zeros_like(dw)
+    for out in (a, b):
+        _lib.call("smvs_conv3d_wgrad", _lib.ptr(x), _lib.ptr(gy), _lib.ptr(out), _lib.ptr(ws), nws, 1, 4, 6, 4, 8, 16, 1, _lib.current_stream(dev))
+    assert torch.equal(a, b)
     with pytest.raises(_lib.SatMVSNativeError):
-        _lib.call("smvs_conv3d_wgrad", _lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), 1, 4, 6, 4, 8, 16, 3, _lib.current_stream(dev))
+        _lib.call("smvs_conv3d_wgrad", _lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), None, 0, 1, 4, 6, 4, 8, 16, 3, _lib.current_stream(dev))
     with pytest.raises(_lib.SatMVSNativeError):
-        _lib.call("smvs_conv3d_wgrad", None, _lib.ptr(gy), _lib.ptr(dw), 1, 4, 6, 4, 8, 16, 1, _lib.current_stream(dev))
+        _lib.call("smvs_conv3d_wgrad", None, _lib.ptr(gy), _lib.ptr(dw), None, 0, 1, 4, 6, 4, 8, 16, 1, _lib.current_stream(dev))
+    with pytest.raises(_lib.SatMVSNativeError):
+        _lib.call("smvs_conv3d_wgrad", _lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), _lib.ptr(ws), 143, 1, 4, 6, 4, 8, 16, 1, _lib.current_stream(dev))
 
 
 @pytest.mark.parametrize("kind,B,C,dims,relu", [("plain", 1, 8, (8, 24, 48), True), ("plain", 2, 5, (3, 7, 33), True), ("plain", 1, 64, (2, 6, 12), False),
