@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """The training step of tools/bench_train_step.py captured in one HIP graph (forward, loss, backward, RMSprop) and replayed:
 the eager step is bound by the host (32 k launches per step), the graph by the GPU.
-    python tools/bench_train_graph.py [steps] [casred|casmvs|ucs]"""
+    python tools/bench_train_graph.py [steps] [casred|casmvs|ucs] [rpc|pinhole] [ndepths, e.g. 64,32,8]"""
 import os, sys, time
 import torch
 import torch.nn.functional as F
@@ -15,14 +15,17 @@ H, W, nd = 384, 768, [48, 32, 8]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 torch.manual_seed(0)
 model = sys.argv[2] if len(sys.argv) > 2 else "casred"
+geo = sys.argv[3] if len(sys.argv) > 3 else "rpc"                              # the reference's train.py defaults: --model casmvs --geo_model pinhole --ndepths 64,32,8
+if len(sys.argv) > 4:
+    nd = [int(v) for v in sys.argv[4].split(",")]
 if model == "casred":
-    net = CascadeREDNet("rpc", min_interval=2.5, ndepths=nd)
+    net = CascadeREDNet(geo, min_interval=2.5, ndepths=nd)
 elif model == "casmvs":
     from satmvs_amd.networks.casmvs import CascadeMVSNet
-    net = CascadeMVSNet("rpc", min_interval=2.5, ndepths=nd)
+    net = CascadeMVSNet(geo, min_interval=2.5, ndepths=nd)
 else:
     from satmvs_amd.networks.ucs import UCSNet
-    net = UCSNet("rpc", stage_configs=nd)
+    net = UCSNet(geo, stage_configs=nd)
 net = net.to(dev).train()
 opt = torch.optim.RMSprop(net.parameters(), lr=1e-3, alpha=0.9, capturable=True)
 imgs = torch.randn(1, 3, 3, H, W, device=dev)
@@ -30,7 +33,23 @@ rpc = rpc_synth.make_view_rpcs(3, H, W, seed=0)[None]
 pm = {"stage1": torch.from_numpy(rpc_synth.rescale_rpc(rpc, 4)).to(dev), "stage2": torch.from_numpy(rpc_synth.rescale_rpc(rpc, 2)).to(dev),
       "stage3": torch.from_numpy(rpc).to(dev)}
 dv = torch.tensor([[0.0, 400.0]], device=dev)
-gt = {s: torch.full((1, H // k, W // k), 200.0, device=dev) for s, k in (("stage1", 4), ("stage2", 2), ("stage3", 1))}
+if geo == "pinhole":                                                           # K.E matrices as dataset/virdataset.py hands them over, intrinsics rows scaled per stage
+    import numpy as np
+    full = np.zeros((1, 3, 4, 4))
+    for v in range(3):
+        f = 1.1 * W
+        K = np.array([[f, 0, W / 2.0, 0], [0, f, H / 2.0, 0], [0, 0, 1.0, 0], [0, 0, 0, 1]])
+        E = np.eye(4)
+        E[:3, 3] = [25.0 * v * (-1) ** v, 3.0 * v, 0.5 * v]
+        full[0, v] = K @ E
+
+    def _scaled(s):
+        m = full.copy()
+        m[:, :, :2, :] /= s
+        return torch.from_numpy(m).to(dev)
+    pm = {"stage1": _scaled(4), "stage2": _scaled(2), "stage3": _scaled(1)}
+    dv = torch.tensor([[400.0, 700.0]], device=dev)
+gt = {s: torch.full((1, H // k, W // k), 550.0 if geo == "pinhole" else 200.0, device=dev) for s, k in (("stage1", 4), ("stage2", 2), ("stage3", 1))}
 
 
 def loss_fn(out, gt):
@@ -50,5 +69,5 @@ for _ in range(steps):
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) * 1e3)
 ts.sort()
-print(model + " graphed training step (satmvs_amd.train_graph), 3-view 768x384, planes %s: median %.1f ms (min %.1f, max %.1f), loss %.4f"
+print(model + " " + geo + " graphed training step (satmvs_amd.train_graph), 3-view 768x384, planes %s: median %.1f ms (min %.1f, max %.1f), loss %.4f"
       % (nd, ts[len(ts) // 2], ts[0], ts[-1], float(loss)))
