@@ -184,10 +184,10 @@ extern "C" SMVS_EXPORT int smvs_batchnorm_train_fwd(const float* x, const float*
     const int rc = bn_geometry(a, B, C, N);
     if (rc) return rc;
     a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
-    a.saved = saved_mean_rstd; a.sums = workspace; a.eps = eps; a.momentum = momentum; a.relu = relu != 0;
+    a.saved = saved_mean_rstd; a.sums = workspace; a.eps = eps; a.momentum = momentum; a.relu = (relu & 1) != 0;
     a.vec4 = (N % 4 == 0) && bn_aligned16(x) && bn_aligned16(y);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
+    hipError_t e = (relu & SMVS_BN_WORKSPACE_ZERO) ? hipSuccess : hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "batchnorm workspace clear: %s", hipGetErrorString(e));
     const dim3 grid((unsigned)(a.nchunk * B), (unsigned)C);
     hipLaunchKernelGGL(bn_stats_kernel<false>, grid, dim3(BN_BLOCK), 0, st, a);
@@ -207,10 +207,10 @@ extern "C" SMVS_EXPORT int smvs_batchnorm_train_bwd(const float* dy, const float
     const int rc = bn_geometry(a, B, C, N);
     if (rc) return rc;
     a.x = x; a.dy = dy; a.dx = dx; a.gamma = gamma; a.beta = beta; a.saved = const_cast<float*>(saved_mean_rstd); a.sums = workspace;
-    a.dgamma = dgamma; a.dbeta = dbeta; a.relu = relu != 0;
+    a.dgamma = dgamma; a.dbeta = dbeta; a.relu = (relu & 1) != 0;
     a.vec4 = (N % 4 == 0) && bn_aligned16(x) && bn_aligned16(dy) && bn_aligned16(dx);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
+    hipError_t e = (relu & SMVS_BN_WORKSPACE_ZERO) ? hipSuccess : hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "batchnorm workspace clear: %s", hipGetErrorString(e));
     const dim3 grid((unsigned)(a.nchunk * B), (unsigned)C);
     hipLaunchKernelGGL(bn_stats_kernel<true>, grid, dim3(BN_BLOCK), 0, st, a);

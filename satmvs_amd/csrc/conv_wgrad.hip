@@ -63,11 +63,28 @@ __device__ __forceinline__ float reduce4_rows(float a, float b, float c, float d
     return a;
 }
 
+#ifndef SMVS_WGRAD2_XCD
+#define SMVS_WGRAD2_XCD 0               // sharers adjacent + one contiguous run of workgroups per XCD (the 3-D kernel's order).  Measured in round 5 on the casred graphed step, alternating: 58.6 / 58.1 against 59.0 / 58.2 ms -- inside the spread; off
+#endif
+
 template <int S>
 __global__ __launch_bounds__(256)
 void conv3x3_wgrad_kernel(const WgradParams p)
 {
     const int lane = threadIdx.x & 63;
+#if SMVS_WGRAD2_XCD
+    // (round 5, from the 3-D kernel below) the waves that read the same rows -- every channel pair wants a gradient row, every output
+    // group a window row -- run fastest in the unit order and every XCD gets one contiguous run of workgroups: sharers meet in one L2
+    int unit = (int)xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);   // one wave = one unit
+    unit = __builtin_amdgcn_readfirstlane(unit);
+    const int total = p.ncp * p.ncog * p.nxs * p.nrc * p.nbc;
+    if (unit >= total) return;
+    const int cp = unit % p.ncp; unit /= p.ncp;
+    const int cog = unit % p.ncog; unit /= p.ncog;
+    const int rc = unit % p.nrc; unit /= p.nrc;
+    const int xs = unit % p.nxs;
+    const int bc = unit / p.nxs;
+#else
     int unit = blockIdx.x * 4 + (threadIdx.x >> 6);                  // one wave = one unit
     unit = __builtin_amdgcn_readfirstlane(unit);
     const int total = p.ncp * p.ncog * p.nxs * p.nrc * p.nbc;
@@ -78,6 +95,7 @@ void conv3x3_wgrad_kernel(const WgradParams p)
     const int cp = unit % p.ncp; unit /= p.ncp;
     const int cog = unit % p.ncog;
     const int bc = unit / p.ncog;
+#endif
     const int b0 = bc * p.bchunk, b1 = min(p.B, b0 + p.bchunk);
     const int H = p.H, W = p.W, HW = H * W;
     const int HX = S * H, WX = S * W, HWX = HX * WX;                  // the window tensor's plane
@@ -282,6 +300,9 @@ struct Wgrad3Params {
     float* part;                        // null: sums go to dw with float atomics; else (groups, waves per group, 144) partial sums for conv3d_wgrad_fold
 };
 
+#ifndef SMVS_WGRAD3_XCD
+#define SMVS_WGRAD3_XCD 1               // sharers of a row adjacent in the unit order + one contiguous run of workgroups per XCD (0: the first order, A/B)
+#endif
 #ifndef SMVS_WGRAD3_COUNTED
 #define SMVS_WGRAD3_COUNTED 0           // 1: stride 1 on the explicitly counted two-set row pipeline below.  Built and measured in round 5 (tests green): 10.4 against 9.9 ms per 5 casmvs steps -- row latency is not what bounds the kernel (two-ahead through the compiler: 9.9 as well); off
 #endif
@@ -291,10 +312,26 @@ __global__ __launch_bounds__(256)
 void conv3d_wgrad_kernel(const Wgrad3Params p)
 {
     const int lane = threadIdx.x & 63;
-    long long unit = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave = one unit
+    // Which waves read the same rows: a grid row (8 channels of one (b, d, y-range, x-strip)) is wanted by every window-channel pair and
+    // depth tap -- ncp x 3 waves, 24 at stage 2's conv0 -- a window row by the three depth taps of neighbouring planes and every grid
+    // group.  Round 5: with the row chunk fastest and workgroups dealt round-robin over the 8 XCDs those sharers sat on different XCDs and
+    // each L2 fetched its own copy (2.2 GB of L2 misses per launch for 0.23 GB of tensors: the kernel ran at the fabric's rate).  Now depth
+    // tap, channel pair and grid group run fastest and every XCD gets one contiguous run of the workgroup order (xcd_remap): the sharers
+    // are neighbours on one XCD, in flight together.
+    const uint32_t wg = SMVS_WGRAD3_XCD ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    long long unit = (long long)wg * 4 + (threadIdx.x >> 6);           // one wave = one unit
     const long long total = (long long)p.ncp * p.ncog * p.nxs * p.nrc * 3 * p.ndc * p.B;
     if (unit >= total) return;
-    // row chunk fastest, then column strip, depth tap, plane chunk, channel pair, output group, batch: neighbouring waves share rows in L2
+#if SMVS_WGRAD3_XCD
+    const int kd = __builtin_amdgcn_readfirstlane((int)(unit % 3)); unit /= 3;
+    const int cp = __builtin_amdgcn_readfirstlane((int)(unit % p.ncp)); unit /= p.ncp;
+    const int cog = __builtin_amdgcn_readfirstlane((int)(unit % p.ncog)); unit /= p.ncog;
+    const int rc = __builtin_amdgcn_readfirstlane((int)(unit % p.nrc)); unit /= p.nrc;
+    const int xs = __builtin_amdgcn_readfirstlane((int)(unit % p.nxs)); unit /= p.nxs;
+    const int dc = __builtin_amdgcn_readfirstlane((int)(unit % p.ndc));
+    const int b = __builtin_amdgcn_readfirstlane((int)(unit / p.ndc));
+#else
+    // (first form) row chunk fastest, then column strip, depth tap, plane chunk, channel pair, output group, batch
     const int rc = __builtin_amdgcn_readfirstlane((int)(unit % p.nrc)); unit /= p.nrc;
     const int xs = __builtin_amdgcn_readfirstlane((int)(unit % p.nxs)); unit /= p.nxs;
     const int kd = __builtin_amdgcn_readfirstlane((int)(unit % 3)); unit /= 3;
@@ -302,6 +339,7 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
     const int cp = __builtin_amdgcn_readfirstlane((int)(unit % p.ncp)); unit /= p.ncp;
     const int cog = __builtin_amdgcn_readfirstlane((int)(unit % p.ncog));
     const int b = __builtin_amdgcn_readfirstlane((int)(unit / p.ncog));
+#endif
     const int D = p.D, H = p.H, W = p.W, HW = H * W;
     const int DX = S * D, HX = S * H, WX = S * W, HWX = HX * WX;
     const size_t csx = (size_t)DX * HWX, csy = (size_t)D * HW;        // channel strides (elements)

@@ -664,6 +664,15 @@ class CostRegNet(nn.Module):
     def forward(self, x):
         if self._use_native(x):
             return self.native_forward(x)
+        if x.is_cuda and self.training and torch.is_grad_enabled() and not (SW.train_composite_mask & 64):
+            # one zero fill for everything the native backward accumulates into: the 11 weight gradients and the BatchNorm sums
+            n = sum(((p.numel() + 3) & ~3) for k, p in self.named_parameters() if k.endswith("conv.weight") or k == "prob.weight")
+            n += sum(8 * m.num_features + 8 for m in self.modules() if isinstance(m, nn.BatchNorm3d))
+            with _WgradArena(n, x.device):
+                return self._composite(x)
+        return self._composite(x)
+
+    def _composite(self, x):
         c0 = self.conv0(x)
         c2 = self.conv2(self.conv1(c0))
         c4 = self.conv4(self.conv3(c2))

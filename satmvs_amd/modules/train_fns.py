@@ -387,13 +387,13 @@ class _Conv3x3WgradFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
-def _conv3d_wgrad(window, grid, weight_shape, stride):
-    """dw (zero-filled, then smvs_conv3d_wgrad in its two-stage, deterministic form: per-wave partial sums in a scratch buffer from torch's
-    allocator, folded by a second kernel)."""
+def _conv3d_wgrad(window, grid, weight_shape, stride, zeroed=None):
+    """dw (zero-filled -- `zeroed`: a slice of the forward's arena, else a fresh fill -- then smvs_conv3d_wgrad in its two-stage,
+    deterministic form: per-wave partial sums in a scratch buffer from torch's allocator, folded by a second kernel)."""
     dev = window.device
     B, Cg, D, H, W = grid.shape
     Cw = window.shape[1]
-    dw = torch.zeros(weight_shape, dtype=torch.float32, device=dev)
+    dw = zeroed.view(weight_shape) if zeroed is not None and zeroed.device == dev else torch.zeros(weight_shape, dtype=torch.float32, device=dev)
     nws = _lib.load().smvs_conv3d_wgrad_workspace_floats(B, Cw, Cg, D, H, W)
     ws = torch.empty((max(nws, 1),), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -489,6 +489,8 @@ class _Conv3dNativeFn(torch.autograd.Function):
                       dims[0], dims[1], dims[2], 0, _lib.current_stream(x.device))
         ctx.save_for_backward(x, weight)
         ctx.kind = kind
+        arena = getattr(_TLS, "arena", None)
+        ctx.zeroed = arena.take(weight.numel()) if arena is not None else None      # the weight gradient's memory, zeroed with the forward's one fill
         return out
 
     @staticmethod
@@ -508,7 +510,8 @@ class _Conv3dNativeFn(torch.autograd.Function):
                           dy.shape[2], dy.shape[3], dy.shape[4], 0, _lib.current_stream(dev))
             if ctx.needs_input_grad[1]:
                 window, grid = (dy, x) if kind == "t2" else (x, dy)         # the tensor read through the taps / the one on the output grid
-                dw = _conv3d_wgrad(window, grid, weight.shape, stride)
+                buf, ctx.zeroed = ctx.zeroed, None                          # (a second backward through the same graph gets fresh memory)
+                dw = _conv3d_wgrad(window, grid, weight.shape, stride, buf)
         return dx, dw, None
 
 
@@ -552,14 +555,18 @@ class _BatchNormReluFn(torch.autograd.Function):
         N = x.numel() // (B * C)
         y = torch.empty_like(x)
         saved = torch.empty((C, 2), dtype=torch.float32, device=x.device)
-        ws = torch.empty((2 * C,), dtype=torch.float64, device=x.device)
+        arena = getattr(_TLS, "arena", None)
+        zf = arena.take(4 * C) if arena is not None and arena.buf.device == x.device else None      # 2 C doubles, zeroed by the forward's one fill
+        zb = arena.take(4 * C) if zf is not None else None                                          # ... and the backward's
+        ws = zf.view(torch.float64) if zf is not None else torch.empty((2 * C,), dtype=torch.float64, device=x.device)
         track = bn.track_running_stats and bn.running_mean is not None
         with torch.cuda.device(x.device):
             _lib.call("smvs_batchnorm_train_fwd", _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bn.running_mean) if track else None,
-                      _lib.ptr(bn.running_var) if track else None, float(bn.momentum), float(bn.eps), 1 if relu else 0, _lib.ptr(y), _lib.ptr(saved),
-                      _lib.ptr(ws), B, C, N, _lib.current_stream(x.device))
+                      _lib.ptr(bn.running_var) if track else None, float(bn.momentum), float(bn.eps), (1 if relu else 0) | (2 if zf is not None else 0),
+                      _lib.ptr(y), _lib.ptr(saved), _lib.ptr(ws), B, C, N, _lib.current_stream(x.device))
         ctx.save_for_backward(x, gamma, beta, saved)
         ctx.relu = bool(relu)
+        ctx.zeroed = zb
         return y
 
     @staticmethod
@@ -570,9 +577,11 @@ class _BatchNormReluFn(torch.autograd.Function):
         N = x.numel() // (B * C)
         dx = torch.empty_like(x)
         dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
-        ws = torch.empty((2 * C,), dtype=torch.float64, device=x.device)
+        zb, ctx.zeroed = ctx.zeroed, None                                   # (a second backward through the same graph clears its own)
+        ws = zb.view(torch.float64) if zb is not None else torch.empty((2 * C,), dtype=torch.float64, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.call("smvs_batchnorm_train_bwd", _lib.ptr(dy), _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(saved), 1 if ctx.relu else 0,
+            _lib.call("smvs_batchnorm_train_bwd", _lib.ptr(dy), _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(saved),
+                      (1 if ctx.relu else 0) | (2 if zb is not None else 0),
                       _lib.ptr(dx), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(ws), B, C, N, _lib.current_stream(x.device))
         return dx, dgb[0], dgb[1], None, None
 

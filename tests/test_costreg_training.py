@@ -347,3 +347,74 @@ def test_featnet_training_native_vs_torch(dev, arch):
     for n, b in net64.named_buffers():
         if b.dtype.is_floating_point:
             assert dist(res["native"][3][n], b.detach()) <= 1e-5, n
+
+
+@pytest.mark.parametrize("tag", ["casmvs", "ucs"])
+def test_graphed_training_step_3d_matches_eager(dev, golden, tag):
+    """satmvs_amd.train_graph.GraphedTrainStep over CascadeMVSNet / UCSNet: the native 3-D operators under HIP-graph capture.
+    Same seed, same sample: the first replay's loss equals the eager step's to 1e-6 and its gradients to 2e-4 of their scale, the
+    capture's warm-up leaves parameters / BatchNorm buffers untouched, the second replay equals the eager run's second step (the packed
+    kernel-layout weights of smvs_conv3d_fwd follow the parameters a replay stepped: bump_param_epoch), BatchNorm's running statistics
+    and num_batches_tracked move once per replay, and evaluation after the replays runs on the CURRENT parameters (native inference ==
+    torch composite)."""
+    import torch.nn.functional as F
+    from satmvs_amd import rpc_synth
+    from satmvs_amd.networks import casmvs, ucs
+    from satmvs_amd.train_graph import GraphedTrainStep
+    gc = golden("cascade")
+    nd = [int(v) for v in gc["ndepths"]]
+    imgs = torch.from_numpy(gc["imgs"]).to(dev)
+    rpc = gc["rpc"]
+    proj = {"stage1": torch.from_numpy(rpc_synth.rescale_rpc(rpc, 4)).to(dev), "stage2": torch.from_numpy(rpc_synth.rescale_rpc(rpc, 2)).to(dev),
+            "stage3": torch.from_numpy(rpc).to(dev)}
+    dv = torch.from_numpy(gc["dv"]).to(dev)
+    gts = {s: torch.full((1, 64 // k, 128 // k), 230.0, device=dev) for s, k in (("stage1", 4), ("stage2", 2), ("stage3", 1))}
+
+    def loss_fn(out, gt):
+        return sum(w * F.smooth_l1_loss(out[s]["depth"], gt[s], reduction="mean") for s, w in (("stage1", 0.5), ("stage2", 1.0), ("stage3", 2.0)))
+
+    def make():
+        torch.manual_seed(0)
+        net = casmvs.CascadeMVSNet("rpc", min_interval=2.5, ndepths=nd) if tag == "casmvs" else ucs.UCSNet("rpc", stage_configs=nd)
+        net = net.to(dev).train()
+        return net, torch.optim.RMSprop(net.parameters(), lr=1e-4, alpha=0.9, capturable=True)
+
+    net_e, opt_e = make()
+    opt_e.zero_grad(set_to_none=True)
+    loss_e = loss_fn(net_e(imgs, proj, dv), gts)
+    loss_e.backward()
+    grads_e = {k: p.grad.clone() for k, p in net_e.named_parameters()}
+    opt_e.step()
+    opt_e.zero_grad(set_to_none=True)
+    loss_e2 = float(loss_fn(net_e(imgs, proj, dv), gts).detach())
+
+    net_g, opt_g = make()
+    before = {k: v.clone() for k, v in net_g.state_dict().items()}
+    step = GraphedTrainStep(net_g, opt_g, loss_fn)
+    step._capture((imgs, proj, dv, gts))
+    for k, v in net_g.state_dict().items():
+        assert torch.equal(v, before[k]), "the capture's warm-up changed %s" % k
+    step._sig = None
+    loss_g, out_g = step(imgs, proj, dv, gts)
+    loss_g, loss_e = float(loss_g), float(loss_e.detach())
+    assert abs(loss_g - loss_e) <= 1e-6 * abs(loss_e)
+    for k, p in net_g.named_parameters():
+        scale = float(grads_e[k].abs().max())
+        assert float((p.grad - grads_e[k]).abs().max()) <= 2e-4 * scale + 1e-9, k
+    tracked = [b for n, b in net_g.named_buffers() if n.endswith("num_batches_tracked")]
+    counts = sorted(set(int(b) for b in tracked))
+    loss2, _ = step(imgs, proj, dv, gts)
+    loss2 = float(loss2)
+    assert np.isfinite(loss2) and loss2 != loss_g
+    assert abs(loss2 - loss_e2) <= 2e-3 * abs(loss_e2), (loss2, loss_e2)
+    assert sorted(set(int(b) for b in tracked)) == [c + (c // min(counts)) for c in counts]    # every BatchNorm moved by its calls per step
+    net_g.eval()
+    with torch.no_grad():
+        nat = net_g(imgs, proj, dv)["stage3"]["depth"].clone()
+        os_env = __import__("os").environ
+        os_env["SMVS_COSTREG_TORCH"] = "1"; os_env["SMVS_FEATNET_TORCH"] = "1"
+        try:
+            comp = net_g(imgs, proj, dv)["stage3"]["depth"].clone()
+        finally:
+            del os_env["SMVS_COSTREG_TORCH"]; del os_env["SMVS_FEATNET_TORCH"]
+    assert float((nat - comp).abs().max()) <= 1e-3, float((nat - comp).abs().max())
