@@ -418,3 +418,41 @@ def test_graphed_training_step_3d_matches_eager(dev, golden, tag):
         finally:
             del os_env["SMVS_COSTREG_TORCH"]; del os_env["SMVS_FEATNET_TORCH"]
     assert float((nat - comp).abs().max()) <= 1e-3, float((nat - comp).abs().max())
+
+
+def test_training_replicas_on_threads(dev, golden):
+    """What nn.DataParallel does around a training forward (train.py:129): torch.nn.parallel.replicate + parallel_apply, one thread per
+    replica (both on cuda:0 here).  The native training operators keep per-thread state (the zero-fill arena) and a shared pack cache:
+    two replicas running concurrently must give the parent's parameters exactly twice the gradient of a single run (1e-4 of the scale:
+    other accumulation order of the two branches), finite and with every BatchNorm buffer finite."""
+    import torch.nn.functional as F
+    from satmvs_amd import rpc_synth
+    from satmvs_amd.networks import casmvs
+    gc = golden("cascade")
+    nd = [int(v) for v in gc["ndepths"]]
+    imgs = torch.from_numpy(gc["imgs"]).to(dev)
+    rpc = gc["rpc"]
+    proj = {"stage1": torch.from_numpy(rpc_synth.rescale_rpc(rpc, 4)).to(dev), "stage2": torch.from_numpy(rpc_synth.rescale_rpc(rpc, 2)).to(dev),
+            "stage3": torch.from_numpy(rpc).to(dev)}
+    dv = torch.from_numpy(gc["dv"]).to(dev)
+
+    def loss_of(out):
+        return sum(w * F.smooth_l1_loss(out[s]["depth"], torch.full_like(out[s]["depth"], 230.0)) for s, w in (("stage1", 0.5), ("stage2", 1.0), ("stage3", 2.0)))
+
+    torch.manual_seed(2)
+    net = casmvs.CascadeMVSNet("rpc", min_interval=2.5, ndepths=nd).to(dev).train()
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    loss_of(net(imgs, proj, dv)).backward()
+    single = {k: p.grad.clone() for k, p in net.named_parameters()}
+    net.load_state_dict(state)
+    net.zero_grad()
+    reps = torch.nn.parallel.replicate(net, [0, 0])
+    outs = torch.nn.parallel.parallel_apply(reps, [(imgs, proj, dv), (imgs, proj, dv)], devices=[0, 0])
+    (loss_of(outs[0]) + loss_of(outs[1])).backward()
+    torch.cuda.synchronize()
+    for k, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        scale = float(single[k].abs().max())
+        assert float((p.grad - 2 * single[k]).abs().max()) <= 2e-4 * 2 * scale + 1e-9, (k, float((p.grad - 2 * single[k]).abs().max()), scale)
+    for k, b in net.named_buffers():
+        assert torch.isfinite(b.float()).all(), k
