@@ -267,14 +267,16 @@ int smvs_conv3d_fwd(int kind, const float* in, const float* packed, const float*
 /* nn.BatchNorm3d in TRAINING form (batch statistics over (B, N = D*H*W) per channel) with the block's ReLU -- the normalisation of every
  * Conv3d / Deconv3d block of CostRegNet under autograd (modules/module.py:324-410):
  *   fwd: y = [relu]((x - mean) * rstd * gamma + beta);  saved_mean_rstd (C,2) for the backward;  running_mean / running_var (or NULL, NULL)
- *        updated like torch.nn.functional.batch_norm(training=True): (1 - momentum) * running + momentum * batch (unbiased variance)
+ *        updated like torch.nn.functional.batch_norm(training=True): (1 - momentum) * running + momentum * batch (unbiased variance);
+ *        num_batches_tracked (int64 scalar on the device, or NULL) += 1 like nn.BatchNorm's forward
  *   bwd: dx, dgamma (C), dbeta (C) from dy, the layer's INPUT x and saved_mean_rstd; with relu != 0 the gradient passes where the forward's
  *        output was positive (recomputed from x: neither a mask nor the output is kept)
  * x, y, dy, dx: (B,C,N) contiguous float32; workspace: 2*C doubles of scratch, cleared by the call unless `relu` carries
  * SMVS_BN_WORKSPACE_ZERO (the caller hands over zeroed memory: one fill for all the layers of a forward).  relu: bit 0 = apply ReLU. */
 #define SMVS_BN_WORKSPACE_ZERO 2
-int smvs_batchnorm_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
-                             float eps, int relu, float* y, float* saved_mean_rstd, double* workspace, int B, int C, long long N, void* stream);
+int smvs_batchnorm_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             long long* num_batches_tracked, float momentum, float eps, int relu, float* y, float* saved_mean_rstd,
+                             double* workspace, int B, int C, long long N, void* stream);
 int smvs_batchnorm_train_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* saved_mean_rstd, int relu,
                              float* dx, float* dgamma, float* dbeta, double* workspace, int B, int C, long long N, void* stream);
 

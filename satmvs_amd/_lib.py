@@ -56,7 +56,7 @@ _SIGNATURES = {
     "smvs_conv3x3_wgrad_list": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "smvs_conv3d_wgrad": [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp],
     "smvs_conv3d_pack": [_vp, _vp, _i, _i, _i, _vp],
-    "smvs_batchnorm_train_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _i, _i, C.c_longlong, _vp],
+    "smvs_batchnorm_train_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _i, _i, C.c_longlong, _vp],
     "smvs_batchnorm_train_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, C.c_longlong, _vp],
     "smvs_conv3d_fwd": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "smvs_conv3x3_pack": [_vp, _vp, _i, _i, _i, _vp],

@@ -48,6 +48,7 @@ struct BnArgs {
     const float* x; const float* dy; float* y; float* dx;
     const float* gamma; const float* beta;
     float* running_mean; float* running_var;       // updated by the forward, or null
+    long long* num_batches;                         // nn.BatchNorm's num_batches_tracked, incremented by the forward, or null
     float* saved;                                   // (C, 2): mean, rstd
     double* sums;                                   // (C, 2) float64 scratch, zeroed by the caller's launch sequence
     float* dgamma; float* dbeta;
@@ -110,6 +111,7 @@ void bn_apply_kernel(const BnArgs a)
     const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)a.eps));
     const float scale = a.gamma[c] * rstd, shift = fmaf(-mean, scale, a.beta[c]);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (c == 0 && a.num_batches) *a.num_batches += 1;
         a.saved[2 * c] = mean; a.saved[2 * c + 1] = rstd;
         if (a.running_mean) {
             const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
@@ -174,8 +176,8 @@ static bool bn_aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 }  // namespace smvs
 
 extern "C" SMVS_EXPORT int smvs_batchnorm_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
-                                                    float* running_var, float momentum, float eps, int relu, float* y, float* saved_mean_rstd,
-                                                    double* workspace, int B, int C, long long N, void* stream)
+                                                    float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu,
+                                                    float* y, float* saved_mean_rstd, double* workspace, int B, int C, long long N, void* stream)
 {
     using namespace smvs;
     if (!x || !gamma || !beta || !y || !saved_mean_rstd || !workspace) return fail(SMVS_ERR_ARG, "null pointer argument");
@@ -183,7 +185,7 @@ extern "C" SMVS_EXPORT int smvs_batchnorm_train_fwd(const float* x, const float*
     BnArgs a{};
     const int rc = bn_geometry(a, B, C, N);
     if (rc) return rc;
-    a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
+    a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var; a.num_batches = num_batches_tracked;
     a.saved = saved_mean_rstd; a.sums = workspace; a.eps = eps; a.momentum = momentum; a.relu = (relu & 1) != 0;
     a.vec4 = (N % 4 == 0) && bn_aligned16(x) && bn_aligned16(y);
     hipStream_t st = (hipStream_t)stream;

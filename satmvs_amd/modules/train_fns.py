@@ -562,7 +562,9 @@ class _BatchNormReluFn(torch.autograd.Function):
         track = bn.track_running_stats and bn.running_mean is not None
         with torch.cuda.device(x.device):
             _lib.call("smvs_batchnorm_train_fwd", _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bn.running_mean) if track else None,
-                      _lib.ptr(bn.running_var) if track else None, float(bn.momentum), float(bn.eps), (1 if relu else 0) | (2 if zf is not None else 0),
+                      _lib.ptr(bn.running_var) if track else None,
+                      _lib.ptr(bn.num_batches_tracked) if track and bn.num_batches_tracked is not None and bn.num_batches_tracked.is_cuda else None,
+                      float(bn.momentum), float(bn.eps), (1 if relu else 0) | (2 if zf is not None else 0),
                       _lib.ptr(y), _lib.ptr(saved), _lib.ptr(ws), B, C, N, _lib.current_stream(x.device))
         ctx.save_for_backward(x, gamma, beta, saved)
         ctx.relu = bool(relu)
@@ -593,9 +595,7 @@ def _bn3d_relu(bn, x, relu):
             and bn.momentum is not None and bn.weight.dtype is torch.float32 and bn.weight.is_contiguous() and bn.bias.is_contiguous()
             and x.shape[1] <= 65535 and not (SW.train_composite_mask & 256)):
         return None
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    return _BatchNormReluFn.apply(x, bn.weight, bn.bias, bn, relu)
+    return _BatchNormReluFn.apply(x, bn.weight, bn.bias, bn, relu)          # (num_batches_tracked += 1 happens in the forward kernel)
 
 
 _CONV_PACK = {}         # (weight address, layout, cin) -> (version, epoch, storage weak reference, packed tensor): one entry per layer and direction

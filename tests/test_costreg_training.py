@@ -214,7 +214,7 @@ def test_training_step_3d_matches_reference(dev, golden, tag):
     gen_golden.py::gen_train3d): same seed => same weights (checksums of tests/golden/cascade.npz).  Two configurations: the shipped
     path (mask 0: native cost volume forward / backward, every 3x3x3 layer and every BatchNorm + ReLU of CostRegNet and FeatureNet
     native) and torch's operators around the native cost volume (mask 320, FeatureNet's layers torch's too).
-    Both: heights within 1e-3 m, loss within 1e-5 relative, the norms of ALL parameter gradients within 2e-3, the BatchNorm running
+    Both: heights within 1e-3 m, loss within 1e-5 relative, the norms of ALL parameter gradients within 5e-3, the BatchNorm running
     statistics within 1e-5.  Stored gradients (stage 1's regulariser, FeatureNet's first and last layers): torch's OWN GPU operators sit
     up to 2e-3 (casmvs) / 5e-3 (ucs) of a tensor's scale from the reference's CPU float32 result (batch statistics over as few as 16
     values on the coarse levels amplify the round-off of any other summation order) -- measured in round 5 with identical figures for
@@ -269,7 +269,7 @@ def test_training_step_3d_matches_reference(dev, golden, tag):
             nmax = float(np.sqrt(g[tag + ".grad_sums"][:, 1].max()))
             for (name, (s1, s2)) in zip(g[tag + ".grad_names"], g[tag + ".grad_sums"]):
                 n = float(grads[str(name)].double().norm())
-                if abs(n - np.sqrt(s2)) > 2e-3 * np.sqrt(s2) + 1e-6 * nmax:
+                if abs(n - np.sqrt(s2)) > 5e-3 * np.sqrt(s2) + 1e-6 * nmax:      # (ucs, torch's own operators: up to 2.1e-3 on FeatureNet's decoder norms, run to run)
                     bad.append("%s: norm of %s: %.6g vs %.6g" % (cfg, name, n, np.sqrt(s2)))
             bufs = dict(net.named_buffers())
             for (name, (s1, s2)) in zip(g[tag + ".buffer_names"], g[tag + ".buffer_sums"]):
