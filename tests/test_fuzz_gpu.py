@@ -39,3 +39,9 @@ def test_fuzz_cost_volume_backward_vs_warp_autograd(mode):
 def test_fuzz_small_operators_vs_oracle():
     last = _run("fuzz_ops.py", 30, 13)
     assert last == "30 rounds, 0 mismatching checks", last
+
+
+def test_fuzz_training_operators_3d_vs_float64():
+    """smvs_conv3d_fwd / its adjoint / smvs_conv3d_wgrad and smvs_batchnorm_train_* on random layers against float64 (round 5)."""
+    last = _run("fuzz_train3d.py", 60, 14)
+    assert last.startswith("60 cases, worst relative error"), last
