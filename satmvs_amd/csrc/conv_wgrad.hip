@@ -300,6 +300,9 @@ struct Wgrad3Params {
     float* part;                        // null: sums go to dw with float atomics; else (groups, waves per group, 144) partial sums for conv3d_wgrad_fold
 };
 
+#ifndef SMVS_WGRAD3_GC1
+#define SMVS_WGRAD3_GC1 1               // single-channel grid tensors (the `prob` layer) on the one-grid-channel instance (0: the 8-channel group, A/B)
+#endif
 #ifndef SMVS_WGRAD3_XCD
 #define SMVS_WGRAD3_XCD 1               // sharers of a row adjacent in the unit order + one contiguous run of workgroups per XCD (0: the first order, A/B)
 #endif
@@ -307,7 +310,9 @@ struct Wgrad3Params {
 #define SMVS_WGRAD3_COUNTED 0           // 1: stride 1 on the explicitly counted two-set row pipeline below.  Built and measured in round 5 (tests green): 10.4 against 9.9 ms per 5 casmvs steps -- row latency is not what bounds the kernel (two-ahead through the compiler: 9.9 as well); off
 #endif
 
-template <int S>
+// GC: grid channels a wave carries -- 8, or 1 for the single-channel `prob` layer (round 5: with 8 it ran seven padding channels, a quarter
+// of the step's weight-gradient row iterations for one eighth of the useful work)
+template <int S, int GC>
 __global__ __launch_bounds__(256)
 void conv3d_wgrad_kernel(const Wgrad3Params p)
 {
@@ -357,15 +362,15 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
     const uint32_t cy = x < W ? (uint32_t)x * 4u : SMVS_OOB;
     const int nco = min(8, p.Cout - cog * 8);
     const int ch1 = two ? (int)(csx * 4) : 0;                         // byte offset of the pair's second channel (odd counts: the first again, not published)
-    int gch[8];                                                       // byte offsets of the 8 grid channels (beyond Cout: the last one again, not published)
+    int gch[GC];                                                       // byte offsets of the 8 grid channels (beyond Cout: the last one again, not published)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) gch[j] = (int)((size_t)min(j, nco - 1) * csy * 4);
+    for (int j = 0; j < GC; ++j) gch[j] = (int)((size_t)min(j, nco - 1) * csy * 4);
 
-    float acc[2][8][9];
+    float acc[2][GC][9];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < GC; ++j)
 #pragma unroll
             for (int k = 0; k < 9; ++k) acc[c][j][k] = 0.0f;
 
@@ -373,7 +378,7 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
     const int zd = S * d + kd - 1;                                    // window plane of this grid plane and depth tap
     if (zd < 0 || zd >= DX) continue;
     const BufRsrc rx = make_rsrc(p.x + ((size_t)b * p.Cin + ci0) * csx + (size_t)zd * HWX, (uint32_t)(ch1 + HWX * 4));
-    const BufRsrc ry = make_rsrc(p.dy + ((size_t)b * p.Cout + cog * 8) * csy + (size_t)d * HW, (uint32_t)(gch[7] + HW * 4));
+    const BufRsrc ry = make_rsrc(p.dy + ((size_t)b * p.Cout + cog * 8) * csy + (size_t)d * HW, (uint32_t)(gch[GC - 1] + HW * 4));
     float win[2][3][3];
     auto load_row = [&](int yy, float (&dst)[2][3]) {                 // yy: row of the window plane; every load unconditional (see the 2-D kernel)
         i32x4 r = rx.v;
@@ -384,15 +389,15 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
 #pragma unroll
             for (int k = 0; k < 3; ++k) dst[c][k] = llvm_raw_buffer_load_f32(r, (int)cx[k], c * ch1 + so, 0);
     };
-    auto load_g = [&](int yy, float (&dst)[8]) {
+    auto load_g = [&](int yy, float (&dst)[GC]) {
         i32x4 r = ry.v;
         r.z = yy < y1 ? r.z : 0;
         const int so = yy < y1 ? yy * W * 4 : 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[j] = llvm_raw_buffer_load_f32(r, (int)cy, gch[j] + so, 0);
+        for (int j = 0; j < GC; ++j) dst[j] = llvm_raw_buffer_load_f32(r, (int)cy, gch[j] + so, 0);
     };
     // The rows of iteration y: window row y + 1 (S = 1) / rows 2y, 2y + 1 (S = 2) and grid row y.
-    auto fma_row = [&](const float (&fresh)[S][2][3], const float (&g)[8]) __attribute__((always_inline)) {
+    auto fma_row = [&](const float (&fresh)[S][2][3], const float (&g)[GC]) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -401,7 +406,7 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
                 else { win[c][0][k] = win[c][2][k]; win[c][1][k] = fresh[0][c][k]; win[c][2][k] = fresh[1][c][k]; }
             }
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < GC; ++j)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -409,7 +414,7 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
 #pragma unroll
                     for (int k = 0; k < 3; ++k) acc[c][j][r * 3 + k] = fmaf(g[j], win[c][r][k], acc[c][j][r * 3 + k]);
     };
-    if constexpr (!(S == 1 && SMVS_WGRAD3_COUNTED)) {
+    if constexpr (!(S == 1 && GC == 8 && SMVS_WGRAD3_COUNTED)) {
         if (S == 1) {
             float r0[2][3], r1[2][3];
             load_row(y0 - 1, r0);
@@ -427,7 +432,7 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
                 for (int k = 0; k < 3; ++k) { win[c][2][k] = r0[c][k]; win[c][0][k] = win[c][1][k] = 0.0f; }
         }
     }
-    if constexpr (S == 1 && SMVS_WGRAD3_COUNTED) {
+    if constexpr (S == 1 && GC == 8 && SMVS_WGRAD3_COUNTED) {
         // (every load of this path goes through wg_load: one compiler-visible load whose value is first used inside the row loop would
         //  put the compiler's own vmcnt(0) INTO the loop)
         {
@@ -479,12 +484,12 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
         }
         wg_wait<0>();                                                 // nothing of ours in flight when the next plane starts
     } else {
-        float new_n[S][2][3], g_n[8];
+        float new_n[S][2][3], g_n[GC];
 #pragma unroll
         for (int q = 0; q < S; ++q) load_row(S == 1 ? y0 + 1 : S * y0 + q, new_n[q]);
         load_g(y0, g_n);
         for (int y = y0; y < y1; ++y) {
-            float fresh[S][2][3], g[8];
+            float fresh[S][2][3], g[GC];
 #pragma unroll
             for (int q = 0; q < S; ++q)
 #pragma unroll
@@ -492,7 +497,7 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
 #pragma unroll
                     for (int k = 0; k < 3; ++k) fresh[q][c][k] = new_n[q][c][k];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] = g_n[j];
+            for (int j = 0; j < GC; ++j) g[j] = g_n[j];
 #pragma unroll
             for (int q = 0; q < S; ++q) load_row(y + 1 < y1 ? (S == 1 ? y + 2 : S * (y + 1) + q) : HX, new_n[q]);
             load_g(y + 1, g_n);
@@ -503,12 +508,13 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
     }
     }   // grid planes of this wave
     // reduce over the lanes four values at a time; lanes 15 / 31 / 47 / 63 publish values 4m + {0, 2, 1, 3}; value index (c * 8 + j) * 9 + k
-    auto value = [&](int i) -> float { return acc[i / 72][(i % 72) / 9][i % 9]; };
+    auto value = [&](int i) -> float { return (i % 72) / 9 < GC ? acc[i / 72][(i % 72) / 9 < GC ? (i % 72) / 9 : 0][i % 9] : 0.0f; };
     const int q = lane >> 4;
     const int sel = q == 1 ? 2 : q == 2 ? 1 : q;
     const bool publisher = (lane & 15) == 15;
 #pragma unroll
     for (int m = 0; m < 36; ++m) {
+        if (((4 * m) % 72) / 9 >= GC && ((4 * m + 3) % 72) / 9 >= GC) continue;      // (GC = 1: only the groups that hold channel 0's sums)
         const float v = reduce4_rows(value(4 * m), value(4 * m + 1), value(4 * m + 2), value(4 * m + 3));
         const int i = 4 * m + sel;
         if (publisher) {
@@ -693,8 +699,14 @@ extern "C" SMVS_EXPORT int smvs_conv3d_wgrad(const float* window, const float* g
     const int ndc = p.ndc;
     const long long units = base * ndc * p.nrc;
     if ((units + 3) / 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "too many work units");
-    if (stride == 1) hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
-    else             hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    const dim3 grd((unsigned)((units + 3) / 4));
+    if (Cgrid == 1 && SMVS_WGRAD3_GC1) {
+        if (stride == 1) hipLaunchKernelGGL((conv3d_wgrad_kernel<1, 1>), grd, dim3(256), 0, (hipStream_t)stream, p);
+        else             hipLaunchKernelGGL((conv3d_wgrad_kernel<2, 1>), grd, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        if (stride == 1) hipLaunchKernelGGL((conv3d_wgrad_kernel<1, 8>), grd, dim3(256), 0, (hipStream_t)stream, p);
+        else             hipLaunchKernelGGL((conv3d_wgrad_kernel<2, 8>), grd, dim3(256), 0, (hipStream_t)stream, p);
+    }
     if (workspace) hipLaunchKernelGGL(conv3d_wgrad_fold_kernel, dim3((unsigned)(p.ncp * p.ncog * 3)), dim3(192), 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "conv3d_wgrad launch: %s", hipGetErrorString(e));
