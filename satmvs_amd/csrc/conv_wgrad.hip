@@ -14,6 +14,8 @@
 // 144 sums are reduced over the 64 lanes on the DPP network and lane 63 adds them to dW with float atomics (the caller zeroes
 // dW): the association differs from MIOpen's like any split-K GEMM's does.
 // The bias gradient rides along in the waves of input-channel pair 0.
+#include <type_traits>
+
 #include "smvs_device.h"
 #include "smvs_host.h"
 
@@ -300,6 +302,9 @@ struct Wgrad3Params {
     float* part;                        // null: sums go to dw with float atomics; else (groups, waves per group, 144) partial sums for conv3d_wgrad_fold
 };
 
+#ifndef SMVS_WGRAD3_ROTATE
+#define SMVS_WGRAD3_ROTATE 1            // stride 1: four rotating row slots, loop unrolled by four (0: the sliding window, A/B)
+#endif
 #ifndef SMVS_WGRAD3_GC1
 #define SMVS_WGRAD3_GC1 1               // single-channel grid tensors (the `prob` layer) on the one-grid-channel instance (0: the 8-channel group, A/B)
 #endif
@@ -483,6 +488,51 @@ void conv3d_wgrad_kernel(const Wgrad3Params p)
             step(y + 1, sw[1], sg[1]);
         }
         wg_wait<0>();                                                 // nothing of ours in flight when the next plane starts
+    } else if constexpr (S == 1 && SMVS_WGRAD3_ROTATE) {
+        // Rotating window (round 5): FOUR row slots per window channel -- a step reads slots t, t+1, t+2 (mod 4) as window rows 0..2 and
+        // the row of the NEXT step lands in slot t+3 while it runs -- and two sets of grid values; the loop is unrolled by four so every
+        // slot index is a constant: no window slide, no hand-over copies (the first form spent ~50 of its ~125 vector instructions per row
+        // on those moves).
+        float rw[2][4][3], gs[2][GC];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { rw[c][0][k] = win[c][1][k]; rw[c][1][k] = win[c][2][k]; }      // rows y0 - 1, y0 (the prologue's)
+        auto load_slot = [&](int yy, int slot) __attribute__((always_inline)) {      // window row yy (outside the plane / past the chunk: zeros) -> slot
+            i32x4 r = rx.v;
+            const bool ok = yy >= 0 && yy < HX;
+            r.z = ok ? r.z : 0;
+            const int so = ok ? yy * WX * 4 : 0;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) rw[c][slot][k] = llvm_raw_buffer_load_f32(r, (int)cx[k], c * ch1 + so, 0);
+        };
+        load_slot(y0 + 1, 2);
+        load_g(y0, gs[0]);
+        auto four_steps = [&](const int y, auto guarded) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int yy = y + u;
+                load_slot(yy + 1 < y1 ? yy + 2 : HX, (u + 3) & 3);
+                load_g(yy + 1, gs[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!decltype(guarded)::value || yy < y1) {           // (guarded: the last, partial group of a chunk -- wave-uniform)
+#pragma unroll
+                    for (int j = 0; j < GC; ++j)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                                for (int k = 0; k < 3; ++k)
+                                    acc[c][j][r * 3 + k] = fmaf(gs[u & 1][j], rw[c][(u + r) & 3][k], acc[c][j][r * 3 + k]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // (whole groups without the guards -- four_steps(y, std::false_type{}) -- want 270 registers: 62 spilled at two waves per SIMD)
+        for (int y = y0; y < y1; y += 4) four_steps(y, std::true_type{});
     } else {
         float new_n[S][2][3], g_n[GC];
 #pragma unroll
