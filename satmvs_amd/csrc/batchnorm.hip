@@ -21,6 +21,7 @@ namespace smvs {
 
 constexpr int BN_BLOCK = 256;
 constexpr int BN_CHUNK = BN_BLOCK * 4 * 16;        // elements of one channel a block walks: 16 float4 per thread
+constexpr int BN_UNROLL = 4;                        // ... four of them in flight at a time
 
 __device__ __forceinline__ double bn_wave_sum(double v)
 {
@@ -80,11 +81,19 @@ void bn_stats_kernel(const BnArgs a)
         }
     };
     if (a.vec4) {
-        for (long long i = i0 + threadIdx.x * 4; i < i1; i += BN_BLOCK * 4) {
-            const float4 xv = *reinterpret_cast<const float4*>(a.x + row + i);
-            float4 gv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (BWD) gv = *reinterpret_cast<const float4*>(a.dy + row + i);
-            one(xv.x, gv.x); one(xv.y, gv.y); one(xv.z, gv.z); one(xv.w, gv.w);
+        // four independent 16-byte loads per stream in flight per thread (one at a time left the full-volume layers at ~1.5 TB/s)
+        for (long long i = i0 + threadIdx.x * 4; i < i1; i += BN_BLOCK * 4 * BN_UNROLL) {
+            float4 xv[BN_UNROLL], gv[BN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) {
+                const long long iu = i + (long long)u * BN_BLOCK * 4;
+                const bool in = iu < i1;
+                xv[u] = in ? *reinterpret_cast<const float4*>(a.x + row + iu) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                gv[u] = (BWD && in) ? *reinterpret_cast<const float4*>(a.dy + row + iu) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u)
+                if (i + (long long)u * BN_BLOCK * 4 < i1) { one(xv[u].x, gv[u].x); one(xv[u].y, gv[u].y); one(xv[u].z, gv[u].z); one(xv[u].w, gv[u].w); }
         }
     } else {
         for (long long i = i0 + threadIdx.x; i < i1; i += BN_BLOCK) one(a.x[row + i], BWD ? a.dy[row + i] : 0.0f);
@@ -121,9 +130,18 @@ void bn_apply_kernel(const BnArgs a)
     }
     auto one = [&](float xv) { const float r = fmaf(xv, scale, shift); return a.relu ? fmaxf(r, 0.0f) : r; };
     if (a.vec4) {
-        for (long long i = i0 + threadIdx.x * 4; i < i1; i += BN_BLOCK * 4) {
-            const float4 xv = *reinterpret_cast<const float4*>(a.x + row + i);
-            *reinterpret_cast<float4*>(a.y + row + i) = make_float4(one(xv.x), one(xv.y), one(xv.z), one(xv.w));
+        for (long long i = i0 + threadIdx.x * 4; i < i1; i += BN_BLOCK * 4 * BN_UNROLL) {
+            float4 xv[BN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) {
+                const long long iu = i + (long long)u * BN_BLOCK * 4;
+                xv[u] = iu < i1 ? *reinterpret_cast<const float4*>(a.x + row + iu) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) {
+                const long long iu = i + (long long)u * BN_BLOCK * 4;
+                if (iu < i1) *reinterpret_cast<float4*>(a.y + row + iu) = make_float4(one(xv[u].x), one(xv[u].y), one(xv[u].z), one(xv[u].w));
+            }
         }
     } else {
         for (long long i = i0 + threadIdx.x; i < i1; i += BN_BLOCK) a.y[row + i] = one(a.x[row + i]);
@@ -150,10 +168,20 @@ void bn_bwd_dx_kernel(const BnArgs a)
         return scale * (g - t1 - xh * t2);
     };
     if (a.vec4) {
-        for (long long i = i0 + threadIdx.x * 4; i < i1; i += BN_BLOCK * 4) {
-            const float4 xv = *reinterpret_cast<const float4*>(a.x + row + i);
-            const float4 gv = *reinterpret_cast<const float4*>(a.dy + row + i);
-            *reinterpret_cast<float4*>(a.dx + row + i) = make_float4(one(xv.x, gv.x), one(xv.y, gv.y), one(xv.z, gv.z), one(xv.w, gv.w));
+        for (long long i = i0 + threadIdx.x * 4; i < i1; i += BN_BLOCK * 4 * BN_UNROLL) {
+            float4 xv[BN_UNROLL], gv[BN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) {
+                const long long iu = i + (long long)u * BN_BLOCK * 4;
+                const bool in = iu < i1;
+                xv[u] = in ? *reinterpret_cast<const float4*>(a.x + row + iu) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                gv[u] = in ? *reinterpret_cast<const float4*>(a.dy + row + iu) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) {
+                const long long iu = i + (long long)u * BN_BLOCK * 4;
+                if (iu < i1) *reinterpret_cast<float4*>(a.dx + row + iu) = make_float4(one(xv[u].x, gv[u].x), one(xv[u].y, gv[u].y), one(xv[u].z, gv[u].z), one(xv[u].w, gv[u].w));
+            }
         }
     } else {
         for (long long i = i0 + threadIdx.x; i < i1; i += BN_BLOCK) a.dx[row + i] = one(a.x[row + i], a.dy[row + i]);
