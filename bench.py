@@ -142,6 +142,38 @@ def measured_traffic(workload):
     return None
 
 
+def tile_build(_lib, feats, rpc, depth, out, V, C, D, H, W, stream, plane_coef=True):
+    """(step, kernel, fold) of one tile through the C ABI.  step = what a caller issues per tile: smvs_rpc_plane_coef (folds the
+    source cubics at every plane's height: one tiny launch) + smvs_rpc_costvol_fwd_pc (the build; its waves take the bivariate
+    cubics where their heights are their planes', the trivariate ones elsewhere).  kernel = the build alone on already folded
+    coefficients (the dominant kernel, what the roofline is quoted on).  plane_coef=False: smvs_rpc_costvol_fwd, the
+    trivariate chain for every voxel (round 5's path)."""
+    srcs = _lib.ptr_array(feats[1:])
+    keep = [srcs]
+    if not plane_coef:
+        def kernel():
+            _lib.call("smvs_rpc_costvol_fwd", _lib.ptr(feats[0]), srcs, V - 1, _lib.ptr(rpc), _lib.ptr(depth), 1,
+                      _lib.ptr(out), 1, C, D, H, W, 0, D, D, 0, stream)
+        kernel.keep = keep
+        return kernel, kernel, (lambda: None)
+    pc = torch.empty(_lib.load().smvs_rpc_plane_coef_bytes(1, V - 1, D) // 8, dtype=torch.float64, device=out.device)
+    keep.append(pc)
+
+    def fold():
+        _lib.call("smvs_rpc_plane_coef", _lib.ptr(rpc), _lib.ptr(depth), 1, _lib.ptr(pc), 1, V - 1, D, H, W, 0, D, stream)
+
+    def kernel():
+        _lib.call("smvs_rpc_costvol_fwd_pc", _lib.ptr(feats[0]), srcs, V - 1, _lib.ptr(rpc), _lib.ptr(depth), 1, _lib.ptr(pc),
+                  _lib.ptr(out), 1, C, D, H, W, 0, D, D, 0, stream)
+
+    def step():
+        fold()
+        kernel()
+    step.keep = keep
+    fold()
+    return step, kernel, fold
+
+
 def prewarm(step, seconds):
     """Untimed launches for `seconds` of wall clock: the timed region then runs at steady (power-limited) clocks
     whatever --warmup says; a cold MI355X ramps for ~0.2 s and would charge that to the first launches."""
@@ -218,17 +250,16 @@ def side_workloads(dev, stream):
         lo, hi = SIDE_HEIGHTS[name]
         depth = torch.linspace(lo, hi, D, dtype=torch.float32).view(1, D, 1, 1).expand(1, D, H, W).contiguous().to(dev)
         out = torch.empty((1, C, D, H, W), dtype=torch.float32, device=dev)
-        srcs = _lib.ptr_array(feats[1:])
-
-        def step():
-            _lib.call("smvs_rpc_costvol_fwd", _lib.ptr(feats[0]), srcs, V - 1, _lib.ptr(rpc), _lib.ptr(depth), 1,
-                      _lib.ptr(out), 1, C, D, H, W, 0, D, D, 0, stream)
+        step, kernel, _ = tile_build(_lib, feats, rpc, depth, out, V, C, D, H, W, stream)
         prewarm(step, 0.3)                                      # like the headline: the inputs were just built on the host, the clocks have dropped
-        _, ms = time_steps(step, 30)
+        _, ms_step = time_steps(step, 30)
+        _, ms = time_steps(kernel, 30)
         bpv = algorithmic_bytes_per_voxel(V, C, D)
-        extra[name] = {"kernel": kernel_name(V, C, D), "ms": round(ms, 4), "prewarm_seconds": 0.3, "Mvox/s": round(D * H * W / ms / 1e3, 1),
-                       "roofline_frac": round(bpv * D * H * W / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        del feats, out
+        extra[name] = {"kernel": kernel_name(V, C, D), "ms": round(ms, 4), "ms_with_fold": round(ms_step, 4), "prewarm_seconds": 0.3,
+                       "Mvox/s": round(D * H * W / ms_step / 1e3, 1),
+                       "roofline_frac": round(bpv * D * H * W / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "note": "ms / roofline_frac: the build kernel on folded plane coefficients; ms_with_fold / Mvox/s: smvs_rpc_plane_coef + the build, as a caller issues them"}
+        del feats, out, step, kernel
     # cfg2 with per-pixel jittered hypotheses (SURVEY 8d's second height variant: what cascade stages 2-3 hand over --
     # plane + N(0, 2 m) per pixel, wider tap boxes than plane-constant heights)
     V, C, D, H, W = WORKLOADS["cfg2_rpc_3view_768x384x64_c32"]
@@ -239,10 +270,11 @@ def side_workloads(dev, stream):
     srcs = _lib.ptr_array(feats[1:])
 
     plain = make_inputs(V, C, D, D, 0, H, W, dev)[2]
+    steps_by_depth = {id(plain): tile_build(_lib, feats, rpc, plain, out, V, C, D, H, W, stream)[0],
+                      id(depth): tile_build(_lib, feats, rpc, depth, out, V, C, D, H, W, stream)[0]}
 
-    def launch_with(dd):
-        _lib.call("smvs_rpc_costvol_fwd", _lib.ptr(feats[0]), srcs, V - 1, _lib.ptr(rpc), _lib.ptr(dd), 1,
-                  _lib.ptr(out), 1, C, D, H, W, 0, D, D, 0, stream)
+    def launch_with(dd):                                        # fold + build, whatever the heights are (the jittered tile's waves fail the
+        steps_by_depth[id(dd)]()                                # plane check and evaluate the trivariate cubics)
     # the kernel runs at the board power limit, so a figure depends on what ran before it: plain and jittered launches ALTERNATE
     # here (same thermal state) and the record carries both
     for _ in range(20):
@@ -259,17 +291,35 @@ def side_workloads(dev, stream):
         "kernel": kernel_name(V, C, D), "ms": round(ms, 4), "Mvox/s": round(D * H * W / ms / 1e3, 1),
         "roofline_frac": round(bpv * D * H * W / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "ms_plain_heights_interleaved": round(ms_plain, 4),
-        "note": "same tile, heights = plane + N(0, 2 m) per pixel; timed alternating with plain-height launches (same thermal state)"}
+        "note": "same tile, heights = plane + N(0, 2 m) per pixel; timed alternating with plain-height launches (same thermal state); both "
+                "are smvs_rpc_plane_coef + smvs_rpc_costvol_fwd_pc: the jittered tile's waves fail the plane check and take the trivariate cubics"}
+    # the trivariate chain on the plain tile (smvs_rpc_costvol_fwd = no folded coefficients: round 5's path), alternating with the default
+    tri = tile_build(_lib, feats, rpc, plain, out, V, C, D, H, W, stream, plane_coef=False)[0]
+    for _ in range(20):
+        launch_with(plain); tri()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(40)]
+    torch.cuda.synchronize()
+    for a, b, c in evs:
+        a.record(); launch_with(plain); b.record(); tri(); c.record()
+    torch.cuda.synchronize()
+    ms_pc = float(np.mean([a.elapsed_time(b) for a, b, c in evs]))
+    ms_tri = float(np.mean([b.elapsed_time(c) for a, b, c in evs]))
+    extra["cfg2_trivariate_chain_768x384x64_c32"] = {
+        "ms": round(ms_tri, 4), "roofline_frac": round(bpv * D * H * W / (ms_tri * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "ms_plane_coefficients_interleaved": round(ms_pc, 4),
+        "note": "smvs_rpc_costvol_fwd (every voxel through the 20-coefficient cubics) alternating with fold + smvs_rpc_costvol_fwd_pc on the same tile"}
     # the other arithmetic instance on the same tile (smvs_set_arith): launches ALTERNATE with the default's, and the two volumes
     # are compared voxel by voxel
     default_mode = _lib.get_arith()
     other = "exact" if default_mode == "fused" else "fused"
     out2 = torch.empty_like(out)
 
+    builds = {id(out): tile_build(_lib, feats, rpc, plain, out, V, C, D, H, W, stream)[0],
+              id(out2): tile_build(_lib, feats, rpc, plain, out2, V, C, D, H, W, stream)[0]}
+
     def launch_mode(mode, dst):
         _lib.set_arith(mode)
-        _lib.call("smvs_rpc_costvol_fwd", _lib.ptr(feats[0]), srcs, V - 1, _lib.ptr(rpc), _lib.ptr(plain), 1,
-                  _lib.ptr(dst), 1, C, D, H, W, 0, D, D, 0, stream)
+        builds[id(dst)]()
     try:
         for _ in range(20):
             launch_mode(default_mode, out); launch_mode(other, out2)
@@ -292,7 +342,7 @@ def side_workloads(dev, stream):
                 other, "the reference's float32 rounding sequence, bit-identical to the oracle" if other == "exact" else "fused arithmetic", default_mode)}
     finally:
         _lib.set_arith(default_mode)
-    del plain, out2
+    del plain, out2, builds, steps_by_depth, tri
     del feats, out, depth
     # cfg5: pinhole (homography) volume, 3-view 768x384x64, C=32
     V, C, D, H, W = 3, 32, 64, 384, 768
@@ -476,15 +526,14 @@ def cfg4_strong(dev, stream, rank, world, dist, barrier):
     nd = hi - lo
     feats, rpc, depth = make_inputs(V, C, nd, D, lo, H, W, dev)
     out = torch.empty((1, C, max(nd, 1), H, W), dtype=torch.float32, device=dev)
-    srcs = _lib.ptr_array(feats[1:])
+    build = tile_build(_lib, feats, rpc, depth, out, V, C, nd, H, W, stream)[0] if nd > 0 else None
     state = torch.rand((3, 1, H, W), dtype=torch.float64, device=dev) if world > 1 else None
 
     ex_stream = torch.cuda.Stream(device=dev) if state is not None else None
 
     def step(overlap=True):
         if nd > 0:
-            _lib.call("smvs_rpc_costvol_fwd", _lib.ptr(feats[0]), srcs, V - 1, _lib.ptr(rpc), _lib.ptr(depth), 1,
-                      _lib.ptr(out), 1, C, nd, H, W, 0, nd, nd, 0, stream)
+            build()                                             # smvs_rpc_plane_coef + smvs_rpc_costvol_fwd_pc
         if state is not None and overlap:                       # see main(): the exchange trails the step's kernel on its own stream
             ex_stream.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(ex_stream):
@@ -563,14 +612,13 @@ def main():
         h0, h1 = SIDE_HEIGHTS[args.workload]
         depth = torch.linspace(h0, h1, D, dtype=torch.float32)[lo:hi].view(1, D_local, 1, 1).expand(1, D_local, H, W).contiguous().to(dev)
     out = torch.empty((1, C, max(D_local, 1), H, W), dtype=torch.float32, device=dev)
-    srcs = _lib.ptr_array(feats[1:])
     stream = _lib.current_stream(dev)
     state = torch.rand((3, 1, H, W), dtype=torch.float64, device=dev) if world > 1 else None
-
-    def launch():
-        if D_local > 0:
-            _lib.call("smvs_rpc_costvol_fwd", _lib.ptr(feats[0]), srcs, V - 1, _lib.ptr(rpc), _lib.ptr(depth), 1,
-                      _lib.ptr(out), 1, C, D_local, H, W, 0, D_local, D_local, 0, stream)
+    # One step = what a caller issues per tile: smvs_rpc_plane_coef (the source cubics folded at every plane's height, one tiny
+    # launch) + smvs_rpc_costvol_fwd_pc (the build).  Both are inside the timed region; `kernel` (the build alone) is timed
+    # separately for the roofline of the dominant kernel.
+    use_pc = os.environ.get("SMVS_BENCH_TRIVARIATE") != "1"       # A/B only: 1 = smvs_rpc_costvol_fwd, the trivariate chain for every voxel
+    launch, kernel, _ = tile_build(_lib, feats, rpc, depth, out, V, C, D_local, H, W, stream, plane_coef=use_pc) if D_local > 0 else ((lambda: None),) * 3
 
     # A scene is a stream of tiles: the exchange of tile k waits for tile k's kernel (stream order through wait_stream) but tile
     # k+1's kernel does not wait for it -- it runs on its own stream, RCCL's kernels under the next build.  Exchanges stay in
@@ -592,8 +640,9 @@ def main():
     for _ in range(args.warmup):
         step()
     elapsed, _ = time_steps(step, args.steps, barrier)
-    # the kernel alone (no exchange) for the roofline: same launches, HIP events around each
-    _, kern_ms = time_steps(launch, min(args.steps, 100))
+    # the dominant kernel alone (no fold, no exchange) for the roofline: HIP events around each launch; and fold + build together
+    _, kern_ms = time_steps(kernel, min(args.steps, 100))
+    _, both_ms = time_steps(launch, min(args.steps, 100))
 
     exchange = None
     if dist is not None:
@@ -649,7 +698,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel_name(V, C, D_local),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload) if world == 1 else None,
-                         "bytes_per_voxel": bpv, "kernel_ms": round(kern_ms, 4)},
+                         "bytes_per_voxel": bpv, "kernel_ms": round(kern_ms, 4), "fold_plus_kernel_ms": round(both_ms, 4),
+                         "note": "one step = smvs_rpc_plane_coef (fold of the source cubics per plane, ~2 us) + smvs_rpc_costvol_fwd_pc; `value` and "
+                                 "ms_per_step time both, kernel_ms / achieved / frac are the build kernel alone (HIP events on its stream)"},
         }
         line["devices"] = ids
         if exchange is not None:

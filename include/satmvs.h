@@ -124,6 +124,31 @@ int smvs_homo_costvol_fwd(const float* ref_fea, const float* const* src_fea, int
                           const double* proj, const float* depth, int depth_is_4d, float* out_var,
                           int B, int C, int D, int H, int W,
                           int d_begin, int d_end, int D_out, int d_out_off, void* stream);
+/* ---- plane-constant heights: collapsed source cubics (round 6) -------------------------------------
+ * Stage 1 of every reference cascade sweeps PLANE-CONSTANT heights (networks/casred.py:138-149,
+ * modules/depth_range.py:23-42; modules/warping.py:329-332 accepts the (B,D) form, and the broadcast (B,D,H,W)
+ * form carries the same numbers).  With a plane's height fixed, RPC_Obj2Photo's four trivariate cubics per source
+ * view (modules/warping.py:218-252, RPC_PLH_COEF :183-207) are bivariate in (lat, lon): 10 coefficients instead of 20.
+ *   smvs_rpc_plane_coef        folds them once per (batch item, plane, source) into `plane_coef`, a caller-owned device
+ *                              buffer of smvs_rpc_plane_coef_bytes(B, n_src, D) bytes, 64-byte aligned (doubles: the planes'
+ *                              heights -- depth[b,d], or depth[b,d,0,0] of a 4-D tensor -- at b D + d, padded to a multiple
+ *                              of 8; then [b][source][cubic][d][6]: the H-dependent 6 of the 10 bivariate coefficients of each
+ *                              cubic); only planes [d_begin, d_end) are written (a plane-at-a-time caller folds what it builds).
+ *   smvs_rpc_costvol_fwd_pc    = smvs_rpc_costvol_fwd with that buffer (NULL: identical to smvs_rpc_costvol_fwd).  Every
+ *                              wave compares its own heights with the folded planes' and takes the bivariate cubics
+ *                              only when all of them match; any other wave (per-voxel hypotheses, a jittered pixel, NaN)
+ *                              evaluates the trivariate cubics as before -- the result never depends on trusting the caller.
+ * Same polynomials re-associated: source coordinates move by float64 rounding (~1e-13 px), volumes stay inside every
+ * tolerance of smvs_rpc_costvol_fwd.  `plane_coef` must have been prepared from the same rpc / depth / D; it can be
+ * reused for any number of launches (plane windows, shards) of that geometry.  rpc (B,V,170), V = n_src + 1. */
+size_t smvs_rpc_plane_coef_bytes(int B, int n_src, int D);
+int smvs_rpc_plane_coef(const double* rpc, const float* depth, int depth_is_4d, double* plane_coef,
+                        int B, int n_src, int D, int H, int W, int d_begin, int d_end, void* stream);
+int smvs_rpc_costvol_fwd_pc(const float* ref_fea, const float* const* src_fea, int n_src,
+                            const double* rpc, const float* depth, int depth_is_4d, const double* plane_coef,
+                            float* out_var, int B, int C, int D, int H, int W,
+                            int d_begin, int d_end, int D_out, int d_out_off, void* stream);
+
 /* The same two launches with the heights generated in the kernel (see smvs_height_gen above). */
 int smvs_rpc_costvol_fwd_gen(const float* ref_fea, const float* const* src_fea, int n_src,
                              const double* rpc, const smvs_height_gen* gen, float* out_var,

@@ -22,6 +22,8 @@ _vp, _i, _sz, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 _SIGNATURES = {
     "smvs_rpc_costvol_fwd": [_vp, _vp, _i, _vp, _vp, _i, _vp] + [_i] * 9 + [_vp],
     "smvs_homo_costvol_fwd": [_vp, _vp, _i, _vp, _vp, _i, _vp] + [_i] * 9 + [_vp],
+    "smvs_rpc_plane_coef": [_vp, _vp, _i, _vp] + [_i] * 7 + [_vp],
+    "smvs_rpc_costvol_fwd_pc": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp] + [_i] * 9 + [_vp],
     "smvs_rpc_warp_fwd": [_vp, _vp, _vp, _vp, _i, _vp] + [_i] * 5 + [_vp],
     "smvs_rpc_warp_bwd": [_vp, _vp, _vp, _vp, _i, _vp] + [_i] * 5 + [_vp],
     "smvs_homo_warp_fwd": [_vp, _vp, _vp, _i, _vp] + [_i] * 5 + [_vp],
@@ -71,7 +73,7 @@ _SIGNATURES = {
     "smvs_featnet_pack_weights": [_vp, _i, _i, _vp, _vp],
     "smvs_featnet_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 5 + [_vp],
 }
-_SIZE_FUNCS = {"smvs_red_packed_floats": [_i], "smvs_red_workspace_bytes": [_i] * 4,
+_SIZE_FUNCS = {"smvs_rpc_plane_coef_bytes": [_i] * 3, "smvs_red_packed_floats": [_i], "smvs_red_workspace_bytes": [_i] * 4,
                "smvs_red_pred_workspace_bytes": [_i] * 4, "smvs_costreg_packed_floats": [_i],
                "smvs_costreg_workspace_bytes": [_i] * 5, "smvs_featnet_packed_floats": [_i] * 2,
                "smvs_featnet_workspace_bytes": [_i] * 5, "smvs_conv3x3_packed_floats": [_i] * 2,

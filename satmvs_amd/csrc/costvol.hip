@@ -43,10 +43,35 @@ static std::atomic<int> g_arith{SMVS_ARITH_FUSED};
 
 hipError_t launch_costvol_fused(int geo_kind, const CostVolParams& p, hipStream_t st);     // costvol_fused.hip
 
+// Folds every source view's four direct cubics at the normalised height of every plane (smvs_device.h, "plane-constant
+// heights"): one thread per (batch item, plane, source, cubic).  The plane's height is depth[b, d] or, for a (B,D,H,W)
+// tensor, the height of the plane's first pixel -- the consuming kernel checks its own heights against record[0].
+__global__ __launch_bounds__(64)
+void rpc_plane_coef_kernel(const double* __restrict__ rpc, const float* __restrict__ depth, int is4d, double* __restrict__ pc,
+                           int B, int n_src, int D, size_t HW, int d_begin, int nd)
+{
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= B * nd * n_src * 4) return;
+    const int i = idx & 3, s = (idx >> 2) % n_src, bp = idx / (4 * n_src), b = bp / nd, bd = b * D + d_begin + (bp - b * nd);
+    const float hf = is4d ? depth[(size_t)bd * HW] : depth[bd];
+    const double* r = rpc + ((size_t)b * (n_src + 1) + s + 1) * RPC_LEN;
+    const double Hn = ((double)hf - r[I_H_OFF]) * (1.0 / r[I_H_SCALE]);       // as o2p_xn normalises it
+    const int base = i == 0 ? I_SNUM : i == 1 ? I_SDEN : i == 2 ? I_LNUM : I_LDEN;
+    const double* c = r + base;
+    double* o = pc + pc_header_doubles((size_t)B * D) + pc_offset(b, s, i, bd - b * D, n_src, D);
+    o[0] = fma(Hn, fma(Hn, fma(Hn, c[19], c[9]), c[3]), c[0]);
+    o[1] = fma(Hn, fma(Hn, c[13], c[5]), c[1]);
+    o[2] = fma(Hn, fma(Hn, c[16], c[6]), c[2]);
+    o[3] = fma(Hn, c[10], c[4]);
+    o[4] = fma(Hn, c[17], c[7]);
+    o[5] = fma(Hn, c[18], c[8]);
+    if (s == 0 && i == 0) pc[bd] = (double)hf;
+}
+
 static int costvol_fwd(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,
                        const double* geo, const float* depth, int depth_is_4d, const smvs_height_gen* gen, float* out,
                        int B, int C, int D, int H, int W, int d_begin, int d_end, int D_out, int d_out_off,
-                       void* stream)
+                       void* stream, const double* plane_coef = nullptr)
 {
     if (!ref_fea || !src_fea || !geo || (!depth && !gen) || !out) return fail(SMVS_ERR_ARG, "null pointer argument");
     if (n_src < 1 || n_src > MAX_SRC) return fail(SMVS_ERR_ARG, "n_src must be in [1,7] (2..8 views), got %d", n_src);
@@ -61,7 +86,7 @@ static int costvol_fwd(int geo_kind, const float* ref_fea, const float* const* s
     CostVolParams p{};
     p.ref = ref_fea;
     for (int s = 0; s < n_src; ++s) p.src[s] = src_fea[s];
-    p.geo = geo; p.depth = depth; p.out = out;
+    p.geo = geo; p.depth = depth; p.out = out; p.pc = plane_coef;
     p.B = B; p.V = n_src + 1; p.C = C; p.D = D; p.H = H; p.W = W;
     p.d_begin = d_begin; p.d_end = d_end; p.D_out = D_out; p.d_out_off = d_out_off;
     // arithmetic of this call: the bits the call carries (depth_is_4d / gen->arith), else the process default
@@ -93,11 +118,11 @@ static int costvol_fwd(int geo_kind, const float* ref_fea, const float* const* s
 extern "C" {
 
 #ifdef SMVS_TIMING
-SMVS_EXPORT int smvs_debug_timing(unsigned long long* out8, int reset)
+SMVS_EXPORT int smvs_debug_timing(unsigned long long* out12, int reset)
 {
     hipDeviceSynchronize();
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(smvs::smvs_timing), 64) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(smvs::smvs_timing), z, 64) != hipSuccess) return 1; }
+    if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(smvs::smvs_timing), 96) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[12] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(smvs::smvs_timing), z, 96) != hipSuccess) return 1; }
     return 0;
 }
 #endif
@@ -117,6 +142,39 @@ SMVS_EXPORT int smvs_rpc_costvol_fwd(const float* ref_fea, const float* const* s
 {
     return smvs::costvol_fwd(0, ref_fea, src_fea, n_src, rpc, depth, depth_is_4d, nullptr, out_var,
                              B, C, D, H, W, d_begin, d_end, D_out, d_out_off, stream);
+}
+
+SMVS_EXPORT size_t smvs_rpc_plane_coef_bytes(int B, int n_src, int D)
+{
+    if (B < 1 || D < 1 || n_src < 1 || n_src > smvs::MAX_SRC) return 0;
+    return smvs::pc_total_doubles(B, n_src, D) * sizeof(double);
+}
+
+SMVS_EXPORT int smvs_rpc_plane_coef(const double* rpc, const float* depth, int depth_is_4d, double* plane_coef,
+                                    int B, int n_src, int D, int H, int W, int d_begin, int d_end, void* stream)
+{
+    using namespace smvs;
+    if (!rpc || !depth || !plane_coef) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if (n_src < 1 || n_src > MAX_SRC) return fail(SMVS_ERR_ARG, "n_src must be in [1,7] (2..8 views), got %d", n_src);
+    if (B < 1 || D < 1 || H < 1 || W < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
+    if (d_begin < 0 || d_end > D || d_begin > d_end) return fail(SMVS_ERR_ARG, "bad plane range [%d,%d) of %d", d_begin, d_end, D);
+    if ((long long)B * D * n_src * 4 >= (1ll << 31)) return fail(SMVS_ERR_ARG, "too many planes");
+    if (d_begin == d_end) return SMVS_OK;
+    const int n = B * (d_end - d_begin) * n_src * 4;
+    hipLaunchKernelGGL(rpc_plane_coef_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, rpc, depth,
+                       (depth_is_4d & ~SMVS_CALL_ARITH_MASK) ? 1 : 0, plane_coef, B, n_src, D, (size_t)H * W, d_begin, d_end - d_begin);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "rpc_plane_coef launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
+}
+
+SMVS_EXPORT int smvs_rpc_costvol_fwd_pc(const float* ref_fea, const float* const* src_fea, int n_src,
+                                        const double* rpc, const float* depth, int depth_is_4d, const double* plane_coef,
+                                        float* out_var, int B, int C, int D, int H, int W,
+                                        int d_begin, int d_end, int D_out, int d_out_off, void* stream)
+{
+    return smvs::costvol_fwd(0, ref_fea, src_fea, n_src, rpc, depth, depth_is_4d, nullptr, out_var,
+                             B, C, D, H, W, d_begin, d_end, D_out, d_out_off, stream, plane_coef);
 }
 
 SMVS_EXPORT int smvs_rpc_costvol_fwd_gen(const float* ref_fea, const float* const* src_fea, int n_src,

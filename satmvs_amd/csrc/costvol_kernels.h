@@ -31,6 +31,8 @@ struct CostVolParams {
     int group_rows;                 // ... and tile rows per group of the chunk-major order (<= 1: row by row)
     float rV, r_half_wm1, r_half_hm1;   // RN(1/V), RN(1/((W-1)/2)), RN(1/((H-1)/2)) in float32, divided once on the host
     float kw;                       // fused arithmetic (AR = 1): factor on the tap weights and the ref feature, see smvs_device.h
+    const double* pc;               // rpc only, may be null: per-plane folded source cubics (smvs_rpc_plane_coef; layout: smvs_device.h,
+                                    // "plane-constant heights")
 };
 
 // AR, the arithmetic of the variance: 0 = the reference's float32 rounding sequence, 1 = fused (contract tolerance)
@@ -258,6 +260,9 @@ constexpr int DM_NBUF = 2;
 #ifndef SMVS_O2P_PLANES
 #define SMVS_O2P_PLANES 4          // planes per evaluation pass of a source view's cubics
 #endif
+#ifndef SMVS_PC_PLANES
+#define SMVS_PC_PLANES 4           // ... and of the bivariate (plane-constant) chain: 6 folded coefficients per plane and cubic in SGPRs
+#endif
 #ifndef SMVS_WPS_DP8
 #define SMVS_WPS_DP8 2                // waves per SIMD the 8-plane instance is compiled for
 #endif
@@ -291,7 +296,7 @@ constexpr int STORE_AUX = SMVS_STORE_AUX;
 // profiling builds only (tools/ab_build.sh x -DSMVS_TIMING): per-wave phase stamps in shader clocks, read back through
 // smvs_debug_timing().  [0] geometry phase, [1] box + setup, [2] channel-pair loop, [3] of which spent in the vmcnt waits,
 // [4] of which in the lgkmcnt waits of the last plane, [5] DMA issue
-__device__ unsigned long long smvs_timing[8];
+__device__ unsigned long long smvs_timing[12];      // [8] heights + plane check (prefetch), [9] reciprocal scales + ref view, [10] source views + taps
 __device__ __forceinline__ unsigned long long now() { unsigned long long t = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return t; }
 #define SMVS_T(...) __VA_ARGS__
 #else
@@ -430,6 +435,29 @@ void costvol_dma_kernel(const CostVolParams p)
         }
     }
 
+    // Plane-constant heights?  Every lane's DP heights equal the heights the coefficients were folded for: the whole wave
+    // takes the bivariate source cubics.  Wave-uniform; a single differing lane (per-voxel hypotheses, a NaN) sends the
+    // wave down the trivariate chain.  The coefficient runs of the wave's planes are pulled into the scalar cache first, in
+    // one block of back-to-back touches that overlaps the height loads above.
+    bool use_pc = false;
+    const cgeo_t pc_co = as_cgeo(p.pc) + pc_header_doubles((size_t)p.B * p.D);      // coefficient area, pc_offset()
+    const int dg0 = min(dg, p.d_end - 1);
+    if constexpr (GEO == 0) {
+        if (p.pc != nullptr && p.depth_is_4d != HEIGHT_GENERATED && !(SMVS_ABLATE & 4) && np > 0) {      // (np <= 0: shared form, a wave past the last plane only stages)
+            const int npl = min(DP, p.d_end - dg);
+            const cgeo_t hdr = scalar_prefetch(pc_co + pc_offset(b, 0, 0, dg0, NSRC, p.D), (uint32_t)(npl * PC_PER_CUBIC * 8),
+                                               (uint32_t)(p.D * PC_PER_CUBIC * 8), 4 * NSRC, as_cgeo(p.pc) + (size_t)b * p.D + dg0);
+            double hpl[DP];
+#pragma unroll
+            for (int pl = 0; pl < DP; ++pl) hpl[pl] = hdr[min(pl, p.d_end - 1 - dg0)];
+            bool eq = true;
+#pragma unroll
+            for (int pl = 0; pl < DP; ++pl) eq = eq && (hf[pl] == (float)hpl[pl]);
+            use_pc = __ballot(!eq) == 0ull;
+        }
+    }
+
+    SMVS_T(const unsigned long long t_chk = now();)
     // ---- A: taps of the group's planes -----------------------------------------------------------
     TapD tap[DP][NSRC];
     uint32_t txy[DP][NSRC];
@@ -462,13 +490,9 @@ void costvol_dma_kernel(const CostVolParams p)
         // ref view, image -> ground: plane-invariant part once per pixel, Horner in the height per plane
         P2OPix px;
         p2o_pixel(geo_b, ref_n, fx, fy, px);
-#pragma unroll
-        for (int pl = 0; pl < DP; ++pl) {
-            p2o_plane(launder(geo_b), ref_n, px, (double)hf[pl], lat[pl], lon[pl]);
-            pin(lat[pl]); pin(lon[pl]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        p2o_planes<DP>(launder(geo_b), ref_n, px, hf, lat, lon);
     }
+    SMVS_T(const unsigned long long t_ref = now();)
     // PQ planes per pass: every source coefficient is fetched into SGPRs once for all of them
     constexpr int PQ = DP < SMVS_O2P_PLANES ? DP : SMVS_O2P_PLANES;
     static_assert(DP % PQ == 0, "planes per pass");
@@ -486,10 +510,18 @@ void costvol_dma_kernel(const CostVolParams p)
                 }
             } else if (GEO == 0) {
                 double samp[PQ], line[PQ];
-                double hh[PQ];
+                if (use_pc) {
+                    constexpr int PQC = PQ < SMVS_PC_PLANES ? PQ : SMVS_PC_PLANES;     // planes per pass of the bivariate chain
 #pragma unroll
-                for (int u = 0; u < PQ; ++u) hh[u] = (double)hf[pq + u];
-                o2p_xn<PQ>(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat + pq, lon + pq, hh, samp, line);
+                    for (int v = 0; v < PQ; v += PQC)
+                        o2p_pc_xn<PQC>(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat + pq + v, lon + pq + v,
+                                       pc_co + pc_offset(b, s, 0, dg + pq + v, NSRC, p.D), (size_t)p.D * PC_PER_CUBIC, samp + v, line + v);
+                } else {
+                    double hh[PQ];
+#pragma unroll
+                    for (int u = 0; u < PQ; ++u) hh[u] = (double)hf[pq + u];
+                    o2p_xn<PQ>(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat + pq, lon + pq, hh, samp, line);
+                }
 #pragma unroll
                 for (int u = 0; u < PQ; ++u) {
                     gxs[u] = div_half_int((float)samp[u], half_wm1, r_half_wm1) - 1.0f;
@@ -540,6 +572,25 @@ void costvol_dma_kernel(const CostVolParams p)
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if constexpr (GEO == 0 && DP > 1) {
+        // A group cut short by the end of the sweep: its tail planes carry the last plane's height, but a pass of the
+        // bivariate chain read the records of the planes BEHIND the sweep for them -- give them the last plane's taps
+        // (what the trivariate chain computes for them; they are never stored).  Wave-uniform, taken by tail groups only.
+        if (use_pc && np < DP) {
+#pragma unroll
+            for (int pl = 1; pl < DP; ++pl)
+                if (pl >= np) {
+#pragma unroll
+                    for (int s = 0; s < NSRC; ++s) {
+                        tap[pl][s] = tap[pl - 1][s];
+                        txy[pl][s] = txy[pl - 1][s];
+                        const uint32_t bit = (okmask >> ((pl - 1) * NSRC + s)) & 1u;
+                        okmask = (okmask & ~(1u << (pl * NSRC + s))) | (bit << (pl * NSRC + s));
+                    }
+                }
+        }
     }
 
     SMVS_T(const unsigned long long t_geo = now();)
@@ -884,6 +935,7 @@ void costvol_dma_kernel(const CostVolParams p)
                 atomicAdd(&smvs_timing[0], t_geo - t_start); atomicAdd(&smvs_timing[1], t_setup - t_geo);
                 atomicAdd(&smvs_timing[2], t_end - t_setup); atomicAdd(&smvs_timing[3], t_vm);
                 atomicAdd(&smvs_timing[5], t_dma); atomicAdd(&smvs_timing[4], t_st); atomicAdd(&smvs_timing[7], 1ull);
+                atomicAdd(&smvs_timing[8], t_chk - t_start); atomicAdd(&smvs_timing[9], t_ref - t_chk); atomicAdd(&smvs_timing[10], t_geo - t_ref);
             }
         }
 #endif
@@ -907,7 +959,12 @@ void costvol_dma_kernel(const CostVolParams p)
             for (int s = 0; s < NSRC; ++s) {
                 if (GEO == 0) {
                     double samp, line;
-                    o2p_xn<1>(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], &latp, &lonp, &h, &samp, &line);
+                    if (use_pc) {
+                        o2p_pc_xn<1>(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], &latp, &lonp,
+                                     pc_co + pc_offset(b, s, 0, d, NSRC, p.D), (size_t)p.D * PC_PER_CUBIC, &samp, &line);
+                    } else {
+                        o2p_xn<1>(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], &latp, &lonp, &h, &samp, &line);
+                    }
                     tp[s] = tap_from_pixel((float)samp, (float)line, H, W, half_wm1, half_hm1);
                 } else {
                     const cgeo_t P = geo_d + s * 16;

@@ -277,6 +277,31 @@ __device__ __forceinline__ void p2o_plane(cgeo_t r, const RpcInv& n, const P2OPi
     lon = fma(qo, r[I_LON_SCALE], r[I_LON_OFF]);
 }
 
+// The same for N planes of the pixel: the nine wave-uniform constants (height offset, the four c19, output scales and
+// offsets) are fetched once for all of them -- p2o_plane in a loop re-reads them per plane behind three dependent
+// scalar-load waits each.
+template <int N>
+__device__ __forceinline__ void p2o_planes(cgeo_t r, const RpcInv& n, const P2OPix& o, const float* hei, double* lat, double* lon)
+{
+    const double h_off = r[I_H_OFF];
+    const double c19[4] = {r[I_LATNUM + 19], r[I_LATDEN + 19], r[I_LONNUM + 19], r[I_LONDEN + 19]};
+    const double lat_s = r[I_LAT_SCALE], lon_s = r[I_LON_SCALE];
+    const double lat_o = to_vgpr(r[I_LAT_OFF]), lon_o = to_vgpr(r[I_LON_OFF]);      // one copy for the N planes
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const double z = ((double)hei[u] - h_off) * n.h;
+        double q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = fma(z, fma(z, fma(z, c19[i], o.C[i]), o.B[i]), o.A[i]);
+        double qa, qo;
+        div_pair(q[0], q[1], q[2], q[3], qa, qo);
+        lat[u] = fma(qa, lat_s, lat_o);
+        lon[u] = fma(qo, lon_s, lon_o);
+        pin(lat[u]); pin(lon[u]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // RPC_Obj2Photo (warping.py:218-252) at N ground points at once (N planes of one pixel), one cubic at a time.
 // n = {1/LAT_SCALE, 1/LONG_SCALE, 1/HEIGHT_SCALE}.
 template <int N>
@@ -302,6 +327,138 @@ __device__ __forceinline__ void o2p_xn(cgeo_t r, const RpcInv& n, const double* 
             q[i][u] = fma(H[u], fma(H[u], fma(H[u], k[19], C[u]), B[u]), A[u]);
             pin(q[i][u]);
         }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const cgeo_t rr = launder(r);
+    const double so = to_vgpr(rr[I_SAMP_OFF]), lo = to_vgpr(rr[I_LINE_OFF]);     // one copy for the N points
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        double qs, ql;
+        div_pair(q[0][u], q[1][u], q[2][u], q[3][u], qs, ql);
+        samp[u] = fma(qs, rr[I_SAMP_SCALE], so);
+        line[u] = fma(ql, rr[I_LINE_SCALE], lo);
+    }
+}
+
+// ---- plane-constant heights: the source cubics collapse to bivariate ones (round 6) ----------------------
+// Stage 1 of every cascade hands the warp PLANE-CONSTANT heights (networks/casred.py:138-149,
+// modules/depth_range.py:23-42; modules/warping.py:329-332 accepts the (B,D) form).  With the normalised height H
+// of a plane fixed, a source view's cubic sum_i c_i m_i(P,L,H) is a cubic in (P,L) alone with 10 coefficients
+//   k0 (1)   = c0 + H c3 + H^2 c9 + H^3 c19     k1 (L)   = c1 + H c5 + H^2 c13     k2 (P)   = c2 + H c6 + H^2 c16
+//   k3 (LP)  = c4 + H c10                       k4 (LL)  = c7 + H c17              k5 (PP)  = c8 + H c18
+//   LLL: c11        LPP: c12        LLP: c14        PPP: c15                        (plane-invariant: read from the RPC itself)
+// (monomial order 1,L,P,H,LP,LH,PH,LL,PP,HH,PLH,LLL,LPP,LHH,LLP,PPP,PHH,LLH,PPH,HHH, warping.py:183-207).  A tiny
+// pre-kernel (rpc_plane_coef_kernel, costvol.hip) folds k0..k5 once per (batch item, plane, source, cubic) into a
+// caller-owned workspace, and a wave whose 64 x DP heights all equal their planes' heights (checked, wave-uniform
+// branch) evaluates 7 monomial products + 4 x (1 move + 9 FMAs) per source and plane instead of 6/4 moves + 76 FMAs +
+// the height normalisation.  Same polynomial, re-associated: coordinates move by float64 rounding only (~1e-13 px, like
+// the Horner form vs the reference's order).  Per-voxel heights (stages 2-3, jittered planes) fail the check and take
+// the trivariate chain above.
+// Workspace layout (doubles): [0, pc_header_doubles(B D)) the planes' heights, (b, d) at b D + d; then the folded
+// coefficients as [b][source][cubic: SNUM, SDEN, LNUM, LDEN][d][6]: for one (source, cubic) the planes are contiguous,
+// so the N planes of an evaluation pass are ONE run of 6 N doubles (three s_load_dwordx16 at N = 4) and a wave's DP
+// planes are 4 n_src runs of 48 DP bytes.
+// How the coefficients reach the FMAs (measured, profiles/r06_plane_coef_transport.txt): as SGPR multiplicands through the
+// scalar cache.  The 64 planes' coefficients (25 KB at 3 views) do not fit the CU's 16 KB scalar cache next to the RPC
+// vectors, so every workgroup finds its plane chunk's lines cold, and a cold line costs ~170 clocks whether it is
+// requested back to back or by a dependent use -- the wave therefore pulls its 4 n_src runs in with one block of
+// back-to-back touches (scalar_prefetch) instead of stalling at 16-48 dependent loads.  The alternatives lose: a
+// coalesced vector load of the block + two v_readlane_b32 per coefficient costs 0.65 ms against 0.58 for the trivariate
+// chain (VALU-written SGPRs are slow to consume); broadcast LDS reads cost the LDS pipe what the FMAs save.
+enum : int { PC_PER_CUBIC = 6 };
+__host__ __device__ constexpr size_t pc_header_doubles(size_t planes) { return (planes + 7) & ~(size_t)7; }
+__host__ __device__ constexpr size_t pc_total_doubles(int B, int n_src, int D)
+{
+    // + 64: a group of DP planes cut short by the end of the sweep reads (and discards) up to DP - 1 records past plane D - 1
+    return pc_header_doubles((size_t)B * D) + (size_t)B * D * 4 * PC_PER_CUBIC * n_src + 64;
+}
+// doubles from the start of the coefficient area to (b, source s, cubic i, plane d)
+__host__ __device__ constexpr size_t pc_offset(int b, int s, int i, int d, int n_src, int D)
+{
+    return ((((size_t)b * n_src + s) * 4 + i) * D + d) * PC_PER_CUBIC;
+}
+
+// Touch `runs` runs of `bytes` bytes (wave-uniform, > 0), `stride` bytes apart, from p on, one dword per 64-byte line (p is
+// rounded down to a line), through the scalar cache, and wait.  The destination register is dead; the wait inside the
+// block is what makes that safe (the compiler may hand the register to anything after the statement -- and any later
+// s_waitcnt lgkmcnt(0) would wait for the touches anyway: there is no such thing as a non-blocking scalar prefetch).
+// `also`: one more line to touch (the planes' heights); handed back so that the caller's loads through it are issued
+// after the touches (they then hit) instead of being waited for in front of them.
+__device__ __forceinline__ cgeo_t scalar_prefetch(cgeo_t p, uint32_t bytes, uint32_t stride, uint32_t runs, cgeo_t also)
+{
+    // (readfirstlane: wave-uniform by construction; where the optimiser cannot prove it, the "s" operands must not end in VGPRs)
+    const uintptr_t a = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)p >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p);
+    const cgeo_t p0 = (cgeo_t)(a & ~(uintptr_t)63);
+    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)(bytes + (uint32_t)(a & 63)));
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)(runs * stride));
+    stride = (uint32_t)__builtin_amdgcn_readfirstlane((int)stride);
+    also = (cgeo_t)(((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)also >> 32)) << 32) |
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)also));
+    uint32_t run, off, end, t;
+    asm volatile("s_load_dword %3, %4, 0x0\n\t"
+                 "s_mov_b32 %0, 0\n"
+                 "L_smvs_run_%=:\n\t"
+                 "s_mov_b32 %1, %0\n\t"
+                 "s_add_u32 %2, %0, %6\n"
+                 "L_smvs_touch_%=:\n\t"
+                 "s_load_dword %3, %5, %1\n\t"
+                 "s_add_u32 %1, %1, 64\n\t"
+                 "s_cmp_lt_u32 %1, %2\n\t"
+                 "s_cbranch_scc1 L_smvs_touch_%=\n\t"
+                 "s_add_u32 %0, %0, %7\n\t"
+                 "s_cmp_lt_u32 %0, %8\n\t"
+                 "s_cbranch_scc1 L_smvs_run_%=\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(run), "=&s"(off), "=&s"(end), "=&s"(t), "+s"(also) : "s"(p0), "s"(len), "s"(stride), "s"(total) : "scc", "memory");
+    return also;
+}
+
+// RPC_Obj2Photo (warping.py:218-252) at N consecutive planes of one pixel whose heights are their planes': pc -> the
+// folded coefficients of THIS source at the first of the N planes, cubic 0 (wave-uniform, scalar loads); cubic i is
+// `cubic_stride` doubles further (= 6 D); r = the source view's 170-vector
+template <int N>
+__device__ __forceinline__ void o2p_pc_xn(cgeo_t r, const RpcInv& n, const double* lat, const double* lon,
+                                          cgeo_t pc, size_t cubic_stride, double* samp, double* line)
+{
+    double q[4][N];
+    double P[N], L[N], LL[N], LP[N], PP[N], LLL[N], LPP[N], LLP[N], PPP[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        P[u] = (lat[u] - r[I_LAT_OFF]) * n.a;
+        L[u] = (lon[u] - r[I_LON_OFF]) * n.b;
+        LL[u] = L[u] * L[u]; LP[u] = L[u] * P[u]; PP[u] = P[u] * P[u];
+        LLL[u] = L[u] * LL[u]; LPP[u] = L[u] * PP[u]; LLP[u] = L[u] * LP[u]; PPP[u] = P[u] * PP[u];
+    }
+    constexpr int base[4] = {I_SNUM, I_SDEN, I_LNUM, I_LDEN};
+    // one cubic at a time for all N planes: 6 N folded (one contiguous run) + 4 invariant coefficients in SGPRs (56 at
+    // N = 4), then N independent chains of 1 move + 9 FMAs
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        const cgeo_t c = launder(r) + base[i];
+        const cgeo_t k = launder(pc) + cubic_stride * i;
+        double a[N];
+#pragma unroll
+        for (int u = 0; u < N; ++u) a[u] = to_vgpr(k[PC_PER_CUBIC * u]);
+#pragma unroll
+        for (int u = 0; u < N; ++u) a[u] = fma(L[u], k[PC_PER_CUBIC * u + 1], a[u]);
+#pragma unroll
+        for (int u = 0; u < N; ++u) a[u] = fma(P[u], k[PC_PER_CUBIC * u + 2], a[u]);
+#pragma unroll
+        for (int u = 0; u < N; ++u) a[u] = fma(LP[u], k[PC_PER_CUBIC * u + 3], a[u]);
+#pragma unroll
+        for (int u = 0; u < N; ++u) a[u] = fma(LL[u], k[PC_PER_CUBIC * u + 4], a[u]);
+#pragma unroll
+        for (int u = 0; u < N; ++u) a[u] = fma(PP[u], k[PC_PER_CUBIC * u + 5], a[u]);
+#pragma unroll
+        for (int u = 0; u < N; ++u) a[u] = fma(LLL[u], c[11], a[u]);
+#pragma unroll
+        for (int u = 0; u < N; ++u) a[u] = fma(LPP[u], c[12], a[u]);
+#pragma unroll
+        for (int u = 0; u < N; ++u) a[u] = fma(LLP[u], c[14], a[u]);
+#pragma unroll
+        for (int u = 0; u < N; ++u) { q[i][u] = fma(PPP[u], c[15], a[u]); pin(q[i][u]); }
     }
     __builtin_amdgcn_sched_barrier(0);
     const cgeo_t rr = launder(r);

@@ -25,7 +25,7 @@ from ..rpc_synth import qc_tensor_to_coeffs  # noqa: F401  (host-side layout hel
 
 __all__ = ["homo_warping", "rpc_warping", "rpc_warping_enisum", "RPC_Photo2Obj", "RPC_Obj2Photo",
            "RPC_Photo2Obj_enisum", "RPC_Obj2Photo_enisum", "variance_cost_volume", "qc_dict_to_rpc",
-           "prepare_geometry"]
+           "prepare_geometry", "plane_coefficients"]
 
 
 def _f32c(t):
@@ -189,6 +189,20 @@ def RPC_Obj2Photo_enisum(inlat, inlon, inhei, rpc):
 
 
 # ---- fused cost volume ---------------------------------------------------------------------------------
+def plane_coefficients(geo, depth, is4d, n_src, H, W, d_begin=0, d_end=None):
+    """smvs_rpc_plane_coef: the source views' cubics folded at the height of every plane in [d_begin, d_end) --
+    the workspace smvs_rpc_costvol_fwd_pc takes.  geo (B,V,170) f64, depth (B,D) or (B,D,H,W) f32, both on the GPU."""
+    dev = _lib.require_device(geo, depth)
+    B, D = depth.shape[0], depth.shape[1]
+    d_end = D if d_end is None else d_end
+    nbytes = _lib.load().smvs_rpc_plane_coef_bytes(B, n_src, D)
+    pc = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("smvs_rpc_plane_coef", _lib.ptr(geo), _lib.ptr(depth), is4d, _lib.ptr(pc), B, n_src, D, H, W,
+                  d_begin, d_end, _lib.current_stream(dev))
+    return pc
+
+
 class _CostVolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, geo_kind, geo, depth, is4d, d_begin, d_end, ref_fea, *src_feas):
@@ -202,10 +216,18 @@ class _CostVolFn(torch.autograd.Function):
                 raise ValueError("source feature %s != reference feature %s" % (tuple(s.shape), tuple(ref.shape)))
         nd = d_end - d_begin
         out = torch.empty((B, C, nd, H, W), dtype=torch.float32, device=dev)
-        name = "smvs_rpc_costvol_fwd" if geo_kind == 0 else "smvs_homo_costvol_fwd"
         with torch.cuda.device(dev):
-            _lib.call(name, _lib.ptr(ref), _lib.ptr_array(srcs), len(srcs), _lib.ptr(geo), _lib.ptr(depth), is4d | _lib.call_arith_bits(),
-                      _lib.ptr(out), B, C, D, H, W, d_begin, d_end, nd, 0, _lib.current_stream(dev))
+            st = _lib.current_stream(dev)
+            if geo_kind == 0 and nd > 0:
+                # plane-constant heights (stage 1 of every cascade) collapse the source cubics to bivariate ones: fold them for
+                # the planes of this launch; the kernel checks its own heights against the folded ones wave by wave
+                pc = plane_coefficients(geo, depth, is4d, len(srcs), H, W, d_begin, d_end)
+                _lib.call("smvs_rpc_costvol_fwd_pc", _lib.ptr(ref), _lib.ptr_array(srcs), len(srcs), _lib.ptr(geo), _lib.ptr(depth),
+                          is4d | _lib.call_arith_bits(), _lib.ptr(pc), _lib.ptr(out), B, C, D, H, W, d_begin, d_end, nd, 0, st)
+            else:
+                name = "smvs_rpc_costvol_fwd" if geo_kind == 0 else "smvs_homo_costvol_fwd"
+                _lib.call(name, _lib.ptr(ref), _lib.ptr_array(srcs), len(srcs), _lib.ptr(geo), _lib.ptr(depth), is4d | _lib.call_arith_bits(),
+                          _lib.ptr(out), B, C, D, H, W, d_begin, d_end, nd, 0, st)
         ctx.save_for_backward(geo, depth, ref, *srcs)
         ctx.meta = (geo_kind, is4d, d_begin, d_end, (B, C, D, H, W))
         return out

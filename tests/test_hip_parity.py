@@ -226,6 +226,127 @@ def test_costvol_shared_box_paths_agree(dev, oracle, arith):
         assert torch.equal(warping.variance_cost_volume(f, r, w, "rpc", d_begin=pl, d_end=pl + 1), whole[:, :, pl:pl + 1]), pl
 
 
+# ---- plane-constant heights: collapsed (bivariate) source cubics, smvs_rpc_plane_coef + smvs_rpc_costvol_fwd_pc -------------
+def _build_raw(dev, feats, rpc, depth, use_pc, d_begin=0, d_end=None, pc_from=None):
+    """The volume through the C ABI: smvs_rpc_costvol_fwd (use_pc=False) or smvs_rpc_plane_coef + smvs_rpc_costvol_fwd_pc."""
+    from satmvs_amd import _lib
+    f = [_t(x, dev) for x in feats]
+    r, d = _t(rpc, dev), _t(depth, dev)
+    B, C, H, W = f[0].shape
+    D = d.shape[1]
+    is4d = 1 if d.dim() == 4 else 0
+    d_end = D if d_end is None else d_end
+    out = torch.full((B, C, d_end - d_begin, H, W), 7.0, dtype=torch.float32, device=dev)
+    st = _lib.current_stream(dev)
+    srcs = _lib.ptr_array(f[1:])
+    if not use_pc:
+        _lib.call("smvs_rpc_costvol_fwd", _lib.ptr(f[0]), srcs, len(f) - 1, _lib.ptr(r), _lib.ptr(d), is4d, _lib.ptr(out),
+                  B, C, D, H, W, d_begin, d_end, d_end - d_begin, 0, st)
+        return out, None
+    pc = torch.zeros(_lib.load().smvs_rpc_plane_coef_bytes(B, len(f) - 1, D) // 8, dtype=torch.float64, device=dev)
+    src_d = d if pc_from is None else _t(pc_from, dev)
+    _lib.call("smvs_rpc_plane_coef", _lib.ptr(r), _lib.ptr(src_d), 1 if src_d.dim() == 4 else 0, _lib.ptr(pc), B, len(f) - 1, D, H, W, 0, D, st)
+    _lib.call("smvs_rpc_costvol_fwd_pc", _lib.ptr(f[0]), srcs, len(f) - 1, _lib.ptr(r), _lib.ptr(d), is4d, _lib.ptr(pc), _lib.ptr(out),
+              B, C, D, H, W, d_begin, d_end, d_end - d_begin, 0, st)
+    torch.cuda.synchronize()
+    return out, pc
+
+
+def test_plane_coef_records(dev):
+    """smvs_rpc_plane_coef: the planes' heights at b D + d (padded to a multiple of 8 doubles), then per (b, d) and source the
+    four cubics SNUM, SDEN, LNUM, LDEN folded at the plane's normalised height (the 6 height-dependent of their 10 bivariate
+    coefficients each, laid out [b][source][cubic][d][6]) -- against a float64 numpy evaluation of the same sums (/root/reference/modules/warping.py:183-207
+    monomial order)."""
+    from satmvs_amd import _lib
+    B, V, D, H, W = 2, 4, 5, 12, 20
+    _, rpc, depth = _inputs(B, V, 8, D, H, W, seed=21, jitter=False)
+    depth4 = np.ascontiguousarray(np.broadcast_to(depth[:, :, None, None], (B, D, H, W)))
+    hdr = (B * D + 7) // 8 * 8
+    n = _lib.load().smvs_rpc_plane_coef_bytes(B, V - 1, D) // 8
+    assert n == hdr + B * D * 24 * (V - 1) + 64          # (+ what a cut-short plane group may read behind the last plane)
+    body = B * D * 24 * (V - 1)
+    for dd in (depth, depth4):
+        pc = torch.zeros(n, dtype=torch.float64, device=dev)
+        d = _t(dd, dev)
+        _lib.call("smvs_rpc_plane_coef", _lib.ptr(_t(rpc, dev)), _lib.ptr(d), 1 if d.dim() == 4 else 0, _lib.ptr(pc), B, V - 1, D, H, W, 0, D,
+                  _lib.current_stream(dev))
+        flat = pc.cpu().numpy()
+        assert np.array_equal(flat[:B * D].reshape(B, D), depth.astype(np.float64)) and not flat[B * D:hdr].any()
+        rec = flat[hdr:hdr + body].reshape(B, V - 1, 4, D, 6).transpose(0, 3, 1, 2, 4)          # [b][source][cubic][d][6] -> (b, d, s, i, j)
+        for b in range(B):
+            for s in range(V - 1):
+                r = rpc[b, s + 1]
+                Hn = (depth[b].astype(np.float64) - r[4]) / r[9]
+                for i, base in enumerate((50, 70, 10, 30)):
+                    c = r[base:base + 20]
+                    want = np.stack([c[0] + Hn * c[3] + Hn ** 2 * c[9] + Hn ** 3 * c[19], c[1] + Hn * c[5] + Hn ** 2 * c[13],
+                                     c[2] + Hn * c[6] + Hn ** 2 * c[16], c[4] + Hn * c[10], c[7] + Hn * c[17], c[8] + Hn * c[18]], axis=1)
+                    np.testing.assert_allclose(rec[b, :, s, i], want, rtol=1e-14, atol=1e-18)
+    # a plane window writes the records of its planes only
+    pc = torch.full_like(pc, -3.0)
+    _lib.call("smvs_rpc_plane_coef", _lib.ptr(_t(rpc, dev)), _lib.ptr(_t(depth, dev)), 0, _lib.ptr(pc), B, V - 1, D, H, W, 1, 3, _lib.current_stream(dev))
+    w = pc.cpu().numpy()
+    wr = w[hdr:hdr + body].reshape(B, V - 1, 4, D, 6).transpose(0, 3, 1, 2, 4)
+    assert (wr[:, [0, 3, 4]] == -3.0).all() and np.array_equal(wr[:, 1:3], rec[:, 1:3])
+    assert np.array_equal(w[:B * D].reshape(B, D)[:, 1:3], depth[:, 1:3].astype(np.float64)) and (w[:B * D].reshape(B, D)[:, [0, 3, 4]] == -3.0).all()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=1, V=3, C=32, D=16, H=40, W=72, four=True),      # the headline instance (8 planes per wave), (B,D,H,W) broadcast planes
+    dict(B=2, V=3, C=16, D=11, H=37, W=70, four=False),     # 4 planes per wave, ragged tile, batch 2, odd plane count, (B,D) heights
+    dict(B=1, V=5, C=32, D=8, H=24, W=66, four=True),       # shared-box form, 4 sources
+    dict(B=1, V=2, C=8, D=1, H=16, W=40, four=False),       # one source, one plane
+    dict(B=1, V=7, C=16, D=5, H=20, W=72, four=True),       # 6 sources: 2 planes per wave
+    dict(B=1, V=3, C=10, D=6, H=17, W=33, four=True),       # generic channel count: the direct-gather kernel ignores the coefficients
+])
+def test_plane_coefficients_match_trivariate(dev, oracle, arith, cfg):
+    """Plane-constant heights: waves take the collapsed bivariate source cubics (smvs_device.h, o2p_pc_xn).  Same polynomials
+    re-associated -> float64 coordinates move by ~1e-13 px, so the volume equals the trivariate build's except where a
+    coordinate straddles a float32 rounding boundary (the same allowance as against the oracle), in both arithmetic modes;
+    the exact mode equals the oracle."""
+    feats, rpc, depth = _inputs(cfg["B"], cfg["V"], cfg["C"], cfg["D"], cfg["H"], cfg["W"], seed=12, jitter=False)
+    if cfg["four"]:
+        depth = np.ascontiguousarray(np.broadcast_to(depth[:, :, None, None], depth.shape + (cfg["H"], cfg["W"])))
+    tri, _ = _build_raw(dev, feats, rpc, depth, False)
+    got, _ = _build_raw(dev, feats, rpc, depth, True)
+    _close_f32(got, tri.cpu().numpy())
+    if arith == "exact":
+        _close_f32(got, oracle.costvol_variance(feats, rpc, depth, "rpc"))
+    # plane windows on the same coefficients: bit-identical to the whole sweep
+    D = cfg["D"]
+    for lo, hi in ((0, 1), (D // 2, D), (1, max(2, D - 1))):
+        if hi <= D and lo < hi:
+            part, _ = _build_raw(dev, feats, rpc, depth, True, lo, hi)
+            assert torch.equal(part, got[:, :, lo:hi]), (lo, hi)
+
+
+def test_plane_coefficients_are_checked_not_trusted(dev, oracle):
+    """The kernel compares every wave's heights with the folded planes' and takes the bivariate cubics only where ALL match:
+    (1) one jittered pixel sends its wave down the trivariate chain, and the volume still equals the oracle's; (2) coefficients
+    folded for OTHER heights are never used: the result is bit-identical to smvs_rpc_costvol_fwd; (3) per-voxel heights:
+    identical bits with and without the workspace."""
+    B, V, C, D, H, W = 1, 3, 32, 8, 24, 96
+    feats, rpc, planes = _inputs(B, V, C, D, H, W, seed=14, jitter=False)
+    depth = np.ascontiguousarray(np.broadcast_to(planes[:, :, None, None], (B, D, H, W))).copy()
+    rng = np.random.default_rng(3)
+    for _ in range(6):                                             # one jittered voxel in six (wave, plane) places
+        depth[0, rng.integers(D), rng.integers(H), rng.integers(W)] += 1.5
+    depth[0, 3, 5, 40] = np.nan
+    want = oracle.costvol_variance(feats, rpc, depth, "rpc")
+    got, _ = _build_raw(dev, feats, rpc, depth, True)
+    got = got.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    _close_f32(got[~np.isnan(want)], want[~np.isnan(want)])
+    clean = np.ascontiguousarray(np.broadcast_to(planes[:, :, None, None], (B, D, H, W)))
+    tri, _ = _build_raw(dev, feats, rpc, clean, False)
+    stale, _ = _build_raw(dev, feats, rpc, clean, True, pc_from=clean + 0.25)
+    assert torch.equal(stale, tri)
+    jit = _inputs(B, V, C, D, H, W, seed=14, jitter=True)[2]
+    a, _ = _build_raw(dev, feats, rpc, jit, False)
+    b, _ = _build_raw(dev, feats, rpc, jit, True)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("C", [8, 16])                          # direct kernel / staged kernel
 def test_costvol_out_of_image_and_nan(dev, oracle, C):
     """Large parallax pushes taps off the source image (zero padding); NaN heights must not fault."""

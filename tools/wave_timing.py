@@ -17,18 +17,17 @@ if wl in bench.SIDE_HEIGHTS:
     depth = torch.linspace(lo, hi, D, dtype=torch.float32).view(1, D, 1, 1).expand(1, D, H, W).contiguous().to(dev)
 _lib.set_arith("exact")          # the stamps live in costvol.hip's copy of the kernels (the exact instances)
 out = torch.empty((1, C, D, H, W), dtype=torch.float32, device=dev)
-srcs = _lib.ptr_array(feats[1:])
 st = _lib.current_stream(dev)
-def step():
-    _lib.call("smvs_rpc_costvol_fwd", _lib.ptr(feats[0]), srcs, V - 1, _lib.ptr(rpc), _lib.ptr(depth), 1, _lib.ptr(out), 1, C, D, H, W, 0, D, D, 0, st)
+# SMVS_BENCH_TRIVARIATE=1: smvs_rpc_costvol_fwd (no folded plane coefficients), else fold + smvs_rpc_costvol_fwd_pc
+step = bench.tile_build(_lib, feats, rpc, depth, out, V, C, D, H, W, st, plane_coef=os.environ.get("SMVS_BENCH_TRIVARIATE") != "1")[1]
 for _ in range(20): step()
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 12)()
 lib.smvs_debug_timing(buf, 1)
 n = 20
 for _ in range(n): step()
 lib.smvs_debug_timing(buf, 1)
 w = buf[7]
-names = ["geometry", "box+setup", "pair loop", " vmcnt waits", " store issue", " dma issue"]
+names = ["geometry", "box+setup", "pair loop", " vmcnt waits", " store issue", " dma issue", "", "", " heights+check", " scales+ref view", " source views+taps"]
 print("waves %d staged + %d fallback (%d launches)" % (w, buf[6], n))
-for i in (0, 1, 2, 3, 4, 5):
-    print("%-14s %9.0f clocks per wave" % (names[i], buf[i] / w))
+for i in (0, 8, 9, 10, 1, 2, 3, 4, 5):
+    print("%-20s %9.0f clocks per wave" % (names[i], buf[i] / w))
