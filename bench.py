@@ -410,6 +410,16 @@ def side_workloads(dev, stream):
             rec[st] = {"max_abs_m": float("%.3g" % d.max()), "mae_m": float("%.3g" % d.mean())}
         extra["height_parity_vs_reference"] = rec
         del gnet, gout
+        # ... and at the timed size, both arithmetic modes: the well-conditioned 768x384 cascade of tests/test_full_size_red_conditioned.py
+        # (native pipeline vs a float64 evaluation on the reference's variance volume), in a process of its own
+        try:
+            import subprocess
+            tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "conditioned_parity.py")
+            torch.cuda.empty_cache()
+            r = subprocess.run([sys.executable, tool, "redinf"], capture_output=True, text=True, timeout=300)
+            rec["conditioned_768x384"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as e:                               # noqa: BLE001 -- a side figure must never take the headline down
+            rec["conditioned_768x384"] = {"error": repr(e)[:200]}
     except Exception as e:
         extra["height_parity_vs_reference"] = {"error": repr(e)[:200]}
     # cfg3: one inference cascade forward (FeatureNet + three stages of variance / RED / regression), 48/32/8 planes

@@ -55,20 +55,26 @@ int smvs_red_set_streams(int n);
  *   SMVS_ARITH_EXACT  the reference's float32 rounding sequence operation for operation (sum, sum of squares, two true
  *                     divisions by the view count, mean^2, subtract: networks/casred.py:26-53): bit-identical to the
  *                     CPU oracle; what every bit-level test runs.
- *   SMVS_ARITH_FUSED  (default) the same float64 geometry, float32 tap coordinates and bilinear weights, but the variance
+ *   SMVS_ARITH_FUSED  the same float64 geometry, float32 tap coordinates and bilinear weights, but the variance
  *                     is taken of the differences to the ref feature with its constant factors folded into the weights
  *                     (11 instead of 22 packed operations per plane and channel pair at 3 views).  Differs from the
  *                     reference by float32 rounding only -- |delta| <= 1e-5 * max(1, |v|) on the volume (SURVEY.md
- *                     section 8c; measured <= 3.1e-6 on unit-variance features), regressed heights within north_star's
- *                     1e-3 m.  Against a float64 evaluation of the same taps it is 6x closer than the reference's own
- *                     sequence on photo-consistent features (no meansq - mean^2 cancellation), equal on independent random
- *                     features at 2-3 views, 2-4x the reference's rounding error at 4-8 views (tests/test_fused_arith.py).
- * smvs_set_arith sets the process DEFAULT only (thread-safe; returns the previous default, or -1 for an unknown mode).  The
- * arithmetic of ONE call travels with the call: OR SMVS_CALL_ARITH_EXACT or SMVS_CALL_ARITH_FUSED into the `depth_is_4d`
- * argument of smvs_*_costvol_fwd / smvs_red_pred_planes / smvs_red_volume_planes, or set smvs_height_gen.arith for the *_gen
- * forms; with neither bit the call takes the default.  Two models (or nn.DataParallel replicas on their threads) in one
- * process can therefore run different arithmetics without touching shared state.  Every other entry point that takes
- * `depth_is_4d` ignores the two bits. */
+ *                     section 8c; measured <= 3.1e-6 on unit-variance features).  Against a float64 evaluation of the same
+ *                     taps it is 6x closer than the reference's own sequence on photo-consistent features (no
+ *                     meansq - mean^2 cancellation), equal on independent random features at 2-3 views, 2-4x the
+ *                     reference's rounding error at 4-8 views (tests/test_fused_arith.py).
+ * Which one a call runs:
+ *   - a call may carry its own: OR SMVS_CALL_ARITH_EXACT or SMVS_CALL_ARITH_FUSED into the `depth_is_4d` argument of
+ *     smvs_*_costvol_fwd / smvs_red_pred_planes / smvs_red_volume_planes, or set smvs_height_gen.arith for the *_gen forms
+ *     (two models, or nn.DataParallel replicas on their threads, can run different arithmetics without shared state);
+ *   - the STAND-ALONE builds (smvs_*_costvol_fwd[_gen][_pc]) without a bit take the process default, which starts as
+ *     SMVS_ARITH_FUSED and is moved by smvs_set_arith (thread-safe; returns the previous default, -1 for an unknown mode);
+ *   - the PLANE PIPELINES (smvs_red_pred_planes / smvs_red_volume_planes[_gen]) without a bit run SMVS_ARITH_EXACT whatever
+ *     the process default is (round 6): behind a peaky softmax the fused volume's 1e-5 can move a regressed height by more
+ *     than north_star's 1e-3 m (2.1e-3 m at 3 of 294 912 pixels of the well-conditioned 768 x 384 cascade,
+ *     profiles/r05_cascade_float64.txt), and the build is a few per cent of a pipeline's time.  The Python networks and
+ *     compute_depth_* functions default the same way (satmvs_amd/_lib.py, pipeline_arith_scope).
+ * Every other entry point that takes `depth_is_4d` ignores the two bits. */
 enum { SMVS_ARITH_EXACT = 0, SMVS_ARITH_FUSED = 1 };
 enum { SMVS_CALL_ARITH_EXACT = 0x100, SMVS_CALL_ARITH_FUSED = 0x200, SMVS_CALL_ARITH_MASK = 0x300 };
 int smvs_set_arith(int mode);

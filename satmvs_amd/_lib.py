@@ -169,6 +169,19 @@ class arith_scope:
         return False
 
 
+def scoped_arith():
+    """The mode of the innermost arith_scope of this thread, or None."""
+    return getattr(_scope, "mode", None)
+
+
+def pipeline_arith_scope(own=None):
+    """arith_scope of a plane pipeline / cascade: `own` (a model's arith= argument) if given, else the enclosing arith_scope,
+    else "exact".  The pipelines do NOT follow the process default of the stand-alone builds (set_arith / SMVS_ARITH): behind a
+    peaky softmax the fused volume's 1e-5 can move a regressed height by more than 1e-3 m, and the build is a few per cent of a
+    pipeline's time -- the C entry points (smvs_red_pred_planes, smvs_red_volume_planes) default the same way."""
+    return arith_scope(own or scoped_arith() or "exact")
+
+
 def call_arith_bits():
     """0, or the SMVS_CALL_ARITH_* bit of the innermost arith_scope of this thread."""
     mode = getattr(_scope, "mode", None)

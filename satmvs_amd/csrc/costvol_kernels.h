@@ -420,6 +420,9 @@ void costvol_dma_kernel(const CostVolParams p)
     const uint32_t pix4 = (uint32_t)pix * 4u;
 
     SMVS_T(const unsigned long long t_start = now(); unsigned long long t_vm = 0, t_dma = 0, t_st = 0;)
+    constexpr int PC_LPR = (DP * PC_PER_CUBIC * 8 + 63) / 64 + (DP * PC_PER_CUBIC * 8 % 64 ? 1 : 0);      // 64-byte lines per coefficient run of DP planes
+    const bool pc_maybe = GEO == 0 && p.pc != nullptr && p.depth_is_4d != HEIGHT_GENERATED && !(SMVS_ABLATE & 4) && np > 0;     // (np <= 0: shared form, a wave past the last plane only stages)
+    const int dg0 = min(dg, p.d_end - 1);
     // heights of the group's planes (tail planes shadow the last one; they are never stored)
     float hf[DP];
     if (p.depth_is_4d == HEIGHT_GENERATED) {
@@ -435,28 +438,20 @@ void costvol_dma_kernel(const CostVolParams p)
         }
     }
 
-    // Plane-constant heights?  Every lane's DP heights equal the heights the coefficients were folded for: the whole wave
-    // takes the bivariate source cubics.  Wave-uniform; a single differing lane (per-voxel hypotheses, a NaN) sends the
-    // wave down the trivariate chain.  The coefficient runs of the wave's planes are pulled into the scalar cache first, in
-    // one block of back-to-back touches that overlaps the height loads above.
-    bool use_pc = false;
+    // Plane-coefficient path (smvs_device.h, "plane-constant heights"): the coefficient runs of the wave's planes -- one run
+    // of DP planes per (source, cubic) -- and the line that holds the planes' heights are pulled into the scalar cache now,
+    // while the height loads above are in flight.
     const cgeo_t pc_co = as_cgeo(p.pc) + pc_header_doubles((size_t)p.B * p.D);      // coefficient area, pc_offset()
-    const int dg0 = min(dg, p.d_end - 1);
     if constexpr (GEO == 0) {
-        if (p.pc != nullptr && p.depth_is_4d != HEIGHT_GENERATED && !(SMVS_ABLATE & 4) && np > 0) {      // (np <= 0: shared form, a wave past the last plane only stages)
-            const int npl = min(DP, p.d_end - dg);
-            const cgeo_t hdr = scalar_prefetch(pc_co + pc_offset(b, 0, 0, dg0, NSRC, p.D), (uint32_t)(npl * PC_PER_CUBIC * 8),
-                                               (uint32_t)(p.D * PC_PER_CUBIC * 8), 4 * NSRC, as_cgeo(p.pc) + (size_t)b * p.D + dg0);
-            double hpl[DP];
+        if (pc_maybe) {
 #pragma unroll
-            for (int pl = 0; pl < DP; ++pl) hpl[pl] = hdr[min(pl, p.d_end - 1 - dg0)];
-            bool eq = true;
-#pragma unroll
-            for (int pl = 0; pl < DP; ++pl) eq = eq && (hf[pl] == (float)hpl[pl]);
-            use_pc = __ballot(!eq) == 0ull;
+            for (int r = 0; r < 4 * NSRC; ++r)
+                scalar_touch<PC_LPR>(pc_co + pc_offset(b, r >> 2, r & 3, dg0, NSRC, p.D));
+            scalar_touch<2>(as_cgeo(p.pc) + (size_t)b * p.D + dg0);
         }
     }
 
+    bool use_pc = false;
     SMVS_T(const unsigned long long t_chk = now();)
     // ---- A: taps of the group's planes -----------------------------------------------------------
     TapD tap[DP][NSRC];
@@ -490,6 +485,17 @@ void costvol_dma_kernel(const CostVolParams p)
         // ref view, image -> ground: plane-invariant part once per pixel, Horner in the height per plane
         P2OPix px;
         p2o_pixel(geo_b, ref_n, fx, fy, px);
+        // Plane-constant heights?  Every lane's DP heights equal the heights the coefficients were folded for: the whole wave takes
+        // the bivariate source cubics.  Wave-uniform; a single differing lane (per-voxel hypotheses, a NaN) sends the wave down
+        // the trivariate chain.  Asked HERE, behind the ref pixel's plane-invariant work, so that the heights' latency passes
+        // under it (asked right after the loads it cost ~10 000 clocks per wave: profiles/r06_plane_coef_transport.txt).
+        if (pc_maybe) {
+            const cgeo_t hdr = launder(as_cgeo(p.pc)) + (size_t)b * p.D + dg0;
+            bool eq = true;
+#pragma unroll
+            for (int pl = 0; pl < DP; ++pl) eq = eq && (hf[pl] == (float)hdr[min(pl, p.d_end - 1 - dg0)]);
+            use_pc = __ballot(!eq) == 0ull;
+        }
         p2o_planes<DP>(launder(geo_b), ref_n, px, hf, lat, lon);
     }
     SMVS_T(const unsigned long long t_ref = now();)

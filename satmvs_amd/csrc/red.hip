@@ -1181,6 +1181,7 @@ struct RedRun {
     // pred loop (pred = true): cost-volume plane built here, regression accumulators updated here
     bool pred; int geo_kind; const float* ref_fea; const float* const* src_fea; int n_src; const double* geo;
     const float* depth; int depth_is_4d; const smvs_height_gen* gen; double* acc; int D;
+    smvs_height_gen gen_own;            // the caller's generator with this pipeline's arithmetic default filled in (see red_planes_entry)
     float* reg_volume;                       // pred with acc == null: regularised planes go to (B,D,H,W) instead
     float* block[2];                         // two (B,C,CH,H,W) chunks of variance planes
 };
@@ -1766,6 +1767,17 @@ static int red_planes_entry(int geo_kind, const float* ref_fea, const float* con
     r.wsf = (float*)workspace; r.B = B; r.C = C; r.H = H; r.W = W; r.main = (hipStream_t)stream;
     r.pred = true; r.geo_kind = geo_kind; r.ref_fea = ref_fea; r.src_fea = src_fea; r.n_src = n_src; r.geo = geo;
     r.depth = depth; r.depth_is_4d = depth_is_4d; r.gen = gen; r.acc = acc; r.reg_volume = reg_volume; r.D = D;
+    // Arithmetic of the variance planes: what the call carries; a call that carries nothing gets the reference's rounding
+    // sequence (SMVS_ARITH_EXACT), NOT the process default of the stand-alone builds -- behind a peaky softmax the fused
+    // volume's 1e-5 can move a regressed height by more than north_star's 1e-3 m (2.1e-3 m at 3 of 294 912 pixels of the
+    // conditioned 768 x 384 cascade), and the build is a few per cent of a pipeline's time (include/satmvs.h, smvs_set_arith).
+    if (gen) {
+        r.gen_own = *gen;
+        if (!(r.gen_own.arith & SMVS_CALL_ARITH_MASK)) r.gen_own.arith |= SMVS_CALL_ARITH_EXACT;
+        r.gen = &r.gen_own;
+    } else if (!(r.depth_is_4d & SMVS_CALL_ARITH_MASK)) {
+        r.depth_is_4d |= SMVS_CALL_ARITH_EXACT;
+    }
     const size_t blk = (size_t)red_chunk(B, C, H, W) * B * C * H * W;
     r.block[0] = (float*)((char*)workspace + ((red_bytes + 15) & ~(size_t)15));
     r.block[1] = r.block[0] + blk;

@@ -361,15 +361,16 @@ __device__ __forceinline__ void o2p_xn(cgeo_t r, const RpcInv& n, const double* 
 // How the coefficients reach the FMAs (measured, profiles/r06_plane_coef_transport.txt): as SGPR multiplicands through the
 // scalar cache.  The 64 planes' coefficients (25 KB at 3 views) do not fit the CU's 16 KB scalar cache next to the RPC
 // vectors, so every workgroup finds its plane chunk's lines cold, and a cold line costs ~170 clocks whether it is
-// requested back to back or by a dependent use -- the wave therefore pulls its 4 n_src runs in with one block of
-// back-to-back touches (scalar_prefetch) instead of stalling at 16-48 dependent loads.  The alternatives lose: a
+// requested back to back or by a dependent use -- the wave therefore pulls its 4 n_src runs in with blocks of
+// back-to-back touches (scalar_touch) instead of stalling at 16-48 dependent loads.  The alternatives lose: a
 // coalesced vector load of the block + two v_readlane_b32 per coefficient costs 0.65 ms against 0.58 for the trivariate
 // chain (VALU-written SGPRs are slow to consume); broadcast LDS reads cost the LDS pipe what the FMAs save.
 enum : int { PC_PER_CUBIC = 6 };
 __host__ __device__ constexpr size_t pc_header_doubles(size_t planes) { return (planes + 7) & ~(size_t)7; }
 __host__ __device__ constexpr size_t pc_total_doubles(int B, int n_src, int D)
 {
-    // + 64: a group of DP planes cut short by the end of the sweep reads (and discards) up to DP - 1 records past plane D - 1
+    // + 64: a group of DP planes cut short by the end of the sweep reads (and discards) up to DP - 1 records past plane D - 1,
+    // and the touches of a run cover whole lines
     return pc_header_doubles((size_t)B * D) + (size_t)B * D * 4 * PC_PER_CUBIC * n_src + 64;
 }
 // doubles from the start of the coefficient area to (b, source s, cubic i, plane d)
@@ -378,40 +379,31 @@ __host__ __device__ constexpr size_t pc_offset(int b, int s, int i, int d, int n
     return ((((size_t)b * n_src + s) * 4 + i) * D + d) * PC_PER_CUBIC;
 }
 
-// Touch `runs` runs of `bytes` bytes (wave-uniform, > 0), `stride` bytes apart, from p on, one dword per 64-byte line (p is
-// rounded down to a line), through the scalar cache, and wait.  The destination register is dead; the wait inside the
-// block is what makes that safe (the compiler may hand the register to anything after the statement -- and any later
-// s_waitcnt lgkmcnt(0) would wait for the touches anyway: there is no such thing as a non-blocking scalar prefetch).
-// `also`: one more line to touch (the planes' heights); handed back so that the caller's loads through it are issued
-// after the touches (they then hit) instead of being waited for in front of them.
-__device__ __forceinline__ cgeo_t scalar_prefetch(cgeo_t p, uint32_t bytes, uint32_t stride, uint32_t runs, cgeo_t also)
+// Touch LINES 64-byte lines from p on (rounded down to a line) through the scalar cache, one dword each, and wait.  The
+// loads carry IMMEDIATE offsets and are issued back to back, so the run costs about one scalar-cache latency; a loop
+// that steps an SGPR offset between the loads costs ~200 clocks PER load -- the SALU write of the offset waits for the
+// load in flight that reads it (measured: 13 000 clocks per wave for 50 lines, hits or misses alike,
+// profiles/r06_plane_coef_transport.txt).  The destination register is dead; the wait inside the block is what makes
+// that safe (the compiler may hand the register to anything after the statement -- and any later s_waitcnt lgkmcnt(0)
+// would wait for the touches anyway: there is no such thing as a non-blocking scalar prefetch).
+template <int LINES>
+__device__ __forceinline__ void scalar_touch(cgeo_t p)
 {
-    // (readfirstlane: wave-uniform by construction; where the optimiser cannot prove it, the "s" operands must not end in VGPRs)
+    static_assert(LINES >= 1 && LINES <= 8, "lines per run");
     const uintptr_t a = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)p >> 32)) << 32) |
-                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p);
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p);      // wave-uniform by construction
     const cgeo_t p0 = (cgeo_t)(a & ~(uintptr_t)63);
-    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)(bytes + (uint32_t)(a & 63)));
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)(runs * stride));
-    stride = (uint32_t)__builtin_amdgcn_readfirstlane((int)stride);
-    also = (cgeo_t)(((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)also >> 32)) << 32) |
-                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)also));
-    uint32_t run, off, end, t;
-    asm volatile("s_load_dword %3, %4, 0x0\n\t"
-                 "s_mov_b32 %0, 0\n"
-                 "L_smvs_run_%=:\n\t"
-                 "s_mov_b32 %1, %0\n\t"
-                 "s_add_u32 %2, %0, %6\n"
-                 "L_smvs_touch_%=:\n\t"
-                 "s_load_dword %3, %5, %1\n\t"
-                 "s_add_u32 %1, %1, 64\n\t"
-                 "s_cmp_lt_u32 %1, %2\n\t"
-                 "s_cbranch_scc1 L_smvs_touch_%=\n\t"
-                 "s_add_u32 %0, %0, %7\n\t"
-                 "s_cmp_lt_u32 %0, %8\n\t"
-                 "s_cbranch_scc1 L_smvs_run_%=\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&s"(run), "=&s"(off), "=&s"(end), "=&s"(t), "+s"(also) : "s"(p0), "s"(len), "s"(stride), "s"(total) : "scc", "memory");
-    return also;
+    uint32_t t;
+#define SMVS_TOUCH(k) "s_load_dword %0, %1, 64*" #k "\n\t"
+    if constexpr (LINES == 1) asm volatile(SMVS_TOUCH(0) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p0) : "memory");
+    if constexpr (LINES == 2) asm volatile(SMVS_TOUCH(0) SMVS_TOUCH(1) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p0) : "memory");
+    if constexpr (LINES == 3) asm volatile(SMVS_TOUCH(0) SMVS_TOUCH(1) SMVS_TOUCH(2) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p0) : "memory");
+    if constexpr (LINES == 4) asm volatile(SMVS_TOUCH(0) SMVS_TOUCH(1) SMVS_TOUCH(2) SMVS_TOUCH(3) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p0) : "memory");
+    if constexpr (LINES == 5) asm volatile(SMVS_TOUCH(0) SMVS_TOUCH(1) SMVS_TOUCH(2) SMVS_TOUCH(3) SMVS_TOUCH(4) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p0) : "memory");
+    if constexpr (LINES == 6) asm volatile(SMVS_TOUCH(0) SMVS_TOUCH(1) SMVS_TOUCH(2) SMVS_TOUCH(3) SMVS_TOUCH(4) SMVS_TOUCH(5) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p0) : "memory");
+    if constexpr (LINES == 7) asm volatile(SMVS_TOUCH(0) SMVS_TOUCH(1) SMVS_TOUCH(2) SMVS_TOUCH(3) SMVS_TOUCH(4) SMVS_TOUCH(5) SMVS_TOUCH(6) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p0) : "memory");
+    if constexpr (LINES == 8) asm volatile(SMVS_TOUCH(0) SMVS_TOUCH(1) SMVS_TOUCH(2) SMVS_TOUCH(3) SMVS_TOUCH(4) SMVS_TOUCH(5) SMVS_TOUCH(6) SMVS_TOUCH(7) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p0) : "memory");
+#undef SMVS_TOUCH
 }
 
 // RPC_Obj2Photo (warping.py:218-252) at N consecutive planes of one pixel whose heights are their planes': pc -> the

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 from ..modules.depth_range import stage_hypotheses
 from ..modules.module import CostRegNet, FeatureNet, depth_regression, window_depth_regression
+from .. import _lib
 from ..modules.warping import variance_cost_volume
 
 Align_Corners_Range = False
@@ -24,7 +25,8 @@ class DepthNet(nn.Module):
         assert len(features) == n_proj, "Different number of images and projection matrices"
         assert depth_values.shape[1] == num_depth, "depth_values.shape[1]:{}  num_depth:{}".format(
             depth_values.shape[1], num_depth)
-        volume_variance = variance_cost_volume(features, proj_matrices, depth_values, geo_model, use_qc)
+        with _lib.pipeline_arith_scope():
+            volume_variance = variance_cost_volume(features, proj_matrices, depth_values, geo_model, use_qc)
         reg = cost_regularization(volume_variance).squeeze(1)
         depth, conf = window_depth_regression(reg, depth_values)      # casmvs.py:66-74; native when no gradient is wanted
         return {"depth": depth, "photometric_confidence": conf}
@@ -34,7 +36,8 @@ class CascadeMVSNet(nn.Module):
     def __init__(self, geo_model, refine=False, min_interval=2.5, ndepths=[48, 32, 8], depth_interals_ratio=[4, 2, 1],
                  share_cr=False, grad_method="detach", arch_mode="fpn", cr_base_chs=[8, 8, 8], use_qc=False, arith=None):
         super().__init__()
-        self.arith = arith                      # this model's arithmetic of the variance build (None: the process default)
+        self.arith = arith                      # this model's arithmetic of the variance build: "exact" / "fused"; None = the enclosing
+        # _lib.arith_scope if there is one, else "exact" (_lib.pipeline_arith_scope)
         assert geo_model in ["rpc", "pinhole"]
         assert len(ndepths) == len(depth_interals_ratio)
         if refine:
@@ -55,7 +58,7 @@ class CascadeMVSNet(nn.Module):
 
     def forward(self, imgs, proj_matrices, depth_values):
         from .. import _lib
-        with _lib.arith_scope(getattr(self, "arith", None)):
+        with _lib.pipeline_arith_scope(getattr(self, "arith", None)):
             return self._forward(imgs, proj_matrices, depth_values)
 
     def _forward(self, imgs, proj_matrices, depth_values):

@@ -22,6 +22,7 @@ import torch.nn.functional as F
 from ..modules.depth_range import GeneratedHeights, stage_hypotheses
 from ..modules.module import (FeatureNet, RED_Regularization, StreamingRegression, guard_miopen_find, restore_miopen_find, slice_RED_Regularization,
                               softmax_depth_regression)
+from .. import _lib
 from ..modules.warping import variance_cost_volume
 
 _STAGE_SCALES = {3: {"stage1": 4.0, "stage2": 2.0, "stage3": 1.0}, 2: {"stage1": 4.0, "stage2": 1.0}}
@@ -45,7 +46,8 @@ def compute_depth_when_train(features, proj_matrices, depth_values, num_depth, c
         dv = depth_values if isinstance(depth_values, GeneratedHeights) else depth_values.detach().to(torch.float32).contiguous()
         reg = cost_regularization.native_volume(features, proj_matrices, dv, geo_model, use_qc)
     else:
-        volume_variance = variance_cost_volume(features, proj_matrices, depth_values, geo_model, use_qc)
+        with _lib.pipeline_arith_scope():                          # (the native pipeline defaults the same way, include/satmvs.h)
+            volume_variance = variance_cost_volume(features, proj_matrices, depth_values, geo_model, use_qc)
         reg = cost_regularization(volume_variance)                 # (B,D,H,W)
     depth, confidence = softmax_depth_regression(reg, depth_values)
     return {"depth": depth, "photometric_confidence": confidence}
@@ -69,7 +71,8 @@ def compute_depth_when_pred(features, proj_matrices, depth_values, num_depth, co
         if gen:
             dv = dv.materialize()
         for d in range(num_depth):
-            plane = variance_cost_volume(features, proj_matrices, dv, geo_model, use_qc, d_begin=d, d_end=d + 1)
+            with _lib.pipeline_arith_scope():
+                plane = variance_cost_volume(features, proj_matrices, dv, geo_model, use_qc, d_begin=d, d_end=d + 1)
             reg, *states = cost_regularization(plane.squeeze(2), *states)
             acc.step(reg, dv, d)
     depth, confidence = acc.result()
@@ -83,7 +86,8 @@ class _CascadeRED(nn.Module):
     def __init__(self, geo_model, min_interval=2.5, ndepths=[48, 32, 8], depth_interals_ratio=[4, 2, 1],
                  cr_base_chs=[8, 8, 8], use_qc=False, arith=None):
         super().__init__()
-        self.arith = arith                      # this model's arithmetic of the variance build (None: the process default)
+        self.arith = arith                      # this model's arithmetic of the variance build: "exact" / "fused"; None = the enclosing
+        # _lib.arith_scope if there is one, else "exact" (_lib.pipeline_arith_scope)
         assert geo_model in ["rpc", "pinhole"]
         assert len(ndepths) == len(depth_interals_ratio)
         self.geo_model = geo_model
@@ -101,7 +105,7 @@ class _CascadeRED(nn.Module):
 
     def forward(self, imgs, proj_matrices, depth_values):
         from .. import _lib
-        with _lib.arith_scope(getattr(self, "arith", None)):
+        with _lib.pipeline_arith_scope(getattr(self, "arith", None)):
             return self._forward(imgs, proj_matrices, depth_values)
 
     def _forward(self, imgs, proj_matrices, depth_values):

@@ -10,6 +10,7 @@ import torch.nn.functional as F
 
 from ..modules.depth_range import GeneratedHeights, uncertainty_aware_samples
 from ..modules.module import CostRegNet, FeatureNet, window_depth_regression
+from .. import _lib
 from ..modules.warping import variance_cost_volume
 
 
@@ -17,7 +18,8 @@ def compute_depth(feats, proj_mats, depth_samps, cost_reg, lamb, geo_model, is_t
     num_depth = depth_samps.shape[1]
     n_proj = len(proj_mats) if use_qc else proj_mats.shape[1]
     assert n_proj == len(feats), "Different number of images and projection matrices"
-    volume_variance = variance_cost_volume(feats, proj_mats, depth_samps, geo_model, use_qc)
+    with _lib.pipeline_arith_scope():
+        volume_variance = variance_cost_volume(feats, proj_mats, depth_samps, geo_model, use_qc)
     reg = cost_reg(volume_variance).squeeze(1)
     depth, prob_conf, exp_variance = window_depth_regression(reg, depth_samps, lamb=lamb)      # ucs.py:60-74
     return {"depth": depth, "photometric_confidence": prob_conf, "variance": exp_variance}
@@ -27,7 +29,8 @@ class UCSNet(nn.Module):
     def __init__(self, geo_model, lamb=1.5, stage_configs=[64, 32, 8], grad_method="detach", base_chs=[8, 8, 8],
                  feat_ext_ch=8, use_qc=False, arith=None):
         super().__init__()
-        self.arith = arith                      # this model's arithmetic of the variance build (None: the process default)
+        self.arith = arith                      # this model's arithmetic of the variance build: "exact" / "fused"; None = the enclosing
+        # _lib.arith_scope if there is one, else "exact" (_lib.pipeline_arith_scope)
         assert geo_model in ["rpc", "pinhole"]
         self.geo_model, self.stage_configs, self.grad_method = geo_model, stage_configs, grad_method
         self.base_chs, self.lamb, self.num_stage, self.use_qc = base_chs, lamb, len(stage_configs), use_qc
@@ -39,7 +42,7 @@ class UCSNet(nn.Module):
 
     def forward(self, imgs, proj_matrices, depth_values):
         from .. import _lib
-        with _lib.arith_scope(getattr(self, "arith", None)):
+        with _lib.pipeline_arith_scope(getattr(self, "arith", None)):
             return self._forward(imgs, proj_matrices, depth_values)
 
     def _forward(self, imgs, proj_matrices, depth_values):

@@ -40,8 +40,11 @@ def oracle():
 
 @pytest.fixture(params=["exact", "fused"])
 def arith(request):
-    """Runs the test once per arithmetic of the variance build; leaves the suite's mode ("exact") behind."""
+    """Runs the test once per arithmetic of the variance build -- the process default of the stand-alone builds AND an
+    arith_scope, which the plane pipelines / cascades follow (without one they run "exact" whatever the default is);
+    leaves the suite's mode ("exact") behind."""
     from satmvs_amd import _lib
     _lib.set_arith(request.param)
-    yield request.param
+    with _lib.arith_scope(request.param):
+        yield request.param
     _lib.set_arith(os.environ.get("SMVS_ARITH", "exact"))

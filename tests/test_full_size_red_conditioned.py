@@ -203,15 +203,16 @@ def test_red_cascade_well_conditioned_full_size(dev, tag, arith):
     f64 = red_stages_against_float64(net, imgs, pm, dv, "rpc", var_mode="current")
     ref_note = ""
     if arith == "fused":
-        # for the record: the same stages against the float64 evaluation on the REFERENCE's variance volume (the exact build) -- what the
-        # fused arithmetic's own 1e-5 * max(1, |v|) on the volume turns into at a peaky stage
+        # REPORTED, not asserted: the same stages against the float64 evaluation on the REFERENCE's variance volume (the exact build) --
+        # what the fused arithmetic's own 1e-5 * max(1, |v|) on the volume turns into behind a gain-16 softmax (2.1e-3 m at 3 of 294 912
+        # pixels in round 5).  That is why the cascades and plane pipelines run the exact build unless asked (round 6: _lib.pipeline_arith_scope,
+        # include/satmvs.h); the fused mode reaches this test only through the `arith` fixture's scope, and is held to 1e-3 m on its OWN
+        # volume below.  bench.py's height_parity_vs_reference.conditioned_768x384 carries both figures on the driver's box.
         det = {}
         red_stages_against_float64(net, imgs, pm, dv, "rpc", detail=det)
         ref = {s: (d["native"].double() - d["float64"]).abs() for s, d in det.items()}
         ref_note = " | native (fused volume) vs float64 on the exact volume: max %s, fraction beyond 1e-3 m %s" % (
             {s: "%.3g" % float(e.max()) for s, e in ref.items()}, {s: "%.2g" % float((e > H_TOL).double().mean()) for s, e in ref.items()})
-        for s, e in ref.items():
-            assert float((e > H_TOL).double().mean()) <= 1e-4 and float(e.max()) <= 5e-3, (s, ref_note)
     herr = np.abs(a["stage3"]["depth"][0].cpu().numpy() - truth)[32:-32, 32:-32]
     msg = ("%s (%s arithmetic) gains %s confidence %s | same stage inputs (native-f64, composite-f64, native-composite) %s | free-running native vs composite: "
            "max %s, fraction of pixels beyond 1e-3 m %s | stage 3 vs the rendered surface: median %.2f m, 90 %% %.2f m") % (

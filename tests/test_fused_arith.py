@@ -39,7 +39,8 @@ def dev():
 def fused():
     from satmvs_amd import _lib
     _lib.set_arith("fused")
-    yield
+    with _lib.arith_scope("fused"):         # (the plane pipelines / cascades follow a scope, not the process default)
+        yield
     _lib.set_arith(os.environ.get("SMVS_ARITH", "exact"))
 
 
@@ -268,7 +269,9 @@ def test_arithmetic_travels_with_the_call(dev):
 
 def test_models_carry_their_own_arithmetic(dev):
     """Two networks in one process, one built with arith="exact" and one with arith="fused", same weights and inputs: each forward
-    equals the forward of the same network under the process-wide mode of that name -- whatever the process default is."""
+    equals the forward of the same network inside an arith_scope of that name -- whatever the process default is.  A network
+    built without arith= and called outside any scope runs "exact" (round 6: cascades and plane pipelines do not follow the
+    process default of the stand-alone builds)."""
     from satmvs_amd import _lib
     from satmvs_amd.networks import casmvs, casred
     import test_full_size_cascade as FS
@@ -292,14 +295,14 @@ def test_models_carry_their_own_arithmetic(dev):
         with torch.no_grad():
             want = {}
             for mode in ("exact", "fused"):
-                _lib.set_arith(mode)
-                want[mode] = plain(imgs, pm, dv)["depth"].clone()
-            _lib.set_arith("exact")
+                with _lib.arith_scope(mode):
+                    want[mode] = plain(imgs, pm, dv)["depth"].clone()
             assert not torch.equal(want["exact"], want["fused"])
             for default in ("exact", "fused"):
                 _lib.set_arith(default)
                 for mode in ("fused", "exact"):
                     assert torch.equal(nets[mode](imgs, pm, dv)["depth"], want[mode]), (cls.__name__, default, mode)
+                assert torch.equal(plain(imgs, pm, dv)["depth"], want["exact"]), (cls.__name__, default, "no scope -> exact")
         _lib.set_arith("exact")
 
 
