@@ -223,6 +223,18 @@ int smvs_rpc_geo_consistency(const float* depth_ref, const double* rpc_ref, cons
                              unsigned char* mask, float* depth_reproj, double* x_src, double* y_src,
                              double* x_back, double* y_back, void* stream);
 
+/* The pinhole twin: one (reference, source) pair of tools/pinhole_filter.py:7-67 (reproject_with_depth +
+ * check_geometric_consistency).  mats (device): P_ref, inverse(P_ref), P_src, inverse(P_src), row-major 4 x 4 float64 with
+ * P = [K @ E[:3]; 0 0 0 1] (:17-24; formed and inverted by the caller, on the host like the reference).  Reference pixel * depth
+ * -> world -> source pixel in float64, float32 coordinates into cv2.remap(INTER_LINEAR, default border: constant 0), the
+ * sampled depth back into the reference view; mask = (|reprojected - pixel| < p_thre) & (|sampled - depth| / depth <
+ * float32(relative_d_thre)).  depth_ref (H,W), depth_src (Hs,Ws) float32; mask uint8; depth_reproj float32 (0 outside the
+ * mask when x_back / y_back are NULL, the raw sampled depth when they are given); x_src, y_src, x_back, y_back (H,W) float32. */
+int smvs_pinhole_geo_consistency(const float* depth_ref, const float* depth_src, const double* mats,
+                                 int H, int W, int Hs, int Ws, double p_thre, double relative_d_thre,
+                                 unsigned char* mask, float* depth_reproj, float* x_src, float* y_src,
+                                 float* x_back, float* y_back, void* stream);
+
 /* ---- GroupNorm(1, C) of the recurrent regulariser, training path -------------------------------------
  * reference: modules/module.py:15-20 (three nn.GroupNorm(1, C, 1e-5) per ConvGRU cell) and :38-52 (sigmoid / tanh of
  * the normalised gates); differentiated by train.py:284.  x (B,C,HW) float32 with batch stride x_batch_stride elements

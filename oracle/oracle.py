@@ -279,6 +279,52 @@ def filter_depth(depths, rpcs, p_ratio, d_ratio, geo_consist_num, prob=None, con
     return np.logical_and(photo, geo_sum >= geo_consist_num), averaged
 
 
+def _pinhole_mats(K_ref, E_ref, K_src, E_src):
+    """P = [K @ E[:3]; 0 0 0 1] and its inverse for both views (tools/pinhole_filter.py:17-24), float64."""
+    bottom = np.array([[0.0, 0.0, 0.0, 1.0]])
+    P_ref = np.concatenate((np.matmul(np.asarray(K_ref, np.float64), np.asarray(E_ref, np.float64)[:3]), bottom), axis=0)
+    P_src = np.concatenate((np.matmul(np.asarray(K_src, np.float64), np.asarray(E_src, np.float64)[:3]), bottom), axis=0)
+    return P_ref, np.linalg.inv(P_ref), P_src, np.linalg.inv(P_src)
+
+
+def pinhole_reproject_with_depth(depth_ref, K_ref, E_ref, depth_src, K_src, E_src):
+    """tools/pinhole_filter.py:7-46 of the reference: reference pixel * depth -> world -> source pixel (float64 matrix
+    products, float32 coordinates into cv2.remap with its default border: constant 0), the sampled source depth back into
+    the reference view.  -> sampled depth, reprojected (x, y) float32, source (x, y) float32."""
+    depth_ref = _f32(depth_ref)
+    H, W = depth_ref.shape
+    row, col = np.meshgrid(range(H), range(W), indexing="ij")
+    col, row = col.reshape(1, -1), row.reshape(1, -1)
+    d = depth_ref.reshape(1, -1)
+    P_ref, inv_ref, P_src, inv_src = _pinhole_mats(K_ref, E_ref, K_src, E_src)
+    tmp = np.vstack((d * col, d * row, d, np.ones((1, W * H))))
+    xy = np.matmul(P_src, np.matmul(inv_ref, tmp))
+    xy = xy[:2] / xy[2]
+    xs = xy[0].reshape(H, W).astype(np.float32)
+    ys = xy[1].reshape(H, W).astype(np.float32)
+    sampled = remap_linear_const(depth_src, xs, ys, border=0.0)
+    sv = sampled.reshape(1, -1)
+    tmp = np.vstack((sv * xy[0], sv * xy[1], sv, np.ones((1, W * H))))
+    back = np.matmul(P_ref, np.matmul(inv_src, tmp))
+    back = back[:2] / back[2]
+    return sampled, back[0].reshape(H, W).astype(np.float32), back[1].reshape(H, W).astype(np.float32), xs, ys
+
+
+def pinhole_check_geometric_consistency(depth_ref, K_ref, E_ref, depth_src, K_src, E_src, p_thre=1, relative_d_thre=0.01):
+    """tools/pinhole_filter.py:49-67: mask = |reprojected - pixel| < p_thre and |sampled - depth| / depth < relative_d_thre."""
+    depth_ref = _f32(depth_ref)
+    H, W = depth_ref.shape
+    xr, yr = np.meshgrid(np.arange(0, W), np.arange(0, H))
+    dep, xb, yb, xs, ys = pinhole_reproject_with_depth(depth_ref, K_ref, E_ref, depth_src, K_src, E_src)
+    dist = np.sqrt((xb - xr) ** 2 + (yb - yr) ** 2)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rel = np.abs(dep - depth_ref) / depth_ref
+    mask = np.logical_and(dist < p_thre, rel < relative_d_thre)
+    dep = dep.copy()
+    dep[~mask] = 0
+    return mask, dep, xs, ys
+
+
 def window_regress(reg, depth, lamb=None):
     """casmvs / ucs regression: (depth, window-4 confidence[, lamb * std-dev]) -- orc_window_regress."""
     reg = _f32(reg)

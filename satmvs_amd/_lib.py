@@ -32,6 +32,7 @@ _SIGNATURES = {
     "smvs_costvol_bwd": [_i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp] + [_i] * 5 + [_vp],
     "smvs_rpc_project": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
     "smvs_rpc_geo_consistency": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "smvs_pinhole_geo_consistency": [_vp, _vp, _vp, _i, _i, _i, _i, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "smvs_softmax_regress_fwd": [_vp, _vp, _i, _vp, _vp] + [_i] * 4 + [_vp],
     "smvs_window_regress_fwd": [_vp, _vp, _i, _vp, _vp, _vp, _f] + [_i] * 4 + [_vp],
     "smvs_height_hypotheses": [_vp, _vp, _i, _i, _i, _vp],

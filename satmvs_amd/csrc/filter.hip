@@ -59,9 +59,70 @@ void geo_consistency_kernel(const float* __restrict__ depth_ref, const double* _
     if (x_back) { x_back[i] = xb; y_back[i] = yb; }
 }
 
+// The pinhole twin (/root/reference/tools/pinhole_filter.py:7-67).  mats = P_ref, inverse(P_ref), P_src, inverse(P_src), row-major
+// 4 x 4 float64 (P = [K @ E[:3]; 0 0 0 1], formed and inverted on the host in numpy like the reference does).  Per reference pixel:
+//   tmp = (d x, d y, d, 1);  xy = P_src (inverse(P_ref) tmp);  (x_src, y_src) = float32(xy[:2] / xy[2])
+//   sampled = cv2.remap(depth_src, x_src, y_src, INTER_LINEAR)             default border: constant 0
+//   tmp = (sampled xy0, sampled xy1, sampled, 1) with the UNROUNDED float64 xy;  back = P_ref (inverse(P_src) tmp), float32(back[:2] / back[2])
+//   mask = sqrt((x_back - x)^2 + (y_back - y)^2) < p_thre  and  |sampled - d| / d < float32(relative_d_thre)      (float64 / float32 as numpy promotes)
+__device__ __forceinline__ void mat4_apply(const double* __restrict__ M, double x, double y, double z, double w, double* o)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = ((M[4 * i] * x + M[4 * i + 1] * y) + M[4 * i + 2] * z) + M[4 * i + 3] * w;
+}
+
+__global__ __launch_bounds__(256)
+void pinhole_geo_consistency_kernel(const float* __restrict__ depth_ref, const float* __restrict__ depth_src, const double* __restrict__ mats,
+                                    int H, int W, int Hs, int Ws, double p_thre, float rel_thre,
+                                    unsigned char* __restrict__ mask, float* __restrict__ depth_reproj,
+                                    float* __restrict__ x_src, float* __restrict__ y_src, float* __restrict__ x_back, float* __restrict__ y_back)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)H * W) return;
+    const int y = (int)(i / W), x = (int)(i % W);
+    const double* P_ref = mats, *inv_ref = mats + 16, *P_src = mats + 32, *inv_src = mats + 48;
+    const float df = depth_ref[i];
+    const double d = (double)df;
+    double v[4], w[4];
+    mat4_apply(inv_ref, d * (double)x, d * (double)y, d, 1.0, v);
+    mat4_apply(P_src, v[0], v[1], v[2], v[3], w);
+    const double sx = w[0] / w[2], sy = w[1] / w[2];
+    const float xs = (float)sx, ys = (float)sy;
+    const float sampled = remap_linear_const(depth_src, Hs, Ws, xs, ys, 0.0f);
+    const double sd = (double)sampled;
+    mat4_apply(inv_src, sd * sx, sd * sy, sd, 1.0, v);
+    mat4_apply(P_ref, v[0], v[1], v[2], v[3], w);
+    const float xb = (float)(w[0] / w[2]), yb = (float)(w[1] / w[2]);
+    const double dx = (double)xb - (double)x, dy = (double)yb - (double)y;
+    const double dist = sqrt(dx * dx + dy * dy);
+    const float rel = __fdiv_rn(fabsf(sampled - df), df);
+    const bool ok = (dist < p_thre) && (rel < rel_thre);
+    mask[i] = ok ? 1 : 0;
+    depth_reproj[i] = (ok || x_back) ? sampled : 0.0f;      // reproject_with_depth (x_back given) returns the raw remap value
+    x_src[i] = xs; y_src[i] = ys;
+    if (x_back) { x_back[i] = xb; y_back[i] = yb; }
+}
+
 }  // namespace smvs
 
 extern "C" {
+
+SMVS_EXPORT int smvs_pinhole_geo_consistency(const float* depth_ref, const float* depth_src, const double* mats,
+                                             int H, int W, int Hs, int Ws, double p_thre, double relative_d_thre,
+                                             unsigned char* mask, float* depth_reproj, float* x_src, float* y_src,
+                                             float* x_back, float* y_back, void* stream)
+{
+    using namespace smvs;
+    if (!depth_ref || !depth_src || !mats || !mask || !depth_reproj || !x_src || !y_src) return fail(SMVS_ERR_ARG, "null pointer argument");
+    if ((x_back == nullptr) != (y_back == nullptr)) return fail(SMVS_ERR_ARG, "x_back and y_back go together");
+    if (H < 1 || W < 1 || Hs < 1 || Ws < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
+    const size_t n = (size_t)H * W;
+    hipLaunchKernelGGL(pinhole_geo_consistency_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       depth_ref, depth_src, mats, H, W, Hs, Ws, p_thre, (float)relative_d_thre, mask, depth_reproj, x_src, y_src, x_back, y_back);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "pinhole_geo_consistency launch: %s", hipGetErrorString(e));
+    return SMVS_OK;
+}
 
 SMVS_EXPORT int smvs_rpc_geo_consistency(const float* depth_ref, const double* rpc_ref, const float* depth_src,
                                          const double* rpc_src, int H, int W, int Hs, int Ws, double p_ratio, double d_ratio,

@@ -776,6 +776,67 @@ def gen_filter():
     save("filter", **out)
 
 
+def pinhole_filter_scene(H=64, W=96, V=3, seed=4):
+    """V consistent pinhole depth maps of one smooth surface seen from above (cameras a little apart, rotated about their axes),
+    a blunder patch in the last view: inputs only, built here."""
+    rng = np.random.default_rng(seed)
+
+    def surface(X, Y):
+        return 8.0 * np.sin(0.011 * X + 0.3) * np.cos(0.013 * Y - 0.2)
+    Ks, Es, depths = [], [], []
+    vv, uu = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    for v in range(V):
+        f = 1.15 * W
+        K = np.array([[f, 0.0, W / 2.0 + 0.5 * v], [0.0, f, H / 2.0 - 0.25 * v], [0.0, 0.0, 1.0]])
+        a = 0.03 * v * (-1) ** v
+        R = np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]]) @ np.diag([1.0, -1.0, -1.0])
+        Cc = np.array([18.0 * v * (-1) ** v, 7.0 * v, 400.0 + 0.5 * v])      # (the reference compares the two views' depths as they are: same flying height)
+        E = np.eye(4)
+        E[:3, :3], E[:3, 3] = R, -R @ Cc
+        P = np.concatenate((K @ E[:3], np.array([[0.0, 0.0, 0.0, 1.0]])), axis=0)
+        Pi = np.linalg.inv(P)
+        d = np.full((H, W), 400.0)
+        for _ in range(20):                                    # depth along the ray such that the point lies on the surface
+            Xw = Pi @ np.vstack(((d * uu).ravel(), (d * vv).ravel(), d.ravel(), np.ones(H * W)))
+            Z = surface(Xw[0], Xw[1])
+            d = (R @ np.vstack((Xw[0], Xw[1], Z)) + E[:3, 3:4])[2].reshape(H, W)
+        Ks.append(K); Es.append(E); depths.append(d.astype(np.float32))
+    depths = np.stack(depths)
+    depths[V - 1, 12:22, 28:52] *= 1.03
+    return depths, np.stack(Ks), np.stack(Es), rng
+
+
+def gen_filter_pinhole():
+    """tools/pinhole_filter.py:7-67 run AS IS (reproject_with_depth, check_geometric_consistency) on a three-view pinhole scene.
+    `cv2` is stood in for at import time by a module whose remap() is the oracle's restatement of OpenCV's fixed-point bilinear
+    remap (default border: constant 0) -- so every step is pinned by this fixture EXCEPT cv2.remap itself; nothing of the
+    reference is edited or stored."""
+    import importlib
+    import types
+    from oracle import oracle as orc
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_LINEAR, cv2.BORDER_CONSTANT = 1, 0
+
+    def remap(src, map1, map2, interpolation=None, borderMode=None, borderValue=0):
+        assert interpolation == cv2.INTER_LINEAR and borderMode in (None, cv2.BORDER_CONSTANT)
+        assert map1.dtype == np.float32 and map2.dtype == np.float32
+        return orc.remap_linear_const(src, map1, map2, border=float(borderValue))
+    cv2.remap = remap
+    sys.modules["cv2"] = cv2
+    sys.modules.pop("tools.pinhole_filter", None)
+    ref = importlib.import_module("tools.pinhole_filter")
+    depths, Ks, Es, _ = pinhole_filter_scene()
+    out = {"depths": depths, "K": Ks, "E": Es, "p_thre": np.float64(1.0), "relative_d_thre": np.float64(0.01)}
+    for v in (1, 2):
+        dep, xb, yb, xs, ys = ref.reproject_with_depth(depths[0].copy(), Ks[0], Es[0], depths[v].copy(), Ks[v], Es[v])
+        m, dm, xs2, ys2 = ref.check_geometric_consistency(depths[0].copy(), Ks[0], Es[0], depths[v].copy(), Ks[v], Es[v], 1.0, 0.01)
+        assert np.array_equal(xs, xs2) and np.array_equal(ys, ys2)
+        out.update({"v%d.sampled" % v: dep, "v%d.x_back" % v: xb, "v%d.y_back" % v: yb, "v%d.x_src" % v: xs, "v%d.y_src" % v: ys,
+                    "v%d.mask" % v: m, "v%d.depth_masked" % v: dm})
+        print("   pinhole filter v%d: mask mean %.3f, blunder patch kept %.3f" % (v, m.mean(), m[12:22, 28:52].mean()))
+    save("filter_pinhole", **out)
+
+
 def _import_ref_dataset():
     """The reference's MVSDataset class, imported unmodified behind the import-time stand-ins described in gen_dataset."""
     import types
@@ -885,7 +946,7 @@ def gen_dataset_qc():
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for fn in (gen_iccv, gen_project, gen_grid_sample, gen_rpc_warp, gen_qc, gen_homo, gen_costvol, gen_pred,
-               gen_regress, gen_depth_range, gen_ucs_samples, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad, gen_io, gen_filter, gen_train, gen_train3d, gen_dataset, gen_dataset_qc):
+               gen_regress, gen_depth_range, gen_ucs_samples, gen_cascade, gen_cascade_pinhole, gen_costreg, gen_featnet, gen_photo, gen_grad, gen_io, gen_filter, gen_filter_pinhole, gen_train, gen_train3d, gen_dataset, gen_dataset_qc):
         if only and fn.__name__[4:] not in only:
             continue
         fn()

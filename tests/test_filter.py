@@ -94,3 +94,59 @@ def test_reproject_returns_raw_samples_for_non_finite_heights(golden):
     assert np.isnan(dep).any() and (dep == -999.0).any() == (g["v1.sampled"] == -999.0).any()
     m, dm, _, _ = rpc_filter.check_geometric_consistency(depths[0], rpc[0], depths[1], rpc[1], 1.0, 2.5)
     assert not np.isnan(dm).any() and not m[np.isnan(dep)].any()
+
+
+# ---- the pinhole twin: /root/reference/tools/pinhole_filter.py:7-67 ------------------------------------------------------------
+# tests/golden/filter_pinhole.npz = the reference's own reproject_with_depth / check_geometric_consistency run unmodified
+# (gen_golden.py::gen_filter_pinhole; cv2.remap stood in for by the oracle's restatement, default border 0): pinned except cv2.remap.
+# Tolerances: float32 coordinates to 1 ulp-ish (2e-4 px: the float64 matrix products of numpy's BLAS and of the kernel round
+# differently in the last bit before the cast); where a coordinate sits on a 1/32-px rounding boundary of the remap the sampled
+# depth may come from the neighbouring fraction: <= 1e-3 of the pixels, the rest agree to 1e-3 (depths ~400).
+def _check_pinhole_pair(g, v, dep, xb, yb, xs, ys, m, dm):
+    for got, key in ((xs, "x_src"), (ys, "y_src")):
+        want = g["v%d.%s" % (v, key)]
+        assert got.dtype == want.dtype == np.float32 and got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-4)
+    want = g["v%d.sampled" % v]
+    close = np.abs(dep - want) <= 1e-3
+    assert dep.dtype == want.dtype and close.mean() >= 0.999
+    np.testing.assert_allclose(xb[close], g["v%d.x_back" % v][close], rtol=0, atol=5e-4)
+    np.testing.assert_allclose(yb[close], g["v%d.y_back" % v][close], rtol=0, atol=5e-4)
+    wm = g["v%d.mask" % v]
+    assert m.dtype == wm.dtype and (m != wm).mean() <= 2e-3
+    same = m == wm
+    np.testing.assert_allclose(dm[same], g["v%d.depth_masked" % v][same], rtol=0, atol=1e-3)
+    assert (dm[~m] == 0).all()
+
+
+def test_oracle_pinhole_filter_vs_reference(oracle, golden):
+    g = golden("filter_pinhole")
+    depths, K, E = g["depths"], g["K"], g["E"]
+    for v in (1, 2):
+        dep, xb, yb, xs, ys = oracle.pinhole_reproject_with_depth(depths[0], K[0], E[0], depths[v], K[v], E[v])
+        m, dm, xs2, ys2 = oracle.pinhole_check_geometric_consistency(depths[0], K[0], E[0], depths[v], K[v], E[v],
+                                                                     float(g["p_thre"]), float(g["relative_d_thre"]))
+        assert np.array_equal(xs, xs2) and np.array_equal(ys, ys2)
+        _check_pinhole_pair(g, v, dep, xb, yb, xs, ys, m, dm)
+    assert g["v1.mask"].mean() > 0.8 and g["v2.mask"][12:22, 28:52].mean() < 0.6      # the 3 % blunder patch of the last view is rejected where it matters
+
+
+@pytest.mark.gpu
+def test_pinhole_filter_kernel_matches_reference(oracle, golden):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from satmvs_amd import pinhole_filter
+    g = golden("filter_pinhole")
+    depths, K, E = g["depths"], g["K"], g["E"]
+    for v in (1, 2):
+        dep, xb, yb, xs, ys = pinhole_filter.reproject_with_depth(depths[0], K[0], E[0], depths[v], K[v], E[v])
+        m, dm, xs2, ys2 = pinhole_filter.check_geometric_consistency(depths[0], K[0], E[0], depths[v], K[v], E[v],
+                                                                     float(g["p_thre"]), float(g["relative_d_thre"]))
+        assert np.array_equal(xs, xs2) and np.array_equal(ys, ys2)
+        _check_pinhole_pair(g, v, dep, xb, yb, xs, ys, m, dm)
+        od, oxb, oyb, oxs, oys = oracle.pinhole_reproject_with_depth(depths[0], K[0], E[0], depths[v], K[v], E[v])
+        np.testing.assert_allclose(xs, oxs, rtol=0, atol=2e-4)
+        assert (np.abs(dep - od) <= 1e-3).mean() >= 0.999
+    # the reference's defaults (p_thre=1, relative_d_thre=0.01) and GPU tensors in
+    m2, _, _, _ = pinhole_filter.check_geometric_consistency(torch.from_numpy(depths[0]).cuda(), K[0], E[0], torch.from_numpy(depths[1]).cuda(), K[1], E[1])
+    assert (m2 != g["v1.mask"]).mean() <= 2e-3

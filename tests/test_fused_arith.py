@@ -110,9 +110,10 @@ def test_fused_costvol_vs_oracle_and_float64(dev, oracle, fused, cfg):
     worst_fused, worst_ref = float((e_fused / (scale + 1e-30)).max()), float((e_ref / (scale + 1e-30)).max())
     assert worst_ref <= 8 * EPS and worst_fused <= 8 * V * EPS, (worst_fused / EPS, worst_ref / EPS)
     assert np.sqrt((e_fused ** 2).mean()) <= (1.05 if V <= 3 else V) * np.sqrt((e_ref ** 2).mean())
-    # the exact instance reproduces the reference bit for bit on the same inputs (mode switch takes effect per call)
-    _lib.set_arith("exact")
-    T._close_f32(warping.variance_cost_volume(f, r, d, "rpc"), want)
+    # the exact instance reproduces the reference bit for bit on the same inputs (the mode travels with the call: the inner scope wins
+    # over the `fused` fixture's)
+    with _lib.arith_scope("exact"):
+        T._close_f32(warping.variance_cost_volume(f, r, d, "rpc"), want)
 
 
 def test_fused_costvol_golden(dev, golden, fused):
