@@ -309,7 +309,8 @@ int smvs_conv3d_fwd(int kind, const float* in, const float* packed, const float*
 
 /* nn.BatchNorm3d in TRAINING form (batch statistics over (B, N = D*H*W) per channel) with the block's ReLU -- the normalisation of every
  * Conv3d / Deconv3d block of CostRegNet under autograd (modules/module.py:324-410):
- *   fwd: y = [relu]((x - mean) * rstd * gamma + beta);  saved_mean_rstd (C,2) for the backward;  running_mean / running_var (or NULL, NULL)
+ *   fwd: y = [relu]((x - mean) * rstd * gamma + beta);  saved_mean_rstd (C,2) for the backward (an opaque pair: the mean is kept
+ *        relative to the channel's first element, which both directions re-read from x, so that |mean| >> std loses nothing);  running_mean / running_var (or NULL, NULL)
  *        updated like torch.nn.functional.batch_norm(training=True): (1 - momentum) * running + momentum * batch (unbiased variance);
  *        num_batches_tracked (int64 scalar on the device, or NULL) += 1 like nn.BatchNorm's forward
  *   bwd: dx, dgamma (C), dbeta (C) from dy, the layer's INPUT x and saved_mean_rstd; with relu != 0 the gradient passes where the forward's

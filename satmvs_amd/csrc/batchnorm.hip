@@ -8,7 +8,7 @@
 // per-thread float partial sums (<= 64 elements) folded in float64 over the block and added to a per-channel float64 pair with one
 // atomic per block:
 //   forward   1. bn_stats:  S1 = sum x, S2 = sum x^2 per channel over (B, D*H*W)
-//             2. bn_apply:  y = [relu](x * scale + shift), scale = gamma * rstd, shift = beta - mean * scale; one thread per channel
+//             2. bn_apply:  y = [relu]((x - mean) * scale + beta), scale = gamma * rstd; one thread per channel
 //                           stores (mean, rstd) for the backward and updates running_mean / running_var (unbiased, momentum) like
 //                           torch.nn.functional.batch_norm(training=True)
 //   backward  3. bn_bwd_stats:  with dy' = dy where the forward's output was positive (the SAME fma recomputed from x: no mask tensor,
@@ -50,7 +50,7 @@ struct BnArgs {
     const float* gamma; const float* beta;
     float* running_mean; float* running_var;       // updated by the forward, or null
     long long* num_batches;                         // nn.BatchNorm's num_batches_tracked, incremented by the forward, or null
-    float* saved;                                   // (C, 2): mean, rstd
+    float* saved;                                   // (C, 2): mean of (x - pivot) with pivot = x[0, c, 0] (re-read by the backward), rstd
     double* sums;                                   // (C, 2) float64 scratch, zeroed by the caller's launch sequence
     float* dgamma; float* dbeta;
     int B, C; long long N;                          // N = D*H*W
@@ -66,18 +66,27 @@ void bn_stats_kernel(const BnArgs a)
     const int c = blockIdx.y, b = blockIdx.x / a.nchunk, ch = blockIdx.x % a.nchunk;
     const size_t row = ((size_t)b * a.C + c) * (size_t)a.N;
     const long long i0 = (long long)ch * BN_CHUNK, i1 = min(a.N, i0 + BN_CHUNK);
-    float mean = 0.0f, rstd = 0.0f, scale = 0.0f, shift = 0.0f;
+    float mean = 0.0f, rstd = 0.0f, scale = 0.0f, shift = 0.0f;      // mean: of (x - pivot), see below
     if (BWD) {
         mean = a.saved[2 * c]; rstd = a.saved[2 * c + 1];
-        scale = a.gamma[c] * rstd; shift = fmaf(-mean, scale, a.beta[c]);
+        scale = a.gamma[c] * rstd; shift = a.beta[c];      // y = (x - mean) * scale + beta: the centred form (x * scale + (beta - mean * scale) cancels for |mean| >> std)
     }
+    // Forward: sums of (x - pivot) and (x - pivot)^2 with the channel's first element as the pivot (the same for every block of
+    // the channel; bn_apply_kernel re-reads it).  E[x^2] - E[x]^2 on raw float32 partial sums cancels catastrophically for a
+    // channel whose |mean| is much larger than its spread (relative error of the variance ~1e-6 (mean / std)^2: x = 100 + 0.1 n
+    // loses everything); shifted by a sample of the channel the two terms are of the size of the variance itself.
+    // The pivot stays part of the centring everywhere: x - mean is formed as (x - pivot) - mean(x - pivot), whose two terms are exact /
+    // small, instead of against a float32 mean whose own rounding (1.5e-5 at 150) times gamma * rstd would show in y.
+    const float pivot = a.x[(size_t)c * (size_t)a.N];
     float s1 = 0.0f, s2 = 0.0f;
     auto one = [&](float xv, float gv) {
         if (BWD) {
-            const float g = (!a.relu || fmaf(xv, scale, shift) > 0.0f) ? gv : 0.0f;
-            s1 += g; s2 = fmaf(g, (xv - mean) * rstd, s2);
+            const float xc = (xv - pivot) - mean;
+            const float g = (!a.relu || fmaf(xc, scale, shift) > 0.0f) ? gv : 0.0f;
+            s1 += g; s2 = fmaf(g, xc * rstd, s2);
         } else {
-            s1 += xv; s2 = fmaf(xv, xv, s2);
+            const float dv = xv - pivot;
+            s1 += dv; s2 = fmaf(dv, dv, s2);
         }
     };
     if (a.vec4) {
@@ -114,21 +123,23 @@ void bn_apply_kernel(const BnArgs a)
     const size_t row = ((size_t)b * a.C + c) * (size_t)a.N;
     const long long i0 = (long long)ch * BN_CHUNK, i1 = min(a.N, i0 + BN_CHUNK);
     const double cnt = (double)a.B * (double)a.N;
-    const double m = a.sums[2 * c] / cnt;
-    double var = a.sums[2 * c + 1] / cnt - m * m;
+    const double ms = a.sums[2 * c] / cnt;                        // mean of (x - pivot), see bn_stats_kernel
+    const double m = (double)a.x[(size_t)c * (size_t)a.N] + ms;
+    double var = a.sums[2 * c + 1] / cnt - ms * ms;
     var = var > 0.0 ? var : 0.0;
-    const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-    const float scale = a.gamma[c] * rstd, shift = fmaf(-mean, scale, a.beta[c]);
+    const float pivot = a.x[(size_t)c * (size_t)a.N];
+    const float mean = (float)m, mshift = (float)ms, rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float scale = a.gamma[c] * rstd, shift = a.beta[c];      // y = (x - mean) * scale + beta, centred
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (c == 0 && a.num_batches) *a.num_batches += 1;
-        a.saved[2 * c] = mean; a.saved[2 * c + 1] = rstd;
+        a.saved[2 * c] = mshift; a.saved[2 * c + 1] = rstd;            // (mean of x - pivot: the backward kernels centre the same way)
         if (a.running_mean) {
             const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
             a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * mean;
             a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
         }
     }
-    auto one = [&](float xv) { const float r = fmaf(xv, scale, shift); return a.relu ? fmaxf(r, 0.0f) : r; };
+    auto one = [&](float xv) { const float r = fmaf((xv - pivot) - mshift, scale, shift); return a.relu ? fmaxf(r, 0.0f) : r; };
     if (a.vec4) {
         for (long long i = i0 + threadIdx.x * 4; i < i1; i += BN_BLOCK * 4 * BN_UNROLL) {
             float4 xv[BN_UNROLL];
@@ -156,15 +167,17 @@ void bn_bwd_dx_kernel(const BnArgs a)
     const long long i0 = (long long)ch * BN_CHUNK, i1 = min(a.N, i0 + BN_CHUNK);
     const double cnt = (double)a.B * (double)a.N;
     const float mean = a.saved[2 * c], rstd = a.saved[2 * c + 1];
-    const float scale = a.gamma[c] * rstd, shift = fmaf(-mean, scale, a.beta[c]);
+    const float scale = a.gamma[c] * rstd, shift = a.beta[c];      // y = (x - mean) * scale + beta, centred
     const float t1 = (float)(a.sums[2 * c] / cnt), t2 = (float)(a.sums[2 * c + 1] / cnt);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         a.dbeta[c] = (float)a.sums[2 * c];
         a.dgamma[c] = (float)a.sums[2 * c + 1];
     }
+    const float pivot = a.x[(size_t)c * (size_t)a.N];
     auto one = [&](float xv, float gv) {
-        const float g = (!a.relu || fmaf(xv, scale, shift) > 0.0f) ? gv : 0.0f;
-        const float xh = (xv - mean) * rstd;
+        const float xc = (xv - pivot) - mean;                          // mean: of (x - pivot), as saved by the forward
+        const float g = (!a.relu || fmaf(xc, scale, shift) > 0.0f) ? gv : 0.0f;
+        const float xh = xc * rstd;
         return scale * (g - t1 - xh * t2);
     };
     if (a.vec4) {

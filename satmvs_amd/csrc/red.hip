@@ -1112,9 +1112,6 @@ constexpr int RING = 2 * NSL_MAX;
 struct RedPipe {
     hipStream_t rec, dec;
     hipEvent_t enc[RING], state[RING], done[RING];
-    // per-level chains (round 6): one stream per ConvGRU level instead of one recurrent stream for all four, see RedIssuer::per_level()
-    hipStream_t lev[4];
-    hipEvent_t lstate[4][RING];
 };
 
 static RedPipe* red_pipe_create()
@@ -1131,10 +1128,7 @@ static RedPipe* red_pipe_create()
         ok = hipEventCreateWithFlags(&p->enc[r], hipEventDisableTiming) == hipSuccess
           && hipEventCreateWithFlags(&p->state[r], hipEventDisableTiming) == hipSuccess
           && hipEventCreateWithFlags(&p->done[r], hipEventDisableTiming) == hipSuccess;
-    for (int g = 0; g < 4 && ok; ++g) {
-        ok = (pr ? hipStreamCreateWithPriority(&p->lev[g], hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&p->lev[g], hipStreamNonBlocking)) == hipSuccess;
-        for (int r = 0; r < RING && ok; ++r) ok = hipEventCreateWithFlags(&p->lstate[g][r], hipEventDisableTiming) == hipSuccess;
-    }
+
     if (!ok) { delete p; return nullptr; }        // (the few objects created before the failure are abandoned: the device is unusable anyway)
     return p;
 }
@@ -1172,10 +1166,6 @@ struct RedPipeLease {
             for (RedPipe* q : pool(d)) {
                 (void)hipStreamDestroy(q->rec); (void)hipStreamDestroy(q->dec);
                 for (int r = 0; r < RING; ++r) { (void)hipEventDestroy(q->enc[r]); (void)hipEventDestroy(q->state[r]); (void)hipEventDestroy(q->done[r]); }
-                for (int g = 0; g < 4; ++g) {
-                    (void)hipStreamDestroy(q->lev[g]);
-                    for (int r = 0; r < RING; ++r) (void)hipEventDestroy(q->lstate[g][r]);
-                }
                 delete q;
             }
             pool(d).clear();
@@ -1183,9 +1173,6 @@ struct RedPipeLease {
     }
 };
 
-#ifndef SMVS_RED_PER_LEVEL_DEFAULT
-#define SMVS_RED_PER_LEVEL_DEFAULT 0
-#endif
 static std::atomic<int> g_red_streams{2};     // smvs_red_set_streams(): 0 = caller's stream only (capture-safe)
 
 struct RedRun {
@@ -1241,13 +1228,11 @@ struct RedIssuer {
     // store + load of the partial sums) and the x halves compete with the chain for the CUs: 57 -> 54 us per plane at stage 1,
     // 98 -> 100 at stage 2, 262 -> 288 at stage 3.  Off; tuning builds: SMVS_RED_XSPLIT=1.
     bool xsplit() const { return !fused() && tune_int("SMVS_RED_XSPLIT", 0) == 1; }
-    // Per-level chains (round 6): the four ConvGRU levels of a plane are independent of each other (only the decoder crosses
-    // levels), and a level-batched launch lasts as long as its slowest level plus what the levels cost each other (16.8 us for
-    // jobs of 9-13 us at cascade stage 1).  With one stream per level every level walks its own chain of 4 launches per plane
-    // at its own pace -- no event between levels, one wait per chunk for the encoder, one event per level and chunk for the
-    // decoder; the plane loop is then bound by the slowest LEVEL's chain instead of the sum of the slowest jobs of each stage.
-    // Same kernels, same job bodies, same order of operations per element: bits are unchanged.
-    bool per_level() const { return multi && !fused() && !xsplit() && tune_int("SMVS_RED_PER_LEVEL", SMVS_RED_PER_LEVEL_DEFAULT) == 1; }
+    // Per-level chains (one stream per ConvGRU level, every level walking its own 4 launches per plane, no event between levels):
+    // built and measured in round 6, REJECTED -- 175 / 198 / 377 us per plane at cascade stages 1 / 2 / 3 against 55 / 92 / 226 for
+    // the level-batched chain, 19.2-20.2 ms per cascade forward against 7.6-7.7 (profiles/r06_red_per_level.txt).  Six concurrent
+    // streams of dependent small launches cost the runtime far more per launch than the levels' different lengths cost the batched
+    // launch; the code is gone.
 
     // the variance plane of plane k as a strided view for the convolutions that read it
     void cost_view(int k, ConvArgs& a) const
@@ -1322,11 +1307,7 @@ struct RedIssuer {
         const int enc_out[3] = {16, 32, 64};
         double* stats = stats_of(k);
         double* stats_next = d + 1 < d_end ? stats_of(k + 1) : nullptr;
-        const bool pl = per_level();
-        if (multi && k % ws.CH == 0) {                                     // later planes of the chunk follow on the same stream(s)
-            if (pl) { for (int g = 0; g < 4; ++g) (void)hipStreamWaitEvent(P.lev[g], P.enc[k % RING], 0); }
-            else (void)hipStreamWaitEvent(sR, P.enc[k % RING], 0);
-        }
+        if (multi && k % ws.CH == 0) (void)hipStreamWaitEvent(sR, P.enc[k % RING], 0);   // later planes of the chunk follow on the same stream
         ConvJobs gate{}, cand{};
         GruJobs gru{};
         gate.n = cand.n = gru.n = 4; gru.B = B;
@@ -1366,27 +1347,6 @@ struct RedIssuer {
             u.vec = tune_int("SMVS_GRU_VEC", 1) == 1 && hw % 4 == 0 && ((uintptr_t)u.h | (uintptr_t)u.h_out | (uintptr_t)u.hsnap | (uintptr_t)u.gates | (uintptr_t)u.rh | (uintptr_t)u.cand) % 16 == 0;
             u.HC = hc; u.HW = hw; u.gx = (int)(((size_t)hc * hw / (u.vec ? 4 : 1) + 255) / 256); u.blk0 = nb_gru;
             nb_gru += u.gx * B;
-        }
-        if (pl) {
-            // one chain per level on its own stream: gate convolution -> gate apply -> candidate convolution -> combine
-            for (int q = 0; q < 4; ++q) {
-                const int g = 3 - q;
-                const hipStream_t sL = P.lev[g];
-                ConvJobs one{};
-                one.n = 1; one.j[0] = gate.j[q]; one.j[0].blk0 = 0;
-                const int nbg = (q < 3 ? gate.j[q + 1].blk0 : nb_gate) - gate.j[q].blk0;
-                GruJobs gone{};
-                gone.n = 1; gone.B = B; gone.j[0] = gru.j[q]; gone.j[0].blk0 = 0;
-                const int nbu = gru.j[q].gx * B;
-                hipLaunchKernelGGL(conv_jobs_kernel, dim3(nbg), dim3(256), 0, sL, one);
-                hipLaunchKernelGGL(gru_gate_apply_kernel, dim3(nbu), dim3(256), 0, sL, gone);
-                one.j[0] = cand.j[q]; one.j[0].blk0 = 0;
-                const int nbc = (q < 3 ? cand.j[q + 1].blk0 : nb_cand) - cand.j[q].blk0;
-                hipLaunchKernelGGL(conv_jobs_kernel, dim3(nbc), dim3(256), 0, sL, one);
-                hipLaunchKernelGGL(gru_combine_kernel, dim3(nbu), dim3(256), 0, sL, gone);
-                if ((k + 1) % ws.CH == 0 || d + 1 == d_end) (void)hipEventRecord(P.lstate[g][k % RING], sL);
-            }
-            return SMVS_OK;
         }
         if (tune_int("SMVS_RED_SPLIT_JOBS", 0)) {                       // tuning builds: one launch per level, to time the jobs
             for (int pass = 0; pass < 2; ++pass) {
@@ -1530,8 +1490,7 @@ struct RedIssuer {
         float* wsf = r.wsf;
         const float* packed = r.packed;
         const size_t npix = (size_t)B * r.H * r.W;
-        if (multi && per_level()) { for (int g = 0; g < 4; ++g) (void)hipStreamWaitEvent(sD, P.lstate[g][(k0 + n - 1) % RING], 0); }
-        else if (multi) (void)hipStreamWaitEvent(sD, P.state[(k0 + n - 1) % RING], 0);
+        if (multi) (void)hipStreamWaitEvent(sD, P.state[(k0 + n - 1) % RING], 0);
         for (int g = 3; g >= 1; --g) {
             // sum[g-1] = relu(upconv{g}(state4' or sum[g])) + state{g}'
             ConvArgs u{};

@@ -115,13 +115,20 @@ def scale_rpc_qc(rpcs, factor):
 class MVSDataset:
     """Drop-in for dataset.satmvsdataset.MVSDataset (a torch Dataset: __len__ / __getitem__); modes "train", "val", "test",
     "pred"; `use_qc` selects the QC-dictionary samples (get_sample_qc / get_pred_sample_qc).  The "train" mode augments every view
-    with the reference's random_color unless another `augment` (a PIL image -> PIL image callable) is given; augment=False
+    with the reference's random_color (drawing from np.random like the reference, or from RandomState(seed) when `seed` is given)
+    unless another `augment` (a PIL image -> PIL image callable) is given; augment=False
     switches it off."""
 
-    def __init__(self, data_folder, mode, view_num, ref_view=2, use_qc=False, augment=None):
+    def __init__(self, data_folder, mode, view_num, ref_view=2, use_qc=False, augment=None, seed=None):
         assert mode in ["train", "val", "test", "pred"]
         self.data_folder, self.mode, self.view_num, self.ref_view, self.use_qc = data_folder, mode, view_num, ref_view, use_qc
-        self.augment = image_augment if augment is None else (augment or None)
+        # seed: a reproducible stream for the default augmentation (np.random.RandomState(seed)) instead of the global np.random state the
+        # reference draws from; with DataLoader workers pass a per-worker seed through worker_init_fn (every worker copies the dataset)
+        self.rng = np.random.RandomState(seed) if seed is not None else None
+        if augment is None and self.rng is not None:
+            self.augment = lambda image: random_color(image, self.rng)
+        else:
+            self.augment = image_augment if augment is None else (augment or None)
         if mode == "pred" or ref_view < 0:
             self.sample_list = gen_all_mvs_list_rpc(data_folder, view_num)
         else:

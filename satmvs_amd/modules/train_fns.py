@@ -13,6 +13,7 @@ from __future__ import annotations
 import threading
 
 import torch
+from torch.autograd.function import once_differentiable
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -75,6 +76,7 @@ class _GroupNorm1Fn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         x, w, y, stats = ctx.saved_tensors
         xbs, act = ctx.meta
@@ -112,6 +114,7 @@ class _GroupNormPairFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         x, w1, w2, y, stats = ctx.saved_tensors
         B, C2, H, W = x.shape
@@ -144,6 +147,7 @@ class _GruMulCatFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dcat):
         r, h = ctx.saved_tensors
         B, Ch, H, W = h.shape
@@ -169,6 +173,7 @@ class _GruBlendFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         u, h, y = ctx.saved_tensors
         dy = _f32c_fast(dy)
@@ -321,6 +326,7 @@ class _PlaneViewsFn(torch.autograd.Function):
         return p.unsqueeze(0).expand(d_num, *p.shape).unbind(0)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, *grads):
         real = [g for g in grads if g is not None and not _is_placeholder(g)]
         total = None
@@ -356,6 +362,7 @@ class _Conv3x3WgradFn(torch.autograd.Function):
         return F.conv2d(x, weight, bias, stride=stride, padding=1)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         has_bias, stride, transposed = ctx.meta
@@ -418,6 +425,7 @@ class _Conv3dWgradFn(torch.autograd.Function):
         return F.conv3d(x, weight, None, stride=stride, padding=1)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         stride, transposed = ctx.meta
@@ -444,8 +452,9 @@ def _conv3d_packed(weight, layout, cin, cout):
     packed = torch.empty((_lib.load().smvs_conv3d_packed_floats(cin, cout),), dtype=torch.float32, device=weight.device)
     with torch.cuda.device(weight.device):
         _lib.call("smvs_conv3d_pack", _lib.ptr(weight), _lib.ptr(packed), cin, cout, layout, _lib.current_stream(weight.device))
-    if len(_CONV_PACK) > 256:
-        _CONV_PACK.clear()
+    if sum(1 for k in _CONV_PACK if k[3] == key[3]) > 256:          # per device (nn.DataParallel: ~120 entries per replica device);
+        for k in [k for k in _CONV_PACK if k[3] == key[3]][:128]:     # the oldest half of THIS device's entries goes (dicts keep insertion order)
+            del _CONV_PACK[k]
     _CONV_PACK[key] = (weight._version, _PARAM_EPOCH[0], StorageWeakRef(weight.untyped_storage()), packed)
     return packed
 
@@ -494,6 +503,7 @@ class _Conv3dNativeFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         kind = ctx.kind
@@ -572,6 +582,7 @@ class _BatchNormReluFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         x, gamma, beta, saved = ctx.saved_tensors
         dy = _f32c_fast(dy)
@@ -592,7 +603,8 @@ def _bn3d_relu(bn, x, relu):
     """[relu](bn(x)) for a training nn.BatchNorm3d / nn.BatchNorm2d on the native kernels, or None where they do not apply (evaluation
     mode, CPU, no affine parameters, cumulative-average momentum, SMVS_TRAIN_COMPOSITE_MASK bit 256): the caller keeps torch's operators."""
     if not (bn.training and x.is_cuda and x.dim() in (4, 5) and x.dtype is torch.float32 and torch.is_grad_enabled() and bn.affine
-            and bn.momentum is not None and bn.weight.dtype is torch.float32 and bn.weight.is_contiguous() and bn.bias.is_contiguous()
+            and bn.momentum is not None and bn.weight.dtype is torch.float32 and bn.bias.dtype is torch.float32
+            and bn.weight.is_contiguous() and bn.bias.is_contiguous() and x.shape[1] == bn.num_features      # (a mismatch: torch's operator raises its own error)
             and x.shape[1] <= 65535 and not (SW.train_composite_mask & 256)):
         return None
     return _BatchNormReluFn.apply(x, bn.weight, bn.bias, bn, relu)          # (num_batches_tracked += 1 happens in the forward kernel)
@@ -612,8 +624,9 @@ def _conv_packed(weight, layout, cin, cout):
     packed = torch.empty((_lib.load().smvs_conv3x3_packed_floats(cin, cout),), dtype=torch.float32, device=weight.device)
     with torch.cuda.device(weight.device):
         _lib.call("smvs_conv3x3_pack", _lib.ptr(weight), _lib.ptr(packed), cin, cout, layout, _lib.current_stream(weight.device))
-    if len(_CONV_PACK) > 256:
-        _CONV_PACK.clear()
+    if sum(1 for k in _CONV_PACK if k[3] == key[3]) > 256:          # per device (nn.DataParallel: ~120 entries per replica device);
+        for k in [k for k in _CONV_PACK if k[3] == key[3]][:128]:     # the oldest half of THIS device's entries goes (dicts keep insertion order)
+            del _CONV_PACK[k]
     _CONV_PACK[key] = (weight._version, _PARAM_EPOCH[0], StorageWeakRef(weight.untyped_storage()), packed)
     return packed
 
@@ -658,6 +671,7 @@ class _Conv3x3NativeFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         xa, xb, weight, out = ctx.saved_tensors
         kind = ctx.kind
@@ -799,6 +813,7 @@ class _ConvGRUCellFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dnew):
         x, h, gw, gb, ow, ob, rw, uw, nw_, gates, ru, xc, craw, cand, stats_g, stats_o = ctx.saved_tensors
         dev = x.device

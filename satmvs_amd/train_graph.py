@@ -92,12 +92,40 @@ class GraphedTrainStep:
         self._graph = None
         from .modules import module as _m
         from .modules import train_fns as _t
-        _t._CONV_PACK.clear()
+        # only the entries packed from THIS model's parameters (keyed on the source address; the weak reference names the storage):
+        # other models and inference paths of the process keep theirs
+        mine = {p.untyped_storage()._cdata for p in self.model.parameters()} | {b.untyped_storage()._cdata for b in self.model.buffers()}
+
+        def from_model(ref):
+            try:
+                return (not ref.expired()) and ref.cdata in mine
+            except Exception:                                 # noqa: BLE001 -- an unreadable reference: drop the entry
+                return True
+        for k in [k for k, v in _t._CONV_PACK.items() if from_model(v[2])]:
+            del _t._CONV_PACK[k]
         with _m._PACK_CACHE_LOCK:
-            _m._PACK_CACHE.clear()
+            for k in [k for k, v in _m._PACK_CACHE.items() if any(from_model(r) for r in v[1])]:
+                del _m._PACK_CACHE[k]
 
     def _capture(self, args, warmup=None):
+        import gc
         dev = args[0].device
+        # Objects that own HIP resources (an earlier model's CUDAGraph and its private pool, streams, events) must not be finalised
+        # by the cyclic garbage collector in the MIDDLE of the side-stream warm-up or of the capture: seen once in four runs of the GPU
+        # suite as "Fatal Python error: Segmentation fault ... Garbage-collecting" inside the warm-up's first forward (round 6,
+        # profiles/r06_gc_during_capture.txt).  torch.cuda.graph() itself collects before it captures; the warm-up runs before that, so
+        # the same is done here, with the device idle, and the collector stays off until the graph is captured.
+        torch.cuda.synchronize(dev)
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture_locked(args, warmup, dev)
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _capture_locked(self, args, warmup, dev):
         self._static = _map(args, lambda t: t.detach().clone())
         # the warm-up steps (allocator, MIOpen's find, lazily created optimizer state) must not train: parameters, buffers and
         # optimizer state are put back IN PLACE afterwards -- the graph holds their addresses

@@ -19,6 +19,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _finalise_between_tests(request):
+    """GPU tests: objects that own HIP resources (graphs with private pools, streams, events, big tensors) are finalised BETWEEN
+    tests, with the device idle -- not by a cyclic collection that happens to run in the middle of a later test's capture or
+    side-stream work (seen as a segmentation fault "Garbage-collecting" inside test_graphed_training_step_matches_eager's warm-up,
+    one run in four, round 6)."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import gc
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        gc.collect()
+
+
 @pytest.fixture(scope="session")
 def golden():
     cache = {}

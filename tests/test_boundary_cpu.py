@@ -407,6 +407,12 @@ def test_train_mode_augments_like_the_reference():
     np.random.seed(3)
     on = D.MVSDataset(scene, "train", 3)[0]["imgs"]
     assert on.shape == off[0]["imgs"].shape and not np.array_equal(on, off[0]["imgs"])
+    # seed=: a reproducible augmentation stream of the dataset's own, independent of the global np.random state
+    a = D.MVSDataset(scene, "train", 3, seed=11)[0]["imgs"]
+    np.random.seed(99)
+    b = D.MVSDataset(scene, "train", 3, seed=11)[0]["imgs"]
+    c = D.MVSDataset(scene, "train", 3, seed=12)[0]["imgs"]
+    assert np.array_equal(a, b) and not np.array_equal(a, c) and not np.array_equal(a, off[0]["imgs"])
 
 
 def test_arith_scope_is_thread_local_and_matches_the_header():

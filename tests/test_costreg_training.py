@@ -117,7 +117,8 @@ def test_conv3d_wgrad_accumulates_and_rejects_bad_arguments(dev):
 
 
 @pytest.mark.parametrize("kind,B,C,dims,relu", [("plain", 1, 8, (8, 24, 48), True), ("plain", 2, 5, (3, 7, 33), True), ("plain", 1, 64, (2, 6, 12), False),
-                                               ("plain", 3, 16, (4, 12, 30), True), ("big", 1, 8, (8, 96, 192), True)])
+                                               ("plain", 3, 16, (4, 12, 30), True), ("big", 1, 8, (8, 96, 192), True),
+                                               ("offset", 2, 6, (4, 12, 30), True), ("offset", 1, 8, (8, 48, 96), False)])
 def test_batchnorm3d_train_relu_native(dev, kind, B, C, dims, relu):
     """[relu](nn.BatchNorm3d(x)) in training form on smvs_batchnorm_train_fwd / _bwd against a float64 evaluation: output, input gradient,
     dgamma, dbeta within 2e-5 of their scales (1e-5 for the output), running statistics and num_batches_tracked updated like torch's."""
@@ -129,7 +130,12 @@ def test_batchnorm3d_train_relu_native(dev, kind, B, C, dims, relu):
         bn.running_mean.uniform_(-1, 1); bn.running_var.uniform_(0.5, 2.0)
     bn64 = torch.nn.BatchNorm3d(C, momentum=0.1).double().train()
     bn64.load_state_dict({k: v.detach().double().cpu() if v.dtype.is_floating_point else v.cpu() for k, v in bn.state_dict().items()})
-    x = (torch.randn(B, C, *dims, device=dev) * 2.0 + 0.7).requires_grad_(True)
+    x = (torch.randn(B, C, *dims, device=dev) * 2.0 + 0.7)
+    if kind == "offset":
+        # a channel whose |mean| is 1000 x its spread (round-5 advisor finding): sums of x and x^2 in float32 would lose the variance
+        # entirely; the kernels sum (x - pivot) and apply (x - mean) * scale + beta
+        x = 100.0 + 0.1 * torch.randn(B, C, *dims, device=dev) + torch.linspace(-50.0, 50.0, C, device=dev).view(1, C, 1, 1, 1)
+    x = x.requires_grad_(True)
     y = T._bn3d_relu(bn, x, relu)
     assert y is not None and "BatchNormRelu" in type(y.grad_fn).__name__
     gy = torch.randn_like(y)
