@@ -72,6 +72,16 @@ struct CostVolBwdParams {
 #ifndef SMVS_BWD_LDS
 #define SMVS_BWD_LDS 1                 // 0: never take the boxed path (A/B)
 #endif
+#ifdef SMVS_BWD_TIMING
+// profiling builds only (tools/ab_build.sh x -DSMVS_BWD_TIMING, AB_SRC=costvol_bwd.hip): per-wave phase stamps of the boxed path in shader
+// clocks, read back through smvs_debug_timing_bwd().  [0] geometry + set-up, [1] top-of-channel wait for the loads, [2] flush of the
+// previous channel's boxes, [3] issue of the next loads / boxes, [4] plane loop, [7] waves
+__device__ unsigned long long smvs_bwd_timing[8];
+__device__ __forceinline__ unsigned long long bnow() { unsigned long long t = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return t; }
+#define SMVS_BT(...) __VA_ARGS__
+#else
+#define SMVS_BT(...)
+#endif
 // one word per tap: 00 | y0 << 15 | x0 while the geometry runs, then the byte offset the tap's path wants
 constexpr uint32_t TAP_DROPPED = 0x80000000u;      // = SMVS_OOB: a load through it returns 0
 constexpr uint32_t TAP_PARTIAL = 0xC0000000u;      // | (y0+1) << 15 | (x0+1): some corner lies outside the image
@@ -192,6 +202,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
     const int dchunk = L % p.dct; L /= p.dct;
     const int ytile = L % p.yt;
     const int b = L / p.yt;
+    SMVS_BT(const unsigned long long bt_start = bnow(); unsigned long long bt_wait = 0, bt_flush = 0, bt_issue = 0, bt_planes = 0;)
     const int lane = threadIdx.x;                           // blockDim = (64, BWD_WAVES): threadIdx.y = wave
     const int wv_ = threadIdx.y;
     // The wave's pixels: a 32 x 2 patch (the two waves side by side) where the boxed path exists; kernels without it (more
@@ -213,6 +224,9 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
     BufRsrc rs[NSRC];
 #pragma unroll
     for (int s = 0; s < NSRC; ++s) rs[s] = make_rsrc(p.src[s] + (size_t)b * C * HW, (uint32_t)C * (uint32_t)HW * 4u);
+    // (the boxed path's per-channel traffic -- flush atomics, reference value, gradient planes -- goes through descriptors as well:
+    // scalar channel offsets instead of 64-bit address arithmetic per lane, and lanes that have nothing to add carry an out-of-range
+    // offset instead of sitting under a branch: round 6, profiles/r06_bwd_phases.txt)
 
     // the wave's gradient boxes start out clear; every flush leaves them clear again
     const uint32_t wave_lds = BOX ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr(lds_all) + (uint32_t)(wv_ * WAVE_LDS))) : 0u;
@@ -387,9 +401,24 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
         // ================================ boxed waves ==========================================================
         // DMA slot map of a feature box: lane l of instruction j lays down cells (row 4j + l/16, columns 4(l%16) .. +3); cells
         // beyond the image or the tensor hold other rows' data or zeros -- no full tap reads them
-        uint32_t dvo[NSRC];
+        BufRsrc rgs[NSRC];
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) dvo[s] = (uint32_t)((box_g0[s] + (lane >> 4) * W + (lane & 15) * 4) * 4);
+        for (int s = 0; s < NSRC; ++s) rgs[s] = make_rsrc(p.grad_src[s] + (size_t)b * C * HW, (uint32_t)C * (uint32_t)HW * 4u);
+        const BufRsrc rref = make_rsrc(p.ref + (size_t)b * C * HW, (uint32_t)C * (uint32_t)HW * 4u);
+        const BufRsrc rgref = make_rsrc(p.grad_ref + (size_t)b * C * HW, (uint32_t)C * (uint32_t)HW * 4u);
+        const uint32_t pix4 = (uint32_t)pix * 4u;
+        // the gradient planes of channel cc for this chunk: one descriptor per channel (64-bit scalar arithmetic once), plane k in the scalar offset
+        auto load_planes = [&](int cc, float (&dst)[DCH]) {
+            const BufRsrc rv = make_rsrc(p.grad_var + (((size_t)b * C + cc) * D + d0) * HW, (uint32_t)(d1 - d0) * (uint32_t)HW * 4u);
+#pragma unroll
+            for (int k = 0; k < DCH; ++k) dst[k] = llvm_raw_buffer_load_f32(rv.v, (int)pix4, min(k, d1 - d0 - 1) * HW * 4, 0);
+        };
+        uint32_t dvo[NSRC], gvo[NSRC];                      // (gvo: the lane's cell of box row 0 inside one H x W gradient plane, bytes)
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) {
+            dvo[s] = (uint32_t)((box_g0[s] + (lane >> 4) * W + (lane & 15) * 4) * 4);
+            gvo[s] = (uint32_t)((box_g0[s] + lane) * 4);
+        }
         auto stage = [&](int cn, int par) {
             const int so = cn * HW * 4;
 #pragma unroll
@@ -421,10 +450,14 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
             for (int s = 0; s < NSRC; ++s) {
                 float v[BOX_H];
                 gbox_take8(gbox_lds + (uint32_t)(s * GBOX_BYTES) + (uint32_t)lane * 8u, v);
-                float* q = p.grad_src[s] + ((size_t)b * C + c) * HW + box_g0[s] + lane;
+                const BufRsrc& rg = rgs[s];
+                const int so = c * HW * 4;
 #pragma unroll
-                for (int i = 0; i < BOX_H; ++i)
-                    if (v[i] != 0.0f && !((SMVS_BWD_ABLATE & 1) && v[i] != 1234.5f)) unsafeAtomicAdd(q + i * W, v[i]);
+                for (int i = 0; i < BOX_H; ++i) {
+                    // untouched cells (still 0) send nothing: their lanes carry an out-of-range offset, which the range check drops
+                    const bool send = v[i] != 0.0f && !((SMVS_BWD_ABLATE & 1) && v[i] != 1234.5f);
+                    (void)llvm_raw_buffer_atomic_fadd_f32(v[i], rg.v, (int)(send ? gvo[s] : SMVS_OOB), so + i * W4, 0);
+                }
             }
         };
         // Round 5: the gradient planes run TWO channels ahead.  They are the kernel's only stream that always misses the caches (2.4 GB
@@ -441,6 +474,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
             for (int k = 0; k < DCH; ++k) g_far[k] = gp[((size_t)min(1, C - 1) * D + min(k, d1 - d0 - 1)) * HW];
         }
         float gref_prev = 0.0f;
+        SMVS_BT(const unsigned long long bt_geo = bnow();)
         stage(0, 0);
         if constexpr (NFB == 3) stage(min(1, C - 1), 1);
         auto channel = [&](const int c, float (&gcur)[DCH]) __attribute__((always_inline)) {
@@ -451,27 +485,31 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
             // this channel's boxes, r (requested one iteration ago) and g (two iterations ago) have arrived once only the newest DCH
             // operations -- the gradient planes of channel c + 1 -- are still in flight
             // (three box buffers: the boxes of channel c + 1 -- 2 NSRC instructions, issued in front of those planes -- may be in flight too)
+            SMVS_BT(const unsigned long long bt0 = bnow();)
             if constexpr (NFB == 3) {
                 if (c == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NSRC) : "memory");     // (the prologue issued the boxes of channel 1 last)
                 else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NSRC + DCH) : "memory");
             } else if (c == 0 || AHEAD == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the prologue issued the boxes last)
             else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DCH) : "memory");
+            SMVS_BT(const unsigned long long bt1 = bnow(); bt_wait += bt1 - bt0;)
             const float r = r_next;
             float gq[DCH];
 #pragma unroll
             for (int k = 0; k < DCH; ++k) gq[k] = gcur[k];
             if (c > 0) {                                    // the previous channel's sums leave while this one is worked on
                 flush_boxes(c - 1);
-                if (active && !((SMVS_BWD_ABLATE & 4) && gref_prev != 1234.5f)) unsafeAtomicAdd(grefp + (size_t)(c - 1) * HW, gref_prev);
+                if (!((SMVS_BWD_ABLATE & 4) && gref_prev != 1234.5f))
+                    (void)llvm_raw_buffer_atomic_fadd_f32(gref_prev, rgref.v, (int)(active ? pix4 : SMVS_OOB), (c - 1) * HW * 4, 0);
             }
+            SMVS_BT(const unsigned long long bt2 = bnow(); bt_flush += bt2 - bt1;)
             {
                 const int cn = min(c + 1, C - 1), cf = min(c + AHEAD, C - 1);
-                r_next = refp[(size_t)cn * HW];                 // (ahead of the boxes: it must have arrived by the next channel)
+                r_next = llvm_raw_buffer_load_f32(rref.v, (int)pix4, cn * HW * 4, 0);     // (ahead of the boxes: it must have arrived by the next channel)
                 if constexpr (NFB == 3) stage(cf, (c + 2) % 3);
                 else stage(cn, (c + 1) & 1);
-#pragma unroll
-                for (int k = 0; k < DCH; ++k) gcur[k] = gp[((size_t)cf * D + min(k, d1 - d0 - 1)) * HW];
+                load_planes(cf, gcur);
             }
+            SMVS_BT(const unsigned long long bt3 = bnow(); bt_issue += bt3 - bt2;)
             const int choff = c * HW * 4;
             const uint32_t fpar = wave_lds + (uint32_t)((NFB == 3 ? c % 3 : (c & 1)) * NSRC * FBOX_BYTES);
             float gref = 0.0f;
@@ -578,6 +616,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
                 }
             }
             gref_prev = gref;
+            SMVS_BT(bt_planes += bnow() - bt3;)
         };
         if constexpr (AHEAD == 2) {
             for (int c = 0; c < C; c += 2) {
@@ -588,7 +627,15 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
             for (int c = 0; c < C; ++c) channel(c, g_next);
         }
         flush_boxes(C - 1);
-        if (active && !((SMVS_BWD_ABLATE & 4) && gref_prev != 1234.5f)) unsafeAtomicAdd(grefp + (size_t)(C - 1) * HW, gref_prev);
+        if (!((SMVS_BWD_ABLATE & 4) && gref_prev != 1234.5f))
+            (void)llvm_raw_buffer_atomic_fadd_f32(gref_prev, rgref.v, (int)(active ? pix4 : SMVS_OOB), (C - 1) * HW * 4, 0);
+#ifdef SMVS_BWD_TIMING
+        if (lane == 0) {
+            atomicAdd(&smvs_bwd_timing[0], bt_geo - bt_start); atomicAdd(&smvs_bwd_timing[1], bt_wait); atomicAdd(&smvs_bwd_timing[2], bt_flush);
+            atomicAdd(&smvs_bwd_timing[3], bt_issue); atomicAdd(&smvs_bwd_timing[4], bt_planes); atomicAdd(&smvs_bwd_timing[5], bnow() - bt_start);
+            atomicAdd(&smvs_bwd_timing[7], 1ull);
+        }
+#endif
         return;
     }
 
@@ -716,6 +763,16 @@ static hipError_t launch_bwd(const CostVolBwdParams& p, hipStream_t st)
 }
 
 }  // namespace smvs
+
+#ifdef SMVS_BWD_TIMING
+extern "C" SMVS_EXPORT int smvs_debug_timing_bwd(unsigned long long* out8, int reset)
+{
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(smvs::smvs_bwd_timing), 64) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(smvs::smvs_bwd_timing), z, 64) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 extern "C" SMVS_EXPORT int smvs_costvol_bwd(int geo_kind, const float* grad_var, const float* ref_fea,
                                             const float* const* src_fea, int n_src, const double* geo,

@@ -629,6 +629,10 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* base, uint32_t bytes)
 
 __device__ void llvm_raw_buffer_store_f32(float v, i32x4 rsrc, int voffset, int soffset, int aux)
     __asm("llvm.amdgcn.raw.buffer.store.f32");
+// float atomic add through a buffer descriptor (the returned old value is ignored by every caller: the no-return form is issued);
+// a lane whose offset is out of range (SMVS_OOB) is dropped by the range check -- no branch around the instruction
+__device__ float llvm_raw_buffer_atomic_fadd_f32(float v, i32x4 rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.atomic.fadd.f32");
 
 // The two helpers below write M0 (the LDS-DMA destination register) inside the asm and list it as clobbered, which is
 // the correct declaration: the compiler never keeps a value in M0 across a statement that clobbers it (its own M0 users
