@@ -515,7 +515,9 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
             float gref = 0.0f;
             if (any_hole == 0) {
                 // Interior of the image (every tap of the chunk is a full tap, every lane and plane is live): straight-line code,
-                // the next plane's taps are requested before this plane's are waited for
+                // the next plane's taps are requested before this plane's are waited for.  (Round 6: a TWO-pass form -- sample all
+                // planes, then 8 independent planes of mean / contributions / adds with no wait in between -- measured SLOWER, 178 k
+                // against 171 k clocks per wave in this loop: its time is not dependent-issue latency, profiles/r06_bwd_phases.txt.)
                 f32x2 nq[2][NSRC], sq[2][NSRC];
 #pragma unroll
                 for (int s = 0; s < NSRC; ++s) fbox_read(fpar + (uint32_t)(s * FBOX_BYTES) + tt[0][s], nq[0][s], sq[0][s]);
