@@ -69,6 +69,12 @@ struct CostVolBwdParams {
 #ifndef SMVS_BWD_FLUSH_TOGETHER
 #define SMVS_BWD_FLUSH_TOGETHER 0      // 1: (1-2 source views) the flush exchanges of every view in flight together, one wait.  Measured in round 5: 3.92 against 3.93 ms -- the two LDS round trips per channel are not what the waves wait for; off
 #endif
+#ifndef SMVS_BWD_KEEP_WEIGHTS
+#define SMVS_BWD_KEEP_WEIGHTS 1        // boxed path, 1-2 source views: tap weights kept in registers over the channel loop (A/B switch)
+#endif
+#ifndef SMVS_BWD_MEAN_MUL
+#define SMVS_BWD_MEAN_MUL 1            // interior waves: mean over the views as sum * RN(1/V) instead of the exact division (A/B switch)
+#endif
 #ifndef SMVS_BWD_LDS
 #define SMVS_BWD_LDS 1                 // 0: never take the boxed path (A/B)
 #endif
@@ -401,6 +407,32 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
         // ================================ boxed waves ==========================================================
         // DMA slot map of a feature box: lane l of instruction j lays down cells (row 4j + l/16, columns 4(l%16) .. +3); cells
         // beyond the image or the tensor hold other rows' data or zeros -- no full tap reads them
+        // 1-2 source views: the four weights of every tap stay in registers over the channel loop ({nw, ne}, {sw, se}: 4 per tap instead of
+        // the 2 fractions) -- rebuilding them per channel was 10 of a plane's 44 VALU instructions, and the plane loop is bound by VALU
+        // issue + the LDS pipe at 2 waves per SIMD (round 6, profiles/r06_bwd_phases.txt); with more views the registers are not there.
+        constexpr bool KEEPW = SMVS_BWD_KEEP_WEIGHTS && NSRC <= 2;
+        f32x2 kwn[KEEPW ? DCH : 1][NSRC], kws[KEEPW ? DCH : 1][NSRC];
+        if constexpr (KEEPW) {
+#pragma unroll
+            for (int k = 0; k < DCH; ++k)
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s) {
+                    const float w = tf[k][s][0], n = tf[k][s][1];
+                    const f32x2 ew = {1.0f - w, w};
+                    kwn[k][s] = ew * (1.0f - n);
+                    kws[k][s] = ew * n;
+                }
+        }
+        auto tap_weights = [&](int k, int s, f32x2& wn, f32x2& ws) __attribute__((always_inline)) {
+            if constexpr (KEEPW) { wn = kwn[k][s]; ws = kws[k][s]; }
+            else {
+                asm volatile("" : "+v"(tf[k][s][0]), "+v"(tf[k][s][1]));      // opaque per use: else every weight is hoisted out of the channel loop
+                const float w = tf[k][s][0], n = tf[k][s][1];
+                const f32x2 ew = {1.0f - w, w};
+                wn = ew * (1.0f - n);
+                ws = ew * n;
+            }
+        };
         BufRsrc rgs[NSRC];
 #pragma unroll
         for (int s = 0; s < NSRC; ++s) rgs[s] = make_rsrc(p.grad_src[s] + (size_t)b * C * HW, (uint32_t)C * (uint32_t)HW * 4u);
@@ -537,17 +569,13 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
                         if (k == 0) fbox_wait_n<2 * NSRC>(nq[0][s], sq[0][s]);
                         else if (k + 1 < DCH) fbox_wait_n<6 * NSRC>(nq[k & 1][s], sq[k & 1][s]);
                         else fbox_wait_n<4 * NSRC>(nq[k & 1][s], sq[k & 1][s]);
-                        asm volatile("" : "+v"(tf[k][s][0]), "+v"(tf[k][s][1]));
-                        const float w = tf[k][s][0], n = tf[k][s][1];
-                        const f32x2 ew = {1.0f - w, w};
-                        wn[s] = ew * (1.0f - n);
-                        ws[s] = ew * n;
+                        tap_weights(k, s, wn[s], ws[s]);
                         const f32x2 acc = __builtin_elementwise_fma(sq[k & 1][s], ws[s], nq[k & 1][s] * wn[s]);
                         const float t = acc.x + acc.y;
                         wv[s] = t;
                         sum = sum + t;
                     }
-                    const float m = div_by_views(sum, fV, rV);
+                    const float m = SMVS_BWD_MEAN_MUL ? sum * rV : div_by_views(sum, fV, rV);      // (the gradient's tolerance, not the forward's bits: one multiply)
                     gref = fmaf(g, r - m, gref);
 #pragma unroll
                     for (int s = 0; s < NSRC; ++s) {
@@ -589,11 +617,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
                     }
                     // the same four products tap_from_grid forms, two per v_pk_mul_f32; the warped value sums north and south
                     // in one v_pk_fma_f32 and the two halves last (another order than the forward's: within its rounding)
-                    asm volatile("" : "+v"(tf[k][s][0]), "+v"(tf[k][s][1]));      // opaque per use: else every weight is hoisted out of the channel loop
-                    const float w = tf[k][s][0], n = tf[k][s][1];
-                    const f32x2 ew = {1.0f - w, w};
-                    wn[s] = ew * (1.0f - n);
-                    ws[s] = ew * n;
+                    tap_weights(k, s, wn[s], ws[s]);
                     const f32x2 an = {a0, a1}, as = {a2, a3};
                     const f32x2 acc = __builtin_elementwise_fma(as, ws[s], an * wn[s]);
                     const float t = acc.x + acc.y;
