@@ -138,7 +138,8 @@ int smvs_homo_costvol_fwd(const float* ref_fea, const float* const* src_fea, int
  *   smvs_rpc_plane_coef        folds them once per (batch item, plane, source) into `plane_coef`, a caller-owned device
  *                              buffer of smvs_rpc_plane_coef_bytes(B, n_src, D) bytes, 64-byte aligned (doubles: the planes'
  *                              heights -- depth[b,d], or depth[b,d,0,0] of a 4-D tensor -- at b D + d, padded to a multiple
- *                              of 8; then [b][source][cubic][d][6]: the H-dependent 6 of the 10 bivariate coefficients of each
+ *                              of 8; 24 doubles per batch item: the views' reciprocal scales, divided once; then
+ *                              [b][source][cubic][d][6]: the H-dependent 6 of the 10 bivariate coefficients of each
  *                              cubic); only planes [d_begin, d_end) are written (a plane-at-a-time caller folds what it builds).
  *   smvs_rpc_costvol_fwd_pc    = smvs_rpc_costvol_fwd with that buffer (NULL: identical to smvs_rpc_costvol_fwd).  Every
  *                              wave compares its own heights with the folded planes' and takes the bivariate cubics

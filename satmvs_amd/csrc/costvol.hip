@@ -58,7 +58,7 @@ void rpc_plane_coef_kernel(const double* __restrict__ rpc, const float* __restri
     const double Hn = ((double)hf - r[I_H_OFF]) * (1.0 / r[I_H_SCALE]);       // as o2p_xn normalises it
     const int base = i == 0 ? I_SNUM : i == 1 ? I_SDEN : i == 2 ? I_LNUM : I_LDEN;
     const double* c = r + base;
-    double* o = pc + pc_header_doubles((size_t)B * D) + pc_offset(b, s, i, bd - b * D, n_src, D);
+    double* o = pc + pc_header_doubles((size_t)B * D, B) + pc_offset(b, s, i, bd - b * D, n_src, D);
     o[0] = fma(Hn, fma(Hn, fma(Hn, c[19], c[9]), c[3]), c[0]);
     o[1] = fma(Hn, fma(Hn, c[13], c[5]), c[1]);
     o[2] = fma(Hn, fma(Hn, c[16], c[6]), c[2]);
@@ -66,6 +66,16 @@ void rpc_plane_coef_kernel(const double* __restrict__ rpc, const float* __restri
     o[4] = fma(Hn, c[17], c[7]);
     o[5] = fma(Hn, c[18], c[8]);
     if (s == 0 && i == 0) pc[bd] = (double)hf;
+    // the views' reciprocal scales, once per batch item (by the threads of the window's first plane): source view s by cubic lane 0, the
+    // ref view by (s, i) = (0, 1)
+    if (bp - b * nd == 0 && (i == 0 || (s == 0 && i == 1))) {
+        const bool refv = i == 1;
+        const double* rv = refv ? rpc + (size_t)b * (n_src + 1) * RPC_LEN : r;
+        double* sc = pc + pc_heights_doubles((size_t)B * D) + (size_t)b * PC_SCALES + (refv ? 0 : 3 * (s + 1));
+        sc[0] = 1.0 / rv[refv ? I_SAMP_SCALE : I_LAT_SCALE];
+        sc[1] = 1.0 / rv[refv ? I_LINE_SCALE : I_LON_SCALE];
+        sc[2] = 1.0 / rv[I_H_SCALE];
+    }
 }
 
 static int costvol_fwd(int geo_kind, const float* ref_fea, const float* const* src_fea, int n_src,

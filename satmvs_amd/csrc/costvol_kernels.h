@@ -441,13 +441,16 @@ void costvol_dma_kernel(const CostVolParams p)
     // Plane-coefficient path (smvs_device.h, "plane-constant heights"): the coefficient runs of the wave's planes -- one run
     // of DP planes per (source, cubic) -- and the line that holds the planes' heights are pulled into the scalar cache now,
     // while the height loads above are in flight.
-    const cgeo_t pc_co = as_cgeo(p.pc) + pc_header_doubles((size_t)p.B * p.D);      // coefficient area, pc_offset()
+    const cgeo_t pc_co = as_cgeo(p.pc) + pc_header_doubles((size_t)p.B * p.D, p.B);      // coefficient area, pc_offset()
     if constexpr (GEO == 0) {
         if (pc_maybe) {
+            // (heights: 8 doubles from wherever in a line the group starts; scales: 24 doubles; then one wait per source view)
+            scalar_touch4<2>(as_cgeo(p.pc) + (size_t)b * p.D + dg0, as_cgeo(p.pc) + pc_heights_doubles((size_t)p.B * p.D) + (size_t)b * PC_SCALES,
+                             as_cgeo(p.pc) + pc_heights_doubles((size_t)p.B * p.D) + (size_t)b * PC_SCALES + 16, as_cgeo(p.pc) + (size_t)b * p.D + dg0);
 #pragma unroll
-            for (int r = 0; r < 4 * NSRC; ++r)
-                scalar_touch<PC_LPR>(pc_co + pc_offset(b, r >> 2, r & 3, dg0, NSRC, p.D));
-            scalar_touch<2>(as_cgeo(p.pc) + (size_t)b * p.D + dg0);
+            for (int s = 0; s < NSRC; ++s)
+                scalar_touch4<PC_LPR>(pc_co + pc_offset(b, s, 0, dg0, NSRC, p.D), pc_co + pc_offset(b, s, 1, dg0, NSRC, p.D),
+                                      pc_co + pc_offset(b, s, 2, dg0, NSRC, p.D), pc_co + pc_offset(b, s, 3, dg0, NSRC, p.D));
         }
     }
 
@@ -472,7 +475,13 @@ void costvol_dma_kernel(const CostVolParams p)
         // The 3 reciprocal scales of every view, correctly rounded, at one IEEE division per WAVE: lane 3v+k
         // divides for (view v, scale k); the quotients travel through the wave's own LDS tile (not yet in use)
         // and come back as broadcast reads, i.e. in VGPRs (18 SGPRs would not survive the coefficient loads).
-        {
+        if (pc_maybe) {
+            // the fold kernel divided already (smvs_device.h, PC_SCALES): scalar loads out of the workspace, copied to VGPRs
+            const cgeo_t sc = launder(as_cgeo(p.pc)) + pc_heights_doubles((size_t)p.B * p.D) + (size_t)b * PC_SCALES;
+            ref_n.a = to_vgpr(sc[0]); ref_n.b = to_vgpr(sc[1]); ref_n.h = to_vgpr(sc[2]);
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s) { src_n[s].a = to_vgpr(sc[3 * s + 3]); src_n[s].b = to_vgpr(sc[3 * s + 4]); src_n[s].h = to_vgpr(sc[3 * s + 5]); }
+        } else {
             const int v = lane / 3, k = lane - 3 * v;
             const int idx = (v == 0) ? (k == 0 ? I_SAMP_SCALE : k == 1 ? I_LINE_SCALE : I_H_SCALE)
                                      : (k == 0 ? I_LAT_SCALE : k == 1 ? I_LON_SCALE : I_H_SCALE);
@@ -482,103 +491,128 @@ void costvol_dma_kernel(const CostVolParams p)
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) { src_n[s].a = slot[3 * s + 3]; src_n[s].b = slot[3 * s + 4]; src_n[s].h = slot[3 * s + 5]; }
         }
-        // ref view, image -> ground: plane-invariant part once per pixel, Horner in the height per plane
-        P2OPix px;
-        p2o_pixel(geo_b, ref_n, fx, fy, px);
-        // Plane-constant heights?  Every lane's DP heights equal the heights the coefficients were folded for: the whole wave takes
-        // the bivariate source cubics.  Wave-uniform; a single differing lane (per-voxel hypotheses, a NaN) sends the wave down
-        // the trivariate chain.  Asked HERE, behind the ref pixel's plane-invariant work, so that the heights' latency passes
-        // under it (asked right after the loads it cost ~10 000 clocks per wave: profiles/r06_plane_coef_transport.txt).
-        if (pc_maybe) {
-            const cgeo_t hdr = launder(as_cgeo(p.pc)) + (size_t)b * p.D + dg0;
-            bool eq = true;
-#pragma unroll
-            for (int pl = 0; pl < DP; ++pl) eq = eq && (hf[pl] == (float)hdr[min(pl, p.d_end - 1 - dg0)]);
-            use_pc = __ballot(!eq) == 0ull;
-        }
-        p2o_planes<DP>(launder(geo_b), ref_n, px, hf, lat, lon);
     }
     SMVS_T(const unsigned long long t_ref = now();)
     // PQ planes per pass: every source coefficient is fetched into SGPRs once for all of them
     constexpr int PQ = DP < SMVS_O2P_PLANES ? DP : SMVS_O2P_PLANES;
     static_assert(DP % PQ == 0, "planes per pass");
+    // Planes and source views for the heights hh.  PC: every plane's height is the one its coefficients were folded for (the bivariate
+    // source cubics, smvs_device.h); else the trivariate chain.
+    auto planes_and_sources = [&](auto pc_tag, const float (&hh)[DP]) __attribute__((always_inline)) {
+        constexpr bool PC = decltype(pc_tag)::value;
+        okmask = 0;
 #pragma unroll
-    for (int pq = 0; pq < DP; pq += PQ) {
-        const cgeo_t geo_d = launder(geo_b);
-#pragma unroll
-        for (int s = 0; s < NSRC; ++s) {
-            float gxs[PQ], gys[PQ];
-            if (SMVS_ABLATE & 4) {
-#pragma unroll
-                for (int u = 0; u < PQ; ++u) {
-                    gxs[u] = ((float)fx + 0.37f + 0.011f * hf[pq + u] * (float)(s + 1)) / half_wm1 - 1.0f;
-                    gys[u] = ((float)fy + 0.21f) / half_hm1 - 1.0f;
-                }
-            } else if (GEO == 0) {
-                double samp[PQ], line[PQ];
-                if (use_pc) {
-                    constexpr int PQC = PQ < SMVS_PC_PLANES ? PQ : SMVS_PC_PLANES;     // planes per pass of the bivariate chain
-#pragma unroll
-                    for (int v = 0; v < PQ; v += PQC)
-                        o2p_pc_xn<PQC>(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat + pq + v, lon + pq + v,
-                                       pc_co + pc_offset(b, s, 0, dg + pq + v, NSRC, p.D), (size_t)p.D * PC_PER_CUBIC, samp + v, line + v);
-                } else {
-                    double hh[PQ];
-#pragma unroll
-                    for (int u = 0; u < PQ; ++u) hh[u] = (double)hf[pq + u];
-                    o2p_xn<PQ>(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat + pq, lon + pq, hh, samp, line);
-                }
-#pragma unroll
-                for (int u = 0; u < PQ; ++u) {
-                    gxs[u] = div_half_int((float)samp[u], half_wm1, r_half_wm1) - 1.0f;
-                    gys[u] = div_half_int((float)line[u], half_hm1, r_half_hm1) - 1.0f;
-                }
-            } else {
-                const cgeo_t P = geo_d + s * 16;
-#pragma unroll
-                for (int u = 0; u < PQ; ++u) {
-                    const double hh = (double)hf[pq + u];
-                    const double rx = fma(P[1], fy, P[0] * fx) + P[2];
-                    const double ry = fma(P[5], fy, P[4] * fx) + P[6];
-                    const double rz = fma(P[9], fy, P[8] * fx) + P[10];
-                    const double X = fma(rx, hh, P[3]), Y = fma(ry, hh, P[7]), Z = fma(rz, hh, P[11]);
-                    gxs[u] = (float)((X / Z) / ((W - 1) * 0.5) - 1.0);
-                    gys[u] = (float)((Y / Z) / ((H - 1) * 0.5) - 1.0);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < PQ; ++u) {
-                const int pl = pq + u;
-                // same arithmetic as tap_from_grid (ATen unnormalise, floor, weights)
-                const float px = fmaf(gxs[u] + 1.0f, (float)W * 0.5f, -0.5f);
-                const float py = fmaf(gys[u] + 1.0f, (float)H * 0.5f, -0.5f);
-                const float xw = floorf(px), yn = floorf(py);
-                const float w = px - xw, e = 1.0f - w, n = py - yn, so = 1.0f - n;
-                // A footprint that misses the image reads the zero cells: 0 * weight = 0 for any finite
-                // weight, NaN for the NaN weights of a NaN / infinite coordinate -- what four masked
-                // gathers contribute.  v_cvt_i32_f32 saturates and maps NaN to 0, so the unsigned tests
-                // reject every far-away coordinate (a NaN one passes with NaN weights: NaN either way).
-                if constexpr (AR == AR_FUSED) {
-                    // the variance's constant factor rides on the weights (smvs_device.h, "fused arithmetic")
-                    const float sk = so * p.kw, nk = n * p.kw;
-                    tap[pl][s].wn.x = sk * e; tap[pl][s].wn.y = sk * w;
-                    tap[pl][s].ws.x = nk * e; tap[pl][s].ws.y = nk * w;
-                } else {
-                    tap[pl][s].wn.x = so * e; tap[pl][s].wn.y = so * w;
-                    tap[pl][s].ws.x = n * e;  tap[pl][s].ws.y = n * w;
-                }
-                const int ix0 = cvt_i32_sat(xw), iy0 = cvt_i32_sat(yn);
-                const bool ok = ((uint32_t)(ix0 + 1) <= (uint32_t)W) && ((uint32_t)(iy0 + 1) <= (uint32_t)H);
-                txy[pl][s] = (uint32_t)((iy0 + 1) * (2 * BW) + (ix0 + 1)); // dword index relative to image corner (-1,-1); used only if ok
-                if (ok) okmask |= 1u << (pl * NSRC + s);
-                if (ok && active && pl < np) {
-                    lo_x[s] = min(lo_x[s], ix0); hi_x[s] = max(hi_x[s], ix0);
-                    lo_y[s] = min(lo_y[s], iy0); hi_y[s] = max(hi_y[s], iy0);
-                }
-            }
+        for (int s = 0; s < NSRC; ++s) { lo_x[s] = lo_y[s] = INT_MAX; hi_x[s] = hi_y[s] = INT_MIN; }
+        if (GEO == 0 && !(SMVS_ABLATE & 4)) {
+            // ref view, image -> ground: plane-invariant part once per pixel, Horner in the height per plane.  (Formed inside, so that the
+            // 24 registers of the pixel part die before the source passes: a wave that has to redo its planes forms them again.)
+            P2OPix px;
+            p2o_pixel(geo_b, ref_n, fx, fy, px);
+            p2o_planes<DP>(launder(geo_b), ref_n, px, hh, lat, lon);
         }
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pq = 0; pq < DP; pq += PQ) {
+            const cgeo_t geo_d = launder(geo_b);
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s) {
+                float gxs[PQ], gys[PQ];
+                if (SMVS_ABLATE & 4) {
+#pragma unroll
+                    for (int u = 0; u < PQ; ++u) {
+                        gxs[u] = ((float)fx + 0.37f + 0.011f * hh[pq + u] * (float)(s + 1)) / half_wm1 - 1.0f;
+                        gys[u] = ((float)fy + 0.21f) / half_hm1 - 1.0f;
+                    }
+                } else if (GEO == 0) {
+                    double samp[PQ], line[PQ];
+                    if constexpr (PC) {
+                        // planes per pass of the bivariate chain: 4 where the instance has 256 registers (8 planes per wave, 2 waves per SIMD), 2 in the
+                        // 168-register instances (9 monomial registers pairs per plane in flight: 4 planes spilled 20 registers to scratch)
+                        constexpr int PQW = DP >= 8 ? SMVS_PC_PLANES : 2, PQC = PQ < PQW ? PQ : PQW;
+#pragma unroll
+                        for (int v = 0; v < PQ; v += PQC)
+                            o2p_pc_xn<PQC>(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat + pq + v, lon + pq + v,
+                                           pc_co + pc_offset(b, s, 0, dg + pq + v, NSRC, p.D), (size_t)p.D * PC_PER_CUBIC, samp + v, line + v);
+                    } else {
+                        double hd[PQ];
+#pragma unroll
+                        for (int u = 0; u < PQ; ++u) hd[u] = (double)hh[pq + u];
+                        o2p_xn<PQ>(geo_d + (size_t)(s + 1) * RPC_LEN, src_n[s], lat + pq, lon + pq, hd, samp, line);
+                    }
+#pragma unroll
+                    for (int u = 0; u < PQ; ++u) {
+                        gxs[u] = div_half_int((float)samp[u], half_wm1, r_half_wm1) - 1.0f;
+                        gys[u] = div_half_int((float)line[u], half_hm1, r_half_hm1) - 1.0f;
+                    }
+                } else {
+                    const cgeo_t P = geo_d + s * 16;
+#pragma unroll
+                    for (int u = 0; u < PQ; ++u) {
+                        const double hd = (double)hh[pq + u];
+                        const double rx = fma(P[1], fy, P[0] * fx) + P[2];
+                        const double ry = fma(P[5], fy, P[4] * fx) + P[6];
+                        const double rz = fma(P[9], fy, P[8] * fx) + P[10];
+                        const double X = fma(rx, hd, P[3]), Y = fma(ry, hd, P[7]), Z = fma(rz, hd, P[11]);
+                        gxs[u] = (float)((X / Z) / ((W - 1) * 0.5) - 1.0);
+                        gys[u] = (float)((Y / Z) / ((H - 1) * 0.5) - 1.0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < PQ; ++u) {
+                    const int pl = pq + u;
+                    // same arithmetic as tap_from_grid (ATen unnormalise, floor, weights)
+                    const float px_ = fmaf(gxs[u] + 1.0f, (float)W * 0.5f, -0.5f);
+                    const float py_ = fmaf(gys[u] + 1.0f, (float)H * 0.5f, -0.5f);
+                    const float xw = floorf(px_), yn = floorf(py_);
+                    const float w = px_ - xw, e = 1.0f - w, n = py_ - yn, so = 1.0f - n;
+                    // A footprint that misses the image reads the zero cells: 0 * weight = 0 for any finite
+                    // weight, NaN for the NaN weights of a NaN / infinite coordinate -- what four masked
+                    // gathers contribute.  v_cvt_i32_f32 saturates and maps NaN to 0, so the unsigned tests
+                    // reject every far-away coordinate (a NaN one passes with NaN weights: NaN either way).
+                    if constexpr (AR == AR_FUSED) {
+                        // the variance's constant factor rides on the weights (smvs_device.h, "fused arithmetic")
+                        const float sk = so * p.kw, nk = n * p.kw;
+                        tap[pl][s].wn.x = sk * e; tap[pl][s].wn.y = sk * w;
+                        tap[pl][s].ws.x = nk * e; tap[pl][s].ws.y = nk * w;
+                    } else {
+                        tap[pl][s].wn.x = so * e; tap[pl][s].wn.y = so * w;
+                        tap[pl][s].ws.x = n * e;  tap[pl][s].ws.y = n * w;
+                    }
+                    const int ix0 = cvt_i32_sat(xw), iy0 = cvt_i32_sat(yn);
+                    const bool ok = ((uint32_t)(ix0 + 1) <= (uint32_t)W) && ((uint32_t)(iy0 + 1) <= (uint32_t)H);
+                    txy[pl][s] = (uint32_t)((iy0 + 1) * (2 * BW) + (ix0 + 1)); // dword index relative to image corner (-1,-1); used only if ok
+                    if (ok) okmask |= 1u << (pl * NSRC + s);
+                    if (ok && active && pl < np) {
+                        lo_x[s] = min(lo_x[s], ix0); hi_x[s] = max(hi_x[s], ix0);
+                        lo_y[s] = min(lo_y[s], iy0); hi_y[s] = max(hi_y[s], iy0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // Plane-constant heights?  SPECULATED: where folded coefficients are at hand the wave runs the bivariate chain on the heights
+    // they were folded FOR (wave-uniform values out of the workspace, already in the scalar cache) and only afterwards compares
+    // them with its own 64 x DP heights -- by then the (B,D,H,W) loads issued at the top have long landed, so their HBM latency
+    // (~4 000 clocks under full write load when asked behind the ref pixel's work, 10 000 when asked at once:
+    // profiles/r06_plane_coef_transport.txt) is off the wave's critical path.  A single differing lane (per-voxel hypotheses, a
+    // jittered pixel, a NaN, a stale workspace) and the wave redoes its planes on the trivariate chain with its own heights: the
+    // result never depends on trusting the caller.
+    bool geometry_done = false;
+    if constexpr (GEO == 0) {
+        if (pc_maybe) {
+            const cgeo_t hdr = launder(as_cgeo(p.pc)) + (size_t)b * p.D + dg0;
+            float hs[DP];
+#pragma unroll
+            for (int pl = 0; pl < DP; ++pl) hs[pl] = (float)hdr[min(pl, p.d_end - 1 - dg0)];
+            planes_and_sources(std::true_type(), hs);
+            bool eq = true;
+#pragma unroll
+            for (int pl = 0; pl < DP; ++pl) eq = eq && (hf[pl] == hs[pl]);
+            use_pc = __ballot(!eq) == 0ull;
+            geometry_done = use_pc;
+        }
     }
+    if (!geometry_done) planes_and_sources(std::false_type(), hf);
 
     if constexpr (GEO == 0 && DP > 1) {
         // A group cut short by the end of the sweep: its tail planes carry the last plane's height, but a pass of the

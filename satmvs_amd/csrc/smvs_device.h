@@ -226,8 +226,13 @@ __device__ __forceinline__ double to_vgpr(double s)
 
 // A(P,L), B(P,L), C(P,L) of one cubic at N points
 template <int N>
-__device__ __forceinline__ void cubic_abc_xn(cgeo_t k, const double* P, const double* L, double* A, double* B, double* C)
+__device__ __forceinline__ void cubic_abc_xn(cgeo_t kp, const double* P, const double* L, double* A, double* B, double* C)
 {
+    // all 19 coefficients requested before the first is used: one wait per cubic (the compiler's own order of use put two)
+    double k[19];
+#pragma unroll
+    for (int j = 0; j < 19; ++j) k[j] = kp[j];
+    __builtin_amdgcn_sched_barrier(0);
     const double v4 = to_vgpr(k[4]), v5 = to_vgpr(k[5]), v6 = to_vgpr(k[6]);
     const double v7 = to_vgpr(k[7]), v8 = to_vgpr(k[8]), v9 = to_vgpr(k[9]);
 #pragma unroll
@@ -354,7 +359,8 @@ __device__ __forceinline__ void o2p_xn(cgeo_t r, const RpcInv& n, const double* 
 // the height normalisation.  Same polynomial, re-associated: coordinates move by float64 rounding only (~1e-13 px, like
 // the Horner form vs the reference's order).  Per-voxel heights (stages 2-3, jittered planes) fail the check and take
 // the trivariate chain above.
-// Workspace layout (doubles): [0, pc_header_doubles(B D)) the planes' heights, (b, d) at b D + d; then the folded
+// Workspace layout (doubles): [0, pc_heights_doubles(B D)) the planes' heights, (b, d) at b D + d; the views' reciprocal scales (below);
+// then, from pc_header_doubles(B D, B) on, the folded
 // coefficients as [b][source][cubic: SNUM, SDEN, LNUM, LDEN][d][6]: for one (source, cubic) the planes are contiguous,
 // so the N planes of an evaluation pass are ONE run of 6 N doubles (three s_load_dwordx16 at N = 4) and a wave's DP
 // planes are 4 n_src runs of 48 DP bytes.
@@ -365,13 +371,18 @@ __device__ __forceinline__ void o2p_xn(cgeo_t r, const RpcInv& n, const double* 
 // back-to-back touches (scalar_touch) instead of stalling at 16-48 dependent loads.  The alternatives lose: a
 // coalesced vector load of the block + two v_readlane_b32 per coefficient costs 0.65 ms against 0.58 for the trivariate
 // chain (VALU-written SGPRs are slow to consume); broadcast LDS reads cost the LDS pipe what the FMAs save.
-enum : int { PC_PER_CUBIC = 6 };
-__host__ __device__ constexpr size_t pc_header_doubles(size_t planes) { return (planes + 7) & ~(size_t)7; }
+// Behind the heights, per batch item: the 3 reciprocal scales of every view (PC_SCALES doubles per batch item: view v at 3 v --
+// 1/SAMP_SCALE, 1/LINE_SCALE, 1/HEIGHT_SCALE for the ref view, 1/LAT_SCALE, 1/LONG_SCALE, 1/HEIGHT_SCALE for a source view),
+// IEEE divisions done once by the fold kernel: a wave that has the workspace reads them as scalars instead of dividing itself and
+// passing the quotients through LDS (a 9 000-clock latency chain at the start of every wave: global load -> division -> LDS round trip).
+enum : int { PC_PER_CUBIC = 6, PC_SCALES = 24 };
+__host__ __device__ constexpr size_t pc_heights_doubles(size_t planes) { return (planes + 7) & ~(size_t)7; }
+__host__ __device__ constexpr size_t pc_header_doubles(size_t planes, int B) { return pc_heights_doubles(planes) + (size_t)B * PC_SCALES; }
 __host__ __device__ constexpr size_t pc_total_doubles(int B, int n_src, int D)
 {
     // + 64: a group of DP planes cut short by the end of the sweep reads (and discards) up to DP - 1 records past plane D - 1,
     // and the touches of a run cover whole lines
-    return pc_header_doubles((size_t)B * D) + (size_t)B * D * 4 * PC_PER_CUBIC * n_src + 64;
+    return pc_header_doubles((size_t)B * D, B) + (size_t)B * D * 4 * PC_PER_CUBIC * n_src + 64;
 }
 // doubles from the start of the coefficient area to (b, source s, cubic i, plane d)
 __host__ __device__ constexpr size_t pc_offset(int b, int s, int i, int d, int n_src, int D)
@@ -406,6 +417,31 @@ __device__ __forceinline__ void scalar_touch(cgeo_t p)
 #undef SMVS_TOUCH
 }
 
+// The same for four runs at once (one wait for 4 LINES lines: the four cubics of one source view)
+template <int LINES>
+__device__ __forceinline__ void scalar_touch4(cgeo_t pa, cgeo_t pb, cgeo_t pc, cgeo_t pd)
+{
+    static_assert(LINES >= 1 && LINES <= 7, "lines per run");
+    auto line0 = [](cgeo_t p) {
+        const uintptr_t a = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)p >> 32)) << 32) |
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p);
+        return (cgeo_t)(a & ~(uintptr_t)63);
+    };
+    const cgeo_t q0 = line0(pa), q1 = line0(pb), q2 = line0(pc), q3 = line0(pd);
+    uint32_t t;
+#define SMVS_T4(k) "s_load_dword %0, %1, 64*" #k "\n\ts_load_dword %0, %2, 64*" #k "\n\ts_load_dword %0, %3, 64*" #k "\n\ts_load_dword %0, %4, 64*" #k "\n\t"
+#define SMVS_T4_ASM(body) asm volatile(body "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(q0), "s"(q1), "s"(q2), "s"(q3) : "memory")
+    if constexpr (LINES == 1) SMVS_T4_ASM(SMVS_T4(0));
+    if constexpr (LINES == 2) SMVS_T4_ASM(SMVS_T4(0) SMVS_T4(1));
+    if constexpr (LINES == 3) SMVS_T4_ASM(SMVS_T4(0) SMVS_T4(1) SMVS_T4(2));
+    if constexpr (LINES == 4) SMVS_T4_ASM(SMVS_T4(0) SMVS_T4(1) SMVS_T4(2) SMVS_T4(3));
+    if constexpr (LINES == 5) SMVS_T4_ASM(SMVS_T4(0) SMVS_T4(1) SMVS_T4(2) SMVS_T4(3) SMVS_T4(4));
+    if constexpr (LINES == 6) SMVS_T4_ASM(SMVS_T4(0) SMVS_T4(1) SMVS_T4(2) SMVS_T4(3) SMVS_T4(4) SMVS_T4(5));
+    if constexpr (LINES == 7) SMVS_T4_ASM(SMVS_T4(0) SMVS_T4(1) SMVS_T4(2) SMVS_T4(3) SMVS_T4(4) SMVS_T4(5) SMVS_T4(6));
+#undef SMVS_T4_ASM
+#undef SMVS_T4
+}
+
 // RPC_Obj2Photo (warping.py:218-252) at N consecutive planes of one pixel whose heights are their planes': pc -> the
 // folded coefficients of THIS source at the first of the N planes, cubic 0 (wave-uniform, scalar loads); cubic i is
 // `cubic_stride` doubles further (= 6 D); r = the source view's 170-vector
@@ -430,27 +466,36 @@ __device__ __forceinline__ void o2p_pc_xn(cgeo_t r, const RpcInv& n, const doubl
         __builtin_amdgcn_sched_barrier(0);
         const cgeo_t c = launder(r) + base[i];
         const cgeo_t k = launder(pc) + cubic_stride * i;
+        // every coefficient of the batch requested before the first is used: ONE wait per cubic (left to itself the compiler requests
+        // them in the order of use, behind three waits)
+        double kk[N][PC_PER_CUBIC];
+#pragma unroll
+        for (int u = 0; u < N; ++u)
+#pragma unroll
+            for (int j = 0; j < PC_PER_CUBIC; ++j) kk[u][j] = k[PC_PER_CUBIC * u + j];
+        const double c11 = c[11], c12 = c[12], c14 = c[14], c15 = c[15];
+        __builtin_amdgcn_sched_barrier(0);
         double a[N];
 #pragma unroll
-        for (int u = 0; u < N; ++u) a[u] = to_vgpr(k[PC_PER_CUBIC * u]);
+        for (int u = 0; u < N; ++u) a[u] = to_vgpr(kk[u][0]);
 #pragma unroll
-        for (int u = 0; u < N; ++u) a[u] = fma(L[u], k[PC_PER_CUBIC * u + 1], a[u]);
+        for (int u = 0; u < N; ++u) a[u] = fma(L[u], kk[u][1], a[u]);
 #pragma unroll
-        for (int u = 0; u < N; ++u) a[u] = fma(P[u], k[PC_PER_CUBIC * u + 2], a[u]);
+        for (int u = 0; u < N; ++u) a[u] = fma(P[u], kk[u][2], a[u]);
 #pragma unroll
-        for (int u = 0; u < N; ++u) a[u] = fma(LP[u], k[PC_PER_CUBIC * u + 3], a[u]);
+        for (int u = 0; u < N; ++u) a[u] = fma(LP[u], kk[u][3], a[u]);
 #pragma unroll
-        for (int u = 0; u < N; ++u) a[u] = fma(LL[u], k[PC_PER_CUBIC * u + 4], a[u]);
+        for (int u = 0; u < N; ++u) a[u] = fma(LL[u], kk[u][4], a[u]);
 #pragma unroll
-        for (int u = 0; u < N; ++u) a[u] = fma(PP[u], k[PC_PER_CUBIC * u + 5], a[u]);
+        for (int u = 0; u < N; ++u) a[u] = fma(PP[u], kk[u][5], a[u]);
 #pragma unroll
-        for (int u = 0; u < N; ++u) a[u] = fma(LLL[u], c[11], a[u]);
+        for (int u = 0; u < N; ++u) a[u] = fma(LLL[u], c11, a[u]);
 #pragma unroll
-        for (int u = 0; u < N; ++u) a[u] = fma(LPP[u], c[12], a[u]);
+        for (int u = 0; u < N; ++u) a[u] = fma(LPP[u], c12, a[u]);
 #pragma unroll
-        for (int u = 0; u < N; ++u) a[u] = fma(LLP[u], c[14], a[u]);
+        for (int u = 0; u < N; ++u) a[u] = fma(LLP[u], c14, a[u]);
 #pragma unroll
-        for (int u = 0; u < N; ++u) { q[i][u] = fma(PPP[u], c[15], a[u]); pin(q[i][u]); }
+        for (int u = 0; u < N; ++u) { q[i][u] = fma(PPP[u], c15, a[u]); pin(q[i][u]); }
     }
     __builtin_amdgcn_sched_barrier(0);
     const cgeo_t rr = launder(r);

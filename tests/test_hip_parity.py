@@ -263,8 +263,8 @@ def test_plane_coef_records(dev):
     depth4 = np.ascontiguousarray(np.broadcast_to(depth[:, :, None, None], (B, D, H, W)))
     hdr = (B * D + 7) // 8 * 8
     n = _lib.load().smvs_rpc_plane_coef_bytes(B, V - 1, D) // 8
-    assert n == hdr + B * D * 24 * (V - 1) + 64          # (+ what a cut-short plane group may read behind the last plane)
-    body = B * D * 24 * (V - 1)
+    body, co = B * D * 24 * (V - 1), hdr + 24 * B      # (behind the heights: 24 doubles per batch item for the views' reciprocal scales)
+    assert n == co + body + 64          # (+ what a cut-short plane group may read behind the last plane)
     for dd in (depth, depth4):
         pc = torch.zeros(n, dtype=torch.float64, device=dev)
         d = _t(dd, dev)
@@ -272,7 +272,12 @@ def test_plane_coef_records(dev):
                   _lib.current_stream(dev))
         flat = pc.cpu().numpy()
         assert np.array_equal(flat[:B * D].reshape(B, D), depth.astype(np.float64)) and not flat[B * D:hdr].any()
-        rec = flat[hdr:hdr + body].reshape(B, V - 1, 4, D, 6).transpose(0, 3, 1, 2, 4)          # [b][source][cubic][d][6] -> (b, d, s, i, j)
+        rec = flat[co:co + body].reshape(B, V - 1, 4, D, 6).transpose(0, 3, 1, 2, 4)          # [b][source][cubic][d][6] -> (b, d, s, i, j)
+        sc = flat[hdr:co].reshape(B, 8, 3)
+        for b in range(B):
+            assert np.array_equal(sc[b, 0], 1.0 / rpc[b, 0][[6, 5, 9]])                 # ref view: 1/SAMP_SCALE, 1/LINE_SCALE, 1/HEIGHT_SCALE (IEEE divisions)
+            for s in range(V - 1):
+                assert np.array_equal(sc[b, s + 1], 1.0 / rpc[b, s + 1][[7, 8, 9]])     # source views: 1/LAT_SCALE, 1/LONG_SCALE, 1/HEIGHT_SCALE
         for b in range(B):
             for s in range(V - 1):
                 r = rpc[b, s + 1]
@@ -286,7 +291,7 @@ def test_plane_coef_records(dev):
     pc = torch.full_like(pc, -3.0)
     _lib.call("smvs_rpc_plane_coef", _lib.ptr(_t(rpc, dev)), _lib.ptr(_t(depth, dev)), 0, _lib.ptr(pc), B, V - 1, D, H, W, 1, 3, _lib.current_stream(dev))
     w = pc.cpu().numpy()
-    wr = w[hdr:hdr + body].reshape(B, V - 1, 4, D, 6).transpose(0, 3, 1, 2, 4)
+    wr = w[co:co + body].reshape(B, V - 1, 4, D, 6).transpose(0, 3, 1, 2, 4)
     assert (wr[:, [0, 3, 4]] == -3.0).all() and np.array_equal(wr[:, 1:3], rec[:, 1:3])
     assert np.array_equal(w[:B * D].reshape(B, D)[:, 1:3], depth[:, 1:3].astype(np.float64)) and (w[:B * D].reshape(B, D)[:, [0, 3, 4]] == -3.0).all()
 
