@@ -55,7 +55,7 @@ void rpc_plane_coef_kernel(const double* __restrict__ rpc, const float* __restri
     const int i = idx & 3, s = (idx >> 2) % n_src, bp = idx / (4 * n_src), b = bp / nd, bd = b * D + d_begin + (bp - b * nd);
     const float hf = is4d ? depth[(size_t)bd * HW] : depth[bd];
     const double* r = rpc + ((size_t)b * (n_src + 1) + s + 1) * RPC_LEN;
-    const double Hn = ((double)hf - r[I_H_OFF]) * (1.0 / r[I_H_SCALE]);       // as o2p_xn normalises it
+    const double Hn = ((double)hf - r[I_H_OFF]) * recip_scale(r[I_H_SCALE]);       // as o2p_xn normalises it (the kernel's own reciprocal)
     const int base = i == 0 ? I_SNUM : i == 1 ? I_SDEN : i == 2 ? I_LNUM : I_LDEN;
     const double* c = r + base;
     double* o = pc + pc_header_doubles((size_t)B * D, B) + pc_offset(b, s, i, bd - b * D, n_src, D);
@@ -72,9 +72,9 @@ void rpc_plane_coef_kernel(const double* __restrict__ rpc, const float* __restri
         const bool refv = i == 1;
         const double* rv = refv ? rpc + (size_t)b * (n_src + 1) * RPC_LEN : r;
         double* sc = pc + pc_heights_doubles((size_t)B * D) + (size_t)b * PC_SCALES + (refv ? 0 : 3 * (s + 1));
-        sc[0] = 1.0 / rv[refv ? I_SAMP_SCALE : I_LAT_SCALE];
-        sc[1] = 1.0 / rv[refv ? I_LINE_SCALE : I_LON_SCALE];
-        sc[2] = 1.0 / rv[I_H_SCALE];
+        sc[0] = recip_scale(rv[refv ? I_SAMP_SCALE : I_LAT_SCALE]);
+        sc[1] = recip_scale(rv[refv ? I_LINE_SCALE : I_LON_SCALE]);
+        sc[2] = recip_scale(rv[I_H_SCALE]);
     }
 }
 

@@ -353,7 +353,6 @@ void costvol_dma_kernel(const CostVolParams p)
     static_assert(BW % 4 == 0 && CT % 2 == 0 && 2 * DP + 2 <= 63 && DP * NSRC <= 32, "chunks / steps / vmcnt bookkeeping / tap mask");
     __shared__ __attribute__((aligned(16))) uint32_t tile_all[SHARED ? 1 : WV_WAVES][(TILE_DW + 3) & ~3];
     __shared__ __attribute__((aligned(16))) int xch[SHARED ? NW : 1][NSRC][4];   // shared form: every wave's tap extents
-    __shared__ double scr_all[SHARED ? NW : 1][32];                             // shared form: a wave's scratch (reciprocal scales)
 #ifdef SMVS_LDS_PAD
     __shared__ float lds_pad[SMVS_LDS_PAD / 4];            // profiling builds only: caps the workgroups per CU
     if (p.B < 0) lds_pad[threadIdx.x] = 0.0f;
@@ -472,9 +471,7 @@ void costvol_dma_kernel(const CostVolParams p)
 #pragma unroll
     for (int s = 0; s < NSRC; ++s) src_n[s].a = src_n[s].b = src_n[s].h = 0.0;
     if (GEO == 0 && !(SMVS_ABLATE & 4)) {
-        // The 3 reciprocal scales of every view, correctly rounded, at one IEEE division per WAVE: lane 3v+k
-        // divides for (view v, scale k); the quotients travel through the wave's own LDS tile (not yet in use)
-        // and come back as broadcast reads, i.e. in VGPRs (18 SGPRs would not survive the coefficient loads).
+        // The 3 reciprocal scales of every view, in VGPRs (18 SGPRs would not survive the coefficient loads).
         if (pc_maybe) {
             // the fold kernel divided already (smvs_device.h, PC_SCALES): scalar loads out of the workspace, copied to VGPRs
             const cgeo_t sc = launder(as_cgeo(p.pc)) + pc_heights_doubles((size_t)p.B * p.D) + (size_t)b * PC_SCALES;
@@ -482,14 +479,16 @@ void costvol_dma_kernel(const CostVolParams p)
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) { src_n[s].a = to_vgpr(sc[3 * s + 3]); src_n[s].b = to_vgpr(sc[3 * s + 4]); src_n[s].h = to_vgpr(sc[3 * s + 5]); }
         } else {
-            const int v = lane / 3, k = lane - 3 * v;
-            const int idx = (v == 0) ? (k == 0 ? I_SAMP_SCALE : k == 1 ? I_LINE_SCALE : I_H_SCALE)
-                                     : (k == 0 ? I_LAT_SCALE : k == 1 ? I_LON_SCALE : I_H_SCALE);
-            double* slot = SHARED ? scr_all[SHARED ? wave : 0] : reinterpret_cast<double*>(tile);
-            if (lane < 3 * (NSRC + 1)) slot[lane] = 1.0 / p.geo[((size_t)b * p.V + v) * RPC_LEN + idx];
-            ref_n.a = slot[0]; ref_n.b = slot[1]; ref_n.h = slot[2];
+            // no workspace: every lane forms the nine reciprocals itself from scalar-loaded scales (recip_scale: 5 instructions each, no
+            // dependence between them).  Until round 6 lane 3v+k did one IEEE division and the quotients travelled through LDS: a
+            // global load -> ~35-instruction division -> LDS round trip chain of ~10 000 clocks at the start of every wave.
+            const cgeo_t gr = launder(geo_b);
+            ref_n.a = recip_scale(gr[I_SAMP_SCALE]); ref_n.b = recip_scale(gr[I_LINE_SCALE]); ref_n.h = recip_scale(gr[I_H_SCALE]);
 #pragma unroll
-            for (int s = 0; s < NSRC; ++s) { src_n[s].a = slot[3 * s + 3]; src_n[s].b = slot[3 * s + 4]; src_n[s].h = slot[3 * s + 5]; }
+            for (int s = 0; s < NSRC; ++s) {
+                const cgeo_t gs = launder(geo_b) + (size_t)(s + 1) * RPC_LEN;
+                src_n[s].a = recip_scale(gs[I_LAT_SCALE]); src_n[s].b = recip_scale(gs[I_LON_SCALE]); src_n[s].h = recip_scale(gs[I_H_SCALE]);
+            }
         }
     }
     SMVS_T(const unsigned long long t_ref = now();)

@@ -128,6 +128,19 @@ __device__ __forceinline__ void div_pair(double n0, double d0, double n1, double
     q1 = (n1 * d0) * r;
 }
 
+// 1 / d for a scale of the camera model (|d| between 1e-4 and 1e5: no special cases): hardware seed (24 bits) + two Newton steps.
+// Over 2^24 denominators the result equals the IEEE quotient bit for bit (tools/ubench_rcp.hip); where it should ever differ it
+// does so by one unit in the last place, i.e. 1e-16 of a normalised coordinate.  Used wherever the staged cost-volume kernel and the
+// fold kernel need the reciprocal scales (both call THIS function, so a wave computes the same bits with or without a workspace):
+// five independent-ish instructions per scale instead of a ~35-instruction IEEE division behind a global load and an LDS round trip.
+__device__ __forceinline__ double recip_scale(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
 // Loop-invariant part of one view's normalisation: only the three reciprocal scales a direction
 // needs are kept live (6 SGPRs per view); offsets and forward scales are re-read with the
 // coefficient block (scalar cache).  Reciprocals are taken once, in float64.
