@@ -253,7 +253,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
         const cgeo_t geo_b = as_cgeo((GEO == 0) ? p.geo + (size_t)b * p.V * RPC_LEN : p.geo + (size_t)b * (p.V - 1) * 16);
         RpcInv ref_n, src_n[NSRC];
         if (GEO == 0) {
-            ref_n = rpc_inv_image(geo_b);
+            ref_n = rpc_inv_image(geo_b);       // the forward's reciprocals, bit for bit (recip_scale)
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) src_n[s] = rpc_inv_ground(geo_b + (size_t)(s + 1) * RPC_LEN);
         }
@@ -275,12 +275,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
         if (GEO == 0) {
             P2OPix px;
             p2o_pixel(geo_b, ref_n, fx, fy, px);
-#pragma unroll
-            for (int k = 0; k < DCH; ++k) {
-                p2o_plane(launder(geo_b), ref_n, px, (double)hf[k], lat[k], lon[k]);
-                pin(lat[k]); pin(lon[k]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            p2o_planes<DCH>(launder(geo_b), ref_n, px, hf, lat, lon);
         }
 #pragma unroll
         for (int pq = 0; pq < DCH; pq += PQ) {

@@ -149,14 +149,14 @@ struct RpcInv { double a, b, h; };
 __device__ __forceinline__ RpcInv rpc_inv_image(cgeo_t r)    // for photo -> object (ref view)
 {
     RpcInv n;
-    n.a = 1.0 / r[I_SAMP_SCALE]; n.b = 1.0 / r[I_LINE_SCALE]; n.h = 1.0 / r[I_H_SCALE];
+    n.a = recip_scale(r[I_SAMP_SCALE]); n.b = recip_scale(r[I_LINE_SCALE]); n.h = recip_scale(r[I_H_SCALE]);
     return n;
 }
 
 __device__ __forceinline__ RpcInv rpc_inv_ground(cgeo_t r)   // for object -> photo (source views)
 {
     RpcInv n;
-    n.a = 1.0 / r[I_LAT_SCALE]; n.b = 1.0 / r[I_LON_SCALE]; n.h = 1.0 / r[I_H_SCALE];
+    n.a = recip_scale(r[I_LAT_SCALE]); n.b = recip_scale(r[I_LON_SCALE]); n.h = recip_scale(r[I_H_SCALE]);
     return n;
 }
 

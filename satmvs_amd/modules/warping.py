@@ -205,7 +205,7 @@ def plane_coefficients(geo, depth, is4d, n_src, H, W, d_begin=0, d_end=None):
 
 class _CostVolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, geo_kind, geo, depth, is4d, d_begin, d_end, ref_fea, *src_feas):
+    def forward(ctx, geo_kind, geo, depth, is4d, d_begin, d_end, plane_constant, ref_fea, *src_feas):
         dev = _lib.require_device(ref_fea, geo, depth, *src_feas)
         ref = _f32c(ref_fea)
         srcs = [_f32c(s) for s in src_feas]
@@ -218,9 +218,11 @@ class _CostVolFn(torch.autograd.Function):
         out = torch.empty((B, C, nd, H, W), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             st = _lib.current_stream(dev)
-            if geo_kind == 0 and nd > 0:
+            if geo_kind == 0 and nd > 0 and plane_constant:
                 # plane-constant heights (stage 1 of every cascade) collapse the source cubics to bivariate ones: fold them for
-                # the planes of this launch; the kernel checks its own heights against the folded ones wave by wave
+                # the planes of this launch.  The kernel runs its geometry from the folded records and checks its own heights
+                # against them afterwards, wave by wave -- a wave whose heights differ redoes it with the trivariate chain,
+                # which is why heights that vary inside a plane (stages 2 / 3) are not sent this way
                 pc = plane_coefficients(geo, depth, is4d, len(srcs), H, W, d_begin, d_end)
                 _lib.call("smvs_rpc_costvol_fwd_pc", _lib.ptr(ref), _lib.ptr_array(srcs), len(srcs), _lib.ptr(geo), _lib.ptr(depth),
                           is4d | _lib.call_arith_bits(), _lib.ptr(pc), _lib.ptr(out), B, C, D, H, W, d_begin, d_end, nd, 0, st)
@@ -246,7 +248,7 @@ class _CostVolFn(torch.autograd.Function):
             _lib.call("smvs_costvol_bwd", geo_kind, _lib.ptr(g), _lib.ptr(ref), _lib.ptr_array(srcs), len(srcs),
                       _lib.ptr(geo), _lib.ptr(depth), is4d, _lib.ptr(g_ref), _lib.ptr_array(g_srcs),
                       B, C, D, H, W, _lib.current_stream(dev))
-        return (None, None, None, None, None, None, g_ref, *g_srcs)
+        return (None, None, None, None, None, None, None, g_ref, *g_srcs)
 
 
 def prepare_geometry(features, proj_matrices, geo_model="rpc", use_qc=False):
@@ -269,7 +271,7 @@ def prepare_geometry(features, proj_matrices, geo_model="rpc", use_qc=False):
 
 
 def variance_cost_volume(features, proj_matrices, depth_values, geo_model="rpc", use_qc=False,
-                         d_begin=0, d_end=None):
+                         d_begin=0, d_end=None, plane_constant=None):
     """Fused per-channel variance cost volume: (B,C,d_end-d_begin,H,W) float32.
 
     features: list of V tensors (B,C,H,W), view 0 = reference (networks/casred.py:22).
@@ -277,6 +279,10 @@ def variance_cost_volume(features, proj_matrices, depth_values, geo_model="rpc",
                    pinhole -> (B,V,4,4) float64 -- exactly what the reference networks receive.
     depth_values: (B,D) or (B,D,H,W) float32.  [d_begin,d_end) selects the planes to build
     (the pred loop passes d,d+1; a depth shard passes its own range).
+    plane_constant: every pixel of a plane holds the same height (stage 1), so the rpc build may use the folded
+    bivariate source cubics (smvs_rpc_plane_coef + smvs_rpc_costvol_fwd_pc).  None = decide from the argument: (B,D)
+    heights and (B,D,H,W) views broadcast over H and W are; a materialised (B,D,H,W) tensor is taken as per-pixel.
+    True on heights that are not plane-constant is still correct (the kernel checks), only slower.
     """
     ref_fea = features[0]
     B, _, H, W = ref_fea.shape
@@ -289,12 +295,15 @@ def variance_cost_volume(features, proj_matrices, depth_values, geo_model="rpc",
             depth_values = gen.materialize()             # autograd path: the backward kernel takes the tensor
         else:
             return _costvol_generated(features, proj_matrices, gen, geo_model, use_qc, d_begin, d_end)
+    if plane_constant is None:
+        plane_constant = depth_values.dim() == 2 or (depth_values.dim() == 4 and (H == 1 or depth_values.stride(2) == 0)
+                                                     and (W == 1 or depth_values.stride(3) == 0))
     depth, is4d, D = _depth_arg(depth_values, B, H, W)
     d_end = D if d_end is None else d_end
     if not (0 <= d_begin <= d_end <= D):
         raise ValueError("bad plane range [%d,%d) of %d" % (d_begin, d_end, D))
     kind, geo = prepare_geometry(features, proj_matrices, geo_model, use_qc)
-    return _CostVolFn.apply(kind, geo, depth, is4d, d_begin, d_end, ref_fea, *features[1:])
+    return _CostVolFn.apply(kind, geo, depth, is4d, d_begin, d_end, bool(plane_constant), ref_fea, *features[1:])
 
 
 def _costvol_generated(features, proj_matrices, gen, geo_model, use_qc, d_begin, d_end):

@@ -352,6 +352,25 @@ def test_plane_coefficients_are_checked_not_trusted(dev, oracle):
     assert torch.equal(a, b)
 
 
+def test_variance_cost_volume_plane_constant_policy(dev, arith):
+    """variance_cost_volume sends (B,D) heights and H/W-broadcast views through the folded cubics, materialised (B,D,H,W)
+    tensors through the trivariate chain unless told; the bits are the same whichever way (both modes)."""
+    from satmvs_amd.modules import warping
+    B, V, C, D, H, W = 1, 3, 32, 8, 24, 96
+    feats, rpc, planes = _inputs(B, V, C, D, H, W, seed=15, jitter=False)
+    f, r = [_t(x, dev) for x in feats], _t(rpc, dev)
+    p2 = _t(planes, dev)
+    view = p2[:, :, None, None].expand(B, D, H, W)
+    outs = [warping.variance_cost_volume(f, r, p2, "rpc"), warping.variance_cost_volume(f, r, view, "rpc"),
+            warping.variance_cost_volume(f, r, view.contiguous(), "rpc"),
+            warping.variance_cost_volume(f, r, view.contiguous(), "rpc", plane_constant=True),
+            warping.variance_cost_volume(f, r, p2, "rpc", plane_constant=False)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    jit = _t(_inputs(B, V, C, D, H, W, seed=15, jitter=True)[2], dev)
+    assert torch.equal(warping.variance_cost_volume(f, r, jit, "rpc"), warping.variance_cost_volume(f, r, jit, "rpc", plane_constant=True))
+
+
 @pytest.mark.parametrize("C", [8, 16])                          # direct kernel / staged kernel
 def test_costvol_out_of_image_and_nan(dev, oracle, C):
     """Large parallax pushes taps off the source image (zero padding); NaN heights must not fault."""
