@@ -169,6 +169,29 @@ __device__ __forceinline__ void gbox_wait_all(double (&d)[NV][BOX_H])
 #pragma unroll
         for (int i = 0; i < BOX_H; ++i) asm volatile("" : "+v"(d[s][i]));
 }
+// read and clear the lane's cell of box row I (no wait)
+template <int I>
+__device__ __forceinline__ void gbox_take_row(uint32_t addr, double& d)
+{
+    const double zero = 0.0;
+    asm volatile("ds_wrxchg_rtn_b64 %0, %1, %2 offset:%3" : "=&v"(d) : "v"(addr), "v"(zero), "n"(I * BOX_W * 8) : "memory");
+}
+// rows 0 .. NR-1, one wait
+template <int NR>
+__device__ __forceinline__ void gbox_take_rows(uint32_t addr, double (&d)[BOX_H])
+{
+    if constexpr (NR > 0) gbox_take_row<0>(addr, d[0]);
+    if constexpr (NR > 1) gbox_take_row<1>(addr, d[1]);
+    if constexpr (NR > 2) gbox_take_row<2>(addr, d[2]);
+    if constexpr (NR > 3) gbox_take_row<3>(addr, d[3]);
+    if constexpr (NR > 4) gbox_take_row<4>(addr, d[4]);
+    if constexpr (NR > 5) gbox_take_row<5>(addr, d[5]);
+    if constexpr (NR > 6) gbox_take_row<6>(addr, d[6]);
+    if constexpr (NR > 7) gbox_take_row<7>(addr, d[7]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NR; ++i) asm volatile("" : "+v"(d[i]));
+}
 // read and clear the lane's cell of each of the 8 box rows
 __device__ __forceinline__ void gbox_take8(uint32_t addr, float (&v)[BOX_H])
 {
@@ -249,6 +272,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
     uint32_t any_partial = 0, any_take = 0, any_hole = 0;   // wave-uniform: some lane of the wave has such a tap (hole: not a full tap)
     bool boxed = BOX;                                       // wave-uniform: every view's box fits
     int box_g0[NSRC];                                       // wave-uniform: element offset of the box's first cell inside an H x W plane
+    int box_rows[NSRC];                                     // wave-uniform: rows of the box any full tap of the wave touches (the flush visits no other)
     {
         const cgeo_t geo_b = as_cgeo((GEO == 0) ? p.geo + (size_t)b * p.V * RPC_LEN : p.geo + (size_t)b * (p.V - 1) * 16);
         RpcInv ref_n, src_n[NSRC];
@@ -344,6 +368,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
             if (none) { ax = 0; ay = 0; }
             else if (bx - ax + 2 > BOX_W || by - ay + 2 > BOX_H) boxed = false;
             org_x[s] = ax; org_y[s] = ay;
+            box_rows[s] = __builtin_amdgcn_readfirstlane(none ? 0 : min(by - ay + 2, BOX_H));
         }
         // full taps: packed cell -> byte offset inside the box (boxed) or inside the H x W plane
 #pragma unroll
@@ -447,7 +472,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
             gvo[s] = (uint32_t)((box_g0[s] + lane) * 4);
         }
         auto stage = [&](int cn, int par) {
-            const int so = cn * HW * 4;
+            const int so = __builtin_amdgcn_readfirstlane(cn * HW * 4);
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) {
                 const uint32_t fb = wave_lds + (uint32_t)((par * NSRC + s) * FBOX_BYTES);
@@ -475,16 +500,30 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
             }
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) {
-                float v[BOX_H];
-                gbox_take8(gbox_lds + (uint32_t)(s * GBOX_BYTES) + (uint32_t)lane * 8u, v);
+                // only the rows some tap of the wave reaches (wave-uniform, known since the geometry: typically 3-4 of the 8) are
+                // read, cleared and sent: the flush is VALU + LDS issue like the plane loop (round 6, profiles/r06_bwd_phases.txt)
+                // (one branch per view on the row count, straight-line code behind it: a branch per row costs more than the rows save)
+                const uint32_t ga = gbox_lds + (uint32_t)(s * GBOX_BYTES) + (uint32_t)lane * 8u;
                 const BufRsrc& rg = rgs[s];
                 const int so = c * HW * 4;
+                auto rows = [&](auto nrc) __attribute__((always_inline)) {
+                    constexpr int NR = decltype(nrc)::value;
+                    double d[BOX_H];
+                    gbox_take_rows<NR>(ga, d);
 #pragma unroll
-                for (int i = 0; i < BOX_H; ++i) {
-                    // untouched cells (still 0) send nothing: their lanes carry an out-of-range offset, which the range check drops
-                    const bool send = v[i] != 0.0f && !((SMVS_BWD_ABLATE & 1) && v[i] != 1234.5f);
-                    (void)llvm_raw_buffer_atomic_fadd_f32(v[i], rg.v, (int)(send ? gvo[s] : SMVS_OOB), so + i * W4, 0);
-                }
+                    for (int i = 0; i < NR; ++i) {
+                        // untouched cells (still 0) send nothing: their lanes carry an out-of-range offset, which the range check drops
+                        const float v = (float)d[i];
+                        const bool send = v != 0.0f && !((SMVS_BWD_ABLATE & 1) && v != 1234.5f);
+                        (void)llvm_raw_buffer_atomic_fadd_f32(v, rg.v, (int)(send ? gvo[s] : SMVS_OOB), so + i * W4, 0);
+                    }
+                };
+                const int nr = box_rows[s];
+                if (nr == 3) rows(std::integral_constant<int, 3>{});
+                else if (nr == 4) rows(std::integral_constant<int, 4>{});
+                else if (nr == 2) rows(std::integral_constant<int, 2>{});
+                else if (nr == 5) rows(std::integral_constant<int, 5>{});
+                else if (nr != 0) rows(std::integral_constant<int, BOX_H>{});
             }
         };
         // Round 5: the gradient planes run TWO channels ahead.  They are the kernel's only stream that always misses the caches (2.4 GB
