@@ -203,6 +203,11 @@ def plane_coefficients(geo, depth, is4d, n_src, H, W, d_begin=0, d_end=None):
     return pc
 
 
+# below this many voxels the fold's own launch (~2-5 us on the stream) costs more than the ~4 % of the build it saves
+# (bench extra stage3_rpc_3view_768x384x8_c8: 2.4 M voxels, 41.9 us build, 46.9 us with the fold)
+_FOLD_MIN_VOXELS = 8 << 20
+
+
 class _CostVolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, geo_kind, geo, depth, is4d, d_begin, d_end, plane_constant, ref_fea, *src_feas):
@@ -218,7 +223,7 @@ class _CostVolFn(torch.autograd.Function):
         out = torch.empty((B, C, nd, H, W), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             st = _lib.current_stream(dev)
-            if geo_kind == 0 and nd > 0 and plane_constant:
+            if geo_kind == 0 and plane_constant and B * nd * H * W >= _FOLD_MIN_VOXELS:
                 # plane-constant heights (stage 1 of every cascade) collapse the source cubics to bivariate ones: fold them for
                 # the planes of this launch.  The kernel runs its geometry from the folded records and checks its own heights
                 # against them afterwards, wave by wave -- a wave whose heights differ redoes it with the trivariate chain,
@@ -282,7 +287,8 @@ def variance_cost_volume(features, proj_matrices, depth_values, geo_model="rpc",
     plane_constant: every pixel of a plane holds the same height (stage 1), so the rpc build may use the folded
     bivariate source cubics (smvs_rpc_plane_coef + smvs_rpc_costvol_fwd_pc).  None = decide from the argument: (B,D)
     heights and (B,D,H,W) views broadcast over H and W are; a materialised (B,D,H,W) tensor is taken as per-pixel.
-    True on heights that are not plane-constant is still correct (the kernel checks), only slower.
+    True on heights that are not plane-constant is still correct (the kernel checks), only slower.  Builds of fewer than
+    8 Mi voxels never fold: the extra launch costs more than it saves.
     """
     ref_fea = features[0]
     B, _, H, W = ref_fea.shape

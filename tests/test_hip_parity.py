@@ -352,10 +352,15 @@ def test_plane_coefficients_are_checked_not_trusted(dev, oracle):
     assert torch.equal(a, b)
 
 
-def test_variance_cost_volume_plane_constant_policy(dev, arith):
+def test_variance_cost_volume_plane_constant_policy(dev, arith, monkeypatch):
     """variance_cost_volume sends (B,D) heights and H/W-broadcast views through the folded cubics, materialised (B,D,H,W)
-    tensors through the trivariate chain unless told; the bits are the same whichever way (both modes)."""
+    tensors through the trivariate chain unless told (and nothing below _FOLD_MIN_VOXELS: lifted here); the bits are the
+    same whichever way (both modes)."""
     from satmvs_amd.modules import warping
+    monkeypatch.setattr(warping, "_FOLD_MIN_VOXELS", 0)
+    calls = []
+    real = warping.plane_coefficients
+    monkeypatch.setattr(warping, "plane_coefficients", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     B, V, C, D, H, W = 1, 3, 32, 8, 24, 96
     feats, rpc, planes = _inputs(B, V, C, D, H, W, seed=15, jitter=False)
     f, r = [_t(x, dev) for x in feats], _t(rpc, dev)
@@ -365,6 +370,7 @@ def test_variance_cost_volume_plane_constant_policy(dev, arith):
             warping.variance_cost_volume(f, r, view.contiguous(), "rpc"),
             warping.variance_cost_volume(f, r, view.contiguous(), "rpc", plane_constant=True),
             warping.variance_cost_volume(f, r, p2, "rpc", plane_constant=False)]
+    assert len(calls) == 3                                       # (B,D), the broadcast view, the materialised tensor with plane_constant=True
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
     jit = _t(_inputs(B, V, C, D, H, W, seed=15, jitter=True)[2], dev)
