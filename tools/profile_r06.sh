@@ -8,8 +8,11 @@ set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_r06
 mkdir -p "$OUT"
+# ONLY_POWER=1: just the power / clock table (power.txt)
+if [ -z "${ONLY_POWER:-}" ]; then
 python $REPO/bench.py --steps 20 --warmup 5 > "$OUT/bench_driver_flags.json" 2> "$OUT/bench_driver_flags.err"
 python $REPO/bench.py --no-cpu-baseline > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+fi
 {
   echo "# idle board (no process on the GPU): rocm-smi --showpower --showclocks"
   sleep 3; rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | tr '\n' ' '; echo
@@ -28,6 +31,7 @@ python $REPO/bench.py --no-cpu-baseline > "$OUT/bench_default.json" 2> "$OUT/ben
   unset SMVS_BENCH_TRIVARIATE
   ls $REPO/gpurun_ab/f_a1.so $REPO/gpurun_ab/f_a4.so > /dev/null 2>&1 && (cd $REPO && PS_STEPS=6000 PS_DELAY=3.2 tools/power_sweep.sh f_a1 f_a4)
 } > "$OUT/power.txt" 2>&1
+[ -n "${ONLY_POWER:-}" ] && exit 0
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- python $REPO/bench.py --no-cpu-baseline --no-extra > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
 BENCH="python $REPO/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --prewarm-seconds 0.05"
