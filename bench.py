@@ -712,7 +712,7 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload) if world == 1 else None,
                          "bytes_per_voxel": bpv, "kernel_ms": round(kern_ms, 4), "fold_plus_kernel_ms": round(both_ms, 4),
-                         "note": "one step = smvs_rpc_plane_coef (fold of the source cubics per plane, ~2 us) + smvs_rpc_costvol_fwd_pc; `value` and "
+                         "note": "one step = smvs_rpc_plane_coef (fold of the source cubics per plane, 3-5 us) + smvs_rpc_costvol_fwd_pc; `value` and "
                                  "ms_per_step time both, kernel_ms / achieved / frac are the build kernel alone (HIP events on its stream)"},
         }
         line["devices"] = ids
