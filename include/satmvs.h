@@ -356,6 +356,17 @@ int smvs_conv3x3_fwd(int kind, const float* xA, int CA, const float* xB, int CB,
 int smvs_groupnorm1_pair_fwd(const float* x, const float* gamma, const float* beta, const float* gamma2, const float* beta2,
                              float eps, int act, float* y, float* mean_rstd, double* workspace, int B, int C, int HW,
                              void* stream);
+/* The same two forwards with the cell's next step folded into the apply pass (one launch per step and cell less, each):
+ *   _fwd_blend:      additionally out = u * h + (1 - u) * y (modules/module.py:57); u (B,C,HW) at batch stride u_batch_stride elements
+ *                    (the u half of the (B,2C,H,W) gate tensor), h and out (B,C,HW) contiguous; y is written as well (the backward needs it);
+ *   _pair_fwd_mul:   additionally rh = y[:, :C] * h (modules/module.py:43: the second operand of the candidate convolution, which
+ *                    smvs_conv3x3_fwd takes as (x, rh): no concatenation); h, rh (B,C,HW) contiguous. */
+int smvs_groupnorm1_fwd_blend(const float* x, long long x_batch_stride, const float* gamma, const float* beta, float eps,
+                              int act, float* y, float* mean_rstd, double* workspace, const float* u, long long u_batch_stride,
+                              const float* h, float* out, int B, int C, int HW, void* stream);
+int smvs_groupnorm1_pair_fwd_mul(const float* x, const float* gamma, const float* beta, const float* gamma2, const float* beta2,
+                                 float eps, int act, float* y, float* mean_rstd, double* workspace, const float* h, float* rh,
+                                 int B, int C, int HW, void* stream);
 int smvs_groupnorm1_pair_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* gamma2,
                              const float* mean_rstd, int act, float* dx, float* dgamma, float* dbeta, float* dgamma2,
                              float* dbeta2, double* workspace, int B, int C, int HW, void* stream);

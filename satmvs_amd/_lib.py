@@ -41,6 +41,8 @@ _SIGNATURES = {
     "smvs_gru_blend_fwd": [_vp, _vp, _vp, _vp, C.c_longlong, _vp],
     "smvs_gru_blend_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_longlong, _vp],
     "smvs_groupnorm1_pair_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "smvs_groupnorm1_fwd_blend": [_vp, C.c_longlong, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, C.c_longlong, _vp, _vp, _i, _i, _i, _vp],
+    "smvs_groupnorm1_pair_fwd_mul": [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "smvs_groupnorm1_pair_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "smvs_groupnorm1_fwd": [_vp, C.c_longlong, _vp, _vp, _f, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "smvs_groupnorm1_bwd": [_vp, _vp, C.c_longlong, _vp, _vp, _vp, _i, _vp, C.c_longlong, _vp, _vp, _vp, _i, _i, _i, _vp],

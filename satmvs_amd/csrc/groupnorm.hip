@@ -100,12 +100,21 @@ __device__ __forceinline__ void mean_rstd_of(const double* partial, int b, int n
     mean = mr[0]; rstd = mr[1];
 }
 
+// What the ConvGRU cell does with a norm's output right away, folded into the apply pass (round 6: one launch per step and cell less, each way
+// a ~4 us link of a launch-bound chain):
+//   blend (single form, module.py:57):  out = u * h + (1 - u) * y     u (B,C,HW) at batch stride ubs (the u half of the gate tensor), h, out (B,C,HW)
+//   mul   (pair form,  module.py:43):   rh  = y * h for the FIRST half (the r gate) of every sample pair; h, rh (B,C,HW)
+struct GnEpilogue {
+    const float* u; long long ubs; const float* h; float* out;
+    const float* mh; float* rh;
+};
+
 // grid (segments of HW, B*C)
 __global__ __launch_bounds__(GN_THREADS)
 void gn1_apply_kernel(const float* __restrict__ x, long long xbs, const float* __restrict__ gamma, const float* __restrict__ beta,
                       const float* __restrict__ gamma2, const float* __restrict__ beta2,
                       const double* __restrict__ partial, int nblk, float eps, int act, float* __restrict__ y, float* __restrict__ mean_rstd,
-                      int C, int HW)
+                      int C, int HW, const GnEpilogue ep)
 {
     const int row = blockIdx.y, b = row / C, c = row - b * C;
     float mean, rstd;
@@ -116,7 +125,15 @@ void gn1_apply_kernel(const float* __restrict__ x, long long xbs, const float* _
     const float* xp = x + (size_t)b * xbs + (size_t)c * HW;
     float* yp = y + ((size_t)b * C + c) * HW;
     const int i0 = blockIdx.x * GN_ELEMS, i1 = min(i0 + GN_ELEMS, HW);
-    if (((((uintptr_t)xp) | ((uintptr_t)yp)) & 15) == 0 && ((i1 - i0) & 3) == 0 && (i0 & 3) == 0) {
+    // epilogue operands of this row (null: none)
+    const float* up = ep.u ? ep.u + (size_t)b * ep.ubs + (size_t)c * HW : nullptr;
+    const float* hp = ep.u ? ep.h + ((size_t)b * C + c) * HW : nullptr;
+    float* bo = ep.u ? ep.out + ((size_t)b * C + c) * HW : nullptr;
+    const bool mul = ep.mh != nullptr && !(b & 1);
+    const float* mp = mul ? ep.mh + ((size_t)(b >> 1) * C + c) * HW : nullptr;
+    float* mo = mul ? ep.rh + ((size_t)(b >> 1) * C + c) * HW : nullptr;
+    const uintptr_t al = ((uintptr_t)xp) | ((uintptr_t)yp) | ((uintptr_t)up) | ((uintptr_t)hp) | ((uintptr_t)bo) | ((uintptr_t)mp) | ((uintptr_t)mo);
+    if ((al & 15) == 0 && ((i1 - i0) & 3) == 0 && (i0 & 3) == 0) {
         const float4* x4 = reinterpret_cast<const float4*>(xp + i0);
         float4* y4 = reinterpret_cast<float4*>(yp + i0);
         for (int i = threadIdx.x; i < ((i1 - i0) >> 2); i += GN_THREADS) {
@@ -125,9 +142,28 @@ void gn1_apply_kernel(const float* __restrict__ x, long long xbs, const float* _
             r.x = act_fwd(fmaf(v.x, g, o), act); r.y = act_fwd(fmaf(v.y, g, o), act);
             r.z = act_fwd(fmaf(v.z, g, o), act); r.w = act_fwd(fmaf(v.w, g, o), act);
             y4[i] = r;
+            if (up) {
+                // u * h + (1 - u) * y with the products rounded one by one, as smvs_gru_blend_fwd (and torch) forms them
+                const float4 uu = reinterpret_cast<const float4*>(up + i0)[i], hh = reinterpret_cast<const float4*>(hp + i0)[i];
+                float4 q;
+                q.x = uu.x * hh.x + (1.0f - uu.x) * r.x; q.y = uu.y * hh.y + (1.0f - uu.y) * r.y;
+                q.z = uu.z * hh.z + (1.0f - uu.z) * r.z; q.w = uu.w * hh.w + (1.0f - uu.w) * r.w;
+                reinterpret_cast<float4*>(bo + i0)[i] = q;
+            }
+            if (mp) {
+                const float4 hh = reinterpret_cast<const float4*>(mp + i0)[i];
+                float4 q;
+                q.x = r.x * hh.x; q.y = r.y * hh.y; q.z = r.z * hh.z; q.w = r.w * hh.w;
+                reinterpret_cast<float4*>(mo + i0)[i] = q;
+            }
         }
     } else {
-        for (int i = i0 + threadIdx.x; i < i1; i += GN_THREADS) yp[i] = act_fwd(fmaf(xp[i], g, o), act);
+        for (int i = i0 + threadIdx.x; i < i1; i += GN_THREADS) {
+            const float r = act_fwd(fmaf(xp[i], g, o), act);
+            yp[i] = r;
+            if (up) bo[i] = up[i] * hp[i] + (1.0f - up[i]) * r;
+            if (mp) mo[i] = r * mp[i];
+        }
     }
 }
 
@@ -235,7 +271,7 @@ void gn1_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x
 namespace smvs {
 
 static int gn_fwd(const float* x, long long xbs, const float* gamma, const float* beta, const float* gamma2, const float* beta2, float eps, int act,
-                  float* y, float* mean_rstd, double* workspace, int B, int C, int HW, void* stream)
+                  float* y, float* mean_rstd, double* workspace, int B, int C, int HW, void* stream, const GnEpilogue& ep = GnEpilogue{})
 {
     if (!x || !gamma || !beta || !y || !mean_rstd || !workspace) return fail(SMVS_ERR_ARG, "null pointer argument");
     if (B < 1 || C < 1 || HW < 1) return fail(SMVS_ERR_ARG, "non-positive dimension");
@@ -247,7 +283,7 @@ static int gn_fwd(const float* x, long long xbs, const float* gamma, const float
     const int nblk = (int)((n + GN_ELEMS - 1) / GN_ELEMS);
     hipLaunchKernelGGL(gn1_stats_kernel, dim3((unsigned)nblk, B), dim3(GN_THREADS), 0, st, x, xbs, n, workspace);
     hipLaunchKernelGGL(gn1_apply_kernel, dim3((HW + GN_ELEMS - 1) / GN_ELEMS, B * C), dim3(GN_THREADS), 0, st, x, xbs, gamma, beta, gamma2, beta2,
-                       workspace, nblk, eps, act, y, mean_rstd, C, HW);
+                       workspace, nblk, eps, act, y, mean_rstd, C, HW, ep);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMVS_ERR_LAUNCH, "groupnorm1_fwd launch: %s", hipGetErrorString(e));
     return SMVS_OK;
@@ -301,6 +337,32 @@ extern "C" SMVS_EXPORT int smvs_groupnorm1_pair_fwd(const float* x, const float*
 {
     if (!gamma2 || !beta2) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
     return smvs::gn_fwd(x, (long long)C * HW, gamma, beta, gamma2, beta2, eps, act, y, mean_rstd, workspace, 2 * B, C, HW, stream);
+}
+
+// The two norms of a ConvGRU cell with the step that follows them folded into the apply pass (struct GnEpilogue above):
+//   smvs_groupnorm1_fwd_blend      = smvs_groupnorm1_fwd, then out = u * h + (1 - u) * y (module.py:57); u (B,C,HW) at batch stride
+//                                    u_batch_stride (the u half of the gate tensor), h and out (B,C,HW) contiguous; y is written too
+//   smvs_groupnorm1_pair_fwd_mul   = smvs_groupnorm1_pair_fwd, then rh = y[:, :C] * h (module.py:43, the second operand of the candidate
+//                                    convolution, which takes (x, rh) as two tensors: no concatenation); h, rh (B,C,HW) contiguous
+extern "C" SMVS_EXPORT int smvs_groupnorm1_fwd_blend(const float* x, long long x_batch_stride, const float* gamma, const float* beta, float eps,
+                                                     int act, float* y, float* mean_rstd, double* workspace, const float* u,
+                                                     long long u_batch_stride, const float* h, float* out, int B, int C, int HW, void* stream)
+{
+    if (!u || !h || !out) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
+    if (u_batch_stride < (long long)C * HW) return smvs::fail(SMVS_ERR_ARG, "batch stride smaller than one sample");
+    smvs::GnEpilogue ep{};
+    ep.u = u; ep.ubs = u_batch_stride; ep.h = h; ep.out = out;
+    return smvs::gn_fwd(x, x_batch_stride, gamma, beta, nullptr, nullptr, eps, act, y, mean_rstd, workspace, B, C, HW, stream, ep);
+}
+
+extern "C" SMVS_EXPORT int smvs_groupnorm1_pair_fwd_mul(const float* x, const float* gamma, const float* beta, const float* gamma2, const float* beta2,
+                                                        float eps, int act, float* y, float* mean_rstd, double* workspace, const float* h, float* rh,
+                                                        int B, int C, int HW, void* stream)
+{
+    if (!gamma2 || !beta2 || !h || !rh) return smvs::fail(SMVS_ERR_ARG, "null pointer argument");
+    smvs::GnEpilogue ep{};
+    ep.mh = h; ep.rh = rh;
+    return smvs::gn_fwd(x, (long long)C * HW, gamma, beta, gamma2, beta2, eps, act, y, mean_rstd, workspace, 2 * B, C, HW, stream, ep);
 }
 
 extern "C" SMVS_EXPORT int smvs_groupnorm1_pair_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* gamma2,

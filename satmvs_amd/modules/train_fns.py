@@ -777,7 +777,7 @@ def _wgrad_now_or_later(sink, weight, bias, window, win2, grid, stride):
 
 class _ConvGRUCellFn(torch.autograd.Function):
     """A whole ConvGRUCell2 step (reference: module.py:24-57) as ONE autograd node, batch 1: gate convolution over (x, h), both gate norms
-    + sigmoids, cat(x, r*h), candidate convolution, output norm + tanh, blend -- the same six native calls as the piecewise path, and a
+    + sigmoids (+ r*h), candidate convolution over (x, r*h), output norm + tanh (+ blend) -- four native calls, and a
     hand-chained backward in which the three gradient contributions to h and the two to x meet inside the kernels instead of in
     autograd's accumulation adds: the blend's state gradient rides into smvs_gru_mul_cat_bwd_acc, which leaves [dx | dh] in place of the
     candidate convolution's input gradient, and that buffer seeds the gate convolution's input gradient (smvs_conv3x3_fwd's `init`).
@@ -793,29 +793,28 @@ class _ConvGRUCellFn(torch.autograd.Function):
         st = _lib.current_stream(dev)
         rw, rb, uw, ub, nw_, nb_ = [_f32c_fast(t.detach()) for t in (rw, rb, uw, ub, nw_, nb_)]
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        gates, ru, xc, craw, cand, out = e(B, 2 * C, H, W), e(B, 2 * C, H, W), e(B, Cx + C, H, W), e(B, C, H, W), e(B, C, H, W), e(B, C, H, W)
+        gates, ru, rh, craw, cand, out = e(B, 2 * C, H, W), e(B, 2 * C, H, W), e(B, C, H, W), e(B, C, H, W), e(B, C, H, W), e(B, C, H, W)
         stats_g, stats_o = e(2 * B, 2), e(B, 2)
         nblk = (C * HW + 4095) // 4096
         with torch.cuda.device(dev):
             _lib.call("smvs_conv3x3_fwd", 0, _lib.ptr(x), Cx, _lib.ptr(h), C, _lib.ptr(_conv_packed(gw, 0, Cx + C, 2 * C)), _lib.ptr(gb), None,
                       _lib.ptr(gates), B, 2 * C, H, W, 0, st)
-            _lib.call("smvs_groupnorm1_pair_fwd", _lib.ptr(gates), _lib.ptr(rw), _lib.ptr(rb), _lib.ptr(uw), _lib.ptr(ub), float(eps), 1, _lib.ptr(ru),
-                      _lib.ptr(stats_g), _lib.ptr(_gn_scratch(dev, 4 * B * nblk)), B, C, HW, st)
-            r, u = ru[:, :C], ru[:, C:]
-            _lib.call("smvs_gru_mul_cat_fwd", _lib.ptr(x), _lib.ptr(r), _lib.ptr(h), _lib.ptr(xc), B, Cx, C, HW, st)
-            _lib.call("smvs_conv3x3_fwd", 0, _lib.ptr(xc), Cx + C, None, 0, _lib.ptr(_conv_packed(ow, 0, Cx + C, C)), _lib.ptr(ob), None,
+            # (round 6: r * h leaves the gate norms' apply pass and the candidate convolution reads (x, r*h) as two tensors -- no cat launch;
+            # the blend leaves the output norm's apply pass -- no blend launch)
+            _lib.call("smvs_groupnorm1_pair_fwd_mul", _lib.ptr(gates), _lib.ptr(rw), _lib.ptr(rb), _lib.ptr(uw), _lib.ptr(ub), float(eps), 1, _lib.ptr(ru),
+                      _lib.ptr(stats_g), _lib.ptr(_gn_scratch(dev, 4 * B * nblk)), _lib.ptr(h), _lib.ptr(rh), B, C, HW, st)
+            _lib.call("smvs_conv3x3_fwd", 0, _lib.ptr(x), Cx, _lib.ptr(rh), C, _lib.ptr(_conv_packed(ow, 0, Cx + C, C)), _lib.ptr(ob), None,
                       _lib.ptr(craw), B, C, H, W, 0, st)
-            _lib.call("smvs_groupnorm1_fwd", _lib.ptr(craw), C * HW, _lib.ptr(nw_), _lib.ptr(nb_), float(eps), 2, _lib.ptr(cand), _lib.ptr(stats_o),
-                      _lib.ptr(_gn_scratch(dev, 2 * B * nblk)), B, C, HW, st)
-            _lib.call("smvs_gru_blend_fwd", _lib.ptr(u), _lib.ptr(h), _lib.ptr(cand), _lib.ptr(out), h.numel(), st)
-        ctx.save_for_backward(x, h, gw, gb, ow, ob, rw, uw, nw_, gates, ru, xc, craw, cand, stats_g, stats_o)
+            _lib.call("smvs_groupnorm1_fwd_blend", _lib.ptr(craw), C * HW, _lib.ptr(nw_), _lib.ptr(nb_), float(eps), 2, _lib.ptr(cand), _lib.ptr(stats_o),
+                      _lib.ptr(_gn_scratch(dev, 2 * B * nblk)), _lib.ptr(ru[:, C:]), 2 * C * HW, _lib.ptr(h), _lib.ptr(out), B, C, HW, st)
+        ctx.save_for_backward(x, h, gw, gb, ow, ob, rw, uw, nw_, gates, ru, rh, craw, cand, stats_g, stats_o)
         ctx.sink = getattr(_TLS, "sink", None)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dnew):
-        x, h, gw, gb, ow, ob, rw, uw, nw_, gates, ru, xc, craw, cand, stats_g, stats_o = ctx.saved_tensors
+        x, h, gw, gb, ow, ob, rw, uw, nw_, gates, ru, rh, craw, cand, stats_g, stats_o = ctx.saved_tensors
         dev = x.device
         B, Cx, H, W = x.shape
         C = h.shape[1]
@@ -834,7 +833,7 @@ class _ConvGRUCellFn(torch.autograd.Function):
                       C * HW, _lib.ptr(dn[0]), _lib.ptr(dn[1]), _lib.ptr(_gn_scratch(dev, 2 * B * C * nseg)), B, C, HW, st)
             _lib.call("smvs_conv3x3_fwd", 0, _lib.ptr(dcraw), C, None, 0, _lib.ptr(_conv_packed(ow, 2, C, Cx + C)), None, None, _lib.ptr(dxc),
                       B, Cx + C, H, W, 0, st)
-            dow, dob = _wgrad_now_or_later(ctx.sink, ow, ob, xc, None, dcraw, 1)
+            dow, dob = _wgrad_now_or_later(ctx.sink, ow, ob, x, rh, dcraw, 1)
             _lib.call("smvs_gru_mul_cat_bwd_acc", _lib.ptr(dxc), _lib.ptr(r), _lib.ptr(h), _lib.ptr(dh_b), _lib.ptr(dru), B, Cx, C, HW, st)
             _lib.call("smvs_groupnorm1_pair_bwd", _lib.ptr(dru), _lib.ptr(gates), _lib.ptr(ru), _lib.ptr(rw), _lib.ptr(uw), _lib.ptr(stats_g), 1,
                       _lib.ptr(dgates), _lib.ptr(g4[0]), _lib.ptr(g4[1]), _lib.ptr(g4[2]), _lib.ptr(g4[3]), _lib.ptr(_gn_scratch(dev, 4 * B * C * nseg)),

@@ -302,6 +302,12 @@ def test_round3_training_entry_points_validate_arguments(lib):
         _lib.call("smvs_groupnorm1_pair_fwd", d, d, d, None, d, 1e-5, 1, d, d, d, 1, 8, 8, None)
     with pytest.raises(_lib.SatMVSNativeError, match="null pointer"):
         _lib.call("smvs_groupnorm1_pair_bwd", d, d, d, d, d, d, 1, d, d, d, None, d, d, 1, 8, 8, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="null pointer"):
+        _lib.call("smvs_groupnorm1_pair_fwd_mul", d, d, d, d, d, 1e-5, 1, d, d, d, d, None, 1, 8, 8, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="null pointer"):
+        _lib.call("smvs_groupnorm1_fwd_blend", d, 64, d, d, 1e-5, 2, d, d, d, None, 64, d, d, 1, 8, 8, None)
+    with pytest.raises(_lib.SatMVSNativeError, match="batch stride"):
+        _lib.call("smvs_groupnorm1_fwd_blend", d, 64, d, d, 1e-5, 2, d, d, d, d, 63, d, d, 1, 8, 8, None)
     with pytest.raises(_lib.SatMVSNativeError, match="16-byte aligned"):
         _lib.call("smvs_gru_blend_fwd", d, odd, d, d, 64, None)
     with pytest.raises(_lib.SatMVSNativeError, match="non-positive"):

@@ -390,6 +390,38 @@ def test_groupnorm1_native_matches_torch(dev, shape, act, sliced):
         assert float(dx0[:, :C].abs().max()) == 0.0             # the other half of the gate tensor gets no gradient from this norm
 
 
+@pytest.mark.parametrize("B,C,H,W", [(1, 8, 33, 50), (2, 16, 24, 48), (1, 8, 384, 768)])        # scalar path, batch 2, the real tile
+def test_groupnorm1_fused_epilogues_equal_the_separate_launches(dev, B, C, H, W):
+    """smvs_groupnorm1_pair_fwd_mul / smvs_groupnorm1_fwd_blend (the ConvGRU cell's r*h and u-blend folded into the norms' apply pass)
+    give the bits of smvs_groupnorm1_pair_fwd + a product / smvs_groupnorm1_fwd + smvs_gru_blend_fwd."""
+    from satmvs_amd import _lib
+    torch.manual_seed(5)
+    HW = H * W
+    st = _lib.current_stream(dev)
+    gates = torch.randn(B, 2 * C, H, W, device=dev) * 1.3 + 0.2
+    h = torch.randn(B, C, H, W, device=dev)
+    p = [torch.rand(C, device=dev) + 0.5 for _ in range(6)]
+    e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    ws = lambda n: torch.empty(max(64, n), dtype=torch.float64, device=dev)
+    nblk = (C * HW + 4095) // 4096
+    ru0, ru1, rh, s0, s1 = e(B, 2 * C, H, W), e(B, 2 * C, H, W), e(B, C, H, W), e(2 * B, 2), e(2 * B, 2)
+    _lib.call("smvs_groupnorm1_pair_fwd", _lib.ptr(gates), _lib.ptr(p[0]), _lib.ptr(p[1]), _lib.ptr(p[2]), _lib.ptr(p[3]), 1e-5, 1, _lib.ptr(ru0),
+              _lib.ptr(s0), _lib.ptr(ws(4 * B * nblk)), B, C, HW, st)
+    _lib.call("smvs_groupnorm1_pair_fwd_mul", _lib.ptr(gates), _lib.ptr(p[0]), _lib.ptr(p[1]), _lib.ptr(p[2]), _lib.ptr(p[3]), 1e-5, 1, _lib.ptr(ru1),
+              _lib.ptr(s1), _lib.ptr(ws(4 * B * nblk)), _lib.ptr(h), _lib.ptr(rh), B, C, HW, st)
+    assert torch.equal(ru0, ru1) and torch.equal(s0, s1)
+    assert torch.equal(rh, ru0[:, :C] * h)
+    craw = torch.randn(B, C, H, W, device=dev)
+    c0, c1, o0, o1, t0, t1 = e(B, C, H, W), e(B, C, H, W), e(B, C, H, W), e(B, C, H, W), e(B, 2), e(B, 2)
+    u = ru0[:, C:]
+    _lib.call("smvs_groupnorm1_fwd", _lib.ptr(craw), C * HW, _lib.ptr(p[4]), _lib.ptr(p[5]), 1e-5, 2, _lib.ptr(c0), _lib.ptr(t0),
+              _lib.ptr(ws(2 * B * nblk)), B, C, HW, st)
+    _lib.call("smvs_gru_blend_fwd", _lib.ptr(u.contiguous()), _lib.ptr(h), _lib.ptr(c0), _lib.ptr(o0), h.numel(), st)
+    _lib.call("smvs_groupnorm1_fwd_blend", _lib.ptr(craw), C * HW, _lib.ptr(p[4]), _lib.ptr(p[5]), 1e-5, 2, _lib.ptr(c1), _lib.ptr(t1),
+              _lib.ptr(ws(2 * B * nblk)), _lib.ptr(u), 2 * C * HW, _lib.ptr(h), _lib.ptr(o1), B, C, HW, st)
+    assert torch.equal(c0, c1) and torch.equal(t0, t1) and torch.equal(o0, o1)
+
+
 @pytest.mark.parametrize("B,cin,ch,H,W", [(1, 8, 8, 33, 50), (2, 16, 16, 24, 48), (1, 64, 64, 12, 24), (2, 32, 8, 7, 9),
                                            (1, 8, 8, 384, 768)])      # the real tile: level 1 of cascade stage 3
 def test_convgru_cell_native_elementwise_matches_torch(dev, B, cin, ch, H, W):
