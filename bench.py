@@ -631,6 +631,9 @@ def main():
     # launch) + smvs_rpc_costvol_fwd_pc (the build).  Both are inside the timed region; `kernel` (the build alone) is timed
     # separately for the roofline of the dominant kernel.
     use_pc = os.environ.get("SMVS_BENCH_TRIVARIATE") != "1"       # A/B only: 1 = smvs_rpc_costvol_fwd, the trivariate chain for every voxel
+    # a rank's shard below variance_cost_volume's fold threshold (8 Mi voxels: N >= 4 at cfg2) is built as that function would build it
+    from satmvs_amd.modules.warping import _FOLD_MIN_VOXELS
+    use_pc = use_pc and D_local * H * W >= _FOLD_MIN_VOXELS
     launch, kernel, _ = tile_build(_lib, feats, rpc, depth, out, V, C, D_local, H, W, stream, plane_coef=use_pc) if D_local > 0 else ((lambda: None),) * 3
 
     # A scene is a stream of tiles: the exchange of tile k waits for tile k's kernel (stream order through wait_stream) but tile
@@ -712,8 +715,9 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload) if world == 1 else None,
                          "bytes_per_voxel": bpv, "kernel_ms": round(kern_ms, 4), "fold_plus_kernel_ms": round(both_ms, 4),
-                         "note": "one step = smvs_rpc_plane_coef (fold of the source cubics per plane, 3-5 us) + smvs_rpc_costvol_fwd_pc; `value` and "
-                                 "ms_per_step time both, kernel_ms / achieved / frac are the build kernel alone (HIP events on its stream)"},
+                         "note": ("one step = smvs_rpc_plane_coef (fold of the source cubics per plane, 3-5 us) + smvs_rpc_costvol_fwd_pc; `value` and "
+                                  "ms_per_step time both, kernel_ms / achieved / frac are the build kernel alone (HIP events on its stream)") if use_pc else
+                                 "one step = smvs_rpc_costvol_fwd (a shard below 8 Mi voxels is not worth the fold's launch: variance_cost_volume's rule)"},
         }
         line["devices"] = ids
         if exchange is not None:
