@@ -28,6 +28,15 @@ def test_fuzz_cost_volume_forward_vs_oracle():
     assert last.startswith("60 cases: 0 differing voxels"), last
 
 
+def test_fuzz_plane_coefficient_entry_vs_oracle():
+    """smvs_rpc_plane_coef + smvs_rpc_costvol_fwd_pc on random shapes / windows with plane-constant, partly jittered, NaN and fully
+    jittered heights: the oracle's volume up to the voxels whose float32 tap coordinate the re-associated cubics flip (bounded per
+    case by the fuzzer; in total a handful)."""
+    last = _run("fuzz_costvol_fwd.py", 60, 15, "pc")
+    assert last.startswith("60 cases:"), last
+    assert int(last.split()[2]) <= 60, last
+
+
 @pytest.mark.parametrize("mode", ["exact", "fused"])
 def test_fuzz_cost_volume_backward_vs_warp_autograd(mode):
     """(both arithmetics of the forward: the gradient kernel is the same, the library default must run it too)"""
