@@ -296,6 +296,31 @@ def test_plane_coef_records(dev):
     assert np.array_equal(w[:B * D].reshape(B, D)[:, 1:3], depth[:, 1:3].astype(np.float64)) and (w[:B * D].reshape(B, D)[:, [0, 3, 4]] == -3.0).all()
 
 
+def test_reciprocal_scales_equal_the_ieee_quotients(dev):
+    """recip_scale (v_rcp_f64 + two Newton steps: every rpc kernel's 1/SCALE since round 6) against the IEEE quotient the oracle and
+    the reference compute, read back through smvs_rpc_plane_coef's header: bit-equal over 77 000 scales spread log-uniformly over
+    1e-4 .. 1e5 (camera models hold 0.05 .. 20 000) and over the synthetic scenes' own values."""
+    from satmvs_amd import _lib
+    from satmvs_amd import rpc_synth
+    rng = np.random.default_rng(41)
+    B, V = 64, 4
+    n = _lib.load().smvs_rpc_plane_coef_bytes(B, V - 1, 1) // 8
+    hdr = (B + 7) // 8 * 8
+    depth = _t(np.zeros((B, 1), np.float32), dev)
+    bad = 0
+    base = np.stack([rpc_synth.make_view_rpcs(V, 96, 160, seed=1000 + b) for b in range(B)])
+    for it in range(100):
+        rpc = base.copy()
+        if it:                                                    # round 0: the synthetic scenes' own scales; then arbitrary ones
+            rpc[:, :, 5:10] = np.exp(rng.uniform(np.log(1e-4), np.log(1e5), (B, V, 5))) * rng.choice([-1.0, 1.0], (B, V, 5))
+        pc = torch.zeros(n, dtype=torch.float64, device=dev)
+        _lib.call("smvs_rpc_plane_coef", _lib.ptr(_t(rpc, dev)), _lib.ptr(depth), 0, _lib.ptr(pc), B, V - 1, 1, 96, 160, 0, 1, _lib.current_stream(dev))
+        sc = pc.cpu().numpy()[hdr:hdr + 24 * B].reshape(B, 8, 3)[:, :V]
+        want = np.concatenate([1.0 / rpc[:, :1][:, :, [6, 5, 9]], 1.0 / rpc[:, 1:][:, :, [7, 8, 9]]], axis=1)
+        bad += int((sc != want).sum())
+    assert bad == 0, bad
+
+
 @pytest.mark.parametrize("cfg", [
     dict(B=1, V=3, C=32, D=16, H=40, W=72, four=True),      # the headline instance (8 planes per wave), (B,D,H,W) broadcast planes
     dict(B=2, V=3, C=16, D=11, H=37, W=70, four=False),     # 4 planes per wave, ragged tile, batch 2, odd plane count, (B,D) heights
