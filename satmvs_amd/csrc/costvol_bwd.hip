@@ -443,6 +443,14 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
                     kws[k][s] = ew * n;
                 }
         }
+        // ... and so does the tap's address in the gradient box (interior waves; one v_lshl_add per tap, plane and channel otherwise)
+        uint32_t tga[KEEPW ? DCH : 1][NSRC];
+        if constexpr (KEEPW) {
+#pragma unroll
+            for (int k = 0; k < DCH; ++k)
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s) tga[k][s] = gbox_lds + (uint32_t)(s * GBOX_BYTES) + 2u * tt[k][s];
+        }
         auto tap_weights = [&](int k, int s, f32x2& wn, f32x2& ws) __attribute__((always_inline)) {
             if constexpr (KEEPW) { wn = kwn[k][s]; ws = kws[k][s]; }
             else {
@@ -605,7 +613,8 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
                         else fbox_wait_n<4 * NSRC>(nq[k & 1][s], sq[k & 1][s]);
                         tap_weights(k, s, wn[s], ws[s]);
                         const f32x2 acc = __builtin_elementwise_fma(sq[k & 1][s], ws[s], nq[k & 1][s] * wn[s]);
-                        const float t = acc.x + acc.y;
+                        float t = acc.x + acc.y;
+                        asm volatile("" : "+v"(t));         // (one v_add_f32: left to itself the compiler pairs the views' halves up for a v_pk_add_f32 behind three register moves)
                         wv[s] = t;
                         sum = sum + t;
                     }
@@ -615,7 +624,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
                     for (int s = 0; s < NSRC; ++s) {
                         const float gw = g * (wv[s] - m);
                         const f32x2 cn = wn[s] * gw, cs = ws[s] * gw;
-                        if (!(SMVS_BWD_ABLATE & 2)) gbox_add4(gbox_lds + (uint32_t)(s * GBOX_BYTES) + 2u * tt[k][s], cn.x, cn.y, cs.x, cs.y);
+                        if (!(SMVS_BWD_ABLATE & 2)) gbox_add4(KEEPW ? tga[k][s] : gbox_lds + (uint32_t)(s * GBOX_BYTES) + 2u * tt[k][s], cn.x, cn.y, cs.x, cs.y);
                     }
                 }
             } else
