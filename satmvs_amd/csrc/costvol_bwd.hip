@@ -270,6 +270,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
     float tf[DCH][NSRC][2];                                 // x and y fraction of the tap: the four weights are rebuilt per channel (2 registers instead of 4)
     uint32_t take = 0, give = 0;                            // bit d*NSRC+s: fold the west lane's east pair in / hand mine to the east lane
     uint32_t any_partial = 0, any_take = 0, any_hole = 0;   // wave-uniform: some lane of the wave has such a tap (hole: not a full tap)
+    uint32_t all_take = 0;                                  // wave-uniform: a 32-lane row of the patch is one run of cells, west to east, in both rows
     bool boxed = BOX;                                       // wave-uniform: every view's box fits
     int box_g0[NSRC];                                       // wave-uniform: element offset of the box's first cell inside an H x W plane
     int box_rows[NSRC];                                     // wave-uniform: rows of the box any full tap of the wave touches (the flush visits no other)
@@ -354,6 +355,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
                     if (__builtin_amdgcn_ballot_w64((e & TAP_PARTIAL) == TAP_PARTIAL) != 0) any_partial |= bit;
                     if (__builtin_amdgcn_ballot_w64(!full) != 0) any_hole |= bit;
                     if (__builtin_amdgcn_ballot_w64(tk) != 0) any_take |= bit;
+                    if (BOX && __builtin_amdgcn_ballot_w64(tk) == 0xfffffffefffffffeull) all_take |= bit;      // every lane but the two row starts
                 }
                 __builtin_amdgcn_sched_barrier(0);          // one view at a time: its 80 coefficients leave the SGPRs before the next view's arrive
             }
@@ -386,6 +388,7 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
     any_partial = __builtin_amdgcn_readfirstlane(any_partial);
     any_take = __builtin_amdgcn_readfirstlane(any_take);
     any_hole = __builtin_amdgcn_readfirstlane(any_hole);
+    all_take = __builtin_amdgcn_readfirstlane(all_take);
 
     // ---- B: channels ---------------------------------------------------------------------------------------------
     const float* refp = p.ref + (size_t)b * C * HW + pix;
@@ -703,6 +706,11 @@ void costvol_bwd_kernel(const CostVolBwdParams p)
             atomicAdd(&smvs_bwd_timing[0], bt_geo - bt_start); atomicAdd(&smvs_bwd_timing[1], bt_wait); atomicAdd(&smvs_bwd_timing[2], bt_flush);
             atomicAdd(&smvs_bwd_timing[3], bt_issue); atomicAdd(&smvs_bwd_timing[4], bt_planes); atomicAdd(&smvs_bwd_timing[5], bnow() - bt_start);
             atomicAdd(&smvs_bwd_timing[7], 1ull);
+            if (any_hole == 0) {
+                // [6]: low 32 bits = plane-view pairs whose rows are single runs; bits 32.. = waves where ALL are; (reported by tools/wave_timing_bwd.py)
+                const bool every = all_take == (DCH * NSRC >= 32 ? 0xffffffffu : (1u << (DCH * NSRC)) - 1u);
+                atomicAdd(&smvs_bwd_timing[6], (unsigned long long)__builtin_popcount(all_take) + (every ? (1ull << 32) : 0ull));
+            }
         }
 #endif
         return;

@@ -30,3 +30,5 @@ w = buf[7]
 print("%.3f ms per launch (with stamps); boxed waves %d (%d launches)" % (a.elapsed_time(b) / n, w, n))
 for name, i in (("geometry + set-up", 0), ("top-of-channel waits", 1), ("flush", 2), ("issue of loads / boxes", 3), ("plane loop", 4), ("whole wave", 5)):
     print("%-24s %9.0f clocks per wave" % (name, buf[i] / max(w, 1)))
+print("plane-view pairs whose 32-lane rows are single runs of cells: %.1f of %d per boxed wave; waves where all are: %.1f %%"
+      % ((buf[6] & 0xffffffff) / max(w, 1), 16, 100.0 * (buf[6] >> 32) / max(w, 1)))
